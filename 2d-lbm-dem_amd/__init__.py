@@ -1,0 +1,325 @@
+"""2d-lbm-dem_amd -- MI355X-native hot path of cb-geo/2d-lbm-dem behind the reference's own seam.
+
+The reference exposes no library API: its seam is the set of ``void fn(void)`` routines that
+``renderScene()`` calls on file-scope globals (src/main.c:1697-1777). :class:`LbmDem` mirrors that
+seam one-to-one -- same routine names, same call order, same host data layout
+(``f[x][y][q]``, x slow) -- on top of the C ABI in ``include/lbmdem_hip.h``
+(``liblbmdem_hip.so``, hand-written HIP for gfx950).
+
+There is deliberately NO CPU fallback here: if the HIP library is missing or no GPU is present
+every entry point raises. The CPU oracle lives under ``oracle/`` and is test infrastructure only.
+
+The directory name is not a Python identifier; load it with ``importlib`` (see
+``__graft_entry__.load_package()``) or put the repo root on ``sys.path`` and use
+``importlib.import_module("2d-lbm-dem_amd")``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblbmdem_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lbmdem_hip.h")
+
+
+class LbmDemError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+class Physics(C.Structure):
+    """lbmdem_physics -- the initialised globals of main.c:74-118,143,163-165."""
+    _fields_ = [(n, C.c_double) for n in (
+        "rho_moy tau s2 s3 s5 s7 s8 s9 nu reductionR G angleG km kg kt ktm nug num nugt "
+        "mu mum mumb murf distVerlet dtt iterDEM freq amp t").split()] + [
+        ("updateVerlet", C.c_int), ("stepFilm", C.c_int)]
+
+
+class Config(C.Structure):
+    """lbmdem_config"""
+    _fields_ = [("lx", C.c_int), ("ly", C.c_int), ("x_begin", C.c_int), ("x_end", C.c_int),
+                ("halo", C.c_int), ("device", C.c_int), ("nbgrains", C.c_int), ("scale", C.c_double),
+                ("dx", C.c_double), ("dtLB", C.c_double), ("c", C.c_double), ("dt", C.c_double),
+                ("dt2", C.c_double), ("npDEM", C.c_int),
+                ("Mgx", C.c_double), ("Mdx", C.c_double), ("Mby", C.c_double), ("Mhy", C.c_double),
+                ("xG", C.c_double), ("yG", C.c_double), ("phys", Physics)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen liblbmdem_hip.so; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LbmDemError(-2, f"{LIB_PATH} not built -- run __graft_entry__.build() "
+                              "(make -C 2d-lbm-dem_amd/csrc); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    L.lbmdem_last_error.restype = C.c_char_p
+    L.lbmdem_version.restype = C.c_char_p
+    L.lbmdem_nbsteps.restype = C.c_long
+    L.lbmdem_nbsteps.argtypes = [C.c_void_p]
+    L.lbmdem_halo_doubles.restype = C.c_long
+    L.lbmdem_halo_doubles.argtypes = [C.c_void_p]
+    L.lbmdem_free_host.argtypes = [C.c_void_p]
+    L.lbmdem_free_host.restype = None
+    L.lbmdem_run.argtypes = [C.c_void_p, C.c_long]
+    L.lbmdem_set_nbsteps.argtypes = [C.c_void_p, C.c_long]
+    L.lbmdem_derive.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]
+    L.lbmdem_create.argtypes = [C.POINTER(Config), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    for name in ("destroy", "lbm_step", "obst_construction", "collide_stream", "forces_fluid",
+                 "verlet_rebuild", "dem_substep", "sync"):
+        getattr(L, "lbmdem_" + name).argtypes = [C.c_void_p]
+    for name in ("upload_f", "download_f", "download_obst", "total_density", "upload_kinematics",
+                 "download_kinematics", "download_fhf", "set_stream"):
+        getattr(L, "lbmdem_" + name).argtypes = [C.c_void_p, C.c_void_p]
+    L.lbmdem_download_macro.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.lbmdem_download_verlet.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.lbmdem_set_force_mode.argtypes = [C.c_void_p, C.c_int]
+    L.lbmdem_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    L.lbmdem_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.lbmdem_halo_pack.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.lbmdem_halo_unpack.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.lbmdem_fhf_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.lbmdem_get_config.argtypes = [C.c_void_p, C.POINTER(Config)]
+    L.lbmdem_read_sample.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_double)),
+                                     C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.POINTER(C.c_double))]
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    """Names the public header declares (used by the CPU test that checks the ABI surface)."""
+    import re
+    txt = open(HEADER_PATH).read()
+    return sorted(set(re.findall(r"\b(lbmdem_[a-z_0-9]+)\s*\(", txt)))
+
+
+def _chk(rc):
+    if rc != 0:
+        raise LbmDemError(rc, load_library().lbmdem_last_error().decode(errors="replace"))
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def read_sample(path):
+    """read_sample (main.c:609-639) -> (r, x1, x2) in metres."""
+    L = load_library()
+    n = C.c_int(0)
+    pr, p1, p2 = C.POINTER(C.c_double)(), C.POINTER(C.c_double)(), C.POINTER(C.c_double)()
+    _chk(L.lbmdem_read_sample(os.fsencode(path), C.byref(n), C.byref(pr), C.byref(p1), C.byref(p2)))
+    out = tuple(np.ctypeslib.as_array(p, shape=(n.value,)).copy() for p in (pr, p1, p2))
+    for p in (pr, p1, p2):
+        L.lbmdem_free_host(C.cast(p, C.c_void_p))
+    return out
+
+
+def derive(lx, ly, r, scale=1.0, physics: Physics | None = None) -> Config:
+    """Time-step derivation of main.c:1836-1860 (host arithmetic, bit-identical)."""
+    L = load_library()
+    cfg = Config()
+    if physics is None:
+        _chk(L.lbmdem_physics_defaults(C.byref(cfg.phys)))
+    else:
+        cfg.phys = physics
+    r = np.ascontiguousarray(r, dtype=np.float64)
+    _chk(L.lbmdem_derive(C.byref(cfg), int(lx), int(ly), float(scale), len(r), _vp(r)))
+    cfg.x_begin, cfg.x_end, cfg.halo, cfg.device = 0, int(lx), 0, 0
+    return cfg
+
+
+class LbmDem:
+    """One simulation on one GPU (or one x-strip of it). Method names follow the reference.
+
+    >>> sim = LbmDem.from_sample("a08d83.data", lx=600, ly=500)
+    >>> for _ in range(240): sim.renderScene()
+    >>> f = sim.f            # [lx][ly][9], the reference's host layout
+    """
+
+    def __init__(self, lx, ly, r, x1, x2, scale=1.0, device=0, strip=None, halo=0, physics=None):
+        L = load_library()
+        self._L = L
+        self._h = C.c_void_p()
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        x1 = np.ascontiguousarray(x1, dtype=np.float64)
+        x2 = np.ascontiguousarray(x2, dtype=np.float64)
+        if not (len(r) == len(x1) == len(x2)) or len(r) < 1:
+            raise LbmDemError(-1, "r, x1, x2 must be equally long, at least one grain "
+                                  "(the reference cannot run with 0 grains either: main.c:220)")
+        cfg = derive(lx, ly, r, scale, physics)
+        cfg.device = int(device)
+        if strip is not None:
+            cfg.x_begin, cfg.x_end, cfg.halo = int(strip[0]), int(strip[1]), int(halo)
+        self.cfg = cfg
+        self.lx, self.ly, self.n = int(lx), int(ly), len(r)
+        _chk(L.lbmdem_create(C.byref(cfg), _vp(r), _vp(x1), _vp(x2), C.byref(self._h)))
+
+    @classmethod
+    def from_sample(cls, path, lx, ly, **kw):
+        r, x1, x2 = read_sample(path)
+        return cls(lx, ly, r, x1, x2, **kw)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lbmdem_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- the reference's routines -------------------------------------------------------------
+    def renderScene(self, n=1):
+        """n x renderScene() (main.c:1697-1765)."""
+        _chk(self._L.lbmdem_run(self._h, int(n)))
+
+    def lbm_step(self):
+        """reinit_obst_density + obst_construction + collision_streaming + forces_fluid (main.c:1711-1717)."""
+        _chk(self._L.lbmdem_lbm_step(self._h))
+
+    def obst_construction(self):
+        _chk(self._L.lbmdem_obst_construction(self._h))
+
+    def collision_streaming(self):
+        """reinit_obst_density (with the previous obstacle map) + collision_streaming."""
+        _chk(self._L.lbmdem_collide_stream(self._h))
+
+    def forces_fluid(self):
+        _chk(self._L.lbmdem_forces_fluid(self._h))
+
+    def initVerlet(self):
+        """initVerlet + VerletWall (main.c:1519-1594)."""
+        _chk(self._L.lbmdem_verlet_rebuild(self._h))
+
+    VerletWall = initVerlet
+
+    def dem_substep(self):
+        """the integrator + acceleration_grains block of renderScene (main.c:1733-1764)."""
+        _chk(self._L.lbmdem_dem_substep(self._h))
+
+    def final_density(self):
+        """check_density / final_density (main.c:1249-1273)."""
+        s = C.c_double(0)
+        _chk(self._L.lbmdem_total_density(self._h, C.byref(s)))
+        return s.value
+
+    check_density = final_density
+
+    # ---- state ----------------------------------------------------------------------------------
+    @property
+    def nbsteps(self):
+        return int(self._L.lbmdem_nbsteps(self._h))
+
+    @nbsteps.setter
+    def nbsteps(self, v):
+        _chk(self._L.lbmdem_set_nbsteps(self._h, int(v)))
+
+    @property
+    def f(self):
+        out = np.zeros((self.lx, self.ly, 9))
+        _chk(self._L.lbmdem_download_f(self._h, _vp(out)))
+        return out
+
+    @f.setter
+    def f(self, value):
+        a = np.ascontiguousarray(value, dtype=np.float64)
+        if a.shape != (self.lx, self.ly, 9):
+            raise LbmDemError(-1, f"f must have shape {(self.lx, self.ly, 9)}")
+        _chk(self._L.lbmdem_upload_f(self._h, _vp(a)))
+
+    def download_f_into(self, out):
+        _chk(self._L.lbmdem_download_f(self._h, _vp(out)))
+
+    @property
+    def obst(self):
+        out = np.zeros((self.lx, self.ly), dtype=np.int32)
+        _chk(self._L.lbmdem_download_obst(self._h, _vp(out)))
+        return out
+
+    def macro(self):
+        rho, ux, uy = (np.zeros((self.lx, self.ly)) for _ in range(3))
+        _chk(self._L.lbmdem_download_macro(self._h, _vp(rho), _vp(ux), _vp(uy)))
+        return rho, ux, uy
+
+    @property
+    def kinematics(self):
+        """(n, 9): x1 x2 x3 v1 v2 v3 a1 a2 a3"""
+        out = np.zeros((self.n, 9))
+        _chk(self._L.lbmdem_download_kinematics(self._h, _vp(out)))
+        return out
+
+    @kinematics.setter
+    def kinematics(self, k):
+        k = np.ascontiguousarray(k, dtype=np.float64)
+        if k.shape != (self.n, 9):
+            raise LbmDemError(-1, f"kinematics must have shape {(self.n, 9)}")
+        _chk(self._L.lbmdem_upload_kinematics(self._h, _vp(k)))
+
+    @property
+    def fhf(self):
+        out = np.zeros((self.n, 3))
+        _chk(self._L.lbmdem_download_fhf(self._h, _vp(out)))
+        return out
+
+    def verlet(self):
+        """-> (cumul[n], neighbours[npairs], wallflags[n]) in the reference's form."""
+        npairs = C.c_int(0)
+        cumul = np.zeros(self.n, np.int32)
+        wf = np.zeros(self.n, np.int32)
+        _chk(self._L.lbmdem_download_verlet(self._h, None, None, 0, C.byref(npairs), None))
+        neigh = np.zeros(max(npairs.value, 1), np.int32)
+        _chk(self._L.lbmdem_download_verlet(self._h, _vp(cumul), _vp(neigh), len(neigh), C.byref(npairs), _vp(wf)))
+        return cumul, neigh[:npairs.value], wf
+
+    def config(self) -> Config:
+        out = Config()
+        _chk(self._L.lbmdem_get_config(self._h, C.byref(out)))
+        return out
+
+    # ---- plumbing -------------------------------------------------------------------------------
+    def set_force_mode(self, mode):
+        _chk(self._L.lbmdem_set_force_mode(self._h, int(mode)))
+
+    def set_stream(self, hip_stream_ptr):
+        _chk(self._L.lbmdem_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def sync(self):
+        _chk(self._L.lbmdem_sync(self._h))
+
+    def profile_enable(self, on=True):
+        _chk(self._L.lbmdem_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self):
+        ms, cnt = C.c_double(0), C.c_long(0)
+        _chk(self._L.lbmdem_profile_read(self._h, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def halo_doubles(self):
+        return int(self._L.lbmdem_halo_doubles(self._h))
+
+    def halo_pack(self, side, dev_ptr):
+        _chk(self._L.lbmdem_halo_pack(self._h, int(side), C.c_void_p(dev_ptr)))
+
+    def halo_unpack(self, side, dev_ptr):
+        _chk(self._L.lbmdem_halo_unpack(self._h, int(side), C.c_void_p(dev_ptr)))
+
+    def fhf_device(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        _chk(self._L.lbmdem_fhf_device(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value

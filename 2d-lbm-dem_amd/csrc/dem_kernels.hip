@@ -1,0 +1,351 @@
+// dem_kernels.hip -- soft-disc DEM kernels of the MI355X LBM-DEM stepper (gfx950, wave64).
+//
+//  * k_dem_substep: ONE launch per DEM sub-step, one thread per grain. The reference's sub-step
+//    (main.c:1733-1764) is three serial loops -- drift + half kick, acceleration_grains
+//    (main.c:1336-1516), second half kick -- with a global dependency between the first and the
+//    second (contacts need every grain's drifted state). Instead of two launches, each thread
+//    re-derives the drifted state of its few partners from the previous state with the same
+//    arithmetic (bit-identical), so the whole sub-step is a single read-old/write-new pass over a
+//    ping-pong state. No atomics: every contact is evaluated by both partners in the reference's
+//    canonical (i < j) frame (main.c:1442-1448) and partners are visited in ascending index, which
+//    is exactly the order in which the reference's serial loop accumulates into a grain.
+//
+//  * Verlet list (main.c:1519-1594): the reference tests all N^2/2 pairs. Here grains are binned on
+//    a uniform grid (cell = 2 r_max + distVerlet), sorted by cell with a radix sort (hipCUB), and each
+//    grain scans its 3x3 cells with the reference's three predicates (main.c:1529-1532) evaluated
+//    in the (i < j) frame -> the same pair set. The list is kept symmetric (CSR, partners ascending).
+//
+// Diagnostics that depend on the serial contact order (slip, rw, fr, ice through pft/pff/pf/ic,
+// main.c:130-131) are not produced here; they never feed back into x, v, a (SURVEY.md hard part 7).
+
+#include "lbmdem_internal.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace {
+
+struct Force3 { double f1, f2, f3; };
+
+__device__ __forceinline__ double maxt(double x, double y) { return (x < y) ? 0. : y; }  // main.c:211-216
+
+struct GrainState { double x1, x2, v1, v2, v3, r; };
+
+// drifted + half-kicked state of grain j from the previous sub-step's state: main.c:1748-1753
+__device__ __forceinline__ GrainState advance(const Kin& K, const double* __restrict__ r, int j,
+                                              const DemParams& P) {
+  GrainState s;
+  const double a1 = K.a1[j], a2 = K.a2[j], a3 = K.a3[j];
+  const double v1 = K.v1[j], v2 = K.v2[j], v3 = K.v3[j];
+  s.x1 = K.x1[j] + P.dt * v1 + P.dt2 * a1 / 2.;
+  s.x2 = K.x2[j] + P.dt * v2 + P.dt2 * a2 / 2.;
+  s.v1 = v1 + P.dt * a1 / 2.;
+  s.v2 = v2 + P.dt * a2 / 2.;
+  s.v3 = v3 + P.dt * a3 / 2.;
+  s.r = r[j];
+  return s;
+}
+
+// contact force on grain A (lower index) from grain B (higher index).
+// FILM = false: force_grains, main.c:739-774. FILM = true: the inline law of main.c:1365-1395.
+template <bool FILM>
+__device__ __forceinline__ Force3 contact(const GrainState& A, const GrainState& B, const DemParams& P) {
+  Force3 F = {0., 0., 0.};
+  const double xij = A.x1 - B.x1;
+  const double yij = A.x2 - B.x2;
+  const double dist = sqrt(xij * xij + yij * yij);
+  const double dn = dist - A.r - B.r;
+  if (dn >= 0) return F;
+  const double vx = A.v1 - B.v1;
+  const double vy = A.v2 - B.v2;
+  const double xn = xij / dist;
+  const double yn = yij / dist;
+  const double vn = vx * xn + vy * yn;
+  const double vt = -vx * yn + vy * xn - A.v3 * A.r - B.v3 * B.r;
+  double fn = -P.kg * dn - P.nug * vn;
+  if (fn < 0) fn = 0.0;
+  double ft;
+  if (!FILM) {
+    ft = -P.kt * vt * P.dt;
+    const double ftest = P.mu * fn;
+    if (fabs(ft) > ftest) ft = (ft < 0.0) ? ftest : -ftest;
+    F.f3 = -maxt(ft * A.r, fn * P.murf * A.r * B.r);
+  } else {
+    ft = P.kt * vt * P.dt;
+    const double ftest = P.mu * ft;  // sic, main.c:1385
+    if (fabs(ft) > ftest) ft = (ft > 0.0) ? ftest : -ftest;
+    F.f3 = -ft * A.r * P.murf;
+  }
+  F.f1 = fn * xn - ft * yn;
+  F.f2 = fn * yn + ft * xn;
+  return F;
+}
+
+template <bool FILM>
+__global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, const double* __restrict__ m,
+                              const double* __restrict__ It, const double* __restrict__ fhf,
+                              const int* __restrict__ offsets, const int* __restrict__ nbr,
+                              const unsigned char* __restrict__ wallflags, DemParams P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  const GrainState me = advance(in, r, i, P);
+  const double x3 = in.x3[i] + P.dt * in.v3[i] + P.dt2 * in.a3[i] / 2.;
+
+  // acceleration_grains: start from the hydrodynamic force (main.c:1429-1431)
+  double a1 = fhf[i], a2 = fhf[P.n + i], a3 = fhf[2 * P.n + i];
+  const int k0 = offsets[i], k1 = offsets[i + 1];
+  for (int k = k0; k < k1; ++k) {
+    const int j = nbr[k];
+    const GrainState other = advance(in, r, j, P);
+    if (i < j) {  // main.c:1443-1445
+      const Force3 F = contact<FILM>(me, other, P);
+      a1 = a1 + F.f1; a2 = a2 + F.f2; a3 = a3 + F.f3;
+    } else {      // main.c:1446-1448
+      const Force3 F = contact<FILM>(other, me, P);
+      a1 = a1 - F.f1; a2 = a2 - F.f2; a3 = a3 + F.f3;
+    }
+  }
+  // walls: bottom, top, left, right (main.c:1455-1508)
+  const unsigned wf = wallflags[i];
+  if (wf & 1u) {
+    const double dn = me.x2 - me.r - P.Mby;
+    if (dn < 0) {  // force_WallB, main.c:809-828
+      const double vn = me.v2, vt = me.v1;
+      double fn = -P.km * dn - P.num * vn;
+      if (fn < 0) fn = 0.;
+      double ft = P.ktm * vt;
+      const double ftest = P.mumb * fn;
+      if (fabs(ft) > ftest) ft = (ft < 0.0) ? ftest : -ftest;
+      a1 = a1 + ft; a2 = a2 + fn; a3 = a3 + (-(ft * me.r * P.murf));
+    }
+  }
+  if (wf & 2u) {
+    const double dn = -me.x2 - me.r + P.Mhy;
+    if (dn < 0) {  // force_WallT, main.c:846-871
+      const double vn = me.v2;
+      double fn = P.km * dn - P.num * vn;
+      if (fn > 0.) fn = 0.;
+      const double vt = me.v1 + me.v3 * me.r - P.wallT_vel;
+      double ft = fabs(P.ktm * vt);
+      double ftmax;
+      if (vt >= 0) ftmax = P.mumb * fn - P.nugt * vt; else ftmax = P.mumb * fn + P.nugt * vt;
+      if (ft > ftmax) ft = ftmax;
+      if (vt > 0) ft = -ft;
+      a1 = a1 + ft; a2 = a2 + fn; a3 = a3 + ft * me.r * P.murf;
+    }
+  }
+  if (wf & 4u) {
+    const double dn = me.x1 - me.r - P.Mgx;
+    if (dn < 0) {  // force_WallL, main.c:888-904
+      const double vn = me.v1;
+      double fn = -P.km * dn + P.num * vn;
+      if (fn < 0.) fn = 0.;
+      const double vt = me.v2;
+      double ft = P.mum * fn;
+      if (vt > 0) ft = -ft;
+      a1 = a1 + fn; a2 = a2 + ft; a3 = a3 + ft * me.r * P.murf;
+    }
+  }
+  if (wf & 8u) {
+    const double dn = -me.x1 - me.r + P.Mdx;
+    if (dn < 0) {  // force_WallR, main.c:923-936 (ft from the unclamped fn)
+      const double vn = me.v1;
+      double fn = P.km * dn - P.num * vn;
+      const double vt = me.v2;
+      double ft = P.mum * fn;
+      if (vt > 0) ft = -ft;
+      if (fn > 0.) fn = 0.;
+      a1 = a1 + fn; a2 = a2 + (-ft); a3 = a3 + ft * me.r * P.murf;
+    }
+  }
+  // main.c:1511-1515 (mw = 0: SURVEY.md hard part 5)
+  const double mi = m[i], mw = 0.0;
+  a1 = a1 / mi + ((mi - mw) / mi) * P.xG;
+  a2 = (a2 / mi) + ((mi - mw) / mi) * P.yG;
+  a3 = a3 / It[i];
+  // second half kick, main.c:1760-1762
+  out.x1[i] = me.x1; out.x2[i] = me.x2; out.x3[i] = x3;
+  out.v1[i] = me.v1 + P.dt * a1 / 2.;
+  out.v2[i] = me.v2 + P.dt * a2 / 2.;
+  out.v3[i] = me.v3 + P.dt * a3 / 2.;
+  out.a1[i] = a1; out.a2[i] = a2; out.a3[i] = a3;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Verlet list
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int cell_coord(double x, double o, double cs, int nc) {
+  int c = (int)floor((x - o) / cs);
+  return c < 0 ? 0 : (c >= nc ? nc - 1 : c);
+}
+
+__global__ void k_cell_keys(int n, const double* __restrict__ x1, const double* __restrict__ x2, double ox,
+                            double oy, double cs, int ncx, int ncy, unsigned int* __restrict__ keys,
+                            int* __restrict__ vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = (unsigned)(cell_coord(x2[i], oy, cs, ncy) * ncx + cell_coord(x1[i], ox, cs, ncx));
+  vals[i] = i;
+}
+
+__global__ void k_cell_bounds(int n, const unsigned int* __restrict__ keys, int* __restrict__ cell_start,
+                              int* __restrict__ cell_end) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const unsigned c = keys[k];
+  if (k == 0 || keys[k - 1] != c) cell_start[c] = k;
+  if (k == n - 1 || keys[k + 1] != c) cell_end[c] = k + 1;
+}
+
+// the reference's candidate test (main.c:1527-1532), lo < hi
+__device__ __forceinline__ bool verlet_pair(double x1l, double x2l, double rl, double x1h, double x2h,
+                                            double rh, double dV) {
+  const double ddx = x1l - x1h;
+  const double ddy = x2l - x2h;
+  if (((fabs(ddx) - rl - rh) <= dV) && ((fabs(ddy) - rl - rh) <= dV))
+    return (sqrt(ddx * ddx + ddy * ddy) - rl - rh) <= dV;
+  return false;
+}
+
+// MODE 0: count partners; MODE 1: write them (then sort ascending) -- one thread per grain
+template <int MODE>
+__global__ void k_verlet_scan(int n, const double* __restrict__ x1, const double* __restrict__ x2,
+                              const double* __restrict__ r, double ox, double oy, double cs, int ncx, int ncy,
+                              const int* __restrict__ cell_start, const int* __restrict__ cell_end,
+                              const int* __restrict__ sorted, double dV, int* __restrict__ counts,
+                              const int* __restrict__ offsets, int* __restrict__ nbr, long cap,
+                              int* __restrict__ overflow) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double xi = x1[i], yi = x2[i], ri = r[i];
+  const int cx = cell_coord(xi, ox, cs, ncx), cy = cell_coord(yi, oy, cs, ncy);
+  int cnt = 0;
+  const int base = MODE ? offsets[i] : 0;
+  for (int yy = cy - 1; yy <= cy + 1; ++yy) {
+    if (yy < 0 || yy >= ncy) continue;
+    for (int xx = cx - 1; xx <= cx + 1; ++xx) {
+      if (xx < 0 || xx >= ncx) continue;
+      const int c = yy * ncx + xx;
+      const int s = cell_start[c], e = cell_end[c];
+      for (int k = s; k < e; ++k) {
+        const int j = sorted[k];
+        if (j == i) continue;
+        const bool hit = (i < j) ? verlet_pair(xi, yi, ri, x1[j], x2[j], r[j], dV)
+                                 : verlet_pair(x1[j], x2[j], r[j], xi, yi, ri, dV);
+        if (!hit) continue;
+        if (MODE) {
+          if ((long)base + cnt < cap) nbr[base + cnt] = j; else *overflow = 1;
+        }
+        ++cnt;
+      }
+    }
+  }
+  if (!MODE) {
+    counts[i] = cnt;
+  } else {
+    // ascending partner order (insertion sort; lists are ~6 long)
+    const long end = ((long)base + cnt < cap) ? base + cnt : cap;
+    for (long a = base + 1; a < end; ++a) {
+      const int v = nbr[a];
+      long b = a - 1;
+      while (b >= base && nbr[b] > v) { nbr[b + 1] = nbr[b]; --b; }
+      nbr[b + 1] = v;
+    }
+  }
+}
+
+// wall candidate lists as per-grain flags: main.c:1563-1593
+__global__ void k_wall_flags(int n, const double* __restrict__ x1, const double* __restrict__ x2,
+                             const double* __restrict__ r, DemParams P, unsigned char* __restrict__ flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned f = 0;
+  if (x2[i] - r[i] - P.Mby < P.distVerlet) f |= 1u;
+  if (-x2[i] - r[i] + P.Mhy < P.distVerlet) f |= 2u;
+  if (x1[i] - r[i] - P.Mgx < P.distVerlet) f |= 4u;
+  if (-x1[i] - r[i] + P.Mdx < P.distVerlet) f |= 8u;
+  flags[i] = (unsigned char)f;
+}
+
+__global__ void k_set_last_offset(int n, const int* __restrict__ counts, int* __restrict__ offsets) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n] = offsets[n - 1] + counts[n - 1];
+}
+
+inline int key_bits(int ncells) {
+  int b = 1;
+  while ((1L << b) < ncells) ++b;
+  return b;
+}
+
+}  // namespace
+
+int verlet_alloc(VerletDevice& V, int n, double cs, double ox, double oy, double wx, double wy) {
+  V = VerletDevice{};
+  V.cs = cs; V.ox = ox; V.oy = oy;
+  V.ncx = (int)ceil(wx / cs) + 1; if (V.ncx < 1) V.ncx = 1;
+  V.ncy = (int)ceil(wy / cs) + 1; if (V.ncy < 1) V.ncy = 1;
+  const size_t ncell = (size_t)V.ncx * V.ncy;
+  V.cap = (long)n * 32;
+  hipError_t e = hipSuccess;
+  auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 16); };
+  A((void**)&V.keys_in, sizeof(unsigned) * n); A((void**)&V.keys_out, sizeof(unsigned) * n);
+  A((void**)&V.vals_in, sizeof(int) * n); A((void**)&V.vals_out, sizeof(int) * n);
+  A((void**)&V.cell_start, sizeof(int) * ncell); A((void**)&V.cell_end, sizeof(int) * ncell);
+  A((void**)&V.counts, sizeof(int) * n); A((void**)&V.offsets, sizeof(int) * (n + 1));
+  A((void**)&V.nbr, sizeof(int) * V.cap); A((void**)&V.wallflags, n);
+  A((void**)&V.overflow, sizeof(int));
+  if (e != hipSuccess) return -1;
+  V.sort_tmp_bytes = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, V.sort_tmp_bytes, V.keys_in, V.keys_out, V.vals_in,
+                                     V.vals_out, n, 0, key_bits((int)ncell));
+  V.scan_tmp_bytes = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, V.scan_tmp_bytes, V.counts, V.offsets, n);
+  A(&V.sort_tmp, V.sort_tmp_bytes); A(&V.scan_tmp, V.scan_tmp_bytes);
+  if (e != hipSuccess) return -1;
+  if (hipMemset(V.offsets, 0, sizeof(int) * (n + 1)) != hipSuccess) return -1;
+  if (hipMemset(V.wallflags, 0, n) != hipSuccess) return -1;
+  if (hipMemset(V.overflow, 0, sizeof(int)) != hipSuccess) return -1;
+  return 0;
+}
+
+void verlet_free(VerletDevice& V) {
+  void* ps[] = {V.keys_in, V.keys_out, V.vals_in, V.vals_out, V.cell_start, V.cell_end, V.sort_tmp,
+                V.scan_tmp, V.counts, V.offsets, V.nbr, V.wallflags, V.overflow};
+  for (void* p : ps) if (p) (void)hipFree(p);
+  V = VerletDevice{};
+}
+
+void launch_verlet_rebuild(VerletDevice& V, const Kin& K, const double* r, const DemParams& P,
+                           hipStream_t st) {
+  const int n = P.n;
+  const int nb = (n + 255) / 256;
+  const size_t ncell = (size_t)V.ncx * V.ncy;
+  hipLaunchKernelGGL(k_cell_keys, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, V.ox, V.oy, V.cs, V.ncx, V.ncy,
+                     V.keys_in, V.vals_in);
+  (void)hipcub::DeviceRadixSort::SortPairs(V.sort_tmp, V.sort_tmp_bytes, V.keys_in, V.keys_out, V.vals_in,
+                                     V.vals_out, n, 0, key_bits((int)ncell), st);
+  (void)hipMemsetAsync(V.cell_start, 0, sizeof(int) * ncell, st);
+  (void)hipMemsetAsync(V.cell_end, 0, sizeof(int) * ncell, st);
+  hipLaunchKernelGGL(k_cell_bounds, dim3(nb), dim3(256), 0, st, n, V.keys_out, V.cell_start, V.cell_end);
+  hipLaunchKernelGGL(k_verlet_scan<0>, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, r, V.ox, V.oy, V.cs, V.ncx,
+                     V.ncy, V.cell_start, V.cell_end, V.vals_out, P.distVerlet, V.counts, V.offsets, V.nbr,
+                     V.cap, V.overflow);
+  (void)hipcub::DeviceScan::ExclusiveSum(V.scan_tmp, V.scan_tmp_bytes, V.counts, V.offsets, n, st);
+  hipLaunchKernelGGL(k_set_last_offset, dim3(1), dim3(1), 0, st, n, V.counts, V.offsets);
+  hipLaunchKernelGGL(k_verlet_scan<1>, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, r, V.ox, V.oy, V.cs, V.ncx,
+                     V.ncy, V.cell_start, V.cell_end, V.vals_out, P.distVerlet, V.counts, V.offsets, V.nbr,
+                     V.cap, V.overflow);
+  hipLaunchKernelGGL(k_wall_flags, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, r, P, V.wallflags);
+}
+
+void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const double* m,
+                        const double* It, const double* fhf, const VerletDevice& V,
+                        const DemParams& P, int film, hipStream_t st) {
+  const int nb = (P.n + 127) / 128;
+  if (film)
+    hipLaunchKernelGGL(k_dem_substep<true>, dim3(nb), dim3(128), 0, st, in, out, r, m, It, fhf, V.offsets,
+                       V.nbr, V.wallflags, P);
+  else
+    hipLaunchKernelGGL(k_dem_substep<false>, dim3(nb), dim3(128), 0, st, in, out, r, m, It, fhf, V.offsets,
+                       V.nbr, V.wallflags, P);
+}

@@ -1,0 +1,655 @@
+// lbmdem_capi.hip -- the C ABI of liblbmdem_hip.so (include/lbmdem_hip.h): handle, memory, the
+// step driver with the reference's cadences (renderScene, main.c:1697-1765) and state transfer in
+// the reference's host layout. All arithmetic of the hot path lives in lbm_kernels.hip and
+// dem_kernels.hip; the host-side arithmetic here is the one-off time-step derivation
+// (main.c:1836-1860) and per-grain constants (main.c:624-626,1859), kept bit-identical.
+
+#include "../../include/lbmdem_hip.h"
+#include "lbmdem_internal.h"
+
+#include <ctype.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#define REF_PI 3.14159265358979 /* main.c:42 */
+#define RHO_S 2650              /* main.c:44 */
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(LBMDEM_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                  __LINE__);                                                                  \
+  } while (0)
+
+struct lbmdem_handle {
+  lbmdem_config cfg;
+  LatticeView L;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  // lattice
+  double* f[2] = {nullptr, nullptr};
+  int fcur = 0;
+  int* obst[2] = {nullptr, nullptr};
+  int ocur = 0;           // map the current f was produced with ("old" for the next collide_stream)
+  bool obst_pending = false;  // obst[1 - ocur] holds a newer map not yet consumed by collide_stream
+  // grains
+  int n = 0;
+  double* gbuf = nullptr;  // one allocation, carved below
+  Kin kin[2];
+  int kcur = 0;
+  double *r = nullptr, *m = nullptr, *It = nullptr, *rLB = nullptr;
+  double *xc = nullptr, *yc = nullptr, *r2 = nullptr, *rbl0 = nullptr;
+  double* fhf = nullptr;  // [3][n]
+  unsigned char* owner = nullptr;
+  double rmax = 0.0;
+  VerletDevice V{};
+  bool verlet_ok = false;
+  long nbsteps = 0;
+  int force_mode = 0;
+  // derived scalars
+  double fscale12 = 0, fscale3 = 0;
+  double* dpartial = nullptr;
+  // profiling of the dominant kernel
+  bool prof = false;
+  std::vector<hipEvent_t> ev0, ev1;
+  size_t ev_used = 0;
+};
+
+static GrainFluidView gview(const lbmdem_handle* h) {
+  const Kin& K = h->kin[h->kcur];
+  return GrainFluidView{K.x1, K.x2, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0};
+}
+
+static DemParams dem_params(const lbmdem_handle* h) {
+  const lbmdem_config& c = h->cfg;
+  const lbmdem_physics& p = c.phys;
+  DemParams P;
+  P.n = h->n; P.dt = c.dt; P.dt2 = c.dt2;
+  P.kg = p.kg; P.nug = p.nug; P.kt = p.kt; P.mu = p.mu; P.murf = p.murf;
+  P.km = p.km; P.num = p.num; P.ktm = p.ktm; P.mumb = p.mumb; P.mum = p.mum; P.nugt = p.nugt;
+  P.Mgx = c.Mgx; P.Mdx = c.Mdx; P.Mby = c.Mby; P.Mhy = c.Mhy;
+  P.wallT_vel = p.amp * p.freq * cos(p.freq * p.t);
+  P.xG = c.xG; P.yG = c.yG;
+  P.distVerlet = p.distVerlet;
+  return P;
+}
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+const char* lbmdem_last_error(void) { return g_err; }
+const char* lbmdem_version(void) { return "lbmdem-hip 0.1 (gfx950)"; }
+
+int lbmdem_physics_defaults(lbmdem_physics* p) {
+  if (!p) return fail(LBMDEM_EINVAL, "null physics");
+  p->rho_moy = 1000; p->tau = 0.504;
+  p->s2 = 1.5; p->s3 = 1.4; p->s5 = 1.5; p->s7 = 1.5; p->s8 = 1.9841; p->s9 = 1.9841;
+  p->nu = 1e-6; p->reductionR = 0.85;
+  p->G = 9.81; p->angleG = 0.0;
+  p->km = 3e+6; p->kg = 1.6e+6; p->kt = 1.0e+6; p->ktm = 2e+6;
+  p->nug = 6.4e+1; p->num = 8.7e+1; p->nugt = 5e-1;
+  p->mu = .5317; p->mum = .466; p->mumb = .466; p->murf = 0.01;
+  p->distVerlet = 5e-4; p->dtt = 0.; p->iterDEM = 100.;
+  p->freq = 5; p->amp = 4.e-4; p->t = 0;
+  p->updateVerlet = 100; p->stepFilm = 8000;
+  return LBMDEM_OK;
+}
+
+int lbmdem_derive(lbmdem_config* cfg, int lx, int ly, double scale, int nbgrains, const double* r) {
+  if (!cfg || !r || lx < 3 || ly < 3 || nbgrains < 1 || !(scale > 0))
+    return fail(LBMDEM_EINVAL, "lbmdem_derive: bad arguments");
+  const lbmdem_physics& p = cfg->phys;
+  cfg->lx = lx; cfg->ly = ly; cfg->scale = scale; cfg->nbgrains = nbgrains;
+  // main.c:1836-1842
+  cfg->Mgx = 0.;
+  cfg->Mdx = 1.e-3 * lx / 10;
+  cfg->Mhy = 1.e-3 * ly / 10;
+  cfg->Mby = 0.;
+  cfg->xG = -p.G * sin(p.angleG);
+  cfg->yG = -p.G * cos(p.angleG);
+  // main.c:1844-1854
+  cfg->dx = (1. / scale) * (cfg->Mdx - cfg->Mgx) / (lx - 1);
+  double rMin = r[0];
+  for (int i = 1; i <= nbgrains - 1; i++) rMin = fmin(rMin, r[i]);
+  const double dtmax = (1 / p.iterDEM) * REF_PI * rMin * sqrt(REF_PI * RHO_S / p.kg);
+  cfg->dtLB = cfg->dx * cfg->dx * (p.tau - 0.5) / (3 * p.nu);
+  cfg->npDEM = (int)(cfg->dtLB / dtmax + 1);
+  cfg->c = cfg->dx / cfg->dtLB;
+  cfg->dt = cfg->dtLB / cfg->npDEM;
+  cfg->dt2 = cfg->dt * cfg->dt;
+  return LBMDEM_OK;
+}
+
+int lbmdem_read_sample(const char* path, int* nbgrains, double** r_out, double** x1_out, double** x2_out) {
+  if (!path || !nbgrains || !r_out || !x1_out || !x2_out) return fail(LBMDEM_EINVAL, "null argument");
+  FILE* fp = fopen(path, "r");
+  if (!fp) return fail(LBMDEM_EINVAL, "cannot open sample '%s'", path);
+  char line[256];
+  int n = 0;
+  if (!fgets(line, sizeof line, fp) || fscanf(fp, "%d", &n) != 1 || n <= 0) {
+    fclose(fp);
+    return fail(LBMDEM_EINVAL, "bad sample header in '%s'", path);
+  }
+  double* r = (double*)malloc(sizeof(double) * n);
+  double* x1 = (double*)malloc(sizeof(double) * n);
+  double* x2 = (double*)malloc(sizeof(double) * n);
+  if (!r || !x1 || !x2) { fclose(fp); free(r); free(x1); free(x2); return fail(LBMDEM_ENOMEM, "host alloc"); }
+  const double unit = 1e-3;  // main.c:114
+  for (int i = 0; i < n; ++i) {
+    double v[3];
+    for (int k = 0; k < 3; ++k) {
+      int ch;
+      while ((ch = fgetc(fp)) != EOF && (isspace(ch) || ch == ';')) {}
+      if (ch != EOF) ungetc(ch, fp);
+      if (ch == EOF || fscanf(fp, "%le", &v[k]) != 1) {
+        fclose(fp); free(r); free(x1); free(x2);
+        return fail(LBMDEM_EINVAL, "sample '%s' truncated at grain %d", path, i);
+      }
+    }
+    r[i] = v[0] * unit; x1[i] = v[1] * unit; x2[i] = v[2] * unit;
+  }
+  fclose(fp);
+  *nbgrains = n; *r_out = r; *x1_out = x1; *x2_out = x2;
+  return LBMDEM_OK;
+}
+
+void lbmdem_free_host(void* p) { free(p); }
+
+static int paint_into(lbmdem_handle* h, int* obst) {
+  const Kin& K = h->kin[h->kcur];
+  launch_obst_fill(obst, h->L, h->stream);
+  launch_grain_geom(h->n, K.x1, K.x2, h->r, h->rLB, h->cfg.Mgx, h->cfg.Mby, h->cfg.dx, h->xc, h->yc, h->r2,
+                    h->rbl0, h->stream);
+  launch_obst_paint(obst, h->L, gview(h), h->stream);
+  HIP_TRY(hipGetLastError());
+  return LBMDEM_OK;
+}
+
+int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, const double* x2,
+                  lbmdem_handle** out) {
+  if (!cfg || !r || !x1 || !x2 || !out) return fail(LBMDEM_EINVAL, "lbmdem_create: null argument");
+  *out = nullptr;
+  if (cfg->lx < 3 || cfg->ly < 3 || cfg->nbgrains < 1) return fail(LBMDEM_EINVAL, "bad lattice/grain count");
+  if (cfg->x_begin < 0 || cfg->x_end > cfg->lx || cfg->x_begin >= cfg->x_end || cfg->halo < 0)
+    return fail(LBMDEM_EINVAL, "bad strip [%d,%d) halo %d", cfg->x_begin, cfg->x_end, cfg->halo);
+  if (!(cfg->dx > 0) || !(cfg->dt > 0) || cfg->npDEM < 1) return fail(LBMDEM_EINVAL, "derived block not filled (lbmdem_derive)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(LBMDEM_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(LBMDEM_ENODEVICE, "device %d not present (%d devices)", cfg->device, ndev);
+  HIP_TRY(hipSetDevice(cfg->device));
+
+  const int n = cfg->nbgrains;
+  double rmax = r[0];
+  for (int i = 1; i < n; ++i) if (r[i] > rmax) rmax = r[i];
+  const bool cut_lo = cfg->x_begin > 0, cut_hi = cfg->x_end < cfg->lx;
+  const int need = 2 + (int)ceil(rmax / cfg->dx);
+  if ((cut_lo || cut_hi) && cfg->halo < need)
+    return fail(LBMDEM_EINVAL, "strip decomposition needs halo >= %d rows (2 + largest grain radius in nodes)", need);
+
+  lbmdem_handle* h = new lbmdem_handle();
+  h->cfg = *cfg;
+  h->n = n;
+  h->rmax = rmax;
+  LatticeView& L = h->L;
+  L.lx = cfg->lx; L.ly = cfg->ly;
+  L.gx0 = cut_lo ? cfg->x_begin - cfg->halo : 0;
+  if (L.gx0 < 0) L.gx0 = 0;
+  int gx1 = cut_hi ? cfg->x_end + cfg->halo : cfg->lx;
+  if (gx1 > cfg->lx) gx1 = cfg->lx;
+  L.nxl = gx1 - L.gx0;
+  L.xo0 = cfg->x_begin - L.gx0; L.xo1 = cfg->x_end - L.gx0;
+  L.sy = (cfg->ly + 15) & ~15;
+  L.plane = (long)L.nxl * L.sy;
+  L.n = n;
+  L.dx = cfg->dx; L.c = cfg->c; L.Mgx = cfg->Mgx; L.Mby = cfg->Mby;
+  const lbmdem_physics& p = cfg->phys;
+  L.s2 = p.s2; L.s3 = p.s3; L.s5 = p.s5; L.s7 = p.s7; L.s8 = p.s8; L.s9 = p.s9;
+  // force scaling, main.c:1329-1331
+  h->fscale12 = p.rho_moy * 9 * p.nu * p.nu / (cfg->dx * (p.tau - 0.5) * (p.tau - 0.5));
+  h->fscale3 = cfg->dx * p.rho_moy * 9 * p.nu * p.nu / (cfg->dx * (p.tau - 0.5) * (p.tau - 0.5));
+
+#define CREATE_TRY(expr)                                                                             \
+  do {                                                                                               \
+    hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess) {                                                                          \
+      int rc_ = fail(e_ == hipErrorOutOfMemory ? LBMDEM_ENOMEM : LBMDEM_EHIP, "%s failed: %s", #expr, \
+                     hipGetErrorString(e_));                                                         \
+      lbmdem_destroy(h);                                                                             \
+      return rc_;                                                                                    \
+    }                                                                                                \
+  } while (0)
+
+  CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  h->stream = h->own_stream;
+  const size_t fbytes = sizeof(double) * 9 * (size_t)L.plane;
+  CREATE_TRY(hipMalloc((void**)&h->f[0], fbytes));
+  CREATE_TRY(hipMalloc((void**)&h->f[1], fbytes));
+  CREATE_TRY(hipMalloc((void**)&h->obst[0], sizeof(int) * (size_t)L.plane));
+  CREATE_TRY(hipMalloc((void**)&h->obst[1], sizeof(int) * (size_t)L.plane));
+  // grains: 18 kinematic + r m It rLB xc yc r2 rbl0 + 3 fhf = 29 columns
+  const size_t cols = 18 + 8 + 3;
+  CREATE_TRY(hipMalloc((void**)&h->gbuf, sizeof(double) * cols * n));
+  CREATE_TRY(hipMemset(h->gbuf, 0, sizeof(double) * cols * n));
+  {
+    double* p0 = h->gbuf;
+    for (int b = 0; b < 2; ++b) {
+      Kin& K = h->kin[b];
+      K.x1 = p0; K.x2 = p0 + n; K.x3 = p0 + 2 * n; K.v1 = p0 + 3 * n; K.v2 = p0 + 4 * n; K.v3 = p0 + 5 * n;
+      K.a1 = p0 + 6 * n; K.a2 = p0 + 7 * n; K.a3 = p0 + 8 * n;
+      p0 += 9 * (size_t)n;
+    }
+    h->r = p0; h->m = p0 + n; h->It = p0 + 2 * n; h->rLB = p0 + 3 * n;
+    h->xc = p0 + 4 * n; h->yc = p0 + 5 * n; h->r2 = p0 + 6 * n; h->rbl0 = p0 + 7 * n;
+    h->fhf = p0 + 8 * n;
+  }
+  CREATE_TRY(hipMalloc((void**)&h->owner, n));
+  CREATE_TRY(hipMemset(h->owner, 1, n));
+  CREATE_TRY(hipMalloc((void**)&h->dpartial, sizeof(double) * 1024));
+  {
+    // per-grain constants on the host, reference arithmetic: main.c:624-626, 1859
+    std::vector<double> hm(n), hIt(n), hrLB(n);
+    for (int i = 0; i < n; ++i) {
+      hm[i] = RHO_S * REF_PI * r[i] * r[i];
+      hIt[i] = hm[i] * r[i] * r[i] / 2;
+      hrLB[i] = p.reductionR * r[i] / cfg->dx;
+    }
+    CREATE_TRY(hipMemcpy(h->r, r, sizeof(double) * n, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->m, hm.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->It, hIt.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->rLB, hrLB.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->kin[0].x1, x1, sizeof(double) * n, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->kin[0].x2, x2, sizeof(double) * n, hipMemcpyHostToDevice));
+  }
+  // Verlet grid over the fluid domain; grains outside are clamped into the edge cells
+  {
+    const double cs = 2 * rmax + p.distVerlet;
+    const double wx = cfg->dx * (cfg->lx - 1), wy = cfg->dx * (cfg->ly - 1);
+    if (verlet_alloc(h->V, n, cs, cfg->Mgx, cfg->Mby, wx, wy) != 0) {
+      int rc = fail(LBMDEM_ENOMEM, "verlet_alloc failed");
+      lbmdem_destroy(h);
+      return rc;
+    }
+  }
+  // init_density (main.c:716-724) and init_obst (main.c:663-711)
+  launch_fill_equilibrium(h->f[0], L, h->stream);
+  launch_fill_equilibrium(h->f[1], L, h->stream);
+  {
+    int rc = paint_into(h, h->obst[0]);
+    if (rc != LBMDEM_OK) { lbmdem_destroy(h); return rc; }
+  }
+  CREATE_TRY(hipStreamSynchronize(h->stream));
+#undef CREATE_TRY
+  *out = h;
+  return LBMDEM_OK;
+}
+
+int lbmdem_destroy(lbmdem_handle* h) {
+  if (!h) return LBMDEM_OK;
+  (void)hipSetDevice(h->cfg.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (int b = 0; b < 2; ++b) {
+    if (h->f[b]) (void)hipFree(h->f[b]);
+    if (h->obst[b]) (void)hipFree(h->obst[b]);
+  }
+  if (h->gbuf) (void)hipFree(h->gbuf);
+  if (h->owner) (void)hipFree(h->owner);
+  if (h->dpartial) (void)hipFree(h->dpartial);
+  verlet_free(h->V);
+  for (hipEvent_t e : h->ev0) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev1) (void)hipEventDestroy(e);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return LBMDEM_OK;
+}
+
+#define CHECK_H(h) do { if (!(h)) return fail(LBMDEM_EINVAL, "null handle"); HIP_TRY(hipSetDevice((h)->cfg.device)); } while (0)
+
+int lbmdem_obst_construction(lbmdem_handle* h) {
+  CHECK_H(h);
+  int rc = paint_into(h, h->obst[1 - h->ocur]);
+  if (rc == LBMDEM_OK) h->obst_pending = true;
+  return rc;
+}
+
+int lbmdem_collide_stream(lbmdem_handle* h) {
+  CHECK_H(h);
+  const int* ob_old = h->obst[h->ocur];
+  const int* ob_new = h->obst_pending ? h->obst[1 - h->ocur] : h->obst[h->ocur];
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->prof) {
+    if (h->ev_used == h->ev0.size()) {
+      hipEvent_t a, b;
+      HIP_TRY(hipEventCreate(&a));
+      HIP_TRY(hipEventCreate(&b));
+      h->ev0.push_back(a); h->ev1.push_back(b);
+    }
+    e0 = h->ev0[h->ev_used]; e1 = h->ev1[h->ev_used]; ++h->ev_used;
+    HIP_TRY(hipEventRecord(e0, h->stream));
+  }
+  launch_collide_stream(h->f[h->fcur], h->f[1 - h->fcur], ob_old, ob_new, h->L, gview(h), h->stream);
+  if (h->prof) HIP_TRY(hipEventRecord(e1, h->stream));
+  HIP_TRY(hipGetLastError());
+  h->fcur = 1 - h->fcur;
+  if (h->obst_pending) { h->ocur = 1 - h->ocur; h->obst_pending = false; }
+  return LBMDEM_OK;
+}
+
+int lbmdem_forces_fluid(lbmdem_handle* h) {
+  CHECK_H(h);
+  const int* ob = h->obst_pending ? h->obst[1 - h->ocur] : h->obst[h->ocur];
+  if (h->force_mode == 0)
+    launch_forces_parity(h->f[h->fcur], ob, h->L, gview(h), h->fscale12, h->fscale3, h->fhf, h->owner, h->stream);
+  else
+    launch_forces_fast(h->f[h->fcur], ob, h->L, gview(h), h->fscale12, h->fscale3, h->fhf, h->owner, h->stream);
+  HIP_TRY(hipGetLastError());
+  return LBMDEM_OK;
+}
+
+int lbmdem_lbm_step(lbmdem_handle* h) {
+  int rc = lbmdem_obst_construction(h);
+  if (rc == LBMDEM_OK) rc = lbmdem_collide_stream(h);
+  if (rc == LBMDEM_OK) rc = lbmdem_forces_fluid(h);
+  return rc;
+}
+
+int lbmdem_verlet_rebuild(lbmdem_handle* h) {
+  CHECK_H(h);
+  // VerletWall moves the right/top DEM walls: main.c:1555-1561
+  lbmdem_config& c = h->cfg;
+  if (h->nbsteps * c.dt < c.phys.dtt) {
+    c.Mdx = 1.e-3 * c.lx / 10;
+    c.Mhy = (1.e-3 * c.ly / 10);
+  } else {
+    c.Mdx = 1.e-3 * c.lx;
+    c.Mhy = 1.e-3 * c.ly;
+  }
+  launch_verlet_rebuild(h->V, h->kin[h->kcur], h->r, dem_params(h), h->stream);
+  HIP_TRY(hipGetLastError());
+  h->verlet_ok = true;
+  return LBMDEM_OK;
+}
+
+int lbmdem_dem_substep(lbmdem_handle* h) {
+  CHECK_H(h);
+  if (!h->verlet_ok) return fail(LBMDEM_EINVAL, "lbmdem_dem_substep before the first lbmdem_verlet_rebuild");
+  const int film = (h->nbsteps % h->cfg.phys.stepFilm == 0) ? 1 : 0;  // main.c:1342
+  launch_dem_substep(h->kin[h->kcur], h->kin[1 - h->kcur], h->r, h->m, h->It, h->fhf, h->V, dem_params(h),
+                     film, h->stream);
+  HIP_TRY(hipGetLastError());
+  h->kcur = 1 - h->kcur;
+  h->nbsteps++;
+  return LBMDEM_OK;
+}
+
+int lbmdem_run(lbmdem_handle* h, long n_dem_steps) {
+  CHECK_H(h);
+  for (long k = 0; k < n_dem_steps; ++k) {
+    int rc = LBMDEM_OK;
+    if (h->nbsteps % h->cfg.npDEM == 0) rc = lbmdem_lbm_step(h);                                  // main.c:1710-1718
+    if (rc == LBMDEM_OK && h->nbsteps % h->cfg.phys.updateVerlet == 0) rc = lbmdem_verlet_rebuild(h);  // main.c:1721-1724
+    if (rc == LBMDEM_OK) rc = lbmdem_dem_substep(h);                                              // main.c:1733-1764
+    if (rc != LBMDEM_OK) return rc;
+  }
+  return LBMDEM_OK;
+}
+
+int lbmdem_set_force_mode(lbmdem_handle* h, int mode) {
+  if (!h || (mode != 0 && mode != 1)) return fail(LBMDEM_EINVAL, "bad force mode");
+  h->force_mode = mode;
+  return LBMDEM_OK;
+}
+
+// ---- state transfer ---------------------------------------------------------------------------
+
+int lbmdem_upload_f(lbmdem_handle* h, const double* f_aos) {
+  CHECK_H(h);
+  if (!f_aos) return fail(LBMDEM_EINVAL, "null buffer");
+  const LatticeView& L = h->L;
+  const size_t cnt = (size_t)L.nxl * L.ly * 9;
+  double* tmp = nullptr;
+  HIP_TRY(hipMalloc((void**)&tmp, sizeof(double) * cnt));
+  hipError_t e = hipMemcpyAsync(tmp, f_aos + (size_t)L.gx0 * L.ly * 9, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) { launch_aos_to_soa(tmp, h->f[h->fcur], L, h->stream); e = hipStreamSynchronize(h->stream); }
+  (void)hipFree(tmp);
+  HIP_TRY(e);
+  return LBMDEM_OK;
+}
+
+int lbmdem_download_f(lbmdem_handle* h, double* f_aos) {
+  CHECK_H(h);
+  if (!f_aos) return fail(LBMDEM_EINVAL, "null buffer");
+  const LatticeView& L = h->L;
+  const int rows = L.xo1 - L.xo0;
+  const size_t cnt = (size_t)rows * L.ly * 9;
+  double* tmp = nullptr;
+  HIP_TRY(hipMalloc((void**)&tmp, sizeof(double) * cnt));
+  launch_soa_to_aos(h->f[h->fcur], tmp, L, L.xo0, rows, h->stream);
+  hipError_t e = hipMemcpyAsync(f_aos + (size_t)(L.gx0 + L.xo0) * L.ly * 9, tmp, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(tmp);
+  HIP_TRY(e);
+  return LBMDEM_OK;
+}
+
+int lbmdem_download_obst(lbmdem_handle* h, int* obst) {
+  CHECK_H(h);
+  if (!obst) return fail(LBMDEM_EINVAL, "null buffer");
+  const LatticeView& L = h->L;
+  const int* ob = h->obst_pending ? h->obst[1 - h->ocur] : h->obst[h->ocur];
+  const int rows = L.xo1 - L.xo0;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy2D(obst + (size_t)(L.gx0 + L.xo0) * L.ly, sizeof(int) * L.ly, ob + (size_t)L.xo0 * L.sy,
+                      sizeof(int) * L.sy, sizeof(int) * L.ly, rows, hipMemcpyDeviceToHost));
+  return LBMDEM_OK;
+}
+
+int lbmdem_download_macro(lbmdem_handle* h, double* rho, double* ux, double* uy) {
+  CHECK_H(h);
+  if (!rho || !ux || !uy) return fail(LBMDEM_EINVAL, "null buffer");
+  const LatticeView& L = h->L;
+  const int rows = L.xo1 - L.xo0;
+  const size_t cnt = (size_t)rows * L.ly;
+  double* tmp = nullptr;
+  HIP_TRY(hipMalloc((void**)&tmp, sizeof(double) * cnt * 3));
+  launch_macro(h->f[h->fcur], L, L.xo0, rows, tmp, tmp + cnt, tmp + 2 * cnt, h->stream);
+  const size_t off = (size_t)(L.gx0 + L.xo0) * L.ly;
+  hipError_t e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipMemcpy(rho + off, tmp, sizeof(double) * cnt, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(ux + off, tmp + cnt, sizeof(double) * cnt, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(uy + off, tmp + 2 * cnt, sizeof(double) * cnt, hipMemcpyDeviceToHost);
+  (void)hipFree(tmp);
+  HIP_TRY(e);
+  return LBMDEM_OK;
+}
+
+int lbmdem_total_density(lbmdem_handle* h, double* sum) {
+  CHECK_H(h);
+  if (!sum) return fail(LBMDEM_EINVAL, "null buffer");
+  const int nb = 1024;
+  launch_density_partial(h->f[h->fcur], h->L, h->dpartial, nb, h->stream);
+  double part[1024];
+  HIP_TRY(hipMemcpyAsync(part, h->dpartial, sizeof(double) * nb, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  double s = 0.0;
+  for (int k = 0; k < nb; ++k) s += part[k];
+  *sum = s;
+  return LBMDEM_OK;
+}
+
+int lbmdem_upload_kinematics(lbmdem_handle* h, const double* k9) {
+  CHECK_H(h);
+  if (!k9) return fail(LBMDEM_EINVAL, "null buffer");
+  const int n = h->n;
+  std::vector<double> soa(9 * (size_t)n);
+  for (int i = 0; i < n; ++i)
+    for (int c = 0; c < 9; ++c) soa[(size_t)c * n + i] = k9[(size_t)i * 9 + c];
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(h->kin[h->kcur].x1, soa.data(), sizeof(double) * 9 * n, hipMemcpyHostToDevice));
+  return LBMDEM_OK;
+}
+
+int lbmdem_download_kinematics(lbmdem_handle* h, double* k9) {
+  CHECK_H(h);
+  if (!k9) return fail(LBMDEM_EINVAL, "null buffer");
+  const int n = h->n;
+  std::vector<double> soa(9 * (size_t)n);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(soa.data(), h->kin[h->kcur].x1, sizeof(double) * 9 * n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; ++i)
+    for (int c = 0; c < 9; ++c) k9[(size_t)i * 9 + c] = soa[(size_t)c * n + i];
+  return LBMDEM_OK;
+}
+
+int lbmdem_download_fhf(lbmdem_handle* h, double* fhf3) {
+  CHECK_H(h);
+  if (!fhf3) return fail(LBMDEM_EINVAL, "null buffer");
+  const int n = h->n;
+  std::vector<double> soa(3 * (size_t)n);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(soa.data(), h->fhf, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; ++i)
+    for (int c = 0; c < 3; ++c) fhf3[(size_t)i * 3 + c] = soa[(size_t)c * n + i];
+  return LBMDEM_OK;
+}
+
+int lbmdem_download_verlet(lbmdem_handle* h, int* cumul, int* neighbours, int cap, int* npairs,
+                           int* wallflags) {
+  CHECK_H(h);
+  if (!h->verlet_ok) return fail(LBMDEM_EINVAL, "no Verlet list built yet");
+  const int n = h->n;
+  std::vector<int> off(n + 1);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  int ovf = 0;
+  HIP_TRY(hipMemcpy(&ovf, h->V.overflow, sizeof(int), hipMemcpyDeviceToHost));
+  if (ovf) return fail(LBMDEM_ENOMEM, "Verlet list overflow (more than %ld symmetric entries)", h->V.cap);
+  HIP_TRY(hipMemcpy(off.data(), h->V.offsets, sizeof(int) * (n + 1), hipMemcpyDeviceToHost));
+  std::vector<int> nb(off[n] > 0 ? off[n] : 1);
+  if (off[n] > 0) HIP_TRY(hipMemcpy(nb.data(), h->V.nbr, sizeof(int) * off[n], hipMemcpyDeviceToHost));
+  // reference form: for each i the partners j > i, ascending; cumul[i] = running end offset,
+  // never written for the last grain (main.c:1526-1540 with the memset of main.c:1816)
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) {
+    for (int k = off[i]; k < off[i + 1]; ++k) {
+      if (nb[k] > i) {
+        if (neighbours && cnt < cap) neighbours[cnt] = nb[k];
+        ++cnt;
+      }
+    }
+    if (cumul) cumul[i] = (i < n - 1) ? cnt : 0;
+  }
+  if (npairs) *npairs = cnt;
+  if (wallflags) {
+    std::vector<unsigned char> wf(n);
+    HIP_TRY(hipMemcpy(wf.data(), h->V.wallflags, n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) wallflags[i] = wf[i];
+  }
+  if (neighbours && cnt > cap) return fail(LBMDEM_EINVAL, "neighbours[] too small: need %d", cnt);
+  return LBMDEM_OK;
+}
+
+long lbmdem_nbsteps(lbmdem_handle* h) { return h ? h->nbsteps : -1; }
+
+int lbmdem_set_nbsteps(lbmdem_handle* h, long n) {
+  if (!h || n < 0) return fail(LBMDEM_EINVAL, "bad argument");
+  h->nbsteps = n;
+  return LBMDEM_OK;
+}
+
+int lbmdem_get_config(lbmdem_handle* h, lbmdem_config* out) {
+  if (!h || !out) return fail(LBMDEM_EINVAL, "null argument");
+  *out = h->cfg;
+  return LBMDEM_OK;
+}
+
+// ---- streams, timing, multi-GPU plumbing -------------------------------------------------------
+
+int lbmdem_set_stream(lbmdem_handle* h, void* hip_stream) {
+  CHECK_H(h);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return LBMDEM_OK;
+}
+
+int lbmdem_sync(lbmdem_handle* h) {
+  CHECK_H(h);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  int ovf = 0;
+  HIP_TRY(hipMemcpy(&ovf, h->V.overflow, sizeof(int), hipMemcpyDeviceToHost));
+  if (ovf) return fail(LBMDEM_ENOMEM, "Verlet list overflow (more than %ld symmetric entries)", h->V.cap);
+  return LBMDEM_OK;
+}
+
+int lbmdem_profile_enable(lbmdem_handle* h, int on) {
+  CHECK_H(h);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->prof = on != 0;
+  h->ev_used = 0;
+  return LBMDEM_OK;
+}
+
+int lbmdem_profile_read(lbmdem_handle* h, double* mean_ms, long* launches) {
+  CHECK_H(h);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  double tot = 0.0;
+  for (size_t k = 0; k < h->ev_used; ++k) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0[k], h->ev1[k]));
+    tot += ms;
+  }
+  if (mean_ms) *mean_ms = h->ev_used ? tot / (double)h->ev_used : 0.0;
+  if (launches) *launches = (long)h->ev_used;
+  return LBMDEM_OK;
+}
+
+long lbmdem_halo_doubles(lbmdem_handle* h) { return h ? 9L * h->cfg.halo * h->L.ly : -1; }
+
+int lbmdem_halo_pack(lbmdem_handle* h, int side, void* dev_buf) {
+  CHECK_H(h);
+  const LatticeView& L = h->L;
+  const int H = h->cfg.halo;
+  if (!dev_buf || H < 1 || (side != 0 && side != 1)) return fail(LBMDEM_EINVAL, "bad halo_pack arguments");
+  if (L.xo1 - L.xo0 < H) return fail(LBMDEM_EINVAL, "strip narrower than the halo");
+  const int xl0 = side == 0 ? L.xo0 : L.xo1 - H;
+  launch_halo_pack(h->f[h->fcur], L, xl0, H, (double*)dev_buf, h->stream);
+  HIP_TRY(hipGetLastError());
+  return LBMDEM_OK;
+}
+
+int lbmdem_halo_unpack(lbmdem_handle* h, int side, const void* dev_buf) {
+  CHECK_H(h);
+  const LatticeView& L = h->L;
+  const int H = h->cfg.halo;
+  if (!dev_buf || H < 1 || (side != 0 && side != 1)) return fail(LBMDEM_EINVAL, "bad halo_unpack arguments");
+  const int xl0 = side == 0 ? L.xo0 - H : L.xo1;
+  if (xl0 < 0 || xl0 + H > L.nxl) return fail(LBMDEM_EINVAL, "no halo rows on side %d", side);
+  launch_halo_unpack(h->f[h->fcur], L, xl0, H, (const double*)dev_buf, h->stream);
+  HIP_TRY(hipGetLastError());
+  return LBMDEM_OK;
+}
+
+int lbmdem_fhf_device(lbmdem_handle* h, void** fhf, void** owner_mask) {
+  if (!h) return fail(LBMDEM_EINVAL, "null handle");
+  if (fhf) *fhf = h->fhf;
+  if (owner_mask) *owner_mask = h->owner;
+  return LBMDEM_OK;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,107 @@
+// lbmdem_internal.h -- shared between the HIP translation units of liblbmdem_hip.so.
+// Not part of the public ABI (that is include/lbmdem_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+// ---------------------------------------------------------------------------------------------
+// Device-side views (passed by value to kernels)
+// ---------------------------------------------------------------------------------------------
+
+// Local lattice slab: global rows [gx0, gx0 + nxl), all ly columns. Device layout is SoA planes
+// f[q][xl][y] with y contiguous (pitch sy) -- the reference's fast axis (main.c:56) is kept as the
+// fast axis so that an x-strip is one contiguous slab per plane and halo rows are contiguous.
+struct LatticeView {
+  int lx, ly;    // global lattice size
+  int gx0;       // global x of local row 0
+  int nxl;       // local rows (owned + halo)
+  int xo0, xo1;  // owned local rows [xo0, xo1)
+  int sy;        // row pitch in elements
+  long plane;    // nxl * sy
+  int n;         // nbgrains; also the obst code of the lattice-edge walls (main.c:676,681)
+  double dx, c, Mgx, Mby;
+  double s2, s3, s5, s7, s8, s9;
+};
+
+// Grain state used by the fluid kernels. xc, yc, r2, rbl0 are the lattice-unit centre, squared
+// reduced radius and unreduced radius (main.c:1009-1013), refreshed by every obst_construction.
+struct GrainFluidView {
+  const double* x1; const double* x2;
+  const double* v1; const double* v2; const double* v3;
+  const double* xc; const double* yc; const double* r2; const double* rbl0;
+};
+
+struct DemParams {
+  int n;
+  double dt, dt2;
+  double kg, nug, kt, mu, murf;            // grain-grain (main.c:104-113)
+  double km, num, ktm, mumb, mum, nugt;    // walls
+  double Mgx, Mdx, Mby, Mhy;               // DEM wall positions (main.c:201-204,1555-1561)
+  double wallT_vel;                        // amp*freq*cos(freq*t) (main.c:855)
+  double xG, yG;
+  double distVerlet;
+};
+
+// kinematic state, SoA; two copies ping-pong across DEM sub-steps
+struct Kin {
+  double *x1, *x2, *x3, *v1, *v2, *v3, *a1, *a2, *a3;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Launchers (host functions defined in the .hip files)
+// ---------------------------------------------------------------------------------------------
+
+// lbm_kernels.hip
+void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st);
+void launch_grain_geom(int n, const double* x1, const double* x2, const double* r, const double* rLB,
+                       double Mgx, double Mby, double dx, double* xc, double* yc, double* r2,
+                       double* rbl0, hipStream_t st);
+void launch_obst_paint(int* obst, const LatticeView& L, const GrainFluidView& G, hipStream_t st);
+void launch_collide_stream(const double* fin, double* fout, const int* obst_old, const int* obst_new,
+                           const LatticeView& L, const GrainFluidView& G, hipStream_t st);
+void launch_forces_parity(const double* f, const int* obst, const LatticeView& L,
+                          const GrainFluidView& G, double scale12, double scale3, double* fhf,
+                          unsigned char* owner, hipStream_t st);
+void launch_forces_fast(const double* f, const int* obst, const LatticeView& L,
+                        const GrainFluidView& G, double scale12, double scale3, double* fhf,
+                        unsigned char* owner, hipStream_t st);
+void launch_aos_to_soa(const double* aos_rows, double* f, const LatticeView& L, hipStream_t st);
+void launch_soa_to_aos(const double* f, double* aos_rows, const LatticeView& L, int xl0, int nrows,
+                       hipStream_t st);
+void launch_fill_equilibrium(double* f, const LatticeView& L, hipStream_t st);
+void launch_macro(const double* f, const LatticeView& L, int xl0, int nrows, double* rho, double* ux,
+                  double* uy, hipStream_t st);
+void launch_density_partial(const double* f, const LatticeView& L, double* partial, int nblocks,
+                            hipStream_t st);
+void launch_halo_pack(const double* f, const LatticeView& L, int xl0, int nrows, double* buf,
+                      hipStream_t st);
+void launch_halo_unpack(double* f, const LatticeView& L, int xl0, int nrows, const double* buf,
+                        hipStream_t st);
+
+// dem_kernels.hip
+struct VerletDevice {
+  // uniform grid
+  int ncx, ncy;
+  double ox, oy, cs;
+  unsigned int* keys_in; unsigned int* keys_out;
+  int* vals_in; int* vals_out;
+  int* cell_start; int* cell_end;
+  void* sort_tmp; size_t sort_tmp_bytes;
+  void* scan_tmp; size_t scan_tmp_bytes;
+  // symmetric CSR neighbour list, partners ascending
+  int* counts;   // n
+  int* offsets;  // n + 1
+  int* nbr;      // cap
+  long cap;
+  unsigned char* wallflags;  // n
+  int* overflow;             // device flag
+};
+int verlet_alloc(VerletDevice& V, int n, double cs, double ox, double oy, double wx, double wy);
+void verlet_free(VerletDevice& V);
+void launch_verlet_rebuild(VerletDevice& V, const Kin& K, const double* r, const DemParams& P,
+                           hipStream_t st);
+void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const double* m,
+                        const double* It, const double* fhf, const VerletDevice& V,
+                        const DemParams& P, int film, hipStream_t st);

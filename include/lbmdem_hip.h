@@ -1,0 +1,157 @@
+/*
+ * lbmdem_hip.h -- C ABI of the MI355X-native 2D LBM-DEM hot path (liblbmdem_hip.so).
+ *
+ * Drop-in boundary. The reference (cb-geo/2d-lbm-dem, src/main.c) has no plugin/FFI interface:
+ * its seam is the set of `void fn(void)` routines that renderScene() (main.c:1697-1777) calls on
+ * file-scope globals. Each entry point below replaces one of those call sites; the reference line
+ * it stands in for is cited next to it. INTEGRATION.md shows the edit a maintainer of the reference
+ * would make to main.c to call this library instead of its own loops.
+ *
+ * Conventions: plain C types only; every function returns 0 on success and a negative
+ * LBMDEM_E* code on failure (lbmdem_last_error() gives the text); no exceptions cross the ABI;
+ * the library owns all device memory, the caller owns every host buffer; one host thread per
+ * handle. Host-side lattice data uses the REFERENCE layout f[x][y][q], x slow (main.c:56,1802);
+ * the device layout (SoA planes f[q][x][y], y contiguous) is internal.
+ *
+ * There is no CPU fallback: every entry point fails with LBMDEM_ENODEVICE when no HIP device
+ * is usable.
+ */
+#ifndef LBMDEM_HIP_H
+#define LBMDEM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBMDEM_OK 0
+#define LBMDEM_EINVAL (-1)    /* bad argument / bad state */
+#define LBMDEM_ENODEVICE (-2) /* no usable HIP device */
+#define LBMDEM_EHIP (-3)      /* a HIP runtime call failed */
+#define LBMDEM_ENOMEM (-4)
+
+typedef struct lbmdem_handle lbmdem_handle;
+
+/* Physics constants: the initialised globals of main.c:74-118,143,163-165. */
+typedef struct lbmdem_physics {
+  double rho_moy, tau, s2, s3, s5, s7, s8, s9, nu, reductionR; /* main.c:74-94  */
+  double G, angleG;                                            /* main.c:97-98  */
+  double km, kg, kt, ktm, nug, num, nugt;                      /* main.c:104-109 */
+  double mu, mum, mumb, murf;                                  /* main.c:110-113 */
+  double distVerlet, dtt, iterDEM;                             /* main.c:115-118 */
+  double freq, amp, t;                                         /* main.c:163-165 */
+  int updateVerlet;                                            /* main.c:116 */
+  int stepFilm;                                                /* main.c:143 */
+} lbmdem_physics;
+
+/* Run configuration. The derived block is what main() computes at main.c:1836-1860; fill it with
+ * lbmdem_derive() (bit-identical arithmetic) or by hand. */
+typedef struct lbmdem_config {
+  int lx, ly;         /* global lattice (reference macros lx, ly, main.c:27-32) */
+  int x_begin, x_end; /* owned strip [x_begin, x_end) of the global lattice; 0, lx on one GPU */
+  int halo;           /* extra rows kept beyond each interior cut (0 on one GPU) */
+  int device;         /* HIP device ordinal */
+  int nbgrains;
+  double scale;       /* reference macro `scale` (main.c:24-26) */
+  /* derived (main.c:1836-1860) */
+  double dx, dtLB, c, dt, dt2;
+  int npDEM;
+  double Mgx, Mdx, Mby, Mhy; /* wall positions (main.c:201-204,1836-1839) */
+  double xG, yG;             /* gravity components (main.c:1841-1842) */
+  lbmdem_physics phys;
+} lbmdem_config;
+
+/* defaults = the reference's initialisers */
+int lbmdem_physics_defaults(lbmdem_physics* p);
+
+/* Time-step derivation, main.c:1836-1860: dx, dtLB, dtmax, npDEM, c, dt from lx, ly, scale and the
+ * smallest radius (r in metres). Also sets walls and gravity. Uses cfg->phys. */
+int lbmdem_derive(lbmdem_config* cfg, int lx, int ly, double scale, int nbgrains, const double* r);
+
+/* Sample reader, main.c:609-639 (read_sample): comment line, count, then count x "r x y[;]" in
+ * units of 1 mm. Returns metres. Arrays are malloc'ed; release with lbmdem_free_host(). */
+int lbmdem_read_sample(const char* path, int* nbgrains, double** r, double** x1, double** x2);
+void lbmdem_free_host(void* p);
+
+/* Allocation + initial state, replacing main.c:1802-1834,1858-1861: f = w[q] (init_density,
+ * main.c:716-724), grains at rest with m, It from r (main.c:624-635), rLB, and the initial obstacle
+ * map (init_obst, main.c:663-711). r, x1, x2 in metres, nbgrains entries each. */
+int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, const double* x2,
+                  lbmdem_handle** out);
+int lbmdem_destroy(lbmdem_handle* h);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+
+/* One fluid step = main.c:1711-1713,1717: reinit_obst_density (966-986), obst_construction
+ * (991-1065), collision_streaming (1071-1243), forces_fluid (1285-1333). */
+int lbmdem_lbm_step(lbmdem_handle* h);
+/* The same, phase by phase (lbm_step == obst_construction; collide_stream; forces_fluid).
+ * reinit_obst_density is folded into collide_stream: it needs the *previous* obstacle map, which
+ * the library keeps. */
+int lbmdem_obst_construction(lbmdem_handle* h); /* main.c:991-1065 (obst only; act, delta are recomputed on the fly) */
+int lbmdem_collide_stream(lbmdem_handle* h);    /* main.c:966-986 + 1071-1243 */
+int lbmdem_forces_fluid(lbmdem_handle* h);      /* main.c:1285-1333 */
+
+/* initVerlet + VerletWall, main.c:1519-1594 (same pair set; uniform grid + radix sort instead of
+ * the O(N^2) scan). Also moves the right/top DEM walls as VerletWall does (main.c:1555-1561). */
+int lbmdem_verlet_rebuild(lbmdem_handle* h);
+
+/* One DEM sub-step = main.c:1733-1764: drift + half kick, acceleration_grains (1336-1516, film
+ * law when nbsteps % stepFilm == 0), second half kick, nbsteps++. */
+int lbmdem_dem_substep(lbmdem_handle* h);
+
+/* n x renderScene() (main.c:1697-1765) with the reference's cadences: a fluid step when
+ * nbsteps % npDEM == 0, a Verlet rebuild when nbsteps % updateVerlet == 0, then a DEM sub-step.
+ * Device-resident; returns without synchronising. */
+int lbmdem_run(lbmdem_handle* h, long n_dem_steps);
+
+/* hydrodynamic-force kernel choice: 0 = parity (one thread per grain, reference summation order,
+ * bit-exact); 1 = fast (wave per grain, shuffle reduction; differs in the last bits). Default 0. */
+int lbmdem_set_force_mode(lbmdem_handle* h, int mode);
+
+/* ---- state in / out (host layout) ------------------------------------------------------------ */
+
+int lbmdem_upload_f(lbmdem_handle* h, const double* f_aos);   /* [lx][ly][9]; rows of the local strip+halo are read */
+int lbmdem_download_f(lbmdem_handle* h, double* f_aos);       /* [lx][ly][9]; only the OWNED rows are written */
+int lbmdem_download_obst(lbmdem_handle* h, int* obst);        /* [lx][ly]; owned rows */
+int lbmdem_download_macro(lbmdem_handle* h, double* rho, double* ux, double* uy); /* [lx][ly] each; owned rows; sums of f, f*ex, f*ey as write_vtk forms them (main.c:315-319) */
+int lbmdem_total_density(lbmdem_handle* h, double* sum);      /* check_density/final_density, main.c:1249-1273, owned rows */
+/* kinematics table, 9 doubles per grain: x1 x2 x3 v1 v2 v3 a1 a2 a3 */
+int lbmdem_upload_kinematics(lbmdem_handle* h, const double* k9);
+int lbmdem_download_kinematics(lbmdem_handle* h, double* k9);
+int lbmdem_download_fhf(lbmdem_handle* h, double* fhf3);      /* interleaved fhf1,fhf2,fhf3 (main.c:180) */
+/* Verlet lists in the reference's form: cumul[n] (main.c:150,1539), neighbours (j > i, ascending),
+ * wall membership flags per grain (bit0 B, bit1 T, bit2 L, bit3 R; main.c:1563-1593).
+ * `cap` = capacity of neighbours[]; *npairs receives the pair count (call with cap = 0 to size). */
+int lbmdem_download_verlet(lbmdem_handle* h, int* cumul, int* neighbours, int cap, int* npairs,
+                           int* wallflags);
+long lbmdem_nbsteps(lbmdem_handle* h);
+int lbmdem_set_nbsteps(lbmdem_handle* h, long n);
+int lbmdem_get_config(lbmdem_handle* h, lbmdem_config* out);
+
+/* ---- streams, timing, multi-GPU plumbing ------------------------------------------------------ */
+
+int lbmdem_set_stream(lbmdem_handle* h, void* hip_stream); /* NULL = the library's own stream */
+int lbmdem_sync(lbmdem_handle* h);
+/* HIP-event timing of the dominant kernel (fused collide+stream), on the stream it is launched on.
+ * enable, run steps, then read the mean duration and the launch count. */
+int lbmdem_profile_enable(lbmdem_handle* h, int on);
+int lbmdem_profile_read(lbmdem_handle* h, double* mean_ms, long* launches);
+
+/* Strip decomposition along x (one process per GPU). After collide_stream the `halo` outermost
+ * OWNED rows on each interior side are packed into a caller-provided DEVICE buffer
+ * (9 * halo * ly doubles, plane-major), exchanged by the caller (RCCL send/recv via
+ * torch.distributed) and unpacked into the neighbour's halo rows. side: 0 = low x, 1 = high x. */
+long lbmdem_halo_doubles(lbmdem_handle* h);
+int lbmdem_halo_pack(lbmdem_handle* h, int side, void* dev_buf);
+int lbmdem_halo_unpack(lbmdem_handle* h, int side, const void* dev_buf);
+/* Device pointer to the 3*n hydrodynamic-force table (fhf1[n], fhf2[n], fhf3[n]) and to the
+ * n-entry ownership mask (1 = this rank computed the grain) for the cross-rank combine. */
+int lbmdem_fhf_device(lbmdem_handle* h, void** fhf, void** owner_mask);
+
+const char* lbmdem_last_error(void);
+const char* lbmdem_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,237 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+The oracle (oracle/lbmdem_oracle.c) is pinned bit-for-bit to the unmodified reference by
+tests/test_oracle_vs_reference.py and tests/golden/. Everything on the device path is element-wise
+in the reference's expression order and compiled with -ffp-contract=off, so the bar here is exact
+equality (np.array_equal) for f, obst, hydrodynamic forces and grain kinematics -- not a tolerance.
+The only tolerance is on the total-mass reduction (different summation tree).
+"""
+import numpy as np
+import pytest
+
+import samples
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(pkg, po, lx, ly, r, x1, x2):
+    sim = pkg.LbmDem(lx, ly, r, x1, x2)
+    ora = po.Oracle(lx, ly, r, x1, x2)
+    return sim, ora
+
+
+def assert_same_state(sim, ora, what=""):
+    assert np.array_equal(sim.obst, ora.get_obst()), f"{what}: obst differs"
+    fg, fc = sim.f, ora.get_f()
+    if not np.array_equal(fg, fc):
+        bad = np.argwhere(fg != fc)
+        raise AssertionError(f"{what}: f differs at {len(bad)} slots, first {bad[:5].tolist()}, "
+                             f"max abs {np.abs(fg - fc).max():.3e}")
+    assert np.array_equal(sim.fhf, ora.get_fhf()), f"{what}: fhf differs"
+    kg, kc = sim.kinematics, ora.get_grains()[:, :9]
+    assert np.array_equal(kg, kc), f"{what}: kinematics differ, max abs {np.abs(kg - kc).max():.3e}"
+
+
+def small_packing(lx, ly, n, seed):
+    r, x, y = samples.row_packing(lx, ly, n, seed=seed)
+    return samples.to_metres(r, x, y)
+
+
+def test_derivation_matches_oracle(pkg, po):
+    """a0: dx, dtLB, npDEM, c, dt (main.c:1836-1860) computed by the library's host code."""
+    r, x1, x2 = small_packing(128, 96, 12, 3)
+    cfg = pkg.derive(128, 96, r)
+    ora = po.Oracle(128, 96, r, x1, x2)
+    s = ora.scalars()
+    for k in ("dx", "dtLB", "dt", "dt2", "c", "npDEM", "Mgx", "Mdx", "Mby", "Mhy", "xG", "yG"):
+        assert getattr(cfg, k) == s[k], k
+
+
+def test_coupled_small_bit_exact(pkg, po):
+    """Full renderScene loop (fluid step, Verlet rebuild, DEM sub-steps), 5 fluid steps."""
+    lx, ly = 128, 96
+    r, x1, x2 = small_packing(lx, ly, 30, 11)
+    sim, ora = make_pair(pkg, po, lx, ly, r, x1, x2)
+    n = 4 * sim.cfg.npDEM + 1
+    sim.renderScene(n); ora.steps(n)
+    assert ora.act_anomalies() == 0
+    assert_same_state(sim, ora, "coupled small")
+    assert sim.nbsteps == ora.nbsteps == n
+
+
+def test_lbm_moving_grains_perturbed_f(pkg, po):
+    """Fluid phases only, with translating + spinning grains and a perturbed initial f: exercises
+    reinit with non-zero wall velocity, both delta branches of the interpolated bounce-back and the
+    moving-wall term (main.c:966-986, 1154-1222)."""
+    lx, ly = 160, 120
+    r, x1, x2 = small_packing(lx, ly, 40, 5)
+    sim, ora = make_pair(pkg, po, lx, ly, r, x1, x2)
+    rng = np.random.default_rng(42)
+    n = len(r)
+    k = np.zeros((n, 9))
+    k[:, 0], k[:, 1] = x1, x2
+    k[:, 3] = rng.normal(0, 0.02, n)   # v1  [m/s]
+    k[:, 4] = rng.normal(0, 0.02, n)   # v2
+    k[:, 5] = rng.normal(0, 20.0, n)   # v3  [rad/s]
+    f0 = ora.get_f() * (1 + 1e-3 * rng.standard_normal((lx, ly, 9)))
+    sim.kinematics = k; ora.set_kinematics(k)
+    sim.f = f0; ora.set_f(f0)
+    for step in range(6):
+        # move the grains a little between fluid steps so that nodes change state
+        k[:, 0] += 2.0e-5 * np.sign(k[:, 3]); k[:, 1] += 1.5e-5 * np.sign(k[:, 4])
+        sim.kinematics = k; ora.set_kinematics(k)
+        sim.lbm_step(); ora.lbm_steps(1)
+        assert ora.act_anomalies() == 0
+        assert np.array_equal(sim.obst, ora.get_obst()), f"step {step}: obst"
+        fg, fc = sim.f, ora.get_f()
+        assert np.array_equal(fg, fc), f"step {step}: f differs, max abs {np.abs(fg - fc).max():.3e}"
+        assert np.array_equal(sim.fhf, ora.get_fhf()), f"step {step}: fhf"
+    d = ora.get_delta()
+    act = (ora.get_obst() >= 0) & (ora.get_obst() < n)
+    assert ((d > 0) & (d < 0.5))[act].any() and (d >= 0.5)[act].any(), "both delta branches must be hit"
+
+
+def test_ibb_order_hazard_two_grains_one_node_apart(pkg, po):
+    """Two grains separated by a single fluid node: the 0<delta<1/2 branch then reads a solid node of
+    the OTHER grain that the reference's in-place x-outer/y-inner loop may already have rewritten
+    (SURVEY.md hard part 2). Sweep the gap so that several link geometries occur."""
+    lx, ly = 96, 96
+    hits = 0
+    for gap_nodes in (1.2, 1.6, 2.0, 2.4):
+        for ang in (0.0, 0.5 * np.pi, 0.25 * np.pi, 0.75 * np.pi, 0.1):
+            ra, rb = 0.7e-3, 0.6e-3
+            dx = 1e-4 * lx / (lx - 1)
+            # reduced radii are 0.85 r; put the reduced surfaces gap_nodes*dx apart
+            dist = 0.85 * (ra + rb) + gap_nodes * dx
+            c0 = np.array([4.0e-3, 4.2e-3])
+            c1 = c0 + dist * np.array([np.cos(ang), np.sin(ang)])
+            r = np.array([ra, rb]); x1 = np.array([c0[0], c1[0]]); x2 = np.array([c0[1], c1[1]])
+            sim, ora = make_pair(pkg, po, lx, ly, r, x1, x2)
+            k = np.zeros((2, 9)); k[:, 0], k[:, 1] = x1, x2
+            k[:, 3] = [0.01, -0.02]; k[:, 4] = [-0.015, 0.01]; k[:, 5] = [15.0, -25.0]
+            rng = np.random.default_rng(int(gap_nodes * 10) + int(ang * 100))
+            f0 = ora.get_f() * (1 + 1e-2 * rng.standard_normal((lx, ly, 9)))
+            sim.kinematics = k; ora.set_kinematics(k); sim.f = f0; ora.set_f(f0)
+            for _ in range(2):
+                sim.lbm_step(); ora.lbm_steps(1)
+                fg, fc = sim.f, ora.get_f()
+                assert np.array_equal(fg, fc), (gap_nodes, ang, np.abs(fg - fc).max())
+                assert np.array_equal(sim.fhf, ora.get_fhf())
+            # count links whose two-out node is a solid node of the other grain
+            ob, d = ora.get_obst(), ora.get_delta()
+            ex = [0, -1, -1, -1, 0, 1, 1, 1, 0]; ey = [0, 1, 0, -1, -1, -1, 0, 1, 1]
+            for (x, y) in np.argwhere((ob >= 0) & (ob < 2)):
+                for q in range(1, 9):
+                    if 0 < d[x, y, q] < 0.5:
+                        nn = ob[x + 2 * ex[q], y + 2 * ey[q]]
+                        if nn >= 0 and nn < 2 and nn != ob[x, y] and ob[x + ex[q], y + ey[q]] == -1:
+                            hits += 1
+            sim.close()
+    assert hits > 0, "the sweep must actually produce the order-hazard configuration"
+
+
+def test_grains_touching_lattice_edges(pkg, po):
+    """Grains overlapping the lattice-edge walls and the array border: bounding-box clamps
+    (main.c:1016-1023,1300-1303), solid->wall links, border-node streaming."""
+    lx, ly = 80, 64
+    r = np.array([0.8, 0.7, 0.6, 0.9, 0.75]) * 1e-3
+    x1 = np.array([0.3, 7.8, 4.0, 7.9, 0.2]) * 1e-3
+    x2 = np.array([0.4, 0.3, 6.2, 6.1, 3.0]) * 1e-3
+    sim, ora = make_pair(pkg, po, lx, ly, r, x1, x2)
+    rng = np.random.default_rng(1)
+    f0 = ora.get_f() * (1 + 1e-2 * rng.standard_normal((lx, ly, 9)))
+    k = np.zeros((5, 9)); k[:, 0], k[:, 1] = x1, x2; k[:, 3:6] = rng.normal(0, 1, (5, 3)) * [0.01, 0.01, 10]
+    sim.kinematics = k; ora.set_kinematics(k); sim.f = f0; ora.set_f(f0)
+    for _ in range(4):
+        sim.lbm_step(); ora.lbm_steps(1)
+    assert np.array_equal(sim.obst, ora.get_obst())
+    assert np.array_equal(sim.f, ora.get_f())
+    assert np.array_equal(sim.fhf, ora.get_fhf())
+
+
+def test_verlet_pair_set_and_wall_lists(pkg, po):
+    """Uniform grid + radix sort must give exactly the reference's O(N^2) pair set and wall lists."""
+    lx, ly = 512, 384
+    r, x1, x2 = small_packing(lx, ly, 900, 21)
+    sim, ora = make_pair(pkg, po, lx, ly, r, x1, x2)
+    sim.initVerlet(); ora.verlet_rebuild()
+    cumul_g, neigh_g, wf = sim.verlet()
+    cumul_c, neigh_c, cnt, walls = ora.verlet()
+    npairs = int(cumul_c.max())
+    assert npairs > 1000
+    assert np.array_equal(cumul_g, cumul_c)
+    assert np.array_equal(neigh_g, neigh_c[:npairs])
+    for bit, lst in enumerate(walls):
+        assert np.array_equal(np.nonzero(wf & (1 << bit))[0], lst), f"wall list {bit}"
+    cfg = sim.config(); s = ora.scalars()
+    assert cfg.Mdx == s["Mdx"] and cfg.Mhy == s["Mhy"]   # VerletWall moved the DEM walls
+
+
+def test_dem_only_walls_film_and_regular_law(pkg, po):
+    """DEM sub-steps with grains pressed against all four DEM walls (the right/top walls sit at
+    1e-3*lx, 1e-3*ly metres after VerletWall, main.c:1559-1560), contacts, the film-step law at
+    nbsteps % 8000 == 0 (incl. step 0) and the regular law otherwise."""
+    lx, ly = 64, 48
+    r, x1, x2 = small_packing(lx, ly, 10, 9)
+    W, H = 1e-3 * lx, 1e-3 * ly
+    extra_r = np.array([0.8, 0.7, 0.9, 0.6]) * 1e-3
+    extra_x = np.array([W - 0.79e-3, 3.0e-3, 0.55e-3, W - 0.59e-3])
+    extra_y = np.array([10.0e-3, H - 0.69e-3, 20.0e-3, H - 0.58e-3])
+    r = np.concatenate([r, extra_r]); x1 = np.concatenate([x1, extra_x]); x2 = np.concatenate([x2, extra_y])
+    sim, ora = make_pair(pkg, po, lx, ly, r, x1, x2)
+    rng = np.random.default_rng(3)
+    k = np.zeros((len(r), 9)); k[:, 0], k[:, 1] = x1, x2
+    k[:, 3:6] = rng.normal(0, 1, (len(r), 3)) * [0.05, 0.05, 30.0]
+    sim.kinematics = k; ora.set_kinematics(k)
+    for start in (0, 7999, 16000 - 3):
+        sim.nbsteps = start; ora.set_nbsteps(start)
+        sim.initVerlet(); ora.verlet_rebuild()
+        for _ in range(6):
+            sim.dem_substep(); ora.dem_substep()
+        kg, kc = sim.kinematics, ora.get_grains()[:, :9]
+        assert np.array_equal(kg, kc), (start, np.abs(kg - kc).max())
+    g = ora.get_grains()
+    assert (g[:, po.COL["z"]] > 0).sum() >= 4
+
+
+def test_medium_packing_20_fluid_steps_bit_exact(pkg, po):
+    """~600 grains, 20 fluid steps fully coupled (the 1e-6 horizon of BASELINE.md) -- still exact."""
+    lx, ly = 256, 200
+    r, x1, x2 = small_packing(lx, ly, 600, 77)
+    sim, ora = make_pair(pkg, po, lx, ly, r, x1, x2)
+    n = 20 * sim.cfg.npDEM
+    sim.renderScene(n); ora.steps(n)
+    assert_same_state(sim, ora, "medium packing")
+    rho_g = sim.final_density(); rho_c = ora.total_density()
+    assert abs(rho_g - rho_c) <= 1e-12 * abs(rho_c)
+    rho, ux, uy = sim.macro()
+    fc = ora.get_f()
+    assert np.allclose(rho, fc.sum(-1), rtol=1e-14, atol=0)
+
+
+def test_fast_force_kernel_close_to_parity_kernel(pkg, po):
+    lx, ly = 256, 200
+    r, x1, x2 = small_packing(lx, ly, 300, 5)
+    sim, ora = make_pair(pkg, po, lx, ly, r, x1, x2)
+    sim.lbm_step(); sim.lbm_step()
+    exact = sim.fhf
+    sim.set_force_mode(1); sim.forces_fluid()
+    fast = sim.fhf
+    scale = np.abs(exact).max(axis=0)
+    assert np.all(np.abs(fast - exact) <= 1e-12 * scale)
+    ora.lbm_steps(2)
+    assert np.array_equal(exact, ora.get_fhf())
+
+
+def test_error_behaviour(pkg):
+    with pytest.raises(pkg.LbmDemError):
+        pkg.LbmDem(2, 2, [1e-3], [1e-3], [1e-3])
+    with pytest.raises(pkg.LbmDemError):
+        pkg.LbmDem(64, 64, [], [], [])
+    with pytest.raises(pkg.LbmDemError):
+        pkg.read_sample("/nonexistent/sample.data")
+    sim = pkg.LbmDem(64, 64, [0.7e-3], [3e-3], [3e-3])
+    with pytest.raises(pkg.LbmDemError):
+        sim.dem_substep()   # no Verlet list yet
+    with pytest.raises(pkg.LbmDemError):
+        sim.f = np.zeros((3, 3, 9))
