@@ -16,7 +16,7 @@
 // Bit parity with the reference's serial loops is a design constraint: expression association is
 // kept, the file is compiled with -ffp-contract=off, and the one order-dependent read of the
 // reference's in-place IBB loop (a node two links out that the x-outer/y-inner scan has already
-// rewritten) is reproduced by recomputing that node's new value (see value_two_out()).
+// rewritten) is reproduced by recomputing that node's new value (see pull_one()).
 //
 // The equivalence swap+stream == pull, f_new[P][q] = f*[P - e_q][q] (or f*[P][opp q] when P - e_q is
 // off the array), is derived in SURVEY.md "Notes" and verified by tests against the oracle.
@@ -173,11 +173,35 @@ struct Tile {
     return sF[(q * RX + (tx + 1)) * RY + (ty + 1)];
   }
   __device__ __forceinline__ int O(int tx, int ty) const { return sO[(tx + 2) * OY + (ty + 2)]; }
-  // a solid node is "active" when one of its 8 neighbours is fluid (main.c:1039-1052)
-  __device__ __forceinline__ bool active(int tx, int ty) const {
-    return O(tx - 1, ty + 1) == -1 || O(tx - 1, ty) == -1 || O(tx - 1, ty - 1) == -1 ||
-           O(tx, ty - 1) == -1 || O(tx + 1, ty - 1) == -1 || O(tx + 1, ty) == -1 ||
-           O(tx + 1, ty + 1) == -1 || O(tx, ty + 1) == -1;
+  // A solid node is "active" when one of its 8 neighbours was fluid at the moment its owning grain
+  // was painted (main.c:1039-1052). Grains are painted in ascending index, so besides the
+  // neighbours that are fluid in the final map this also counts neighbours now covered by a
+  // HIGHER-index grain that do not lie inside the owner's own disc (they were still fluid when the
+  // owner was painted). Only reachable when reduced discs of different grains touch or overlap.
+  // (A neighbour additionally covered by a third, lower-index disc is not detected: DESIGN.md.)
+  __device__ __forceinline__ bool active(const LatticeView& L, const GrainFluidView& G, int tx, int ty,
+                                         int gx, int gy) const {
+    const int oS = O(tx, ty);
+    bool higher = false;
+#pragma unroll
+    for (int q = 1; q < 9; ++q) {
+      const int o = O(tx + EXq(q), ty + EYq(q));
+      if (o == -1) return true;
+      higher |= (o > oS && o != L.n);
+    }
+    if (!higher) return false;
+    const double xc = G.xc[oS], yc = G.yc[oS], r2 = G.r2[oS], rb = G.rbl0[oS];
+    const double R2 = rb * rb;
+#pragma unroll
+    for (int q = 1; q < 9; ++q) {
+      const int o = O(tx + EXq(q), ty + EYq(q));
+      if (o > oS && o != L.n) {
+        const int x = gx + EXq(q), y = gy + EYq(q);
+        const double d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc);
+        if (!(d2 <= R2 && d2 <= r2)) return true;
+      }
+    }
+    return false;
   }
 };
 
@@ -230,7 +254,7 @@ __device__ __forceinline__ double pull_one(const Tile<TX, TY>& T, const LatticeV
   if (oS == -1) return T.F(q, px - ex, py - ey);  // plain streaming from a fluid node
   const int oP = T.O(px, py);
   if (oP != -1)  // solid -> non-fluid link: active solid nodes reset the slot to w (main.c:1161-1162)
-    return T.active(px - ex, py - ey) ? Wq(q) : T.F(q, px - ex, py - ey);
+    return T.active(L, G, px - ex, py - ey, sxg, syg) ? Wq(q) : T.F(q, px - ex, py - ey);
 
   // P fluid, S an (active) solid node of grain oS: interpolated bounce-back
   const IbbLink k = ibb_link<q>(L, G, oS, sxg, syg);

@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: MLUPS of the coupled 2D LBM-DEM step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path = one fluid (LBM) step -- obstacle rebuild, fused
+collide+IBB+stream kernel, hydrodynamic forces -- plus the npDEM DEM sub-steps that belong to it and
+the Verlet rebuilds that fall inside (renderScene x npDEM, main.c:1697-1765). Nothing is skipped.
+
+Workload at N=1: BASELINE.json configs[3], 4096 x 4096 lattice with 50 000 grains (a deterministic
+synthetic row packing of the same shape as bin/50000.data: radii 0.5-0.9 mm, ~34 % solid nodes;
+/root/reference does not exist on the GPU box). At N>1: the lattice is strip-decomposed along x, one
+process per GPU; scaling is STRONG on configs[4] (8192 x 4096, 50 000 grains) when --gpus > 1, as
+BASELINE.json's north_star asks.
+
+Output: one JSON line on rank 0. `value` = lattice-node updates of the whole job per second / 1e6
+with all state resident in HBM. `roofline` prices the dominant kernel (k_collide_stream) from HIP
+events recorded on its own stream; `cpu_baseline` times the reference's serial C path (prebuilt
+oracle/_ref library when it travelled, else this repo's CPU restatement) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import __graft_entry__ as ge  # noqa: E402
+import samples  # noqa: E402
+
+BYTES_PER_LUP = 148.0   # 9x8 B read + 9x8 B write + 4 B obstacle id
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def workload(ngpus):
+    if ngpus == 1:
+        return dict(name="4096x4096 D2Q9 MRT + 50000 grains (synthetic row packing, seed 1234)",
+                    lx=4096, ly=4096, n=50000, fill_lx=4096)
+    return dict(name="8192x4096 D2Q9 MRT + 50000 grains (synthetic row packing, seed 1234), x-strips",
+                lx=8192, ly=4096, n=50000, fill_lx=8192)
+
+
+def make_sample(w):
+    r, x, y = samples.row_packing(w["fill_lx"], w["ly"], w["n"], seed=1234)
+    return samples.to_metres(r, x, y), (r, x, y)
+
+
+def cpu_baseline(w, sample_mm, npdem):
+    """Serial C path on this host, 1 core, bounded sample: 2 coupled steps (2 fluid steps, 2*npDEM DEM
+    sub-steps, one O(N^2) Verlet build) of the same workload; plus collision_streaming alone."""
+    po = ge.load_oracle()
+    lx, ly = w["lx"], w["ly"]
+    r_mm, x_mm, y_mm = sample_mm
+    ref_path = po.ref_lib_path(lx, ly, fast=True)
+    out = {"cores": 1, "unit": "MLUPS"}
+    nsteps = 2
+    if os.path.exists(ref_path):
+        import tempfile
+        tmp = tempfile.NamedTemporaryFile("w", suffix=".data", delete=False)
+        tmp.close()
+        po.write_sample(tmp.name, r_mm, x_mm, y_mm)
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        saved = os.dup(1)
+        os.dup2(devnull, 1)   # the reference prints per-step lines
+        try:
+            R = po.Reference(lx, ly, tmp.name, fast=True)
+            t0 = time.perf_counter(); R.steps(nsteps * npdem); t1 = time.perf_counter()
+            R.collision_streaming(); t2 = time.perf_counter()
+        finally:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)   # the reference's buffered stdout goes to /dev/null too
+            os.dup2(saved, 1); os.close(devnull); os.close(saved)
+            os.unlink(tmp.name)
+        out["kind"] = "reference"
+        flags = "-Ofast -march=x86-64-v3 (reference Release flags, CMakeLists.txt:17, portable -march)"
+    else:
+        r, x1, x2 = r_mm * 1e-3, x_mm * 1e-3, y_mm * 1e-3
+        O = po.Oracle(lx, ly, r, x1, x2, fast=True)
+        t0 = time.perf_counter(); O.steps(nsteps * npdem); t1 = time.perf_counter()
+        O.collision_streaming(); t2 = time.perf_counter()
+        out["kind"] = "port"
+        flags = "-Ofast -march=native"
+    out["value"] = round(1e-6 * lx * ly * nsteps / (t1 - t0), 3)
+    out["collide_stream_mlups"] = round(1e-6 * lx * ly / (t2 - t1), 3)
+    out["seconds"] = round(t2 - t0, 2)
+    out["sample"] = (f"{nsteps} coupled steps ({nsteps} fluid steps + {nsteps * npdem} DEM sub-steps incl. one "
+                     f"O(N^2) Verlet build) of the same {lx}x{ly}/{w['n']}-grain input, then one "
+                     f"collision_streaming(); serial, {flags}")
+    try:
+        with open("/proc/cpuinfo") as fp:
+            models = [l.split(":", 1)[1].strip() for l in fp if l.startswith("model name")]
+        out["cpu"] = models[0] if models else "unknown"
+        out["host_cores"] = len(models)
+    except OSError:
+        pass
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-mode", type=int, default=0, help="0 = parity hydro-force kernel, 1 = fast")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    pkg = ge.load_package()
+    w = workload(args.gpus)
+    (r, x1, x2), sample_mm = make_sample(w)
+    lx, ly = w["lx"], w["ly"]
+
+    if world == 1:
+        sim = pkg.LbmDem(lx, ly, r, x1, x2, device=local_rank)
+        sim.set_force_mode(args.force_mode)
+        npdem = sim.cfg.npDEM
+
+        def run_steps(k):
+            sim.renderScene(k * npdem)
+
+        def sync():
+            sim.sync()
+        barrier = lambda: None
+        runner = None
+    else:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        strips = pkg.strips_module()
+        runner = strips.make_gpu_runner(pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2,
+                                        force_mode=args.force_mode)
+        sim = runner.sim
+        npdem = sim.cfg.npDEM
+
+        def run_steps(k):
+            runner.render_scene(k * npdem)
+
+        def sync():
+            sim.sync(); torch.cuda.synchronize()
+        barrier = dist.barrier
+
+    run_steps(args.warmup)
+    sync()
+    sim.profile_enable(True)
+    barrier(); sync()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    sync(); barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    kernel_ms, launches = sim.profile_read()
+    sim.profile_enable(False)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    mass = sim.final_density()
+    if not np.isfinite(mass):
+        raise SystemExit("non-finite lattice mass after the timed run")
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        mlups = 1e-6 * lx * ly * args.steps / elapsed
+        cfgd = sim.config()
+        rows = cfgd.x_end - cfgd.x_begin
+        achieved = BYTES_PER_LUP * rows * ly / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        out = {
+            "metric": "MLUPS (D2Q9 collide+stream, coupled LBM-DEM step) on 4096^2 / 50k grains",
+            "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak" if args.gpus == 1 else "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": w["name"], "lx": lx, "ly": ly, "grains": int(len(r)), "npDEM": int(npdem),
+                       "step": "1 fluid step + npDEM DEM sub-steps (+ Verlet rebuild every 100 DEM steps)",
+                       "force_kernel": "parity" if args.force_mode == 0 else "fast",
+                       "decomposition": "none" if args.gpus == 1 else f"{args.gpus} x-strips, halo exchange per fluid step"},
+            "dem_steps_per_s": round(args.steps * npdem / elapsed, 1),
+            "collide_stream_kernel_ms": round(kernel_ms, 4),
+            "collide_stream_kernel_mlups": round(1e-6 * rows * ly / (kernel_ms * 1e-3), 1) if kernel_ms > 0 else None,
+            "roofline": {"bound": "hbm", "kernel": "k_collide_stream", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "bytes_per_lup": BYTES_PER_LUP, "launches_timed": launches,
+                         "note": "algorithmic 148 B/LUP x lattice nodes per launch / mean HIP-event duration"},
+            "total_mass": mass,
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, sample_mm, npdem)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -861,10 +861,21 @@ ORA_API long ora_count_act_anomalies(const ora_sim* s) {
   long bad = 0;
   for (int x = 1; x < s->lx - 1; x++)
     for (int y = 1; y < s->ly - 1; y++) {
-      if (s->obst[NI(s, x, y)] == -1) continue;
+      const int o = s->obst[NI(s, x, y)];
+      if (o == -1) continue;
+      grain_box b = grain_bbox(s, o);
       int any = 0;
-      for (int q = 1; q < NQ; q++)
-        if (s->obst[NI(s, x + EX[q], y + EY[q])] == -1) any = 1;
+      for (int q = 1; q < NQ; q++) {
+        const int nx = x + EX[q], ny = y + EY[q];
+        const int on = s->obst[NI(s, nx, ny)];
+        if (on == -1) any = 1;
+        else if (on > o && on != s->n) {
+          /* covered by a later-painted grain: it was fluid when `o` was painted unless it lies
+           * inside o's own disc */
+          double d2 = (nx - b.xc) * (nx - b.xc) + (ny - b.yc) * (ny - b.yc);
+          if (!(d2 <= b.R2 && d2 <= b.r2)) any = 1;
+        }
+      }
       if (any != (s->act[NI(s, x, y)] == 1)) ++bad;
     }
   return bad;

@@ -84,9 +84,11 @@ void ora_get_verlet(const ora_sim* s, int* cumul, int* neighbours, int* counts4,
                     int* wl, int* wr);
 double ora_total_density(const ora_sim* s);  /* main.c:1249-1273 summation order */
 
-/* Count of solid nodes whose reference `act` flag differs from "has a fluid neighbour in the
- * final obstacle map" (possible only when reduced discs of different grains overlap; see
- * DESIGN.md). The HIP path derives act from the final map, so parity tests assert this is 0. */
+/* Count of solid nodes whose reference `act` flag (set while grains are painted one after the other,
+ * main.c:1039-1052) differs from what the HIP path derives from the FINAL obstacle map: "has a
+ * fluid neighbour, or a neighbour covered by a higher-index grain that is outside the owner's own
+ * disc". A difference needs three mutually overlapping reduced discs; parity tests
+ * assert this is 0 on their inputs. */
 long ora_count_act_anomalies(const ora_sim* s);
 
 #ifdef __cplusplus
