@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the UNMODIFIED reference.
+
+Runs only in the build container, where /root/reference exists: oracle/ref_harness.c compiles the
+reference's src/main.c (one library per lattice size, -O2 -ffp-contract=off) and this script drives
+it. What is committed is data only -- the inputs we authored (grain radii/positions in the
+reference's .data units, initial perturbation seeds) and the reference's outputs -- never the
+reference's source.
+
+    python tests/golden/make_golden.py            # regenerate every fixture
+
+Each case runs in its own process (the reference keeps its state in file-scope globals).
+Large arrays are stored as a strided sample plus the SHA-256 of the full little-endian float64
+buffer, which pins every bit while keeping the repository small.
+"""
+import hashlib
+import multiprocessing as mp
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def perturbation(lx, ly, seed, amp):
+    """Smooth + random multiplicative perturbation of f (applied to whatever f currently is)."""
+    rng = np.random.default_rng(seed)
+    x = np.arange(lx)[:, None, None] / lx
+    y = np.arange(ly)[None, :, None] / ly
+    smooth = 0.02 * np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y) * np.linspace(-1, 1, 9)[None, None, :]
+    return 1.0 + smooth + amp * rng.standard_normal((lx, ly, 9))
+
+
+# ---- case definitions (shared with the tests through cases()) ---------------------------------------
+
+def cases():
+    import samples
+    c = {}
+    # G1: (almost) fluid-only -- the reference cannot run with 0 grains (main.c:220), so one small
+    # grain sits in a corner; f starts from a smooth + noisy perturbation. Fluid phases only.
+    for name, lx, ly in (("G1_fluid_64x48", 64, 48), ("G1_fluid_128x128", 128, 128)):
+        c[name] = dict(kind="lbm", lx=lx, ly=ly, r_mm=[0.5], x_mm=[1.2], y_mm=[1.1], kin=None,
+                       pert=(101, 1e-3), dumps=(1, 10, 50))
+    # G2: one translating + spinning grain -> reinit, both delta branches, moving-wall term, fhf
+    c["G2_moving_grain_96x96"] = dict(kind="lbm", lx=96, ly=96, r_mm=[0.85], x_mm=[4.63], y_mm=[4.21],
+                                      kin=[[0.03, -0.02, 40.0]], pert=(202, 1e-3), dumps=(1, 5, 20),
+                                      drift=[[2.3e-5, -1.7e-5]])
+    # G3: two grains one fluid node apart -> the in-place IBB order hazard (SURVEY.md hard part 2)
+    dx = 0.1 * 96 / 95
+    d = 0.85 * (0.7 + 0.6) + 1.6 * dx
+    ang = 0.25 * np.pi
+    c["G3_hazard_96x96"] = dict(kind="lbm", lx=96, ly=96, r_mm=[0.7, 0.6],
+                                x_mm=[4.0, 4.0 + d * np.cos(ang)], y_mm=[4.2, 4.2 + d * np.sin(ang)],
+                                kin=[[0.01, -0.015, 15.0], [-0.02, 0.01, -25.0]], pert=(303, 1e-2),
+                                dumps=(1, 2, 3))
+    # G4: ~600-grain packing, fully coupled, 20 fluid steps
+    r, x, y = samples.row_packing(256, 200, 600, seed=77)
+    c["G4_coupled_256x200"] = dict(kind="coupled", lx=256, ly=200, r_mm=r, x_mm=x, y_mm=y, fluid_steps=20)
+    # G5: DEM-focused: 240 renderScene calls on a tiny lattice with random initial grain velocities:
+    # film law at step 0, Verlet rebuilds at 0/100/200, grain-grain contacts, and four extra grains
+    # pressed 2-3 um into the left/bottom/right/top DEM walls (the right/top walls sit at 1e-3*lx,
+    # 1e-3*ly metres after the first VerletWall, main.c:1559-1560 -- outside the lattice).
+    r, x, y = samples.row_packing(64, 48, 14, seed=9)
+    r = np.concatenate([r, [0.6, 0.7, 0.8, 0.9]])
+    x = np.concatenate([x, [0.6 - 0.002, 20.0, 64 - 0.8 + 0.002, 30.0]])
+    y = np.concatenate([y, [30.0, 0.7 - 0.003, 10.0, 48 - 0.9 + 0.003]])
+    c["G5_dem_64x48"] = dict(kind="dem", lx=64, ly=48, r_mm=r, x_mm=x, y_mm=y, seed=505, dumps=(1, 120, 240))
+    return c
+
+
+def kin_table(case):
+    r_mm = np.asarray(case["r_mm"], float)
+    n = len(r_mm)
+    k = np.zeros((n, 9))
+    k[:, 0] = np.asarray(case["x_mm"], float) * 1e-3
+    k[:, 1] = np.asarray(case["y_mm"], float) * 1e-3
+    if case.get("kin") is not None:
+        k[:, 3:6] = np.asarray(case["kin"], float)
+    return k
+
+
+def dem_initial_kinematics(case):
+    k = kin_table(case)
+    rng = np.random.default_rng(case["seed"])
+    k[:, 3:6] = rng.normal(0, 1, (len(k), 3)) * [0.05, 0.05, 30.0]
+    return k
+
+
+# ---- drivers (work on anything with the Reference/Oracle interface) ---------------------------------
+
+def run_lbm_case(sim, case):
+    """-> dict of dumps. `sim` has set_f/get_f/set_kinematics/lbm_steps/get_obst/get_fhf."""
+    lx, ly = case["lx"], case["ly"]
+    k = kin_table(case)
+    sim.set_kinematics(k)
+    f0 = sim.get_f() * perturbation(lx, ly, *case["pert"])
+    sim.set_f(f0)
+    out = {}
+    done = 0
+    for target in case["dumps"]:
+        while done < target:
+            if case.get("drift") is not None:
+                k[:, 0:2] += np.asarray(case["drift"], float)
+                sim.set_kinematics(k)
+            sim.lbm_steps(1)
+            done += 1
+        out[f"f_{target}"] = sim.get_f()
+        out[f"obst_{target}"] = sim.get_obst()
+        out[f"fhf_{target}"] = sim.get_fhf()
+    return out
+
+
+def run_coupled_case(sim, case):
+    npdem = sim.scalars()["npDEM"]
+    sim.steps(case["fluid_steps"] * npdem)
+    return {"f": sim.get_f(), "obst": sim.get_obst(), "fhf": sim.get_fhf(), "grains": sim.get_grains()}
+
+
+def run_dem_case(sim, case):
+    sim.set_kinematics(dem_initial_kinematics(case))
+    out = {}
+    done = 0
+    for target in case["dumps"]:
+        sim.steps(target - done)
+        done = target
+        out[f"grains_{target}"] = sim.get_grains()
+    out["f_final"] = sim.get_f()
+    return out
+
+
+def _generate(name, case, q):
+    import pyoracle as po
+    lx, ly = case["lx"], case["ly"]
+    tmp = tempfile.NamedTemporaryFile("w", suffix=".data", delete=False)
+    tmp.close()
+    po.write_sample(tmp.name, case["r_mm"], case["x_mm"], case["y_mm"], comment=f"#golden {name}")
+    R = po.Reference(lx, ly, tmp.name)
+    os.unlink(tmp.name)
+    if case["kind"] == "lbm":
+        res = run_lbm_case(R, case)
+    elif case["kind"] == "coupled":
+        res = run_coupled_case(R, case)
+    else:
+        res = run_dem_case(R, case)
+    res["scalars"] = np.array([R.scalars()[k] for k in po.SCALARS], float)
+    q.put(res)
+
+
+def pack(name, case, res):
+    """Reduce a result dict to what is stored."""
+    out = {"r_mm": np.asarray(case["r_mm"], float), "x_mm": np.asarray(case["x_mm"], float),
+           "y_mm": np.asarray(case["y_mm"], float), "scalars": res["scalars"]}
+    for k, v in res.items():
+        if k == "scalars":
+            continue
+        if isinstance(v, str):
+            out[k] = np.array(v)
+            continue
+        v = np.asarray(v)
+        out[k + "_sha"] = np.array(sha(v))
+        if v.ndim == 3 and v.shape[0] * v.shape[1] > 64 * 48:      # big f dump: strided sample
+            out[k + "_sample"] = v[::4, ::4, :].copy()
+        elif v.ndim == 2 and v.dtype.kind == "i" and v.size > 64 * 48:
+            out[k + "_sample"] = v[::4, ::4].copy()
+        else:
+            out[k] = v
+    return out
+
+
+def main():
+    import pyoracle as po
+    if not po.reference_available():
+        raise SystemExit("the reference is not present here; golden vectors can only be made in the build container")
+    for name, case in cases().items():
+        q = mp.Queue()
+        p = mp.Process(target=_generate, args=(name, case, q))
+        p.start()
+        res = q.get()
+        p.join()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **pack(name, case, res))
+        print("wrote", name, {k: getattr(v, "shape", None) for k, v in pack(name, case, res).items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,68 @@
+"""CPU: the C-ABI library loads and exports every symbol include/lbmdem_hip.h declares; the pure-host
+entry points work without a GPU; device entry points fail loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.load_library()
+    names = pkg.exported_symbols()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(L, n)]
+    assert missing == []
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert set(names) <= exported
+    # nothing but the ABI leaks out of the library
+    assert all(n.startswith("lbmdem_") for n in exported), sorted(exported - set(names))[:5]
+
+
+def test_library_is_gfx950_only(pkg):
+    """The fat binary carries exactly one device target: gfx950 (no multi-arch / compatibility builds)."""
+    import re
+    blob = open(pkg.LIB_PATH, "rb").read()
+    targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-f]+)", blob))
+    assert targets == {b"gfx950"}, targets
+
+
+def test_host_side_derivation_without_gpu(pkg, po):
+    """lbmdem_derive is host arithmetic (main.c:1836-1860): same bits as the oracle."""
+    r = np.array([0.7e-3, 0.52e-3, 0.9e-3])
+    for lx, ly, scale in ((600, 500, 1.0), (4096, 4096, 1.0), (128, 96, 1.25)):
+        cfg = pkg.derive(lx, ly, r, scale)
+        s = po.Oracle(lx, ly, r, [3e-3] * 3, [3e-3] * 3, scale=scale).scalars()
+        for k in ("dx", "dtLB", "dt", "dt2", "c", "npDEM", "Mgx", "Mdx", "Mby", "Mhy", "xG", "yG"):
+            assert getattr(cfg, k) == s[k], (lx, ly, k)
+
+
+def test_sample_reader_without_gpu(pkg, po, tmp_path):
+    p = tmp_path / "s.data"
+    p.write_text("#c\n2\n1.0\t2.0\t3.0\n0.5 4.0 5.0;\n")
+    a = pkg.read_sample(str(p)); b = po.read_sample(str(p))
+    assert all(np.array_equal(u, v) for u, v in zip(a, b))
+    with pytest.raises(pkg.LbmDemError):
+        pkg.read_sample(str(tmp_path / "nope.data"))
+
+
+def test_no_cpu_fallback(pkg):
+    """Without a HIP device lbmdem_create must fail with LBMDEM_ENODEVICE, not compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.LbmDemError) as e:
+        pkg.LbmDem(64, 64, [0.7e-3], [3e-3], [3e-3])
+    assert e.value.code in (-2, -3)
+
+
+def test_product_never_imports_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pk = os.path.join(root, "2d-lbm-dem_amd")
+    for dirpath, _, files in os.walk(pk):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".c", ".cpp")):
+                txt = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "pyoracle" not in txt and "lbmdem_oracle" not in txt and "ora_" not in txt, fn
