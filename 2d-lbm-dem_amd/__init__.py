@@ -86,12 +86,20 @@ def load_library():
     L.lbmdem_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.lbmdem_halo_pack.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.lbmdem_halo_unpack.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.lbmdem_fhf_export.argtypes = [C.c_void_p, C.c_void_p]
+    L.lbmdem_fhf_import.argtypes = [C.c_void_p, C.c_void_p]
     L.lbmdem_fhf_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.lbmdem_get_config.argtypes = [C.c_void_p, C.POINTER(Config)]
     L.lbmdem_read_sample.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_double)),
                                      C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.POINTER(C.c_double))]
     _lib = L
     return L
+
+
+def strips_module():
+    """The x-strip decomposition driver (one process per GPU), imported lazily."""
+    from . import strips
+    return strips
 
 
 def exported_symbols():
@@ -318,6 +326,12 @@ class LbmDem:
 
     def halo_unpack(self, side, dev_ptr):
         _chk(self._L.lbmdem_halo_unpack(self._h, int(side), C.c_void_p(dev_ptr)))
+
+    def fhf_export(self, dev_ptr):
+        _chk(self._L.lbmdem_fhf_export(self._h, C.c_void_p(dev_ptr)))
+
+    def fhf_import(self, dev_ptr):
+        _chk(self._L.lbmdem_fhf_import(self._h, C.c_void_p(dev_ptr)))
 
     def fhf_device(self):
         a, b = C.c_void_p(), C.c_void_p()

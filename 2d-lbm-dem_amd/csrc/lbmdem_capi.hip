@@ -651,5 +651,19 @@ int lbmdem_fhf_device(lbmdem_handle* h, void** fhf, void** owner_mask) {
   return LBMDEM_OK;
 }
 
+int lbmdem_fhf_export(lbmdem_handle* h, void* dev_buf) {
+  CHECK_H(h);
+  if (!dev_buf) return fail(LBMDEM_EINVAL, "null buffer");
+  HIP_TRY(hipMemcpyAsync(dev_buf, h->fhf, sizeof(double) * 3 * h->n, hipMemcpyDeviceToDevice, h->stream));
+  return LBMDEM_OK;
+}
+
+int lbmdem_fhf_import(lbmdem_handle* h, const void* dev_buf) {
+  CHECK_H(h);
+  if (!dev_buf) return fail(LBMDEM_EINVAL, "null buffer");
+  HIP_TRY(hipMemcpyAsync(h->fhf, dev_buf, sizeof(double) * 3 * h->n, hipMemcpyDeviceToDevice, h->stream));
+  return LBMDEM_OK;
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

@@ -1,0 +1,183 @@
+"""x-strip decomposition of the coupled LBM-DEM step across the GPUs of one node.
+
+The reference has nothing distributed (one address space). This module is the
+multi-GPU design of BASELINE.json's north_star, one process per GPU:
+
+* **Fluid**: the lattice is cut along x (the reference's slow axis, which this framework keeps as the
+  slow device axis -- a strip is one contiguous slab per population plane and a halo row is
+  contiguous). Rank k owns rows [x_k, x_{k+1}); it keeps `halo` extra rows on each interior side.
+  After the fused collide+stream kernel has produced the owned rows, the `halo` outermost owned rows
+  travel to the neighbour's halo (one send + one receive per neighbour per fluid step, point to
+  point over xGMI: RCCL through torch.distributed's batched isend/irecv). halo = 2 + the largest
+  grain radius in nodes, so that (a) the next collide+stream finds the f row and the two obstacle
+  rows it reads beyond the cut and (b) the owner of a grain sees every node of the grain's bounding
+  box and computes its hydrodynamic force in the reference's serial order -- results do not depend
+  on the number of GPUs.
+* **Grains**: 50 000 grains are 3.6 MB of state and one DEM sub-step is a ~10 us latency-bound
+  launch, npDEM (12) of them per fluid step. Exchanging ghosts every sub-step would cost more in
+  xGMI latency than the sub-step itself, so the DEM state is REPLICATED: every rank integrates all
+  grains with identical arithmetic, rasterises the grains that overlap its slab, and computes the
+  hydrodynamic force of the grains whose centre it owns. One all-reduce per fluid step (3 doubles
+  per grain, summed as int64 bit patterns: owner's bits + zeros = owner's bits, exact) hands every
+  rank every force. Grains that cross a cut simply change owner at the next fluid step -- no
+  migration messages.
+
+`StripRunner` holds the orchestration only; it talks to a *backend* (the HIP library through
+`GpuStripBackend`, or the CPU oracle in tests) and a *comm* (`TorchComm` over RCCL/gloo, or an
+in-process loop-back in tests), so the same code path is what runs on 8 GPUs and what the
+world_size-2 gloo tests on CPU check.
+"""
+from __future__ import annotations
+
+import math
+
+
+def partition(lx: int, world: int):
+    """Row ranges [x_k, x_{k+1}) of `world` strips, as even as possible."""
+    return [(k * lx // world, (k + 1) * lx // world) for k in range(world)]
+
+
+def halo_rows(rmax: float, dx: float) -> int:
+    """Rows kept beyond a cut: f halo (1) + obstacle halo (2) + bounding box of the largest grain."""
+    return 2 + int(math.ceil(rmax / dx))
+
+
+class StripRunner:
+    """One rank's share of renderScene() (main.c:1697-1765) under x-strip decomposition."""
+
+    def __init__(self, backend, comm, rank: int, world: int):
+        self.b, self.comm, self.rank, self.world = backend, comm, rank, world
+        self.has_lo, self.has_hi = rank > 0, rank < world - 1
+
+    # -- one fluid step, split so that an in-process test can interleave several ranks -------------
+    def fluid_compute(self):
+        self.b.obst_construction()
+        self.b.collision_streaming()
+
+    def halo_post(self):
+        """-> list of (peer, send_buffer, recv_buffer)"""
+        ops = []
+        if self.has_lo:
+            ops.append((self.rank - 1, self.b.halo_pack(0), self.b.halo_recv_buffer(0)))
+        if self.has_hi:
+            ops.append((self.rank + 1, self.b.halo_pack(1), self.b.halo_recv_buffer(1)))
+        return ops
+
+    def halo_finish(self):
+        if self.has_lo:
+            self.b.halo_unpack(0)
+        if self.has_hi:
+            self.b.halo_unpack(1)
+
+    def forces_post(self):
+        self.b.forces_fluid()
+        return self.b.fhf_export()
+
+    def forces_finish(self):
+        self.b.fhf_import()
+
+    def lbm_step(self):
+        self.fluid_compute()
+        if self.world > 1:
+            self.comm.exchange(self.halo_post())
+            self.halo_finish()
+        buf = self.forces_post()
+        if self.world > 1:
+            self.comm.all_reduce_bits(buf)
+            self.forces_finish()
+
+    def render_scene(self, n: int = 1):
+        b = self.b
+        for _ in range(n):
+            if b.nbsteps % b.npDEM == 0:          # main.c:1710
+                self.lbm_step()
+            if b.nbsteps % b.updateVerlet == 0:   # main.c:1721
+                b.initVerlet()
+            b.dem_substep()                       # main.c:1733-1764
+
+
+class TorchComm:
+    """Neighbour exchange + bit-exact all-reduce over torch.distributed (backend "nccl" = RCCL over
+    xGMI on the GPU node, "gloo" in the CPU tests)."""
+
+    def __init__(self, dist, group=None):
+        self.dist, self.group = dist, group
+
+    def exchange(self, ops):
+        d = self.dist
+        p2p = []
+        for peer, send, recv in ops:
+            p2p.append(d.P2POp(d.isend, send, peer, self.group))
+            p2p.append(d.P2POp(d.irecv, recv, peer, self.group))
+        if p2p:
+            for req in d.batch_isend_irecv(p2p):
+                req.wait()
+
+    def all_reduce_bits(self, int64_tensor):
+        self.dist.all_reduce(int64_tensor, op=self.dist.ReduceOp.SUM, group=self.group)
+
+
+class GpuStripBackend:
+    """The HIP library (one LbmDem handle restricted to a strip) + the torch device tensors used as
+    exchange buffers. torch is plumbing here: device memory for the buffers and the process group."""
+
+    def __init__(self, pkg, torch, lx, ly, r, x1, x2, strip, halo, device, force_mode=0):
+        self.torch = torch
+        dev = torch.device("cuda", device)
+        self.sim = pkg.LbmDem(lx, ly, r, x1, x2, device=device, strip=strip, halo=halo)
+        self.sim.set_force_mode(force_mode)
+        # everything is enqueued on torch's current stream so that collectives issued through
+        # torch.distributed are ordered with the kernels
+        self.sim.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        hd = max(self.sim.halo_doubles(), 1)
+        self.send = [torch.empty(hd, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.recv = [torch.empty(hd, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.fhf_buf = torch.empty(3 * self.sim.n, dtype=torch.float64, device=dev)
+        self.npDEM = self.sim.cfg.npDEM
+        self.updateVerlet = self.sim.cfg.phys.updateVerlet
+
+    @property
+    def nbsteps(self):
+        return self.sim.nbsteps
+
+    def obst_construction(self): self.sim.obst_construction()
+    def collision_streaming(self): self.sim.collision_streaming()
+    def forces_fluid(self): self.sim.forces_fluid()
+    def initVerlet(self): self.sim.initVerlet()
+    def dem_substep(self): self.sim.dem_substep()
+
+    def halo_pack(self, side):
+        self.sim.halo_pack(side, self.send[side].data_ptr())
+        return self.send[side]
+
+    def halo_recv_buffer(self, side):
+        return self.recv[side]
+
+    def halo_unpack(self, side):
+        self.sim.halo_unpack(side, self.recv[side].data_ptr())
+
+    def fhf_export(self):
+        self.sim.fhf_export(self.fhf_buf.data_ptr())
+        return self.fhf_buf.view(self.torch.int64)
+
+    def fhf_import(self):
+        self.sim.fhf_import(self.fhf_buf.data_ptr())
+
+
+class _GpuRunner(StripRunner):
+    @property
+    def sim(self):
+        return self.b.sim
+
+
+def make_gpu_runner(pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2, force_mode=0):
+    """Build this rank's strip on its GPU (bench.py --gpus N)."""
+    import torch
+    cfg = pkg.derive(lx, ly, r)
+    halo = halo_rows(float(max(r)), cfg.dx)
+    strip = partition(lx, world)[rank]
+    if world > 1 and strip[1] - strip[0] < halo:
+        raise pkg.LbmDemError(-1, f"strips of {strip[1] - strip[0]} rows are narrower than the halo ({halo})")
+    backend = GpuStripBackend(pkg, torch, lx, ly, r, x1, x2, strip, halo if world > 1 else 0, local_rank,
+                              force_mode)
+    return _GpuRunner(backend, TorchComm(dist), rank, world)

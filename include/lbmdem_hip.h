@@ -147,6 +147,12 @@ int lbmdem_halo_unpack(lbmdem_handle* h, int side, const void* dev_buf);
 /* Device pointer to the 3*n hydrodynamic-force table (fhf1[n], fhf2[n], fhf3[n]) and to the
  * n-entry ownership mask (1 = this rank computed the grain) for the cross-rank combine. */
 int lbmdem_fhf_device(lbmdem_handle* h, void** fhf, void** owner_mask);
+/* Cross-rank combine of the hydrodynamic forces: forces_fluid writes the forces of the grains this
+ * rank owns and exact zeros for the others, so a bit-wise integer SUM all-reduce of the exported
+ * table (3*n doubles viewed as int64) reconstructs every grain's force exactly. export/import copy
+ * the table to/from a caller-provided DEVICE buffer on the handle's stream. */
+int lbmdem_fhf_export(lbmdem_handle* h, void* dev_buf);
+int lbmdem_fhf_import(lbmdem_handle* h, const void* dev_buf);
 
 const char* lbmdem_last_error(void);
 const char* lbmdem_version(void);

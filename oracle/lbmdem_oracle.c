@@ -802,6 +802,12 @@ ORA_API void ora_get_fhf(const ora_sim* s, double* out) {
   }
 }
 
+ORA_API void ora_set_fhf(ora_sim* s, const double* in) {
+  for (int i = 0; i < s->n; ++i) {
+    s->fhf1[i] = in[3 * i]; s->fhf2[i] = in[3 * i + 1]; s->fhf3[i] = in[3 * i + 2];
+  }
+}
+
 ORA_API void ora_get_grains(const ora_sim* s, double* out) {
   for (int i = 0; i < s->n; ++i) {
     double* o = out + (size_t)i * ORA_GRAIN_COLS;

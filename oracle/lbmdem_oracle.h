@@ -73,6 +73,7 @@ int* ora_obst(ora_sim* s);        /* [lx][ly]    */
 int* ora_act(ora_sim* s);         /* [lx][ly]    */
 double* ora_delta(ora_sim* s);    /* [lx][ly][9] */
 void ora_get_fhf(const ora_sim* s, double* out3n);                /* interleaved f1,f2,f3 */
+void ora_set_fhf(ora_sim* s, const double* in3n);                  /* test-only: strip-decomposition tests */
 void ora_get_grains(const ora_sim* s, double* out);               /* n x ORA_GRAIN_COLS */
 void ora_set_kinematics(ora_sim* s, const double* in9n);          /* x1 x2 x3 v1 v2 v3 a1 a2 a3 */
 /* scalars: dx dtLB dt dt2 c npDEM Mgx Mdx Mby Mhy xG yG */

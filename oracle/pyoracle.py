@@ -144,6 +144,10 @@ class Oracle:
     def get_fhf(self):
         out = np.zeros((self.n, 3)); self._call("ora_get_fhf", _vp(out)); return out
 
+    def set_fhf(self, fhf):
+        fhf = np.ascontiguousarray(fhf, dtype=np.float64); assert fhf.shape == (self.n, 3)
+        self._call("ora_set_fhf", _vp(fhf))
+
     def get_grains(self):
         out = np.zeros((self.n, GRAIN_COLS)); self._call("ora_get_grains", _vp(out)); return out
 

@@ -1,0 +1,102 @@
+"""Test-side backends for the strip driver (2d-lbm-dem_amd/strips.py).
+
+OracleStripBackend = "poisoned replica": every rank holds a full-lattice CPU oracle but, after each
+fluid step, overwrites every row it does not own with NaN. Rows a rank legitimately needs beyond its
+cut therefore have to arrive through the halo exchange, and forces of grains it does not own are
+dropped, exactly as on the GPU path -- if the driver's protocol (partition, halo width, exchange
+pattern, ownership, bit-exact force combine, replicated DEM) were wrong, NaNs would reach the
+gathered result. TEST INFRASTRUCTURE ONLY.
+"""
+import numpy as np
+
+
+class OracleStripBackend:
+    def __init__(self, po, torch, lx, ly, r, x1, x2, strip, halo):
+        self.torch = torch
+        self.o = po.Oracle(lx, ly, r, x1, x2)
+        self.lx, self.ly = lx, ly
+        self.xb, self.xe = strip
+        self.H = halo
+        s = self.o.scalars()
+        self.npDEM, self.updateVerlet = s["npDEM"], 100
+        self.dx, self.Mgx = s["dx"], s["Mgx"]
+        self.recv = [torch.empty(max(halo, 1) * ly * 9, dtype=torch.float64) for _ in range(2)]
+        self.fhf_t = None
+
+    @property
+    def nbsteps(self):
+        return self.o.nbsteps
+
+    def obst_construction(self):
+        self.o.reinit()              # reinit_obst_density acts on the previous obstacle map (main.c:1711)
+        self.o.obst_construction()
+
+    def collision_streaming(self):
+        self.o.collision_streaming()
+        f = self.o.f_view()
+        f[:self.xb] = np.nan         # rows this rank does not own are NOT computed on the GPU path
+        f[self.xe:] = np.nan
+
+    def halo_pack(self, side):
+        f = self.o.f_view()
+        rows = f[self.xb:self.xb + self.H] if side == 0 else f[self.xe - self.H:self.xe]
+        return self.torch.from_numpy(rows.copy().reshape(-1))
+
+    def halo_recv_buffer(self, side):
+        return self.recv[side]
+
+    def halo_unpack(self, side):
+        f = self.o.f_view()
+        rows = self.recv[side].numpy().reshape(self.H, self.ly, 9)
+        if side == 0:
+            f[self.xb - self.H:self.xb] = rows
+        else:
+            f[self.xe:self.xe + self.H] = rows
+
+    def forces_fluid(self):
+        self.o.forces_fluid()
+
+    def fhf_export(self):
+        fhf = self.o.get_fhf()
+        g = self.o.get_grains()
+        xc = (g[:, 0] - self.Mgx) / self.dx
+        own = ((self.xb == 0) | (xc >= self.xb)) & ((self.xe == self.lx) | (xc < self.xe))
+        fhf[~own] = 0.0
+        self.fhf_t = self.torch.from_numpy(np.ascontiguousarray(fhf).reshape(-1))
+        return self.fhf_t.view(self.torch.int64)
+
+    def fhf_import(self):
+        self.o.set_fhf(self.fhf_t.numpy().reshape(-1, 3))
+
+    def initVerlet(self): self.o.verlet_rebuild()
+    def dem_substep(self): self.o.dem_substep()
+
+
+class LoopbackComm:
+    """Placeholder comm for runners that are stepped in lock-step inside one process."""
+    def exchange(self, ops): raise RuntimeError("lock-step driver delivers the halos")
+    def all_reduce_bits(self, t): raise RuntimeError("lock-step driver combines the forces")
+
+
+def lockstep_render(runners, n):
+    """Drive several StripRunner objects of ONE process through n renderScene() calls, delivering the
+    halo messages and the force all-reduce by hand (same phases as StripRunner.lbm_step)."""
+    b0 = runners[0].b
+    for _ in range(n):
+        if b0.nbsteps % b0.npDEM == 0:
+            for R in runners: R.fluid_compute()
+            posts = [R.halo_post() for R in runners]
+            for rk, ops in enumerate(posts):
+                for peer, send, _ in ops:
+                    dst = [rv for (p2, _, rv) in posts[peer] if p2 == rk]
+                    assert len(dst) == 1
+                    dst[0].copy_(send)
+            for R in runners: R.halo_finish()
+            bufs = [R.forces_post() for R in runners]
+            total = bufs[0].clone()
+            for t in bufs[1:]: total += t
+            for t in bufs: t.copy_(total)
+            for R in runners: R.forces_finish()
+        if b0.nbsteps % b0.updateVerlet == 0:
+            for R in runners: R.b.initVerlet()
+        for R in runners: R.b.dem_substep()
