@@ -60,6 +60,14 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise LbmDemError(-2, f"{LIB_PATH} not built -- run __graft_entry__.build() "
                               "(make -C 2d-lbm-dem_amd/csrc); there is no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (requested by the
+    # unversioned name), liblbmdem_hip.so links the system one (libamdhip64.so.7). If ours were
+    # loaded first and torch later (the strip driver uses torch.distributed), the process would end
+    # up with two runtimes and torch would see no GPU. Importing torch first makes both share one.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.lbmdem_last_error.restype = C.c_char_p
     L.lbmdem_version.restype = C.c_char_p
@@ -74,7 +82,7 @@ def load_library():
     L.lbmdem_derive.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]
     L.lbmdem_create.argtypes = [C.POINTER(Config), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
     for name in ("destroy", "lbm_step", "obst_construction", "collide_stream", "forces_fluid",
-                 "verlet_rebuild", "dem_substep", "sync"):
+                 "verlet_rebuild", "dem_substep", "sync", "use_own_stream"):
         getattr(L, "lbmdem_" + name).argtypes = [C.c_void_p]
     for name in ("upload_f", "download_f", "download_obst", "total_density", "upload_kinematics",
                  "download_kinematics", "download_fhf", "set_stream"):
@@ -305,7 +313,11 @@ class LbmDem:
         _chk(self._L.lbmdem_set_force_mode(self._h, int(mode)))
 
     def set_stream(self, hip_stream_ptr):
-        _chk(self._L.lbmdem_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+        """Enqueue on a caller-owned hipStream_t; 0/None = the HIP default stream."""
+        _chk(self._L.lbmdem_set_stream(self._h, C.c_void_p(hip_stream_ptr or None)))
+
+    def use_own_stream(self):
+        _chk(self._L.lbmdem_use_own_stream(self._h))
 
     def sync(self):
         _chk(self._L.lbmdem_sync(self._h))

@@ -583,7 +583,14 @@ int lbmdem_get_config(lbmdem_handle* h, lbmdem_config* out) {
 int lbmdem_set_stream(lbmdem_handle* h, void* hip_stream) {
   CHECK_H(h);
   HIP_TRY(hipStreamSynchronize(h->stream));
-  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  h->stream = (hipStream_t)hip_stream;
+  return LBMDEM_OK;
+}
+
+int lbmdem_use_own_stream(lbmdem_handle* h) {
+  CHECK_H(h);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->stream = h->own_stream;
   return LBMDEM_OK;
 }
 

@@ -130,7 +130,11 @@ int lbmdem_get_config(lbmdem_handle* h, lbmdem_config* out);
 
 /* ---- streams, timing, multi-GPU plumbing ------------------------------------------------------ */
 
-int lbmdem_set_stream(lbmdem_handle* h, void* hip_stream); /* NULL = the library's own stream */
+/* Enqueue on a caller-owned hipStream_t (NULL is the HIP default stream -- what PyTorch calls its
+ * default stream), e.g. so that work is ordered with torch.distributed collectives; the library's
+ * private non-blocking stream is the default and lbmdem_use_own_stream() goes back to it. */
+int lbmdem_set_stream(lbmdem_handle* h, void* hip_stream);
+int lbmdem_use_own_stream(lbmdem_handle* h);
 int lbmdem_sync(lbmdem_handle* h);
 /* HIP-event timing of the dominant kernel (fused collide+stream), on the stream it is launched on.
  * enable, run steps, then read the mean duration and the launch count. */

@@ -40,7 +40,8 @@ def test_strips_on_one_gpu_bit_exact(pkg, po, world):
         assert np.array_equal(R.b.sim.fhf, ora.get_fhf())
     # mass over the owned rows adds up to the whole
     tot = sum(R.b.sim.final_density() for R in runners)
-    assert abs(tot - ora.total_density()) <= 1e-12 * ora.total_density()
+    # different summation trees (the reference's is one serial chain over 9*lx*ly values)
+    assert abs(tot - ora.total_density()) <= 1e-10 * ora.total_density()
 
 
 def test_strip_needs_enough_halo(pkg):
