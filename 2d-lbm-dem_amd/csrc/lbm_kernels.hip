@@ -23,6 +23,8 @@
 
 #include "lbmdem_internal.h"
 
+#include <stdlib.h>
+
 namespace {
 
 // D2Q9 direction table (main.c:70-71) and weights (main.c:53-54)
@@ -37,12 +39,21 @@ __host__ __device__ constexpr double Wq(int q) {
   return q == 0 ? 4. / 9 : ((q & 1) ? 1. / 36 : 1. / 9);
 }
 
-// rigid-body velocity of grain i at global node (x, y): main.c:974-975,1172-1173
-__device__ __forceinline__ double wall_ux(const LatticeView& L, const GrainFluidView& G, int i, int y) {
-  return G.v1[i] - (y * L.dx + L.Mby - G.x2[i]) * G.v3[i];
+// the fluid-side record of one grain
+struct GP { double x1, x2, v1, v2, v3, xc, yc, r2; };
+
+__device__ __forceinline__ GP load_gp(const GrainFluidView& G, int i) {
+  const double2* p = reinterpret_cast<const double2*>(G.pk + (long)i * 8);
+  const double2 a = p[0], b = p[1], c = p[2], d = p[3];
+  return GP{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
 }
-__device__ __forceinline__ double wall_uy(const LatticeView& L, const GrainFluidView& G, int i, int x) {
-  return G.v2[i] + (x * L.dx + L.Mgx - G.x1[i]) * G.v3[i];
+
+// rigid-body velocity of a grain at global node (x, y): main.c:974-975,1172-1173
+__device__ __forceinline__ double wall_ux(const LatticeView& L, const GP& g, int y) {
+  return g.v1 - (y * L.dx + L.Mby - g.x2) * g.v3;
+}
+__device__ __forceinline__ double wall_uy(const LatticeView& L, const GP& g, int x) {
+  return g.v2 + (x * L.dx + L.Mgx - g.x1) * g.v3;
 }
 
 // main.c:1082-1116, in registers
@@ -81,16 +92,29 @@ __device__ __forceinline__ void mrt_collide(const LatticeView& L, double (&f)[9]
   f[7] = a * (4 * rho + 2 * eO + epsO + 6 * j_x + 3 * q_xO + 6 * j_y + 3 * q_yO + 9 * p_xyO);
 }
 
-// equilibrium at rho = 1 and the grain's rigid-body velocity: main.c:974-981
-__device__ __forceinline__ void grain_equilibrium(const LatticeView& L, const GrainFluidView& G, int i,
-                                                  int x, int y, double (&f)[9]) {
-  const double ux = wall_ux(L, G, i, y), uy = wall_uy(L, G, i, x);
+// equilibrium at rho = 1 and the grain's rigid-body velocity: main.c:974-981.
+// The reference evaluates eu = (ex*ux + ey*uy)/c for all nine directions. Opposite directions have
+// exactly negated numerators (negation and IEEE rounding commute), so eu[q+4] == -eu[q] bit for bit;
+// products with ex, ey in {0, +-1} are exact (a 0*u term only decides the sign of a zero sum, which
+// 1. + 3*eu and eu*eu then erase). Hence four divisions instead of nine, same bits.
+__device__ __forceinline__ void grain_equilibrium(const LatticeView& L, const GP& g, int x, int y,
+                                                  double (&f)[9]) {
+  const double ux = wall_ux(L, g, y), uy = wall_uy(L, g, x);
   const double u_squ = (ux * ux + uy * uy) / (L.c * L.c);
-#pragma unroll
-  for (int q = 0; q < 9; ++q) {
-    const double eu = (EXq(q) * ux + EYq(q) * uy) / L.c;
-    f[q] = Wq(q) * (1. + 3 * eu + 4.5 * eu * eu - 1.5 * u_squ);
-  }
+  const double k = 1.5 * u_squ;
+  const double e1 = (-ux + uy) / L.c;     // q = 1: (-1, 1)
+  const double e2 = (-ux) / L.c;          // q = 2: (-1, 0)
+  const double e3 = (-ux + (-uy)) / L.c;  // q = 3: (-1,-1)
+  const double e4 = (-uy) / L.c;          // q = 4: ( 0,-1)
+  f[0] = Wq(0) * (1. + 0.0 - k);          // eu = 0: 1. + 3*0 + 4.5*0*0 == 1.
+  f[1] = Wq(1) * (1. + 3 * e1 + 4.5 * e1 * e1 - k);
+  f[5] = Wq(5) * (1. + 3 * (-e1) + 4.5 * e1 * e1 - k);
+  f[2] = Wq(2) * (1. + 3 * e2 + 4.5 * e2 * e2 - k);
+  f[6] = Wq(6) * (1. + 3 * (-e2) + 4.5 * e2 * e2 - k);
+  f[3] = Wq(3) * (1. + 3 * e3 + 4.5 * e3 * e3 - k);
+  f[7] = Wq(7) * (1. + 3 * (-e3) + 4.5 * e3 * e3 - k);
+  f[4] = Wq(4) * (1. + 3 * e4 + 4.5 * e4 * e4 - k);
+  f[8] = Wq(8) * (1. + 3 * (-e4) + 4.5 * e4 * e4 - k);
 }
 
 // wall distance along link q from solid node (x, y) of a disc (xc, yc, r2): main.c:1054-1058
@@ -118,17 +142,22 @@ __global__ void k_obst_fill(int* __restrict__ obst, LatticeView L) {
   }
 }
 
-// per-grain lattice geometry (main.c:1009-1013)
+// per-grain lattice geometry (main.c:1009-1013) + the packed record the fluid kernels read
 __global__ void k_grain_geom(int n, const double* __restrict__ x1, const double* __restrict__ x2,
-                             const double* __restrict__ r, const double* __restrict__ rLB, double Mgx,
-                             double Mby, double dx, double* __restrict__ xc, double* __restrict__ yc,
-                             double* __restrict__ r2, double* __restrict__ rbl0) {
+                             const double* __restrict__ r, const double* __restrict__ rLB,
+                             const double* __restrict__ v1, const double* __restrict__ v2,
+                             const double* __restrict__ v3, double Mgx, double Mby, double dx,
+                             double* __restrict__ xc, double* __restrict__ yc, double* __restrict__ r2,
+                             double* __restrict__ rbl0, double* __restrict__ pk) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  xc[i] = (x1[i] - Mgx) / dx;
-  yc[i] = (x2[i] - Mby) / dx;
-  r2[i] = rLB[i] * rLB[i];
+  const double cx = (x1[i] - Mgx) / dx, cy = (x2[i] - Mby) / dx, rr = rLB[i] * rLB[i];
+  xc[i] = cx;
+  yc[i] = cy;
+  r2[i] = rr;
   rbl0[i] = r[i] / dx;
+  double* o = pk + (long)i * 8;
+  o[0] = x1[i]; o[1] = x2[i]; o[2] = v1[i]; o[3] = v2[i]; o[4] = v3[i]; o[5] = cx; o[6] = cy; o[7] = rr;
 }
 
 // Rasterise the reduced discs (main.c:1016-1032). One wavefront per grain, lanes sweep the
@@ -210,12 +239,11 @@ struct Tile {
 struct IbbLink { double d, uw; };
 
 template <int q>
-__device__ __forceinline__ IbbLink ibb_link(const LatticeView& L, const GrainFluidView& G, int i, int sx,
-                                            int sy) {
+__device__ __forceinline__ IbbLink ibb_link(const LatticeView& L, const GP& g, int sx, int sy) {
   constexpr int ex = EXq(q), ey = EYq(q);
   IbbLink k;
-  k.d = link_delta<q>(sx, sy, G.xc[i], G.yc[i], G.r2[i]);
-  k.uw = ex * wall_ux(L, G, i, sy) + ey * wall_uy(L, G, i, sx);
+  k.d = link_delta<q>(sx, sy, g.xc, g.yc, g.r2);
+  k.uw = ex * wall_ux(L, g, sy) + ey * wall_uy(L, g, sx);
   return k;
 }
 __device__ __forceinline__ bool ibb_far(const IbbLink& k) { return k.d >= 0.5; }
@@ -233,14 +261,22 @@ __device__ __forceinline__ double ibb_near_value(const LatticeView& L, const Ibb
   return 2 * k.d * fN_opp + (1 - 2 * k.d) * f2 + 6 * (Wq(q) / L.c) * k.uw;
 }
 
-// f_new[P][q] for one direction. (px, py) tile coordinates of P, (gx, gy) global.
-template <int q, int TX, int TY>
-__device__ __forceinline__ double pull_one(const Tile<TX, TY>& T, const LatticeView& L,
-                                           const GrainFluidView& G, int px, int py, int gx, int gy) {
+// f_new[P][q] for one direction, P = (gx, gy) global. The node's surroundings come from a context:
+//   C.own(q)     f*[P][q]              (f* = post-collision for fluid nodes, pre-IBB value otherwise)
+//   C.in(d)      f*[P + e_d][opp d]    the population of the neighbour in direction d that points at P
+//   C.o_own(), C.o_nb(d)               obstacle ids of P and of that neighbour
+//   C.act_nb(d)                        `act` flag of that neighbour (asked only for interior solid ones)
+//   C.gp(i)                            fluid-side record of grain i (may be served from registers)
+// so f*[S][q] with S = P - e_q is C.in(opp q) and f*[P + e_q][opp q] is C.in(q).
+// EDGE = false is the specialisation for nodes at least two rows/columns away from every lattice edge
+// (S, P and P + e_q are then all interior): the edge logic disappears.
+template <int q, bool EDGE = true, class Ctx>
+__device__ __forceinline__ double pull_one(const Ctx& C, const LatticeView& L, const GrainFluidView& G,
+                                           int gx, int gy) {
   constexpr int ex = EXq(q), ey = EYq(q), qo = OPPq(q);
   const int sxg = gx - ex, syg = gy - ey;  // source node S = P - e_q
-  if (sxg < 0 || sxg >= L.lx || syg < 0 || syg >= L.ly) return T.F(qo, px, py);  // array edge: main.c:1237
-  const bool s_interior = sxg >= 1 && sxg <= L.lx - 2 && syg >= 1 && syg <= L.ly - 2;
+  if (EDGE && (sxg < 0 || sxg >= L.lx || syg < 0 || syg >= L.ly)) return C.own(qo);  // array edge: main.c:1237
+  const bool s_interior = !EDGE || (sxg >= 1 && sxg <= L.lx - 2 && syg >= 1 && syg <= L.ly - 2);
   if (!s_interior) {
     // S is a lattice-edge wall node. Its slot q was overwritten by the edge copies
     // (main.c:1123-1145) with f*[P][opp q] when P is interior, and -- because the y-edge loop runs
@@ -248,53 +284,80 @@ __device__ __forceinline__ double pull_one(const Tile<TX, TY>& T, const LatticeV
     // still holds its old value.
     const bool s_yedge = (syg == 0 || syg == L.ly - 1) && sxg >= 1 && sxg <= L.lx - 2;
     const bool copied = gy >= 1 && gy <= L.ly - 2 && ((gx >= 1 && gx <= L.lx - 2) || s_yedge);
-    return copied ? T.F(qo, px, py) : T.F(q, px - ex, py - ey);
+    return copied ? C.own(qo) : C.in(qo);
   }
-  const int oS = T.O(px - ex, py - ey);
-  if (oS == -1) return T.F(q, px - ex, py - ey);  // plain streaming from a fluid node
-  const int oP = T.O(px, py);
-  if (oP != -1)  // solid -> non-fluid link: active solid nodes reset the slot to w (main.c:1161-1162)
-    return T.active(L, G, px - ex, py - ey, sxg, syg) ? Wq(q) : T.F(q, px - ex, py - ey);
+  const int oS = C.o_nb(qo);
+  if (oS == -1) return C.in(qo);  // plain streaming from a fluid node
+  if (C.o_own() != -1)  // solid -> non-fluid link: active solid nodes reset the slot to w (main.c:1161-1162)
+    return C.act_nb(qo) ? Wq(q) : C.in(qo);
 
   // P fluid, S an (active) solid node of grain oS: interpolated bounce-back
-  const IbbLink k = ibb_link<q>(L, G, oS, sxg, syg);
-  if (ibb_far(k)) return ibb_far_value<q>(L, k, T.F(qo, px, py), T.F(q, px, py));
-  if (!ibb_near(k)) return T.F(q, px - ex, py - ey);  // neither branch fires: slot keeps its value
+  const IbbLink k = ibb_link<q>(L, C.gp(oS), sxg, syg);
+  if (ibb_far(k)) return ibb_far_value<q>(L, k, C.own(qo), C.own(q));
+  if (!ibb_near(k)) return C.in(qo);  // neither branch fires: slot keeps its value
 
   // 0 < delta < 1/2: the reference reads f[NN][opp q], NN = P + e_q, *in place* (main.c:1181,1213).
   double f2;
   const int nxg = gx + ex, nyg = gy + ey;
-  const bool n_interior = nxg >= 1 && nxg <= L.lx - 2 && nyg >= 1 && nyg <= L.ly - 2;
+  const bool n_interior = !EDGE || (nxg >= 1 && nxg <= L.lx - 2 && nyg >= 1 && nyg <= L.ly - 2);
   if (!n_interior) {
-    f2 = T.F(q, px, py);  // edge wall node: its slot opp q was set by the edge copy to f*[P][q]
+    f2 = C.own(q);  // edge wall node: its slot opp q was set by the edge copy to f*[P][q]
   } else {
-    const int oN = T.O(px + ex, py + ey);
-    f2 = T.F(qo, px + ex, py + ey);  // fluid: post-collision; solid: value before the IBB loop
+    const int oN = C.o_nb(q);
+    f2 = C.in(q);  // fluid: post-collision; solid: value before the IBB loop
     // NN is solid and precedes S in the reference's x-outer/y-inner scan (e_q lexicographically
     // negative, q = 1..4): S reads the value NN's own IBB update has already produced. That update
     // saw S's slot q in its pre-loop state (S comes later), so the chain ends here.
     if (oN != -1 && q <= 4) {
-      const IbbLink kn = ibb_link<qo>(L, G, oN, nxg, nyg);
-      if (ibb_far(kn)) f2 = ibb_far_value<qo>(L, kn, T.F(q, px, py), T.F(qo, px, py));
-      else if (ibb_near(kn)) f2 = ibb_near_value<qo>(L, kn, T.F(q, px, py), T.F(q, px - ex, py - ey));
+      const IbbLink kn = ibb_link<qo>(L, C.gp(oN), nxg, nyg);
+      if (ibb_far(kn)) f2 = ibb_far_value<qo>(L, kn, C.own(q), C.own(qo));
+      else if (ibb_near(kn)) f2 = ibb_near_value<qo>(L, kn, C.own(q), C.in(qo));
     }
   }
-  return ibb_near_value<q>(L, k, T.F(qo, px, py), f2);
+  return ibb_near_value<q>(L, k, C.own(qo), f2);
 }
+
+// context over the LDS tile
+template <int TX, int TY>
+struct TileCtx {
+  const Tile<TX, TY>& T;
+  const LatticeView& L;
+  const GrainFluidView& G;
+  int px, py, gx, gy;
+  __device__ __forceinline__ double own(int q) const { return T.F(q, px, py); }
+  __device__ __forceinline__ double in(int d) const { return T.F(OPPq(d), px + EXq(d), py + EYq(d)); }
+  __device__ __forceinline__ int o_own() const { return T.O(px, py); }
+  __device__ __forceinline__ int o_nb(int d) const { return T.O(px + EXq(d), py + EYq(d)); }
+  __device__ __forceinline__ bool act_nb(int d) const {
+    return T.active(L, G, px + EXq(d), py + EYq(d), gx + EXq(d), gy + EYq(d));
+  }
+  __device__ __forceinline__ GP gp(int i) const { return load_gp(G, i); }
+};
 
 template <int TX, int TY>
 __global__ __launch_bounds__(256) void k_collide_stream(const double* __restrict__ fin,
                                                         double* __restrict__ fout,
                                                         const int* __restrict__ ob_old,
                                                         const int* __restrict__ ob_new, LatticeView L,
-                                                        GrainFluidView G) {
+                                                        GrainFluidView G, int tiles_y, int ntiles,
+                                                        int xcd_remap) {
   using TT = Tile<TX, TY>;
   __shared__ double sF[9 * TT::RX * TT::RY];
   __shared__ int sO[TT::OX * TT::OY];
   TT T{sF, sO};
   const int tid = threadIdx.x;
-  const int ty0 = blockIdx.x * TY;           // global y of the tile origin
-  const int txl0 = L.xo0 + blockIdx.y * TX;  // local row of the tile origin
+  // Tile index. Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), each
+  // with a private L2. With the remap, XCD k walks the k-th contiguous eighth of the tile sequence
+  // (y fastest), so tiles that share halo rows/columns run on the same XCD close in time and the
+  // halo re-reads hit that L2. Placement only affects speed.
+  int t = blockIdx.x;
+  if (xcd_remap) {
+    const int per = gridDim.x >> 3;
+    t = (t & 7) * per + (t >> 3);
+  }
+  if (t >= ntiles) return;
+  const int ty0 = (t % tiles_y) * TY;           // global y of the tile origin
+  const int txl0 = L.xo0 + (t / tiles_y) * TX;  // local row of the tile origin
 
   // obstacle ids, halo 2; positions off the lattice read as "wall" so they never look fluid
   for (int k = tid; k < TT::OX * TT::OY; k += 256) {
@@ -319,7 +382,7 @@ __global__ __launch_bounds__(256) void k_collide_stream(const double* __restrict
     // state: nodes that were solid restart from the grain's equilibrium
     const int oo = interior ? ob_old[node] : -1;
     if (oo != -1) {
-      grain_equilibrium(L, G, oo, gx, y, f);
+      grain_equilibrium(L, load_gp(G, oo), gx, y, f);
     } else {
 #pragma unroll
       for (int q = 0; q < 9; ++q) f[q] = fin[q * L.plane + node];
@@ -337,15 +400,265 @@ __global__ __launch_bounds__(256) void k_collide_stream(const double* __restrict
     if (xl >= L.xo1 || gy >= L.ly) continue;
     const int gx = L.gx0 + xl;
     const long node = (long)xl * L.sy + gy;
+    const TileCtx<TX, TY> C{T, L, G, px, py, gx, gy};
     fout[node] = T.F(0, px, py);
-    fout[1 * L.plane + node] = pull_one<1>(T, L, G, px, py, gx, gy);
-    fout[2 * L.plane + node] = pull_one<2>(T, L, G, px, py, gx, gy);
-    fout[3 * L.plane + node] = pull_one<3>(T, L, G, px, py, gx, gy);
-    fout[4 * L.plane + node] = pull_one<4>(T, L, G, px, py, gx, gy);
-    fout[5 * L.plane + node] = pull_one<5>(T, L, G, px, py, gx, gy);
-    fout[6 * L.plane + node] = pull_one<6>(T, L, G, px, py, gx, gy);
-    fout[7 * L.plane + node] = pull_one<7>(T, L, G, px, py, gx, gy);
-    fout[8 * L.plane + node] = pull_one<8>(T, L, G, px, py, gx, gy);
+    fout[1 * L.plane + node] = pull_one<1>(C, L, G, gx, gy);
+    fout[2 * L.plane + node] = pull_one<2>(C, L, G, gx, gy);
+    fout[3 * L.plane + node] = pull_one<3>(C, L, G, gx, gy);
+    fout[4 * L.plane + node] = pull_one<4>(C, L, G, gx, gy);
+    fout[5 * L.plane + node] = pull_one<5>(C, L, G, gx, gy);
+    fout[6 * L.plane + node] = pull_one<6>(C, L, G, gx, gy);
+    fout[7 * L.plane + node] = pull_one<7>(C, L, G, gx, gy);
+    fout[8 * L.plane + node] = pull_one<8>(C, L, G, gx, gy);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the fused fluid kernel, register-resident "marching" form
+// ---------------------------------------------------------------------------------------------
+//
+// One WAVEFRONT owns a window of 64 consecutive y (62 produce output, the two edge lanes only feed
+// their neighbours) and walks along x over LX rows. Each lane keeps the f* of its column for three
+// consecutive rows in registers (27 doubles); row x+1 is loaded, re-initialised/collided and rotated
+// in while row x is produced. The six diagonal/vertical neighbours a pull needs live in the adjacent
+// lanes and are fetched with cross-lane shuffles; the obstacle ids of the 3x3 neighbourhood are read
+// directly (they are 4-byte, cached). No LDS, no barriers: waves are independent, every load of a
+// row is a full 512-byte coalesced request, and the next row's loads are in flight while the
+// current one is computed. Redundant work: 2 of 64 lanes and 2 of LX+2 rows.
+
+struct Ids3 { int m, c, p; };  // obstacle ids at (y-1, y, y+1) of one row
+
+__device__ __forceinline__ Ids3 load_ids(const int* __restrict__ ob, const LatticeView& L, int xl, int y) {
+  Ids3 r{L.n, L.n, L.n};  // off the lattice reads as "wall": never fluid
+  if (xl >= 0 && xl < L.nxl) {
+    const int* row = ob + (long)xl * L.sy;
+    if (y - 1 >= 0 && y - 1 < L.ly) r.m = row[y - 1];
+    if (y >= 0 && y < L.ly) r.c = row[y];
+    if (y + 1 >= 0 && y + 1 < L.ly) r.p = row[y + 1];
+  }
+  return r;
+}
+
+// `act` of the centre node of a 3x3 block of ids (rows a = x-1, b = x, c = x+1); see Tile::active
+__device__ __forceinline__ bool node_active(const LatticeView& L, const GrainFluidView& G, const Ids3& a,
+                                            const Ids3& b, const Ids3& c, int gx, int gy) {
+  const int o = b.c;
+  // neighbour ids in direction order 1..8: (-1,1) (-1,0) (-1,-1) (0,-1) (1,-1) (1,0) (1,1) (0,1)
+  const int nb[9] = {0, a.p, a.c, a.m, b.m, c.m, c.c, c.p, b.p};
+  bool higher = false;
+#pragma unroll
+  for (int q = 1; q < 9; ++q) {
+    if (nb[q] == -1) return true;
+    higher |= (nb[q] > o && nb[q] != L.n);
+  }
+  if (!higher) return false;
+  const double xc = G.xc[o], yc = G.yc[o], r2 = G.r2[o], rb = G.rbl0[o];
+  const double R2 = rb * rb;
+#pragma unroll
+  for (int q = 1; q < 9; ++q) {
+    if (nb[q] > o && nb[q] != L.n) {
+      const int x = gx + EXq(q), y = gy + EYq(q);
+      const double d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc);
+      if (!(d2 <= R2 && d2 <= r2)) return true;
+    }
+  }
+  return false;
+}
+
+struct RegCtx {
+  double Fo[9];   // f*[P][q]
+  double In[9];   // f*[P + e_d][opp d]
+  int o0;
+  int onb[9];
+  unsigned act;   // bit d: act of the neighbour in direction d
+  const GrainFluidView* G;
+  int gid;        // grain whose record was prefetched for this node (-1: none)
+  GP gpc;
+  __device__ __forceinline__ GP gp(int i) const { return i == gid ? gpc : load_gp(*G, i); }
+  __device__ __forceinline__ double own(int q) const { return Fo[q]; }
+  __device__ __forceinline__ double in(int d) const { return In[d]; }
+  __device__ __forceinline__ int o_own() const { return o0; }
+  __device__ __forceinline__ int o_nb(int d) const { return onb[d]; }
+  __device__ __forceinline__ bool act_nb(int d) const { return (act >> d) & 1u; }
+};
+
+template <bool EDGE, class Ctx>
+__device__ __forceinline__ void store_row(double* __restrict__ fout, const LatticeView& L,
+                                          const GrainFluidView& G, const Ctx& C, long node, int gx, int y) {
+  fout[node] = C.own(0);
+  fout[1 * L.plane + node] = pull_one<1, EDGE>(C, L, G, gx, y);
+  fout[2 * L.plane + node] = pull_one<2, EDGE>(C, L, G, gx, y);
+  fout[3 * L.plane + node] = pull_one<3, EDGE>(C, L, G, gx, y);
+  fout[4 * L.plane + node] = pull_one<4, EDGE>(C, L, G, gx, y);
+  fout[5 * L.plane + node] = pull_one<5, EDGE>(C, L, G, gx, y);
+  fout[6 * L.plane + node] = pull_one<6, EDGE>(C, L, G, gx, y);
+  fout[7 * L.plane + node] = pull_one<7, EDGE>(C, L, G, gx, y);
+  fout[8 * L.plane + node] = pull_one<8, EDGE>(C, L, G, gx, y);
+}
+
+__device__ __forceinline__ double shfl_up1(double v) { return __shfl_up(v, 1, 64); }
+__device__ __forceinline__ double shfl_dn1(double v) { return __shfl_down(v, 1, 64); }
+
+template <int LX, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict__ fin, double* __restrict__ fout,
+                                                  const int* __restrict__ ob_old,
+                                                  const int* __restrict__ ob_new, LatticeView L,
+                                                  GrainFluidView G, int nstrips, int nwork, int xcd_remap) {
+  const int lane = threadIdx.x & 63;
+  int blk = blockIdx.x;
+  if (xcd_remap) {  // XCD k (blocks b % 8 == k) walks the k-th contiguous eighth of the work list
+    const int per = gridDim.x >> 3;
+    blk = (blk & 7) * per + (blk >> 3);
+  }
+  const int w = blk * 4 + (threadIdx.x >> 6);
+  if (w >= nwork) return;  // whole wave
+  const int strip = w % nstrips, seg = w / nstrips;
+  const int y = strip * 62 - 1 + lane;
+  const bool yin = y >= 0 && y < L.ly;
+  const bool writer = lane >= 1 && lane <= 62 && yin;
+  const bool deep_y = strip * 62 >= 2 && strip * 62 + 61 <= L.ly - 3;  // producing lanes 1..62
+  const int xs = L.xo0 + seg * LX;
+  const int xe = xs + LX < L.xo1 ? xs + LX : L.xo1;
+
+  // Software pipeline, per iteration x (producing row x):
+  //   populations + old id of row x+2          are loaded        (used next iteration)
+  //   new ids of row x+3                        are loaded
+  //   record of the grain that owned (x+2, y) in the previous map  is loaded  (reinit of row x+2)
+  //   record of the grain adjacent to (x+1, y)  is loaded         (bounce-back links of row x+1)
+  // so that every divergent path of the row being produced is pure arithmetic on registers.
+  auto row_ok = [&](int xl) { return yin && xl >= 0 && xl < L.nxl; };
+  auto load_old = [&](int xl) { return row_ok(xl) ? ob_old[(long)xl * L.sy + y] : -1; };
+  auto load_raw = [&](int xl, double (&raw)[9]) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) raw[q] = 0.0;
+    if (row_ok(xl)) {
+      const long node = (long)xl * L.sy + y;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) raw[q] = fin[q * L.plane + node];
+    }
+  };
+  auto interior = [&](int xl) {
+    const int gx = L.gx0 + xl;
+    return row_ok(xl) && gx >= 1 && gx <= L.lx - 2 && y >= 1 && y <= L.ly - 2;
+  };
+  // f* of one node: reinit (previous map) + collide (current map)
+  auto make_fstar = [&](int xl, double (&f)[9], int oo, const GP& g, int on) {
+    const bool in = interior(xl);
+    if (in && oo != -1) grain_equilibrium(L, g, L.gx0 + xl, y, f);
+    if (in && on == -1) mrt_collide(L, f);
+  };
+  // the grain next to a fluid node (highest index among the 8 neighbours; walls and fluid excluded)
+  auto adjacent_grain = [&](const Ids3& a, const Ids3& b, const Ids3& c) {
+    int g = -1;
+    const int nb[8] = {a.m, a.c, a.p, b.m, b.p, c.m, c.c, c.p};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g = (nb[k] != L.n && nb[k] > g) ? nb[k] : g;
+    return g;
+  };
+  auto safe_gp = [&](int i) { return load_gp(G, i < 0 ? 0 : i); };
+
+  double Fm[9], F0[9], Fp[9], raw[9];
+  Ids3 iA = load_ids(ob_new, L, xs - 2, y);  // row x-2 (only needed for act of row x-1)
+  Ids3 iB = load_ids(ob_new, L, xs - 1, y);  // row x-1
+  Ids3 iC = load_ids(ob_new, L, xs, y);      // row x
+  Ids3 iD = load_ids(ob_new, L, xs + 1, y);  // row x+1
+  Ids3 iE = load_ids(ob_new, L, xs + 2, y);  // row x+2
+  {
+    int oo = load_old(xs - 1);
+    load_raw(xs - 1, Fm);
+    make_fstar(xs - 1, Fm, oo, safe_gp(oo), iB.c);
+    oo = load_old(xs);
+    load_raw(xs, F0);
+    make_fstar(xs, F0, oo, safe_gp(oo), iC.c);
+  }
+  // Pipeline state at loop entry (iteration x = xs):
+  //   raw   = populations of row x+1        raw2 = populations of row x+2   (two rows of prefetch)
+  //   oo1/oo2/oo3 = previous-map ids of rows x+1 / x+2 / x+3
+  //   gre   = record of the grain that owned (x+1, y) before          (reinit of row x+1)
+  //   gib0  = record of the grain adjacent to (x, y)                   (bounce-back links of row x)
+  //   ids   : rows x-1 .. x+2 in iB..iE, row x+3 in flight (inext)
+  // gfx9 retires vector-memory operations in issue order (one vmcnt counter): waiting for a young
+  // small gather drains every older load. So each iteration issues the small gathers FIRST, then
+  // the nine big row loads, and the stores last -- data is then consumed in the order it was
+  // requested and the row loads really stay in flight for two iterations.
+  double raw2[9];
+  int oo1 = load_old(xs + 1);
+  int oo2 = load_old(xs + 2);
+  int oo3 = load_old(xs + 3);
+  Ids3 inext = load_ids(ob_new, L, xs + 3, y);
+  int gid0 = adjacent_grain(iB, iC, iD);
+  GP gib0 = safe_gp(gid0);
+  GP gre = safe_gp(oo1);
+  load_raw(xs + 1, raw);
+  load_raw(xs + 2, raw2);
+  bool actm = iB.c != -1 && node_active(L, G, iA, iB, iC, L.gx0 + xs - 1, y);
+  bool act0 = iC.c != -1 && node_active(L, G, iB, iC, iD, L.gx0 + xs, y);
+
+  for (int x = xs; x < xe; ++x) {
+    // row x+1 becomes available
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Fp[q] = raw[q];
+    make_fstar(x + 1, Fp, oo1, gre, iD.c);
+    // ---- small gathers for the next iterations, issued first
+    oo1 = oo2;
+    oo2 = oo3;
+    gre = safe_gp(oo1);                           // reinit record of row x+2
+    const int gid1 = adjacent_grain(iC, iD, iE);  // bounce-back grain of row x+1
+    const GP gib1 = safe_gp(gid1);
+    const Ids3 iF = inext;                        // row x+3
+    inext = load_ids(ob_new, L, x + 4, y);
+    oo3 = load_old(x + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the big loads: populations of row x+3
+#pragma unroll
+    for (int q = 0; q < 9; ++q) raw[q] = raw2[q];
+    load_raw(x + 3, raw2);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool actp = iD.c != -1 && node_active(L, G, iC, iD, iE, L.gx0 + x + 1, y);
+
+    RegCtx C;
+    C.G = &G;
+    C.gid = gid0;
+    C.gpc = gib0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) C.Fo[q] = F0[q];
+    C.In[0] = 0.0;
+    C.In[2] = Fm[6];            // (-1, 0): same lane, row x-1, slot opp(2) = 6
+    C.In[6] = Fp[2];            // ( 1, 0)
+    C.In[1] = shfl_dn1(Fm[5]);  // (-1, 1): lane+1, row x-1, slot 5
+    C.In[8] = shfl_dn1(F0[4]);  // ( 0, 1)
+    C.In[7] = shfl_dn1(Fp[3]);  // ( 1, 1)
+    C.In[3] = shfl_up1(Fm[7]);  // (-1,-1): lane-1
+    C.In[4] = shfl_up1(F0[8]);  // ( 0,-1)
+    C.In[5] = shfl_up1(Fp[1]);  // ( 1,-1)
+    C.o0 = iC.c;
+    C.onb[0] = 0;
+    C.onb[1] = iB.p; C.onb[2] = iB.c; C.onb[3] = iB.m; C.onb[4] = iC.m;
+    C.onb[5] = iD.m; C.onb[6] = iD.c; C.onb[7] = iD.p; C.onb[8] = iC.p;
+    const int pack = (actm ? 1 : 0) | (act0 ? 2 : 0) | (actp ? 4 : 0);  // rows x-1, x, x+1 of this lane
+    const int pk_up = __shfl_down(pack, 1, 64);                        // lane+1 (y+1)
+    const int pk_dn = __shfl_up(pack, 1, 64);                          // lane-1 (y-1)
+    C.act = (((pk_up >> 0) & 1u) << 1) | (((pack >> 0) & 1u) << 2) | (((pk_dn >> 0) & 1u) << 3) |
+            (((pk_dn >> 1) & 1u) << 4) | (((pk_dn >> 2) & 1u) << 5) | (((pack >> 2) & 1u) << 6) |
+            (((pk_up >> 2) & 1u) << 7) | (((pk_up >> 1) & 1u) << 8);
+
+    {
+      const int gx = L.gx0 + x;
+      const long node = (long)x * L.sy + y;
+      // wave-uniform: is every producing lane of this row at least two nodes away from all edges?
+      const bool deep = deep_y && gx >= 2 && gx <= L.lx - 3;
+      if (deep) {
+        if (writer) store_row<false>(fout, L, G, C, node, gx, y);
+      } else {
+        if (writer) store_row<true>(fout, L, G, C, node, gx, y);
+      }
+    }
+    // rotate
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { Fm[q] = F0[q]; F0[q] = Fp[q]; }
+    iB = iC; iC = iD; iD = iE; iE = iF;
+    actm = act0; act0 = actp;
+    gid0 = gid1; gib0 = gib1;
   }
 }
 
@@ -371,44 +684,167 @@ __device__ __forceinline__ bool grain_owned(const LatticeView& L, double xc) {
   return (first || xc >= (double)lo) && (last || xc < (double)hi);
 }
 
-// Parity kernel: one thread per grain, the reference's serial x -> y -> q accumulation order.
-__global__ void k_forces_parity(const double* __restrict__ f, const int* __restrict__ obst, LatticeView L,
-                                GrainFluidView G, double scale12, double scale3,
-                                double* __restrict__ fhf, unsigned char* __restrict__ owner) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= L.n) return;
+// Parity kernel: ONE WAVEFRONT PER GRAIN, bit-exact with the reference's serial x -> y -> q
+// accumulation (main.c:1305-1321). The kernel is latency-bound (a grain touches ~0.5 KB of obst and
+// ~2 KB of f scattered over ~20 rows), so it is organised to need only TWO dependent global round
+// trips per grain and little LDS (many resident waves):
+//  A0  the grain's footprint (bounding box + 1) of "obst == i" flags is staged in LDS: one round of
+//      independent loads.
+//  A1  lanes scan the bounding box in the reference's order (x outer, y inner), find boundary nodes
+//      from the LDS flags and compact them (ballot prefix) into an LDS list with their link masks.
+//  A2  one lane per boundary node: all populations of all its links are loaded in one round; every
+//      link yields a term (fnx, fny, -fnx*(y-yc), fny*(x-xc)) -- the products do not depend on the
+//      running sums -- stored in LDS in scan order (prefix sum of link counts).
+//  B   serial, as it must be: three lanes replay the additions in that exact order, one lane per
+//      accumulator chain: h1 += fnx; h2 += fny; h3 = (h3 - fnx*(y-yc)) + fny*(x-xc), all written as
+//      h = (h + a) + b with b = +0.0 for the first two (x + (+0.0) is exact; x - p == x + (-p)).
+constexpr int FORCE_TILE = 40;       // footprint edge staged in LDS (bounding box + 2); larger grains take the slow path
+constexpr int FORCE_BN_CAP = 512;    // boundary nodes kept per grain before a flush
+constexpr int FORCE_TERMS_CAP = 128; // terms replayed per batch
+
+__global__ __launch_bounds__(64) void k_forces_parity(const double* __restrict__ f,
+                                                      const int* __restrict__ obst, LatticeView L,
+                                                      GrainFluidView G, double scale12, double scale3,
+                                                      double* __restrict__ fhf,
+                                                      unsigned char* __restrict__ owner) {
+  __shared__ double sT[FORCE_TERMS_CAP * 4 + 2];      // [term][fnx, fny, -p1, p2], then a zero slot
+  __shared__ unsigned char sIn[FORCE_TILE * FORCE_TILE];  // 1 = node belongs to grain i
+  __shared__ unsigned short sBnK[FORCE_BN_CAP];       // boundary node: index in the bounding box
+  __shared__ unsigned char sBnM[FORCE_BN_CAP];        //                link mask (bit q-1)
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x;
   const double xc = G.xc[i], yc = G.yc[i];
   const bool own = grain_owned(L, xc);
-  if (owner) owner[i] = own ? 1 : 0;
-  double h1 = 0, h2 = 0, h3 = 0;
+  double h = 0.0;  // lanes 0,1,2 hold h1,h2,h3
+  const int zero_slot = FORCE_TERMS_CAP * 4;
+  if (lane == 0) sT[zero_slot] = 0.0;
+  const int a_off = lane < 3 ? lane : 0;  // fnx | fny | -p1
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   int xi, xf, yi, yf;
   if (own && grain_box(L, G, i, xi, xf, yi, yf)) {
-    for (int x = xi; x <= xf; ++x) {
-      const long rowP = (long)(x - L.gx0) * L.sy;
-      for (int y = yi; y <= yf; ++y) {
-        if (obst[rowP + y] != i) continue;
+    const int nx = xf - xi + 1, ny = yf - yi + 1;
+    const int total = nx * ny;
+    const int tx = nx + 2, ty = ny + 2;
+    const bool staged = tx <= FORCE_TILE && ty <= FORCE_TILE && total <= 65535;
+    if (staged) {  // A0
+      for (int k = lane; k < tx * ty; k += 64) {
+        const int x = xi - 1 + k / ty, y = yi - 1 + k % ty;  // in-bounds: the box is clamped to [1, l-2]
+        sIn[k] = obst[(long)(x - L.gx0) * L.sy + y] == i ? 1 : 0;
+      }
+      __syncthreads();
+    }
+    // boundary-node list is consumed whenever it fills up or the scan ends
+    int nbn = 0;
+    for (int base = 0; base < total || nbn > 0; base += 64) {
+      // A1: classify 64 bounding-box nodes
+      if (base < total) {
+        const int k = base + lane;
+        unsigned m = 0;
+        if (k < total) {
+          const int bx = k / ny, by = k % ny;
+          if (staged) {
+            const unsigned char* c = &sIn[(bx + 1) * ty + (by + 1)];
+            if (c[0]) {
 #pragma unroll
-        for (int q = 1; q < 9; ++q) {
-          const int ex = EXq(q), ey = EYq(q), qo = OPPq(q);
-          const long nodeN = (long)(x + ex - L.gx0) * L.sy + (y + ey);
-          if (obst[nodeN] == i) continue;
-          const double s = f[qo * L.plane + rowP + y] + f[q * L.plane + nodeN];
-          const double fnx = s * EXq(qo);
-          const double fny = s * EYq(qo);
-          h1 = h1 + fnx;
-          h2 = h2 + fny;
-          h3 = h3 - fnx * (y - yc) + fny * (x - xc);
+              for (int q = 1; q < 9; ++q)
+                if (!c[EXq(q) * ty + EYq(q)]) m |= 1u << (q - 1);
+            }
+          } else {
+            const int x = xi + bx, y = yi + by;
+            if (obst[(long)(x - L.gx0) * L.sy + y] == i) {
+#pragma unroll
+              for (int q = 1; q < 9; ++q)
+                if (obst[(long)(x + EXq(q) - L.gx0) * L.sy + (y + EYq(q))] != i) m |= 1u << (q - 1);
+            }
+          }
+        }
+        const unsigned long long bal = __ballot(m != 0);
+        if (m != 0) {
+          const int slot = nbn + __popcll(bal & lt_mask);
+          sBnK[slot] = (unsigned short)k;
+          sBnM[slot] = (unsigned char)m;
+        }
+        nbn += __popcll(bal);
+      }
+      const bool last = base + 64 >= total;
+      if (!(last || nbn > FORCE_BN_CAP - 64)) continue;  // wave-uniform: keep collecting
+      __syncthreads();
+      // A2 + B over the collected boundary nodes, 64 at a time
+      for (int b0 = 0; b0 < nbn; b0 += 64) {
+        const int bi = b0 + lane;
+        unsigned mask = 0;
+        double fx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double wx = 0.0, wy = 0.0;
+        if (bi < nbn) {
+          const int k = sBnK[bi];
+          mask = sBnM[bi];
+          const int x = xi + k / ny, y = yi + k % ny;
+          const long nodeP = (long)(x - L.gx0) * L.sy + y;
+          wx = x - xc;
+          wy = y - yc;
+#pragma unroll
+          for (int q = 1; q < 9; ++q) {
+            if (mask & (1u << (q - 1))) {
+              const int qo = OPPq(q);
+              const long nodeN = (long)(x + EXq(q) - L.gx0) * L.sy + (y + EYq(q));
+              const double s = f[qo * L.plane + nodeP] + f[q * L.plane + nodeN];
+              fx[q - 1] = s * EXq(qo);
+              fy[q - 1] = s * EYq(qo);
+            }
+          }
+        }
+        const int cnt = __popc(mask);
+        int pos = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int v = __shfl_up(pos, off, 64);
+          if (lane >= off) pos += v;
+        }
+        const int nterms = __shfl(pos, 63, 64);
+        pos -= cnt;
+        for (int lo = 0; lo < nterms; lo += FORCE_TERMS_CAP) {  // wave-uniform
+          __syncthreads();  // the previous batch has been consumed (one-wave workgroup: cheap)
+          int p = pos;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            if (mask & (1u << q)) {
+              if (p >= lo && p < lo + FORCE_TERMS_CAP) {
+                double* t = &sT[(p - lo) * 4];
+                t[0] = fx[q];
+                t[1] = fy[q];
+                t[2] = fx[q] * (-wy);
+                t[3] = fy[q] * wx;
+              }
+              ++p;
+            }
+          }
+          const int nb = nterms - lo < FORCE_TERMS_CAP ? nterms - lo : FORCE_TERMS_CAP;
+          // pad the batch to a multiple of 8 with zero terms: (h + 0.0) + 0.0 == h exactly
+          const int nb8 = (nb + 7) & ~7;
+          if (lane < 4 * (nb8 - nb)) sT[nb * 4 + lane] = 0.0;
+          __syncthreads();
+          if (lane < 3) {
+            const int b_off = lane == 2 ? 3 : -1;
+            for (int t = 0; t < nb8; t += 8) {
+              double a[8], b[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {  // loads do not depend on h: issue them ahead of the chain
+                a[u] = sT[(t + u) * 4 + a_off];
+                b[u] = sT[b_off >= 0 ? (t + u) * 4 + b_off : zero_slot];
+              }
+#pragma unroll
+              for (int u = 0; u < 8; ++u) h = (h + a[u]) + b[u];
+            }
+          }
         }
       }
+      __syncthreads();
+      nbn = 0;
+      if (last) break;
     }
   }
-  if (own) {
-    fhf[i] = h1 * scale12;
-    fhf[L.n + i] = h2 * scale12;
-    fhf[2 * L.n + i] = h3 * scale3;
-  } else {
-    fhf[i] = 0; fhf[L.n + i] = 0; fhf[2 * L.n + i] = 0;
-  }
+  if (lane == 0 && owner) owner[i] = own ? 1 : 0;
+  if (lane < 3) fhf[lane * L.n + i] = own ? h * (lane == 2 ? scale3 : scale12) : 0.0;
 }
 
 // Fast kernel: one wavefront per grain, lanes take bounding-box nodes, cross-lane shuffle reduction.
@@ -574,10 +1010,11 @@ void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st) {
 }
 
 void launch_grain_geom(int n, const double* x1, const double* x2, const double* r, const double* rLB,
-                       double Mgx, double Mby, double dx, double* xc, double* yc, double* r2,
-                       double* rbl0, hipStream_t st) {
-  hipLaunchKernelGGL(k_grain_geom, dim3((n + 255) / 256), dim3(256), 0, st, n, x1, x2, r, rLB, Mgx, Mby,
-                     dx, xc, yc, r2, rbl0);
+                       const double* v1, const double* v2, const double* v3, double Mgx, double Mby,
+                       double dx, double* xc, double* yc, double* r2, double* rbl0, double* pk,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(k_grain_geom, dim3((n + 255) / 256), dim3(256), 0, st, n, x1, x2, r, rLB, v1, v2, v3, Mgx,
+                     Mby, dx, xc, yc, r2, rbl0, pk);
 }
 
 void launch_obst_paint(int* obst, const LatticeView& L, const GrainFluidView& G, hipStream_t st) {
@@ -585,20 +1022,64 @@ void launch_obst_paint(int* obst, const LatticeView& L, const GrainFluidView& G,
   hipLaunchKernelGGL(k_obst_paint, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, obst, L, G);
 }
 
+template <int TX, int TY>
+static void launch_cs(const double* fin, double* fout, const int* obst_old, const int* obst_new,
+                      const LatticeView& L, const GrainFluidView& G, int remap, hipStream_t st) {
+  const int rows = L.xo1 - L.xo0;
+  const int tiles_y = (L.ly + TY - 1) / TY, tiles_x = (rows + TX - 1) / TX;
+  const int ntiles = tiles_y * tiles_x;
+  const int grid = remap ? ((ntiles + 7) / 8) * 8 : ntiles;
+  hipLaunchKernelGGL((k_collide_stream<TX, TY>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new,
+                     L, G, tiles_y, ntiles, remap);
+}
+
+// tuning knob for experiments: LBMDEM_CS_VARIANT = tile shape (0..3) + 8 * xcd_remap
+static int cs_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("LBMDEM_CS_VARIANT");
+    v = e ? atoi(e) : 24;
+  }
+  return v;
+}
+
+template <int LX, int MINW>
+static void launch_march(const double* fin, double* fout, const int* obst_old, const int* obst_new,
+                         const LatticeView& L, const GrainFluidView& G, int remap, hipStream_t st) {
+  const int rows = L.xo1 - L.xo0;
+  const int nstrips = (L.ly + 61) / 62, nseg = (rows + LX - 1) / LX;
+  const int nwork = nstrips * nseg;
+  int grid = (nwork + 3) / 4;
+  if (remap) grid = ((grid + 7) / 8) * 8;
+  hipLaunchKernelGGL((k_cs_march<LX, MINW>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, L, G,
+                     nstrips, nwork, remap);
+}
+
 void launch_collide_stream(const double* fin, double* fout, const int* obst_old, const int* obst_new,
                            const LatticeView& L, const GrainFluidView& G, hipStream_t st) {
-  constexpr int TX = 8, TY = 64;
-  const int rows = L.xo1 - L.xo0;
-  dim3 grid((L.ly + TY - 1) / TY, (rows + TX - 1) / TX);
-  hipLaunchKernelGGL((k_collide_stream<TX, TY>), grid, dim3(256), 0, st, fin, fout, obst_old, obst_new,
-                     L, G);
+  const int v = cs_variant(), remap = (v >> 3) & 1;
+  switch (v & ~8) {
+    case 0: launch_cs<8, 64>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
+    case 1: launch_cs<4, 64>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
+    case 2: launch_cs<4, 128>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
+    case 3: launch_cs<2, 128>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
+    case 4: launch_cs<16, 32>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
+    case 16: launch_march<16, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
+    case 17: launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
+    case 18: launch_march<8, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
+    case 20: launch_march<16, 3>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
+    case 21: launch_march<32, 3>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
+    case 22: launch_march<8, 3>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
+    case 32: launch_march<16, 4>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
+    case 33: launch_march<32, 4>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
+    default: launch_march<16, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
+  }
 }
 
 void launch_forces_parity(const double* f, const int* obst, const LatticeView& L,
                           const GrainFluidView& G, double scale12, double scale3, double* fhf,
                           unsigned char* owner, hipStream_t st) {
-  hipLaunchKernelGGL(k_forces_parity, dim3((L.n + 63) / 64), dim3(64), 0, st, f, obst, L, G, scale12,
-                     scale3, fhf, owner);
+  hipLaunchKernelGGL(k_forces_parity, dim3(L.n), dim3(64), 0, st, f, obst, L, G, scale12, scale3, fhf, owner);
 }
 
 void launch_forces_fast(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,

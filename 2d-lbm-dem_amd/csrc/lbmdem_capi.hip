@@ -55,6 +55,7 @@ struct lbmdem_handle {
   int kcur = 0;
   double *r = nullptr, *m = nullptr, *It = nullptr, *rLB = nullptr;
   double *xc = nullptr, *yc = nullptr, *r2 = nullptr, *rbl0 = nullptr;
+  double* pk = nullptr;   // [n][8] packed fluid-side grain records
   double* fhf = nullptr;  // [3][n]
   unsigned char* owner = nullptr;
   double rmax = 0.0;
@@ -73,7 +74,7 @@ struct lbmdem_handle {
 
 static GrainFluidView gview(const lbmdem_handle* h) {
   const Kin& K = h->kin[h->kcur];
-  return GrainFluidView{K.x1, K.x2, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0};
+  return GrainFluidView{K.x1, K.x2, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0, h->pk};
 }
 
 static DemParams dem_params(const lbmdem_handle* h) {
@@ -174,8 +175,8 @@ void lbmdem_free_host(void* p) { free(p); }
 static int paint_into(lbmdem_handle* h, int* obst) {
   const Kin& K = h->kin[h->kcur];
   launch_obst_fill(obst, h->L, h->stream);
-  launch_grain_geom(h->n, K.x1, K.x2, h->r, h->rLB, h->cfg.Mgx, h->cfg.Mby, h->cfg.dx, h->xc, h->yc, h->r2,
-                    h->rbl0, h->stream);
+  launch_grain_geom(h->n, K.x1, K.x2, h->r, h->rLB, K.v1, K.v2, K.v3, h->cfg.Mgx, h->cfg.Mby, h->cfg.dx,
+                    h->xc, h->yc, h->r2, h->rbl0, h->pk, h->stream);
   launch_obst_paint(obst, h->L, gview(h), h->stream);
   HIP_TRY(hipGetLastError());
   return LBMDEM_OK;
@@ -243,8 +244,8 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
   CREATE_TRY(hipMalloc((void**)&h->f[1], fbytes));
   CREATE_TRY(hipMalloc((void**)&h->obst[0], sizeof(int) * (size_t)L.plane));
   CREATE_TRY(hipMalloc((void**)&h->obst[1], sizeof(int) * (size_t)L.plane));
-  // grains: 18 kinematic + r m It rLB xc yc r2 rbl0 + 3 fhf = 29 columns
-  const size_t cols = 18 + 8 + 3;
+  // grains: 18 kinematic + r m It rLB xc yc r2 rbl0 + 3 fhf + 8 packed = 37 columns
+  const size_t cols = 18 + 8 + 3 + 8;
   CREATE_TRY(hipMalloc((void**)&h->gbuf, sizeof(double) * cols * n));
   CREATE_TRY(hipMemset(h->gbuf, 0, sizeof(double) * cols * n));
   {
@@ -258,6 +259,7 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
     h->r = p0; h->m = p0 + n; h->It = p0 + 2 * n; h->rLB = p0 + 3 * n;
     h->xc = p0 + 4 * n; h->yc = p0 + 5 * n; h->r2 = p0 + 6 * n; h->rbl0 = p0 + 7 * n;
     h->fhf = p0 + 8 * n;
+    h->pk = p0 + 11 * (size_t)n;
   }
   CREATE_TRY(hipMalloc((void**)&h->owner, n));
   CREATE_TRY(hipMemset(h->owner, 1, n));

@@ -31,6 +31,9 @@ struct GrainFluidView {
   const double* x1; const double* x2;
   const double* v1; const double* v2; const double* v3;
   const double* xc; const double* yc; const double* r2; const double* rbl0;
+  // the same eight values packed per grain, [n][8] = {x1, x2, v1, v2, v3, xc, yc, r2}: one 64-byte
+  // record, fetched with four 16-byte loads by the fluid kernels
+  const double* pk;
 };
 
 struct DemParams {
@@ -56,8 +59,9 @@ struct Kin {
 // lbm_kernels.hip
 void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st);
 void launch_grain_geom(int n, const double* x1, const double* x2, const double* r, const double* rLB,
-                       double Mgx, double Mby, double dx, double* xc, double* yc, double* r2,
-                       double* rbl0, hipStream_t st);
+                       const double* v1, const double* v2, const double* v3, double Mgx, double Mby,
+                       double dx, double* xc, double* yc, double* r2, double* rbl0, double* pk,
+                       hipStream_t st);
 void launch_obst_paint(int* obst, const LatticeView& L, const GrainFluidView& G, hipStream_t st);
 void launch_collide_stream(const double* fin, double* fout, const int* obst_old, const int* obst_new,
                            const LatticeView& L, const GrainFluidView& G, hipStream_t st);

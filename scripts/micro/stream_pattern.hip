@@ -1,0 +1,78 @@
+// Micro-benchmark: how fast can 9 fp64 planes be read and written with the access patterns considered
+// for the fused collide+stream kernel? No arithmetic beyond a dependency-keeping add.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+// A: one wave = 64-wide window (62 writers, offset -1), marches LX rows, prefetch 1 row ahead
+template <int LX, int USE, int OFF, int WORK = 0, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void k_march(const double* __restrict__ fin, double* __restrict__ fout, int lx, int ly,
+                                               long plane, int nstrips, int nwork, int remap) {
+  const int lane = threadIdx.x & 63;
+  int blk = blockIdx.x;
+  if (remap) { const int per = gridDim.x >> 3; blk = (blk & 7) * per + (blk >> 3); }
+  const int w = blk * 4 + (threadIdx.x >> 6);
+  if (w >= nwork) return;
+  const int strip = w % nstrips, seg = w / nstrips;
+  const int y = strip * USE - OFF + lane;
+  const bool yin = y >= 0 && y < ly;
+  const bool writer = lane >= OFF && lane < OFF + USE && yin;
+  const int xs = seg * LX, xe = min(xs + LX, lx);
+  double cur[9], nxt[9];
+  for (int q = 0; q < 9; ++q) cur[q] = yin ? fin[q * plane + (long)xs * ly + y] : 0.0;
+  for (int x = xs; x < xe; ++x) {
+    const int xn = x + 1 < lx ? x + 1 : x;
+    for (int q = 0; q < 9; ++q) nxt[q] = yin ? fin[q * plane + (long)xn * ly + y] : 0.0;
+    // synthetic VALU load: WORK x 9 dependent-per-q fp64 FMAs (independent across q)
+    for (int k = 0; k < WORK; ++k)
+      for (int q = 0; q < 9; ++q) cur[q] = cur[q] * 1.0000001 + 0.5;
+    if (writer) for (int q = 0; q < 9; ++q) fout[q * plane + (long)x * ly + y] = cur[q] + 1.0;
+    for (int q = 0; q < 9; ++q) cur[q] = nxt[q];
+  }
+}
+
+// B: plain grid-stride copy, 16 B per lane
+__global__ void k_copy16(const double2* __restrict__ in, double2* __restrict__ out, long n2) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+    double2 v = in[i]; v.x += 1.0; v.y += 1.0; out[i] = v;
+  }
+}
+// C: plain grid-stride copy, 8 B per lane
+__global__ void k_copy8(const double* __restrict__ in, double* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = in[i] + 1.0;
+}
+
+template <class F> float timeit(F f, int reps = 10) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  f(); hipDeviceSynchronize();
+  hipEventRecord(a); for (int i = 0; i < reps; ++i) f(); hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b); return ms / reps;
+}
+
+int main() {
+  const int lx = 4096, ly = 4096; const long plane = (long)lx * ly; const long n = 9 * plane;
+  double *a, *b; CK(hipMalloc(&a, n * 8)); CK(hipMalloc(&b, n * 8)); CK(hipMemset(a, 0, n * 8)); CK(hipMemset(b, 0, n * 8));
+  const double gb = 2.0 * n * 8 / 1e9;
+  auto rep = [&](const char* name, float ms) { printf("%-48s %.3f ms  %.0f GB/s\n", name, ms, gb / ms * 1e3); };
+  rep("copy 16B/lane grid-stride 2048x256", timeit([&] { hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, 0, (double2*)a, (double2*)b, n / 2); }));
+  rep("copy 8B/lane grid-stride 2048x256", timeit([&] { hipLaunchKernelGGL(k_copy8, dim3(2048), dim3(256), 0, 0, a, b, n); }));
+  rep("copy 8B/lane grid-stride 8192x256", timeit([&] { hipLaunchKernelGGL(k_copy8, dim3(8192), dim3(256), 0, 0, a, b, n); }));
+#define MARCH(LX, USE, OFF, REMAP, NAME) { const int ns = (ly + USE - 1) / USE, nseg = (lx + LX - 1) / LX, nw = ns * nseg; int g = (nw + 3) / 4; if (REMAP) g = (g + 7) / 8 * 8; \
+    rep(NAME, timeit([&] { hipLaunchKernelGGL((k_march<LX, USE, OFF>), dim3(g), dim3(256), 0, 0, a, b, lx, ly, plane, ns, nw, REMAP); })); }
+  MARCH(16, 62, 1, 1, "march LX16 62/64 off-1 remap");
+  MARCH(16, 62, 1, 0, "march LX16 62/64 off-1 noremap");
+  MARCH(16, 64, 0, 1, "march LX16 64/64 aligned remap");
+  MARCH(16, 64, 0, 0, "march LX16 64/64 aligned noremap");
+  MARCH(64, 64, 0, 1, "march LX64 64/64 aligned remap");
+  MARCH(8, 64, 0, 1, "march LX8 64/64 aligned remap");
+  MARCH(32, 62, 1, 1, "march LX32 62/64 off-1 remap");
+#define MARCHW(LX, WORK, MINW, NAME) { const int ns = (ly + 61) / 62, nseg = (lx + LX - 1) / LX, nw = ns * nseg; int g = ((nw + 3) / 4 + 7) / 8 * 8; \
+    rep(NAME, timeit([&] { hipLaunchKernelGGL((k_march<LX, 62, 1, WORK, MINW>), dim3(g), dim3(256), 0, 0, a, b, lx, ly, plane, ns, nw, 1); })); }
+  MARCHW(16, 28, 8, "march LX16 62/64 +252 FMA/row  8 waves/SIMD");
+  MARCHW(16, 56, 8, "march LX16 62/64 +504 FMA/row  8 waves/SIMD");
+  MARCHW(16, 112, 8, "march LX16 62/64 +1008 FMA/row 8 waves/SIMD");
+  MARCHW(16, 56, 2, "march LX16 62/64 +504 FMA/row  (minw 2)");
+  MARCHW(16, 112, 2, "march LX16 62/64 +1008 FMA/row (minw 2)");
+  return 0;
+}

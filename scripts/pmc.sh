@@ -1,0 +1,17 @@
+# usage: bash scripts/pmc.sh <tag> <variant> "<counters>"
+tag=$1; var=$2; ctrs=$3
+cd /tmp && export TMPDIR=/tmp
+LBMDEM_CS_VARIANT=$var rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag -o $tag -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}.log 2>&1
+python - <<PY
+import csv,glob,collections
+f=glob.glob("$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag/**/*counter_collection.csv", recursive=True)
+if not f: print("no counter file"); raise SystemExit
+acc=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
+for row in csv.DictReader(open(f[0])):
+    k=row["Kernel_Name"][:60]
+    acc[k][row["Counter_Name"]]+=float(row["Counter_Value"])
+    cnt[(k,row["Counter_Name"])]+=1
+for k,d in acc.items():
+    if "collide" in k or "march" in k or "forces" in k:
+        print(k, {c: round(v/cnt[(k,c)],1) for c,v in d.items()})
+PY

@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+VARS=${VARS:-"9 16 24 17 25 18 26 19 27"}
+for v in ${TESTVARS:-25}; do echo "pytest variant $v: $(LBMDEM_CS_VARIANT=$v python -m pytest tests -m gpu -x -q 2>&1 | tail -2 | tr '\n' ' ')"; done
+for v in $VARS; do
+  echo "variant $v: $(LBMDEM_CS_VARIANT=$v python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["collide_stream_kernel_ms"], d["roofline"]["frac"])')"
+done
