@@ -266,7 +266,7 @@ __device__ __forceinline__ double ibb_near_value(const LatticeView& L, const Ibb
 //   C.in(d)      f*[P + e_d][opp d]    the population of the neighbour in direction d that points at P
 //   C.o_own(), C.o_nb(d)               obstacle ids of P and of that neighbour
 //   C.act_nb(d)                        `act` flag of that neighbour (asked only for interior solid ones)
-//   C.gp(i)                            fluid-side record of grain i (may be served from registers)
+//   C.gp_nb(d)                         fluid-side record of the grain that owns that neighbour
 // so f*[S][q] with S = P - e_q is C.in(opp q) and f*[P + e_q][opp q] is C.in(q).
 // EDGE = false is the specialisation for nodes at least two rows/columns away from every lattice edge
 // (S, P and P + e_q are then all interior): the edge logic disappears.
@@ -292,7 +292,7 @@ __device__ __forceinline__ double pull_one(const Ctx& C, const LatticeView& L, c
     return C.act_nb(qo) ? Wq(q) : C.in(qo);
 
   // P fluid, S an (active) solid node of grain oS: interpolated bounce-back
-  const IbbLink k = ibb_link<q>(L, C.gp(oS), sxg, syg);
+  const IbbLink k = ibb_link<q>(L, C.gp_nb(qo), sxg, syg);
   if (ibb_far(k)) return ibb_far_value<q>(L, k, C.own(qo), C.own(q));
   if (!ibb_near(k)) return C.in(qo);  // neither branch fires: slot keeps its value
 
@@ -309,7 +309,7 @@ __device__ __forceinline__ double pull_one(const Ctx& C, const LatticeView& L, c
     // negative, q = 1..4): S reads the value NN's own IBB update has already produced. That update
     // saw S's slot q in its pre-loop state (S comes later), so the chain ends here.
     if (oN != -1 && q <= 4) {
-      const IbbLink kn = ibb_link<qo>(L, C.gp(oN), nxg, nyg);
+      const IbbLink kn = ibb_link<qo>(L, C.gp_nb(q), nxg, nyg);
       if (ibb_far(kn)) f2 = ibb_far_value<qo>(L, kn, C.own(q), C.own(qo));
       else if (ibb_near(kn)) f2 = ibb_near_value<qo>(L, kn, C.own(q), C.in(qo));
     }
@@ -331,7 +331,7 @@ struct TileCtx {
   __device__ __forceinline__ bool act_nb(int d) const {
     return T.active(L, G, px + EXq(d), py + EYq(d), gx + EXq(d), gy + EYq(d));
   }
-  __device__ __forceinline__ GP gp(int i) const { return load_gp(G, i); }
+  __device__ __forceinline__ GP gp_nb(int d) const { return load_gp(G, o_nb(d)); }
 };
 
 template <int TX, int TY>
@@ -429,41 +429,74 @@ __global__ __launch_bounds__(256) void k_collide_stream(const double* __restrict
 struct Ids3 { int m, c, p; };  // obstacle ids at (y-1, y, y+1) of one row
 
 __device__ __forceinline__ Ids3 load_ids(const int* __restrict__ ob, const LatticeView& L, int xl, int y) {
-  Ids3 r{L.n, L.n, L.n};  // off the lattice reads as "wall": never fluid
-  if (xl >= 0 && xl < L.nxl) {
-    const int* row = ob + (long)xl * L.sy;
-    if (y - 1 >= 0 && y - 1 < L.ly) r.m = row[y - 1];
-    if (y >= 0 && y < L.ly) r.c = row[y];
-    if (y + 1 >= 0 && y + 1 < L.ly) r.p = row[y + 1];
-  }
+  // branch-free: clamped addresses, then select. (Loads under branches make the compiler fall back to
+  // s_waitcnt vmcnt(0) at every control-flow merge, which drains the prefetch pipeline.)
+  const bool rok = xl >= 0 && xl < L.nxl;
+  const int xc = xl < 0 ? 0 : (xl >= L.nxl ? L.nxl - 1 : xl);
+  const int* row = ob + (long)xc * L.sy;
+  const int ym = y - 1, yp = y + 1;
+  const int cm = ym < 0 ? 0 : (ym >= L.ly ? L.ly - 1 : ym);
+  const int cc = y < 0 ? 0 : (y >= L.ly ? L.ly - 1 : y);
+  const int cp = yp < 0 ? 0 : (yp >= L.ly ? L.ly - 1 : yp);
+  const int vm = row[cm], vc = row[cc], vp = row[cp];
+  Ids3 r;  // off the lattice reads as "wall": never fluid
+  r.m = (rok && cm == ym) ? vm : L.n;
+  r.c = (rok && cc == y) ? vc : L.n;
+  r.p = (rok && cp == yp) ? vp : L.n;
   return r;
 }
 
-// `act` of the centre node of a 3x3 block of ids (rows a = x-1, b = x, c = x+1); see Tile::active
-__device__ __forceinline__ bool node_active(const LatticeView& L, const GrainFluidView& G, const Ids3& a,
-                                            const Ids3& b, const Ids3& c, int gx, int gy) {
+// `act` of the centre node of a 3x3 block of ids (rows a = x-1, b = x, c = x+1); see Tile::active.
+// `own_rec()` returns the record of the grain that owns the centre node (only called on the rare
+// path where a neighbour belongs to a higher-index grain). Requires reductionR < 1 (then the paint
+// test d2 <= R2 && d2 <= r2 reduces to d2 <= r2); the launcher routes other configurations to the
+// LDS-tile kernel.
+template <class RecFn>
+__device__ __forceinline__ bool node_active(const LatticeView& L, const Ids3& a, const Ids3& b,
+                                            const Ids3& c, int gx, int gy, RecFn own_rec) {
   const int o = b.c;
   // neighbour ids in direction order 1..8: (-1,1) (-1,0) (-1,-1) (0,-1) (1,-1) (1,0) (1,1) (0,1)
   const int nb[9] = {0, a.p, a.c, a.m, b.m, c.m, c.c, c.p, b.p};
-  bool higher = false;
+  bool higher = false, fluid = false;
 #pragma unroll
   for (int q = 1; q < 9; ++q) {
-    if (nb[q] == -1) return true;
+    fluid |= nb[q] == -1;
     higher |= (nb[q] > o && nb[q] != L.n);
   }
-  if (!higher) return false;
-  const double xc = G.xc[o], yc = G.yc[o], r2 = G.r2[o], rb = G.rbl0[o];
-  const double R2 = rb * rb;
+  if (fluid || !higher) return fluid;
+  const GP g = own_rec();
+  bool act = false;
 #pragma unroll
   for (int q = 1; q < 9; ++q) {
     if (nb[q] > o && nb[q] != L.n) {
       const int x = gx + EXq(q), y = gy + EYq(q);
-      const double d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc);
-      if (!(d2 <= R2 && d2 <= r2)) return true;
+      const double d2 = (x - g.xc) * (x - g.xc) + (y - g.yc) * (y - g.yc);
+      act |= !(d2 <= g.r2);
     }
   }
-  return false;
+  return act;
 }
+
+// Wave-private LDS ring of grain records: slot [row & 3][lane] holds the record of the grain that owns
+// node (row, lane's column), written by that lane when the row was fetched. A bounce-back link at P
+// reads the record of its solid neighbour from there: LDS waits use lgkmcnt and do not disturb the
+// in-order vmcnt pipeline of the row prefetch, and no load sits inside a divergent path.
+constexpr int REC_RING = 4;
+struct RecRing {
+  double2* base;  // this wave's [REC_RING][4][64] double2
+  __device__ __forceinline__ void put(int row, int lane, const GP& g) const {
+    double2* p = base + (row & (REC_RING - 1)) * 4 * 64 + lane;
+    p[0] = make_double2(g.x1, g.x2);
+    p[64] = make_double2(g.v1, g.v2);
+    p[128] = make_double2(g.v3, g.xc);
+    p[192] = make_double2(g.yc, g.r2);
+  }
+  __device__ __forceinline__ GP get(int row, int lane) const {
+    const double2* p = base + (row & (REC_RING - 1)) * 4 * 64 + lane;
+    const double2 a = p[0], b = p[64], c = p[128], d = p[192];
+    return GP{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+  }
+};
 
 struct RegCtx {
   double Fo[9];   // f*[P][q]
@@ -471,10 +504,9 @@ struct RegCtx {
   int o0;
   int onb[9];
   unsigned act;   // bit d: act of the neighbour in direction d
-  const GrainFluidView* G;
-  int gid;        // grain whose record was prefetched for this node (-1: none)
-  GP gpc;
-  __device__ __forceinline__ GP gp(int i) const { return i == gid ? gpc : load_gp(*G, i); }
+  RecRing ring;
+  int row, lane;  // local row of P and this lane
+  __device__ __forceinline__ GP gp_nb(int d) const { return ring.get(row + EXq(d), lane + EYq(d)); }
   __device__ __forceinline__ double own(int q) const { return Fo[q]; }
   __device__ __forceinline__ double in(int d) const { return In[d]; }
   __device__ __forceinline__ int o_own() const { return o0; }
@@ -520,22 +552,33 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
   const int xs = L.xo0 + seg * LX;
   const int xe = xs + LX < L.xo1 ? xs + LX : L.xo1;
 
-  // Software pipeline, per iteration x (producing row x):
-  //   populations + old id of row x+2          are loaded        (used next iteration)
-  //   new ids of row x+3                        are loaded
-  //   record of the grain that owned (x+2, y) in the previous map  is loaded  (reinit of row x+2)
-  //   record of the grain adjacent to (x+1, y)  is loaded         (bounce-back links of row x+1)
-  // so that every divergent path of the row being produced is pure arithmetic on registers.
+  // Software pipeline. In iteration x (producing row x) the wave issues, in this order,
+  //   (1) small gathers: new ids of row x+4, previous-map id of row x+4, the record of the grain that
+  //       owned (x+2, y) before (reinit of row x+2), the record of the grain that owns (x+3, y) now
+  //   (2) the nine populations of row x+3 into the row buffer it has just consumed (two buffers,
+  //       ping-pong, loop unrolled by two: no register copies, so the loads stay in flight for two
+  //       iterations)
+  //   (3) the nine stores of row x.
+  // gfx9 retires vector-memory operations in issue order (one vmcnt counter), so data must be consumed
+  // in the order it was requested; no other global load exists inside the loop.
+  __shared__ double2 sRec[4 * REC_RING * 4 * 64];
+  const RecRing ring{sRec + (threadIdx.x >> 6) * (REC_RING * 4 * 64)};
   auto row_ok = [&](int xl) { return yin && xl >= 0 && xl < L.nxl; };
-  auto load_old = [&](int xl) { return row_ok(xl) ? ob_old[(long)xl * L.sy + y] : -1; };
+  const int ycl = y < 0 ? 0 : (y >= L.ly ? L.ly - 1 : y);
+  auto node_of = [&](int xl) {  // clamped: always a valid address
+    const int xc = xl < 0 ? 0 : (xl >= L.nxl ? L.nxl - 1 : xl);
+    return (long)xc * L.sy + ycl;
+  };
+  // unconditional (clamped address): every use is guarded by interior(xl), and grain_rec clamps the
+  // id. (A `row_ok ? v : -1` select here makes the compiler sink the load into a branch followed by
+  // s_waitcnt vmcnt(0), which drains the whole prefetch pipeline once per iteration.)
+  auto load_old = [&](int xl) { return ob_old[node_of(xl)]; };
+  // off-lattice positions load a clamped neighbour's values; they are never used (pull_one tests the
+  // bounds of the source node before touching its populations)
   auto load_raw = [&](int xl, double (&raw)[9]) {
+    const long node = node_of(xl);
 #pragma unroll
-    for (int q = 0; q < 9; ++q) raw[q] = 0.0;
-    if (row_ok(xl)) {
-      const long node = (long)xl * L.sy + y;
-#pragma unroll
-      for (int q = 0; q < 9; ++q) raw[q] = fin[q * L.plane + node];
-    }
+    for (int q = 0; q < 9; ++q) raw[q] = fin[q * L.plane + node];
   };
   auto interior = [&](int xl) {
     const int gx = L.gx0 + xl;
@@ -547,17 +590,9 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
     if (in && oo != -1) grain_equilibrium(L, g, L.gx0 + xl, y, f);
     if (in && on == -1) mrt_collide(L, f);
   };
-  // the grain next to a fluid node (highest index among the 8 neighbours; walls and fluid excluded)
-  auto adjacent_grain = [&](const Ids3& a, const Ids3& b, const Ids3& c) {
-    int g = -1;
-    const int nb[8] = {a.m, a.c, a.p, b.m, b.p, c.m, c.c, c.p};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) g = (nb[k] != L.n && nb[k] > g) ? nb[k] : g;
-    return g;
-  };
-  auto safe_gp = [&](int i) { return load_gp(G, i < 0 ? 0 : i); };
+  auto grain_rec = [&](int id) { return load_gp(G, (id < 0 || id >= L.n) ? 0 : id); };
 
-  double Fm[9], F0[9], Fp[9], raw[9];
+  double Fm[9], F0[9], Fp[9], bufA[9], bufB[9];
   Ids3 iA = load_ids(ob_new, L, xs - 2, y);  // row x-2 (only needed for act of row x-1)
   Ids3 iB = load_ids(ob_new, L, xs - 1, y);  // row x-1
   Ids3 iC = load_ids(ob_new, L, xs, y);      // row x
@@ -566,60 +601,49 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
   {
     int oo = load_old(xs - 1);
     load_raw(xs - 1, Fm);
-    make_fstar(xs - 1, Fm, oo, safe_gp(oo), iB.c);
+    make_fstar(xs - 1, Fm, oo, grain_rec(oo), iB.c);
     oo = load_old(xs);
     load_raw(xs, F0);
-    make_fstar(xs, F0, oo, safe_gp(oo), iC.c);
+    make_fstar(xs, F0, oo, grain_rec(oo), iC.c);
   }
-  // Pipeline state at loop entry (iteration x = xs):
-  //   raw   = populations of row x+1        raw2 = populations of row x+2   (two rows of prefetch)
-  //   oo1/oo2/oo3 = previous-map ids of rows x+1 / x+2 / x+3
-  //   gre   = record of the grain that owned (x+1, y) before          (reinit of row x+1)
-  //   gib0  = record of the grain adjacent to (x, y)                   (bounce-back links of row x)
-  //   ids   : rows x-1 .. x+2 in iB..iE, row x+3 in flight (inext)
-  // gfx9 retires vector-memory operations in issue order (one vmcnt counter): waiting for a young
-  // small gather drains every older load. So each iteration issues the small gathers FIRST, then
-  // the nine big row loads, and the stores last -- data is then consumed in the order it was
-  // requested and the row loads really stay in flight for two iterations.
-  double raw2[9];
-  int oo1 = load_old(xs + 1);
+  // records of the current owners of rows x-1 .. x+2 into the ring
+  ring.put(xs - 1, lane, grain_rec(iB.c));
+  ring.put(xs, lane, grain_rec(iC.c));
+  ring.put(xs + 1, lane, grain_rec(iD.c));
+  ring.put(xs + 2, lane, grain_rec(iE.c));
+  int oo1 = load_old(xs + 1);   // previous-map ids of rows x+1, x+2, x+3
   int oo2 = load_old(xs + 2);
   int oo3 = load_old(xs + 3);
   Ids3 inext = load_ids(ob_new, L, xs + 3, y);
-  int gid0 = adjacent_grain(iB, iC, iD);
-  GP gib0 = safe_gp(gid0);
-  GP gre = safe_gp(oo1);
-  load_raw(xs + 1, raw);
-  load_raw(xs + 2, raw2);
-  bool actm = iB.c != -1 && node_active(L, G, iA, iB, iC, L.gx0 + xs - 1, y);
-  bool act0 = iC.c != -1 && node_active(L, G, iB, iC, iD, L.gx0 + xs, y);
+  GP gre = grain_rec(oo1);      // reinit record for row x+1
+  GP rec_next = grain_rec(inext.c);  // owner record of row x+3, goes into the ring next iteration
+  load_raw(xs + 1, bufA);
+  load_raw(xs + 2, bufB);
+  bool actm = iB.c != -1 && node_active(L, iA, iB, iC, L.gx0 + xs - 1, y, [&] { return ring.get(xs - 1, lane); });
+  bool act0 = iC.c != -1 && node_active(L, iB, iC, iD, L.gx0 + xs, y, [&] { return ring.get(xs, lane); });
 
-  for (int x = xs; x < xe; ++x) {
-    // row x+1 becomes available
+  // one iteration; `buf` holds row x+1 on entry and is refilled with row x+3
+  auto iterate = [&](int x, double (&buf)[9]) {
 #pragma unroll
-    for (int q = 0; q < 9; ++q) Fp[q] = raw[q];
+    for (int q = 0; q < 9; ++q) Fp[q] = buf[q];
     make_fstar(x + 1, Fp, oo1, gre, iD.c);
-    // ---- small gathers for the next iterations, issued first
+    const Ids3 iF = inext;  // row x+3
+    // ---- (1) small gathers
     oo1 = oo2;
     oo2 = oo3;
-    gre = safe_gp(oo1);                           // reinit record of row x+2
-    const int gid1 = adjacent_grain(iC, iD, iE);  // bounce-back grain of row x+1
-    const GP gib1 = safe_gp(gid1);
-    const Ids3 iF = inext;                        // row x+3
+    gre = grain_rec(oo1);                      // reinit record of row x+2
     inext = load_ids(ob_new, L, x + 4, y);
     oo3 = load_old(x + 4);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- the big loads: populations of row x+3
-#pragma unroll
-    for (int q = 0; q < 9; ++q) raw[q] = raw2[q];
-    load_raw(x + 3, raw2);
+    // ---- (2) the big loads: populations of row x+3
+    load_raw(x + 3, buf);
     __builtin_amdgcn_sched_barrier(0);
-    const bool actp = iD.c != -1 && node_active(L, G, iC, iD, iE, L.gx0 + x + 1, y);
+    const bool actp = iD.c != -1 && node_active(L, iC, iD, iE, L.gx0 + x + 1, y, [&] { return ring.get(x + 1, lane); });
 
     RegCtx C;
-    C.G = &G;
-    C.gid = gid0;
-    C.gpc = gib0;
+    C.ring = ring;
+    C.row = x;
+    C.lane = lane;
 #pragma unroll
     for (int q = 0; q < 9; ++q) C.Fo[q] = F0[q];
     C.In[0] = 0.0;
@@ -641,7 +665,6 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
     C.act = (((pk_up >> 0) & 1u) << 1) | (((pack >> 0) & 1u) << 2) | (((pk_dn >> 0) & 1u) << 3) |
             (((pk_dn >> 1) & 1u) << 4) | (((pk_dn >> 2) & 1u) << 5) | (((pack >> 2) & 1u) << 6) |
             (((pk_up >> 2) & 1u) << 7) | (((pk_up >> 1) & 1u) << 8);
-
     {
       const int gx = L.gx0 + x;
       const long node = (long)x * L.sy + y;
@@ -653,12 +676,20 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
         if (writer) store_row<true>(fout, L, G, C, node, gx, y);
       }
     }
+    // row x-1 is no longer needed: its ring slot takes the owner records of row x+3; then request
+    // those of row x+4 (consumed at this point of the next iteration)
+    ring.put(x + 3, lane, rec_next);
+    rec_next = grain_rec(inext.c);
     // rotate
 #pragma unroll
     for (int q = 0; q < 9; ++q) { Fm[q] = F0[q]; F0[q] = Fp[q]; }
     iB = iC; iC = iD; iD = iE; iE = iF;
     actm = act0; act0 = actp;
-    gid0 = gid1; gib0 = gib1;
+  };
+
+  for (int x = xs; x < xe; x += 2) {
+    iterate(x, bufA);
+    if (x + 1 < xe) iterate(x + 1, bufB);
   }
 }
 
@@ -1038,7 +1069,7 @@ static int cs_variant() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("LBMDEM_CS_VARIANT");
-    v = e ? atoi(e) : 24;
+    v = e ? atoi(e) : 25;
   }
   return v;
 }
@@ -1057,7 +1088,9 @@ static void launch_march(const double* fin, double* fout, const int* obst_old, c
 
 void launch_collide_stream(const double* fin, double* fout, const int* obst_old, const int* obst_new,
                            const LatticeView& L, const GrainFluidView& G, hipStream_t st) {
-  const int v = cs_variant(), remap = (v >> 3) & 1;
+  int v = cs_variant();
+  const int remap = (v >> 3) & 1;
+  if (!L.reduced_lt1 && (v & ~8) >= 16) v = 1;  // marching kernel assumes reductionR < 1
   switch (v & ~8) {
     case 0: launch_cs<8, 64>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
     case 1: launch_cs<4, 64>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
@@ -1067,12 +1100,8 @@ void launch_collide_stream(const double* fin, double* fout, const int* obst_old,
     case 16: launch_march<16, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
     case 17: launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
     case 18: launch_march<8, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
-    case 20: launch_march<16, 3>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
-    case 21: launch_march<32, 3>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
-    case 22: launch_march<8, 3>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
-    case 32: launch_march<16, 4>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
-    case 33: launch_march<32, 4>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
-    default: launch_march<16, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
+    case 19: launch_march<64, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
+    default: launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
   }
 }
 

@@ -222,6 +222,7 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
   L.dx = cfg->dx; L.c = cfg->c; L.Mgx = cfg->Mgx; L.Mby = cfg->Mby;
   const lbmdem_physics& p = cfg->phys;
   L.s2 = p.s2; L.s3 = p.s3; L.s5 = p.s5; L.s7 = p.s7; L.s8 = p.s8; L.s9 = p.s9;
+  L.reduced_lt1 = p.reductionR < 1.0 ? 1 : 0;
   // force scaling, main.c:1329-1331
   h->fscale12 = p.rho_moy * 9 * p.nu * p.nu / (cfg->dx * (p.tau - 0.5) * (p.tau - 0.5));
   h->fscale3 = cfg->dx * p.rho_moy * 9 * p.nu * p.nu / (cfg->dx * (p.tau - 0.5) * (p.tau - 0.5));

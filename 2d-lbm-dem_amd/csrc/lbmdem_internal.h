@@ -23,6 +23,7 @@ struct LatticeView {
   int n;         // nbgrains; also the obst code of the lattice-edge walls (main.c:676,681)
   double dx, c, Mgx, Mby;
   double s2, s3, s5, s7, s8, s9;
+  int reduced_lt1;  // phys.reductionR < 1: reduced discs lie strictly inside the grains (always, in the reference)
 };
 
 // Grain state used by the fluid kernels. xc, yc, r2, rbl0 are the lattice-unit centre, squared
