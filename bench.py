@@ -36,6 +36,7 @@ import __graft_entry__ as ge  # noqa: E402
 import samples  # noqa: E402
 
 BYTES_PER_LUP = 148.0   # 9x8 B read + 9x8 B write + 4 B obstacle id
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")   # PMC-measured HBM bytes per launch
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -184,6 +185,9 @@ def main():
         cfgd = sim.config()
         rows = cfgd.x_end - cfgd.x_begin
         achieved = BYTES_PER_LUP * rows * ly / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic = None
+        if args.gpus == 1 and "LBMDEM_CS_VARIANT" not in os.environ and os.path.exists(TRAFFIC_FILE):
+            traffic = round(json.load(open(TRAFFIC_FILE))["traffic_bytes_per_launch"])   # same workload + kernel
         out = {
             "metric": "MLUPS (D2Q9 collide+stream, coupled LBM-DEM step) on 4096^2 / 50k grains",
             "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": args.gpus, "steps": args.steps,
@@ -197,10 +201,12 @@ def main():
             "dem_steps_per_s": round(args.steps * npdem / elapsed, 1),
             "collide_stream_kernel_ms": round(kernel_ms, 4),
             "collide_stream_kernel_mlups": round(1e-6 * rows * ly / (kernel_ms * 1e-3), 1) if kernel_ms > 0 else None,
-            "roofline": {"bound": "hbm", "kernel": "k_collide_stream", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": "k_cs_march (fused reinit+collide+IBB+stream)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "bytes_per_lup": BYTES_PER_LUP, "launches_timed": launches,
-                         "note": "algorithmic 148 B/LUP x lattice nodes per launch / mean HIP-event duration"},
+                         "traffic": traffic, "bytes_per_lup": BYTES_PER_LUP, "launches_timed": launches,
+                         "note": "achieved = algorithmic 148 B/LUP x lattice nodes per launch / mean HIP-event "
+                                 "duration; traffic = HBM bytes per launch from rocprofv3 FETCH_SIZE + WRITE_SIZE "
+                                 "(separate passes, calibrated; profiles/r01_c_pmc_traffic.json)"},
             "total_mass": mass,
         }
         if args.gpus == 1 and not args.no_cpu_baseline:

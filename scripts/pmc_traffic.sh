@@ -1,0 +1,28 @@
+# HBM traffic of the fused kernel from PMC counters, calibrated on copy kernels of known size.
+# FETCH_SIZE and WRITE_SIZE need separate passes (TCC slots). Output: gpurun_out/traffic/*.csv + summary.
+cd /tmp && export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/traffic; mkdir -p $O
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/cal_$c -o cal -- $GRAFT_REPO_ROOT/scripts/micro/stream_pattern > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/run_$c -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+done
+python - <<PY
+import csv,glob,collections,json
+O="$O"
+def mean(path, key):
+    f=glob.glob(path+"/**/*counter_collection.csv", recursive=True)[0]
+    acc=collections.defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return {k: sum(v)/len(v) for k,v in acc.items() if key in k}
+out={}
+for c in ("FETCH_SIZE","WRITE_SIZE"):
+    cal=mean(f"{O}/cal_{c}","k_copy8"); cal16=mean(f"{O}/cal_{c}","k_copy16"); run=mean(f"{O}/run_{c}","k_cs_march")
+    out[c]={"copy8_raw":list(cal.values())[0],"copy16_raw":list(cal16.values())[0],"march_raw":list(run.values())[0]}
+known=9*4096*4096*8   # bytes read (and written) by the copy kernels
+for c in out:
+    d=out[c]; d["bytes_per_unit_copy8"]=known/d["copy8_raw"]; d["bytes_per_unit_copy16"]=known/d["copy16_raw"]
+    d["march_bytes_calibrated_8B"]=d["march_raw"]*d["bytes_per_unit_copy8"]
+print(json.dumps(out, indent=1))
+json.dump(out, open(f"{O}/summary.json","w"), indent=1)
+PY

@@ -247,3 +247,50 @@ def test_error_behaviour(pkg):
         sim.dem_substep()   # no Verlet list yet
     with pytest.raises(pkg.LbmDemError):
         sim.f = np.zeros((3, 3, 9))
+
+
+def test_large_grains_take_the_unstaged_force_path(pkg, po):
+    """Grains whose bounding box exceeds the LDS footprint of the force kernel (FORCE_TILE = 40 nodes)
+    and many boundary links per grain (several replay batches)."""
+    lx, ly = 192, 160
+    r = np.array([2.6, 0.7, 3.1]) * 1e-3          # r/dx = 26, 7, 31 nodes
+    x1 = np.array([4.0, 9.3, 13.5]) * 1e-3
+    x2 = np.array([4.5, 11.0, 8.0]) * 1e-3
+    sim, ora = make_pair(pkg, po, lx, ly, r, x1, x2)
+    rng = np.random.default_rng(4)
+    k = np.zeros((3, 9)); k[:, 0], k[:, 1] = x1, x2; k[:, 3:6] = rng.normal(0, 1, (3, 3)) * [0.02, 0.02, 5.0]
+    f0 = ora.get_f() * (1 + 1e-3 * rng.standard_normal((lx, ly, 9)))
+    sim.kinematics = k; ora.set_kinematics(k); sim.f = f0; ora.set_f(f0)
+    for _ in range(3):
+        sim.lbm_step(); ora.lbm_steps(1)
+    assert np.array_equal(sim.obst, ora.get_obst())
+    assert np.array_equal(sim.f, ora.get_f())
+    assert np.array_equal(sim.fhf, ora.get_fhf())
+
+
+def test_every_fused_kernel_variant_is_bit_exact(pkg, po):
+    """The LDS-tile kernel (kept as the fallback for reductionR >= 1) and the marching kernel at
+    several segment lengths, selected through LBMDEM_CS_VARIANT, in fresh processes."""
+    import os, subprocess, sys
+    code = r'''
+import sys, numpy as np
+sys.path[:0] = [%r, %r, %r]
+import __graft_entry__ as ge, pyoracle as po, samples
+pkg = ge.load_package()
+lx, ly = 200, 130
+r, x, y = samples.row_packing(lx, ly, 80, seed=3); r, x1, x2 = samples.to_metres(r, x, y)
+sim = pkg.LbmDem(lx, ly, r, x1, x2); ora = po.Oracle(lx, ly, r, x1, x2)
+rng = np.random.default_rng(1)
+k = np.zeros((len(r), 9)); k[:, 0], k[:, 1] = x1, x2; k[:, 3:6] = rng.normal(0, 1, (len(r), 3)) * [0.03, 0.03, 20.0]
+sim.kinematics = k; ora.set_kinematics(k)
+n = 3 * sim.cfg.npDEM + 1
+sim.renderScene(n); ora.steps(n)
+assert np.array_equal(sim.f, ora.get_f()) and np.array_equal(sim.kinematics, ora.get_grains()[:, :9])
+print("ok")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+       os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"),
+       os.path.dirname(os.path.abspath(__file__)))
+    for variant in ("1", "9", "0", "16", "24", "17", "25", "18", "19"):
+        env = dict(os.environ, LBMDEM_CS_VARIANT=variant)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        assert out.returncode == 0 and "ok" in out.stdout, (variant, out.stdout[-300:], out.stderr[-600:])
