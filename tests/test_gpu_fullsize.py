@@ -1,0 +1,97 @@
+"""GPU: BASELINE.json's full-size configurations.
+
+C3 shape (2048 x 2048, ~7000 grains) and C4 (4096 x 4096, 50 000 grains, the bench workload): the
+first fluid step(s) are compared with the CPU oracle exactly (the oracle needs a few seconds per
+fluid step at these sizes, its O(N^2) Verlet build ~7 s at 50 k grains), then size-independent
+properties are checked over more steps: determinism (two runs, same bits), mass balance, finite and
+positive densities, the Verlet pair set, strip-decomposed == single-domain."""
+import numpy as np
+import pytest
+
+import samples
+
+pytestmark = pytest.mark.gpu
+
+
+def packing(lx, ly, n, seed=1234):
+    r, x, y = samples.row_packing(lx, ly, n, seed=seed)
+    return samples.to_metres(r, x, y)
+
+
+def test_c3_2048_7000_grains_two_fluid_steps_exact(pkg, po):
+    lx = ly = 2048
+    r, x1, x2 = packing(lx, ly, 7000, seed=99)
+    sim = pkg.LbmDem(lx, ly, r, x1, x2)
+    ora = po.Oracle(lx, ly, r, x1, x2)
+    n = sim.cfg.npDEM + 1   # fluid steps at nbsteps 0 and npDEM
+    sim.renderScene(n); ora.steps(n)
+    assert ora.act_anomalies() == 0
+    assert np.array_equal(sim.obst, ora.get_obst())
+    assert np.array_equal(sim.fhf, ora.get_fhf())
+    assert np.array_equal(sim.kinematics, ora.get_grains()[:, :9])
+    fg = sim.f
+    assert np.array_equal(fg, ora.get_f())
+    cg, ng, _ = sim.verlet(); co, no, _, _ = ora.verlet()
+    assert np.array_equal(cg, co) and np.array_equal(ng, no[:len(ng)])
+
+
+def test_c4_4096_50k_first_step_exact_then_properties(pkg, po):
+    lx = ly = 4096
+    r, x1, x2 = packing(lx, ly, 50000)
+    assert len(r) == 50000
+    sim = pkg.LbmDem(lx, ly, r, x1, x2)
+    ora = po.Oracle(lx, ly, r, x1, x2)
+    # one renderScene: fluid step + O(N^2) Verlet build + DEM sub-step on the CPU (~10 s)
+    sim.renderScene(1); ora.steps(1)
+    assert np.array_equal(sim.obst, ora.get_obst())
+    assert np.array_equal(sim.fhf, ora.get_fhf())
+    assert np.array_equal(sim.kinematics, ora.get_grains()[:, :9])
+    cg, ng, _ = sim.verlet(); co, no, _, _ = ora.verlet()
+    assert np.array_equal(cg, co) and np.array_equal(ng, no[:len(ng)]) and len(ng) > 50000
+    f1 = sim.f
+    assert np.array_equal(f1, ora.get_f())
+    solid = float((ora.get_obst() >= 0).mean())
+    assert 0.25 < solid < 0.45          # same regime as bin/50000.data (34 % solid nodes)
+    del ora
+    # properties over 4 more fluid steps
+    npdem = sim.cfg.npDEM
+    sim.renderScene(4 * npdem)
+    f5 = sim.f
+    k5 = sim.kinematics
+    assert np.isfinite(f5).all() and (f5.sum(-1) > 0.5).all()
+    m1, m5 = f1.sum(), f5.sum()
+    assert abs(m5 - m1) / m1 < 1e-4      # moving walls exchange mass with the fluid; no blow-up
+    assert abs(sim.final_density() - m5) <= 1e-10 * m5
+    # determinism: a second simulation gives the same bits
+    sim2 = pkg.LbmDem(lx, ly, r, x1, x2)
+    sim2.renderScene(1 + 4 * npdem)
+    assert np.array_equal(sim2.kinematics, k5)
+    out = np.empty_like(f5); sim2.download_f_into(out)
+    assert np.array_equal(out, f5)
+
+
+def test_strips_equal_single_domain_at_1024(pkg):
+    """Strip-decomposed (4 strips on one GPU) == single domain, bit for bit, on a lattice large enough
+    for many grains to straddle the cuts."""
+    import torch
+    from strip_backends import LoopbackComm, lockstep_render
+    strips = pkg.strips_module()
+    lx, ly = 1024, 768
+    r, x1, x2 = packing(lx, ly, 3000, seed=7)
+    cfg = pkg.derive(lx, ly, r)
+    halo = strips.halo_rows(float(r.max()), cfg.dx)
+    runners = []
+    for rank, strip in enumerate(strips.partition(lx, 4)):
+        be = strips.GpuStripBackend(pkg, torch, lx, ly, r, x1, x2, strip, halo, 0)
+        runners.append(strips.StripRunner(be, LoopbackComm(), rank, 4))
+    n = 3 * cfg.npDEM + 1
+    lockstep_render(runners, n)
+    single = pkg.LbmDem(lx, ly, r, x1, x2)
+    single.renderScene(n)
+    got = np.full((lx, ly, 9), np.nan)
+    for R in runners:
+        R.b.sim.download_f_into(got)
+    assert np.array_equal(got, single.f)
+    for R in runners:
+        assert np.array_equal(R.b.sim.kinematics, single.kinematics)
+        assert np.array_equal(R.b.sim.fhf, single.fhf)
