@@ -89,6 +89,9 @@ def load_library():
         getattr(L, "lbmdem_" + name).argtypes = [C.c_void_p, C.c_void_p]
     L.lbmdem_download_macro.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.lbmdem_download_verlet.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.lbmdem_download_grain_pressure.argtypes = [C.c_void_p, C.c_void_p]
+    L.lbmdem_download_vtk_fields.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+    L.lbmdem_write_vtk.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.lbmdem_set_force_mode.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_profile_enable.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -292,6 +295,24 @@ class LbmDem:
         out = np.zeros((self.n, 3))
         _chk(self._L.lbmdem_download_fhf(self._h, _vp(out)))
         return out
+
+    @property
+    def grain_pressure(self):
+        out = np.zeros(self.n)
+        _chk(self._L.lbmdem_download_grain_pressure(self._h, _vp(out)))
+        return out
+
+    def write_vtk(self, directory=".", nFile=0):
+        """write_vtk (main.c:237-338): five binary legacy-VTK files, byte-identical to the reference's."""
+        _chk(self._L.lbmdem_write_vtk(self._h, os.fsencode(directory), int(nFile)))
+
+    def vtk_fields(self):
+        nx = self.cfg.x_end - self.cfg.x_begin
+        gp = np.zeros((self.ly, nx), np.float32); fp = np.zeros((self.ly, nx), np.float32)
+        gv = np.zeros((self.ly, nx, 3), np.float32); ga = np.zeros((self.ly, nx, 3), np.float32)
+        fv = np.zeros((self.ly, nx, 3), np.float32)
+        _chk(self._L.lbmdem_download_vtk_fields(self._h, _vp(gp), _vp(gv), _vp(ga), _vp(fp), _vp(fv)))
+        return gp, gv, ga, fp, fv
 
     def verlet(self):
         """-> (cumul[n], neighbours[npairs], wallflags[n]) in the reference's form."""

@@ -24,7 +24,7 @@
 
 namespace {
 
-struct Force3 { double f1, f2, f3; };
+struct Force3 { double f1, f2, f3, fn; };  // fn: normal force, accumulated into the grain pressure p
 
 __device__ __forceinline__ double maxt(double x, double y) { return (x < y) ? 0. : y; }  // main.c:211-216
 
@@ -48,12 +48,14 @@ __device__ __forceinline__ GrainState advance(const Kin& K, const double* __rest
 // contact force on grain A (lower index) from grain B (higher index).
 // FILM = false: force_grains, main.c:739-774. FILM = true: the inline law of main.c:1365-1395.
 template <bool FILM>
-__device__ __forceinline__ Force3 contact(const GrainState& A, const GrainState& B, const DemParams& P) {
-  Force3 F = {0., 0., 0.};
+__device__ __forceinline__ Force3 contact(const GrainState& A, const GrainState& B, const DemParams& P,
+                                          bool& touched) {
+  Force3 F = {0., 0., 0., 0.};
   const double xij = A.x1 - B.x1;
   const double yij = A.x2 - B.x2;
   const double dist = sqrt(xij * xij + yij * yij);
   const double dn = dist - A.r - B.r;
+  touched = !(dn >= 0);
   if (dn >= 0) return F;
   const double vx = A.v1 - B.v1;
   const double vy = A.v2 - B.v2;
@@ -77,6 +79,7 @@ __device__ __forceinline__ Force3 contact(const GrainState& A, const GrainState&
   }
   F.f1 = fn * xn - ft * yn;
   F.f2 = fn * yn + ft * xn;
+  F.fn = fn;
   return F;
 }
 
@@ -84,7 +87,8 @@ template <bool FILM>
 __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, const double* __restrict__ m,
                               const double* __restrict__ It, const double* __restrict__ fhf,
                               const int* __restrict__ offsets, const int* __restrict__ nbr,
-                              const unsigned char* __restrict__ wallflags, DemParams P) {
+                              const unsigned char* __restrict__ wallflags, double* __restrict__ pout,
+                              DemParams P) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
   const GrainState me = advance(in, r, i, P);
@@ -92,16 +96,22 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
 
   // acceleration_grains: start from the hydrodynamic force (main.c:1429-1431)
   double a1 = fhf[i], a2 = fhf[P.n + i], a3 = fhf[2 * P.n + i];
+  // grain pressure g.p (main.c:1734, 776-777, 830, 880, 912, 938): reset every sub-step, += fn per
+  // contact in the same order as the accelerations; a separated pair (dn >= 0) adds nothing
+  double pr = 0.0;
+  bool touched;
   const int k0 = offsets[i], k1 = offsets[i + 1];
   for (int k = k0; k < k1; ++k) {
     const int j = nbr[k];
     const GrainState other = advance(in, r, j, P);
     if (i < j) {  // main.c:1443-1445
-      const Force3 F = contact<FILM>(me, other, P);
+      const Force3 F = contact<FILM>(me, other, P, touched);
       a1 = a1 + F.f1; a2 = a2 + F.f2; a3 = a3 + F.f3;
+      if (touched) pr += F.fn;
     } else {      // main.c:1446-1448
-      const Force3 F = contact<FILM>(other, me, P);
+      const Force3 F = contact<FILM>(other, me, P, touched);
       a1 = a1 - F.f1; a2 = a2 - F.f2; a3 = a3 + F.f3;
+      if (touched) pr += F.fn;
     }
   }
   // walls: bottom, top, left, right (main.c:1455-1508)
@@ -116,6 +126,7 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
       const double ftest = P.mumb * fn;
       if (fabs(ft) > ftest) ft = (ft < 0.0) ? ftest : -ftest;
       a1 = a1 + ft; a2 = a2 + fn; a3 = a3 + (-(ft * me.r * P.murf));
+      pr += fn;
     }
   }
   if (wf & 2u) {
@@ -131,6 +142,7 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
       if (ft > ftmax) ft = ftmax;
       if (vt > 0) ft = -ft;
       a1 = a1 + ft; a2 = a2 + fn; a3 = a3 + ft * me.r * P.murf;
+      pr += fn;
     }
   }
   if (wf & 4u) {
@@ -143,6 +155,7 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
       double ft = P.mum * fn;
       if (vt > 0) ft = -ft;
       a1 = a1 + fn; a2 = a2 + ft; a3 = a3 + ft * me.r * P.murf;
+      pr += fn;
     }
   }
   if (wf & 8u) {
@@ -155,6 +168,7 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
       if (vt > 0) ft = -ft;
       if (fn > 0.) fn = 0.;
       a1 = a1 + fn; a2 = a2 + (-ft); a3 = a3 + ft * me.r * P.murf;
+      pr += fn;
     }
   }
   // main.c:1511-1515 (mw = 0: SURVEY.md hard part 5)
@@ -168,6 +182,7 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
   out.v2[i] = me.v2 + P.dt * a2 / 2.;
   out.v3[i] = me.v3 + P.dt * a3 / 2.;
   out.a1[i] = a1; out.a2[i] = a2; out.a3[i] = a3;
+  pout[i] = pr;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -339,13 +354,13 @@ void launch_verlet_rebuild(VerletDevice& V, const Kin& K, const double* r, const
 }
 
 void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const double* m,
-                        const double* It, const double* fhf, const VerletDevice& V,
+                        const double* It, const double* fhf, const VerletDevice& V, double* pout,
                         const DemParams& P, int film, hipStream_t st) {
   const int nb = (P.n + 127) / 128;
   if (film)
     hipLaunchKernelGGL(k_dem_substep<true>, dim3(nb), dim3(128), 0, st, in, out, r, m, It, fhf, V.offsets,
-                       V.nbr, V.wallflags, P);
+                       V.nbr, V.wallflags, pout, P);
   else
     hipLaunchKernelGGL(k_dem_substep<false>, dim3(nb), dim3(128), 0, st, in, out, r, m, It, fhf, V.offsets,
-                       V.nbr, V.wallflags, P);
+                       V.nbr, V.wallflags, pout, P);
 }

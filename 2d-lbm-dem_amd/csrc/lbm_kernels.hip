@@ -1023,6 +1023,44 @@ __global__ void k_halo_unpack(double* __restrict__ f, LatticeView L, int xl0, in
   }
 }
 
+// The five fields write_vtk builds per node (main.c:284-323), float32, in [y][x] order (x fastest), for
+// the owned rows (x offset = first owned row). Fluid sums are accumulated in FLOAT with a double
+// intermediate per addition, exactly as `float += double` does in the reference.
+__global__ void k_vtk_fields(const double* __restrict__ f, const int* __restrict__ obst, LatticeView L,
+                             const double* __restrict__ gp, const double* __restrict__ v1,
+                             const double* __restrict__ v2, const double* __restrict__ a1,
+                             const double* __restrict__ a2, double rho_moy, float* __restrict__ grain_pressure,
+                             float* __restrict__ grain_velocity, float* __restrict__ grain_acceleration,
+                             float* __restrict__ fluid_pressure, float* __restrict__ fluid_velocity) {
+  const int nx = L.xo1 - L.xo0;
+  const long total = (long)nx * L.ly;
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (long)gridDim.x * blockDim.x) {
+    const int xr = (int)(k % nx), y = (int)(k / nx);  // output index = y * nx + xr
+    const long node = (long)(L.xo0 + xr) * L.sy + y;
+    const int i = obst[node];
+    float gpr = -1.f, gv0 = 0.f, gv1 = 0.f, ga0 = 0.f, ga1 = 0.f, fp = 0.f, fv0 = 0.f, fv1 = 0.f;
+    if (i >= 0 && i < L.n) {
+      gpr = (float)gp[i];
+      gv0 = (float)v1[i]; gv1 = (float)v2[i];
+      ga0 = (float)a1[i]; ga1 = (float)a2[i];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const double v = f[q * L.plane + node];
+        fp = (float)((double)fp + v);
+        fv0 = (float)((double)fv0 + v * EXq(q));
+        fv1 = (float)((double)fv1 + v * EYq(q));
+      }
+      fp = (float)((1. / 3.) * rho_moy * ((double)fp - 1.));
+    }
+    grain_pressure[k] = gpr;
+    grain_velocity[3 * k] = gv0; grain_velocity[3 * k + 1] = gv1; grain_velocity[3 * k + 2] = 0.f;
+    grain_acceleration[3 * k] = ga0; grain_acceleration[3 * k + 1] = ga1; grain_acceleration[3 * k + 2] = 0.f;
+    fluid_pressure[k] = fp;
+    fluid_velocity[3 * k] = fv0; fluid_velocity[3 * k + 1] = fv1; fluid_velocity[3 * k + 2] = 0.f;
+  }
+}
+
 inline int grid_for(long total, int block = 256, int cap = 256 * 8) {
   long g = (total + block - 1) / block;
   if (g > cap) g = cap;
@@ -1143,6 +1181,16 @@ void launch_halo_pack(const double* f, const LatticeView& L, int xl0, int nrows,
                       hipStream_t st) {
   hipLaunchKernelGGL(k_halo_pack, dim3(grid_for(9L * nrows * L.ly)), dim3(256), 0, st, f, L, xl0, nrows, buf);
 }
+void launch_vtk_fields(const double* f, const int* obst, const LatticeView& L, const double* gp,
+                       const double* v1, const double* v2, const double* a1, const double* a2,
+                       double rho_moy, float* grain_pressure, float* grain_velocity,
+                       float* grain_acceleration, float* fluid_pressure, float* fluid_velocity,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(k_vtk_fields, dim3(grid_for((long)(L.xo1 - L.xo0) * L.ly)), dim3(256), 0, st, f, obst, L, gp,
+                     v1, v2, a1, a2, rho_moy, grain_pressure, grain_velocity, grain_acceleration,
+                     fluid_pressure, fluid_velocity);
+}
+
 void launch_halo_unpack(double* f, const LatticeView& L, int xl0, int nrows, const double* buf,
                         hipStream_t st) {
   hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(9L * nrows * L.ly)), dim3(256), 0, st, f, L, xl0, nrows,

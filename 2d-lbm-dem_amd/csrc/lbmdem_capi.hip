@@ -56,6 +56,7 @@ struct lbmdem_handle {
   double *r = nullptr, *m = nullptr, *It = nullptr, *rLB = nullptr;
   double *xc = nullptr, *yc = nullptr, *r2 = nullptr, *rbl0 = nullptr;
   double* pk = nullptr;   // [n][8] packed fluid-side grain records
+  double* gp = nullptr;   // [n] grain pressure g.p of the last DEM sub-step (main.c:187,776)
   double* fhf = nullptr;  // [3][n]
   unsigned char* owner = nullptr;
   double rmax = 0.0;
@@ -245,8 +246,8 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
   CREATE_TRY(hipMalloc((void**)&h->f[1], fbytes));
   CREATE_TRY(hipMalloc((void**)&h->obst[0], sizeof(int) * (size_t)L.plane));
   CREATE_TRY(hipMalloc((void**)&h->obst[1], sizeof(int) * (size_t)L.plane));
-  // grains: 18 kinematic + r m It rLB xc yc r2 rbl0 + 3 fhf + 8 packed = 37 columns
-  const size_t cols = 18 + 8 + 3 + 8;
+  // grains: 18 kinematic + r m It rLB xc yc r2 rbl0 + 3 fhf + 8 packed + p = 38 columns
+  const size_t cols = 18 + 8 + 3 + 8 + 1;
   CREATE_TRY(hipMalloc((void**)&h->gbuf, sizeof(double) * cols * n));
   CREATE_TRY(hipMemset(h->gbuf, 0, sizeof(double) * cols * n));
   {
@@ -261,6 +262,7 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
     h->xc = p0 + 4 * n; h->yc = p0 + 5 * n; h->r2 = p0 + 6 * n; h->rbl0 = p0 + 7 * n;
     h->fhf = p0 + 8 * n;
     h->pk = p0 + 11 * (size_t)n;
+    h->gp = p0 + 19 * (size_t)n;
   }
   CREATE_TRY(hipMalloc((void**)&h->owner, n));
   CREATE_TRY(hipMemset(h->owner, 1, n));
@@ -393,8 +395,8 @@ int lbmdem_dem_substep(lbmdem_handle* h) {
   CHECK_H(h);
   if (!h->verlet_ok) return fail(LBMDEM_EINVAL, "lbmdem_dem_substep before the first lbmdem_verlet_rebuild");
   const int film = (h->nbsteps % h->cfg.phys.stepFilm == 0) ? 1 : 0;  // main.c:1342
-  launch_dem_substep(h->kin[h->kcur], h->kin[1 - h->kcur], h->r, h->m, h->It, h->fhf, h->V, dem_params(h),
-                     film, h->stream);
+  launch_dem_substep(h->kin[h->kcur], h->kin[1 - h->kcur], h->r, h->m, h->It, h->fhf, h->V, h->gp,
+                     dem_params(h), film, h->stream);
   HIP_TRY(hipGetLastError());
   h->kcur = 1 - h->kcur;
   h->nbsteps++;
@@ -564,6 +566,97 @@ int lbmdem_download_verlet(lbmdem_handle* h, int* cumul, int* neighbours, int ca
     for (int i = 0; i < n; ++i) wallflags[i] = wf[i];
   }
   if (neighbours && cnt > cap) return fail(LBMDEM_EINVAL, "neighbours[] too small: need %d", cnt);
+  return LBMDEM_OK;
+}
+
+int lbmdem_download_grain_pressure(lbmdem_handle* h, double* p) {
+  CHECK_H(h);
+  if (!p) return fail(LBMDEM_EINVAL, "null buffer");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(p, h->gp, sizeof(double) * h->n, hipMemcpyDeviceToHost));
+  return LBMDEM_OK;
+}
+
+int lbmdem_download_vtk_fields(lbmdem_handle* h, float* grain_pressure, float* grain_velocity,
+                               float* grain_acceleration, float* fluid_pressure, float* fluid_velocity) {
+  CHECK_H(h);
+  if (!grain_pressure || !grain_velocity || !grain_acceleration || !fluid_pressure || !fluid_velocity)
+    return fail(LBMDEM_EINVAL, "null buffer");
+  const LatticeView& L = h->L;
+  const size_t cnt = (size_t)(L.xo1 - L.xo0) * L.ly;
+  float* tmp = nullptr;
+  HIP_TRY(hipMalloc((void**)&tmp, sizeof(float) * cnt * 11));
+  float *d_gp = tmp, *d_gv = tmp + cnt, *d_ga = tmp + 4 * cnt, *d_fp = tmp + 7 * cnt, *d_fv = tmp + 8 * cnt;
+  const int* ob = h->obst_pending ? h->obst[1 - h->ocur] : h->obst[h->ocur];
+  const Kin& K = h->kin[h->kcur];
+  launch_vtk_fields(h->f[h->fcur], ob, L, h->gp, K.v1, K.v2, K.a1, K.a2, h->cfg.phys.rho_moy, d_gp, d_gv, d_ga,
+                    d_fp, d_fv, h->stream);
+  hipError_t e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipMemcpy(grain_pressure, d_gp, sizeof(float) * cnt, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(grain_velocity, d_gv, sizeof(float) * cnt * 3, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(grain_acceleration, d_ga, sizeof(float) * cnt * 3, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(fluid_pressure, d_fp, sizeof(float) * cnt, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(fluid_velocity, d_fv, sizeof(float) * cnt * 3, hipMemcpyDeviceToHost);
+  (void)hipFree(tmp);
+  HIP_TRY(e);
+  return LBMDEM_OK;
+}
+
+// One legacy-VTK file: binary, big-endian float32, RECTILINEAR_GRID with one point-data variable --
+// the byte layout the reference obtains from write_rectilinear_mesh(..., useBinary = 1, ...)
+// (main.c:326-328): header, DIMENSIONS, X/Y/Z_COORDINATES, CELL_DATA, POINT_DATA, one SCALARS
+// (+ LOOKUP_TABLE default) or VECTORS block, no separators after binary blocks.
+static void put_be(FILE* fp, const float* v, size_t n) {
+  std::vector<unsigned char> buf(n * 4);
+  for (size_t k = 0; k < n; ++k) {
+    unsigned char b[4];
+    memcpy(b, &v[k], 4);
+    buf[4 * k] = b[3]; buf[4 * k + 1] = b[2]; buf[4 * k + 2] = b[1]; buf[4 * k + 3] = b[0];
+  }
+  fwrite(buf.data(), 1, buf.size(), fp);
+}
+
+static int write_vtk_file(const char* path, int nx, int ny, const char* name, int dim, const float* data) {
+  FILE* fp = fopen(path, "w+");
+  if (!fp) return fail(LBMDEM_EINVAL, "cannot open '%s' for writing", path);
+  fprintf(fp, "# vtk DataFile Version 2.0\nWritten using VisIt writer\nBINARY\n");
+  fprintf(fp, "DATASET RECTILINEAR_GRID\nDIMENSIONS %d %d 1\n", nx, ny);
+  // coordinates: i * (float)(1/nx) on BOTH axes, z = 0 (main.c:255-258)
+  const float pas = 1. / nx;
+  std::vector<float> xs(nx), ys(ny);
+  for (int i = 0; i < nx; ++i) xs[i] = i * pas;
+  for (int i = 0; i < ny; ++i) ys[i] = i * pas;
+  const float z = 0.f;
+  fprintf(fp, "X_COORDINATES %d float\n", nx); put_be(fp, xs.data(), nx);
+  fprintf(fp, "Y_COORDINATES %d float\n", ny); put_be(fp, ys.data(), ny);
+  fprintf(fp, "Z_COORDINATES 1 float\n"); put_be(fp, &z, 1);
+  fprintf(fp, "CELL_DATA %d\nPOINT_DATA %d\n", (nx - 1) * (ny - 1), nx * ny);
+  if (dim == 1) fprintf(fp, "SCALARS %s float\nLOOKUP_TABLE default\n", name);
+  else fprintf(fp, "VECTORS %s float\n", name);
+  put_be(fp, data, (size_t)nx * ny * dim);
+  fclose(fp);
+  return LBMDEM_OK;
+}
+
+int lbmdem_write_vtk(lbmdem_handle* h, const char* dir, int nfile) {
+  CHECK_H(h);
+  const LatticeView& L = h->L;
+  if (L.xo0 != 0 || L.xo1 != L.lx || L.gx0 != 0)
+    return fail(LBMDEM_EINVAL, "lbmdem_write_vtk needs the whole lattice on this handle; gather strips with "
+                               "lbmdem_download_vtk_fields");
+  const size_t cnt = (size_t)L.lx * L.ly;
+  std::vector<float> gp(cnt), gv(3 * cnt), ga(3 * cnt), fp(cnt), fv(3 * cnt);
+  int rc = lbmdem_download_vtk_fields(h, gp.data(), gv.data(), ga.data(), fp.data(), fv.data());
+  if (rc != LBMDEM_OK) return rc;
+  const char* names[5] = {"grain_pressure", "grain_velocity", "grain_acceleration", "fluid_pressure", "fluid_velocity"};
+  const int dims[5] = {1, 3, 3, 1, 3};
+  const float* data[5] = {gp.data(), gv.data(), ga.data(), fp.data(), fv.data()};
+  for (int k = 0; k < 5; ++k) {
+    char path[4096];
+    snprintf(path, sizeof path, "%s/%s_%.6i.vtk", (dir && *dir) ? dir : ".", names[k], nfile);  // main.c:241-249
+    rc = write_vtk_file(path, L.lx, L.ly, names[k], dims[k], data[k]);
+    if (rc != LBMDEM_OK) return rc;
+  }
   return LBMDEM_OK;
 }
 

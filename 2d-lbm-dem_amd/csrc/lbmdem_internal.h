@@ -84,6 +84,12 @@ void launch_halo_pack(const double* f, const LatticeView& L, int xl0, int nrows,
                       hipStream_t st);
 void launch_halo_unpack(double* f, const LatticeView& L, int xl0, int nrows, const double* buf,
                         hipStream_t st);
+// the five float32 fields of write_vtk (main.c:284-323), [ly][lx] order, owned rows only
+void launch_vtk_fields(const double* f, const int* obst, const LatticeView& L, const double* gp,
+                       const double* v1, const double* v2, const double* a1, const double* a2,
+                       double rho_moy, float* grain_pressure, float* grain_velocity,
+                       float* grain_acceleration, float* fluid_pressure, float* fluid_velocity,
+                       hipStream_t st);
 
 // dem_kernels.hip
 struct VerletDevice {
@@ -108,5 +114,5 @@ void verlet_free(VerletDevice& V);
 void launch_verlet_rebuild(VerletDevice& V, const Kin& K, const double* r, const DemParams& P,
                            hipStream_t st);
 void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const double* m,
-                        const double* It, const double* fhf, const VerletDevice& V,
+                        const double* It, const double* fhf, const VerletDevice& V, double* pout,
                         const DemParams& P, int film, hipStream_t st);

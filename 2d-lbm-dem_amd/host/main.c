@@ -76,6 +76,7 @@ int main(int argc, char** argv) {
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
   long nbsteps = 0;
+  int nFile = 0; /* main.c:147 */
   const int chunk = cfg.phys.updateVerlet;
   const int stepConsole = 400; /* main.c:140 */
   do {
@@ -96,6 +97,11 @@ int main(int argc, char** argv) {
         DIE(lbmdem_run(h, 1), "run");
       }
       ++nbsteps;
+      /* output cadence of renderScene (main.c:1767-1772): write_vtk every stepFilm DEM steps */
+      if (nbsteps % cfg.phys.stepFilm == 0) {
+        DIE(lbmdem_write_vtk(h, ".", nFile), "write_vtk");
+        nFile++;
+      }
     }
     if (nbsteps % chunk == 0) {
       now = time(NULL);

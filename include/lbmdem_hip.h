@@ -124,6 +124,17 @@ int lbmdem_download_fhf(lbmdem_handle* h, double* fhf3);      /* interleaved fhf
  * `cap` = capacity of neighbours[]; *npairs receives the pair count (call with cap = 0 to size). */
 int lbmdem_download_verlet(lbmdem_handle* h, int* cumul, int* neighbours, int cap, int* npairs,
                            int* wallflags);
+/* grain pressure g.p of the last DEM sub-step (main.c:187: sum of the normal contact forces) */
+int lbmdem_download_grain_pressure(lbmdem_handle* h, double* p);
+/* The five float32 fields write_vtk builds (main.c:272-323): grain_pressure[ly][lx], grain_velocity
+ * [ly][lx][3], grain_acceleration[ly][lx][3], fluid_pressure[ly][lx], fluid_velocity[ly][lx][3] (owned
+ * rows: lx = x_end - x_begin); computed on the device with the reference's float accumulation. */
+int lbmdem_download_vtk_fields(lbmdem_handle* h, float* grain_pressure, float* grain_velocity,
+                               float* grain_acceleration, float* fluid_pressure, float* fluid_velocity);
+/* write_vtk (main.c:237-338 -> visit_writer.c write_rectilinear_mesh, binary): writes the five files
+ * <dir>/{grain_pressure,grain_velocity,grain_acceleration,fluid_pressure,fluid_velocity}_NNNNNN.vtk,
+ * byte-identical to the reference's. Single-domain handles only. */
+int lbmdem_write_vtk(lbmdem_handle* h, const char* dir, int nfile);
 long lbmdem_nbsteps(lbmdem_handle* h);
 int lbmdem_set_nbsteps(lbmdem_handle* h, long n);
 int lbmdem_get_config(lbmdem_handle* h, lbmdem_config* out);

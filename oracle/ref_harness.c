@@ -216,6 +216,17 @@ REF_API void ref_get_verlet(int* cumul_out, int* neigh_out, int* counts, int* wb
   memcpy(wr, neighbourWallR, sizeof(int) * nbgrains);
 }
 
+/* write_vtk (main.c:237-338) into `dir`; file names use nFile (main.c:239-249) */
+REF_API int ref_write_vtk(const char* dir, int file_index) {
+  char cwd[4096];
+  if (!getcwd(cwd, sizeof cwd)) return -1;
+  if (chdir(dir) != 0) return -2;
+  nFile = file_index;
+  write_vtk(lx, ly, f, nbgrains, g);
+  if (chdir(cwd) != 0) return -3;
+  return 0;
+}
+
 REF_API double ref_total_density(void) {
   real sum = 0;
   for (int x = 0; x < lx; x++)

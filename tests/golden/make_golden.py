@@ -176,6 +176,23 @@ def pack(name, case, res):
     return out
 
 
+def make_vtk_fixture():
+    """tests/golden/vtk_G5_25steps/*.vtk: the five files the reference's write_vtk (main.c:237-338)
+    produces for case G5 after 25 renderScene calls with nFile = 3 (data written by the reference)."""
+    import pyoracle as po
+    c = cases()["G5_dem_64x48"]
+    tmp = tempfile.NamedTemporaryFile("w", suffix=".data", delete=False)
+    tmp.close()
+    po.write_sample(tmp.name, c["r_mm"], c["x_mm"], c["y_mm"])
+    R = po.Reference(64, 48, tmp.name)
+    os.unlink(tmp.name)
+    R.set_kinematics(dem_initial_kinematics(c))
+    R.steps(25)
+    out = os.path.join(HERE, "vtk_G5_25steps")
+    os.makedirs(out, exist_ok=True)
+    assert R.L.ref_write_vtk(os.fsencode(out), 3) == 0
+
+
 def main():
     import pyoracle as po
     if not po.reference_available():
@@ -188,6 +205,9 @@ def main():
         p.join()
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **pack(name, case, res))
         print("wrote", name, {k: getattr(v, "shape", None) for k, v in pack(name, case, res).items()})
+    p = mp.Process(target=make_vtk_fixture)
+    p.start()
+    p.join()
 
 
 if __name__ == "__main__":

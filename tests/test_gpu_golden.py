@@ -12,3 +12,38 @@ def test_hip_matches_reference_dump(pkg, name):
     sim = gu.GpuAdapter(pkg, name)
     res = gu.run_case(sim, name)
     gu.compare(name, res, grain_cols=list(range(9)))
+
+
+def test_vtk_files_byte_identical_to_the_reference(pkg, tmp_path):
+    """write_vtk (main.c:237-338): the five binary legacy-VTK files for case G5 after 25 renderScene
+    calls must equal, byte for byte, the files the reference wrote (tests/golden/vtk_G5_25steps/)."""
+    import os
+    sim = gu.GpuAdapter(pkg, "G5_dem_64x48")
+    sim.set_kinematics(gu.mg.dem_initial_kinematics(gu.CASES["G5_dem_64x48"]))
+    sim.steps(25)
+    sim.sim.write_vtk(str(tmp_path), 3)
+    ref_dir = os.path.join(gu.HERE, "golden", "vtk_G5_25steps")
+    names = sorted(os.listdir(ref_dir))
+    assert len(names) == 5
+    for name in names:
+        got = open(tmp_path / name, "rb").read()
+        want = open(os.path.join(ref_dir, name), "rb").read()
+        assert got == want, f"{name}: {len(got)} vs {len(want)} bytes, first diff at " \
+                            f"{next((i for i, (a, b) in enumerate(zip(got, want)) if a != b), None)}"
+
+
+def test_grain_pressure_matches_oracle(pkg, po):
+    """g.p (sum of normal contact forces of the last sub-step, main.c:776-777,830,880,912,938)."""
+    import numpy as np
+    name = "G5_dem_64x48"
+    c = gu.CASES[name]
+    r, x1, x2 = gu.inputs_m(name)
+    sim = pkg.LbmDem(c["lx"], c["ly"], r, x1, x2); ora = po.Oracle(c["lx"], c["ly"], r, x1, x2)
+    k = gu.mg.dem_initial_kinematics(c)
+    sim.kinematics = k; ora.set_kinematics(k)
+    seen = 0
+    for n in (1, 1, 23, 100):   # step 0 uses the film law
+        sim.renderScene(n); ora.steps(n)
+        assert np.array_equal(sim.grain_pressure, ora.get_grains()[:, po.COL["p"]])
+        seen = max(seen, int((sim.grain_pressure != 0).sum()))
+    assert seen >= 4            # the four grains pressed into the walls
