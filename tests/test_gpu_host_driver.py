@@ -1,0 +1,43 @@
+"""GPU: the kept C host side (2d-lbm-dem_amd/host/lbmdem) as a drop-in for the reference binary:
+`lbmdem <sample.data>`, the reference's console lines, `final_density:` on stderr (what the
+reference's JUBE benchmark parses, benchmark.xml:99-102), VTK frames at the stepFilm cadence."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "2d-lbm-dem_amd", "host", "lbmdem")
+
+
+def test_usage_error_like_the_reference():
+    out = subprocess.run([EXE], capture_output=True, text=True)
+    assert out.returncode != 0 and "usage" in out.stdout
+
+
+def test_run_matches_oracle_and_writes_a_frame(po, tmp_path):
+    c = gu.CASES["G4_coupled_256x200"]
+    sample = tmp_path / "packing.data"
+    po.write_sample(str(sample), c["r_mm"], c["x_mm"], c["y_mm"], comment="#Length =25 Height =20")
+    nsteps = 8001      # one VTK frame at nbsteps == 8000 (main.c:1767)
+    out = subprocess.run([EXE, str(sample), "--lx", "256", "--ly", "200", "--steps", str(nsteps)],
+                         capture_output=True, text=True, cwd=tmp_path, timeout=600)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert "Nb grains %d" % len(c["r_mm"]) in out.stdout
+    assert re.search(r"dtLB=.*npDEM=\d+", out.stdout)
+    assert "Iteration Number 0, Total density in the system" in out.stdout
+    fd = float(re.search(r"final_density: ([0-9.]+)", out.stderr).group(1))
+    r, x1, x2 = po.read_sample(str(sample))
+    ora = po.Oracle(256, 200, r, x1, x2)
+    ora.steps(nsteps)
+    assert abs(fd - ora.total_density()) < 1e-5
+    frames = sorted(p.name for p in tmp_path.glob("*.vtk"))
+    assert frames == ["fluid_pressure_000000.vtk", "fluid_velocity_000000.vtk", "grain_acceleration_000000.vtk",
+                      "grain_pressure_000000.vtk", "grain_velocity_000000.vtk"]
+    assert os.path.getsize(tmp_path / "fluid_velocity_000000.vtk") > 256 * 200 * 12
