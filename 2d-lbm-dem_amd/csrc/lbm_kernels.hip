@@ -270,12 +270,16 @@ __device__ __forceinline__ double ibb_near_value(const LatticeView& L, const Ibb
 // so f*[S][q] with S = P - e_q is C.in(opp q) and f*[P + e_q][opp q] is C.in(q).
 // EDGE = false is the specialisation for nodes at least two rows/columns away from every lattice edge
 // (S, P and P + e_q are then all interior): the edge logic disappears.
+// Everything of a pull except the interpolated bounce-back itself. Returns true when (P, q) IS an
+// interpolated-bounce-back link (P fluid, source S an interior grain node) -- `out` is then not set.
 template <int q, bool EDGE = true, class Ctx>
-__device__ __forceinline__ double pull_one(const Ctx& C, const LatticeView& L, const GrainFluidView& G,
-                                           int gx, int gy) {
+__device__ __forceinline__ bool pull_classify(const Ctx& C, const LatticeView& L, int gx, int gy, double& out) {
   constexpr int ex = EXq(q), ey = EYq(q), qo = OPPq(q);
   const int sxg = gx - ex, syg = gy - ey;  // source node S = P - e_q
-  if (EDGE && (sxg < 0 || sxg >= L.lx || syg < 0 || syg >= L.ly)) return C.own(qo);  // array edge: main.c:1237
+  if (EDGE && (sxg < 0 || sxg >= L.lx || syg < 0 || syg >= L.ly)) {  // array edge: main.c:1237
+    out = C.own(qo);
+    return false;
+  }
   const bool s_interior = !EDGE || (sxg >= 1 && sxg <= L.lx - 2 && syg >= 1 && syg <= L.ly - 2);
   if (!s_interior) {
     // S is a lattice-edge wall node. Its slot q was overwritten by the edge copies
@@ -284,14 +288,33 @@ __device__ __forceinline__ double pull_one(const Ctx& C, const LatticeView& L, c
     // still holds its old value.
     const bool s_yedge = (syg == 0 || syg == L.ly - 1) && sxg >= 1 && sxg <= L.lx - 2;
     const bool copied = gy >= 1 && gy <= L.ly - 2 && ((gx >= 1 && gx <= L.lx - 2) || s_yedge);
-    return copied ? C.own(qo) : C.in(qo);
+    out = copied ? C.own(qo) : C.in(qo);
+    return false;
   }
   const int oS = C.o_nb(qo);
-  if (oS == -1) return C.in(qo);  // plain streaming from a fluid node
-  if (C.o_own() != -1)  // solid -> non-fluid link: active solid nodes reset the slot to w (main.c:1161-1162)
-    return C.act_nb(qo) ? Wq(q) : C.in(qo);
+  if (oS == -1) {  // plain streaming from a fluid node
+    out = C.in(qo);
+    return false;
+  }
+  if (C.o_own() != -1) {  // solid -> non-fluid link: active solid nodes reset the slot to w (main.c:1161-1162)
+    out = C.act_nb(qo) ? Wq(q) : C.in(qo);
+    return false;
+  }
+  return true;
+}
 
-  // P fluid, S an (active) solid node of grain oS: interpolated bounce-back
+// Is the node two links out, NN = P + e_q, an interior node? (only asked for bounce-back links)
+template <int q, bool EDGE>
+__device__ __forceinline__ bool nn_interior(const LatticeView& L, int gx, int gy) {
+  const int nxg = gx + EXq(q), nyg = gy + EYq(q);
+  return !EDGE || (nxg >= 1 && nxg <= L.lx - 2 && nyg >= 1 && nyg <= L.ly - 2);
+}
+
+// The interpolated bounce-back value of link (P, q): P fluid, S = P - e_q an (active) node of a grain.
+template <int q, bool EDGE = true, class Ctx>
+__device__ __forceinline__ double ibb_eval(const Ctx& C, const LatticeView& L, int gx, int gy) {
+  constexpr int ex = EXq(q), ey = EYq(q), qo = OPPq(q);
+  const int sxg = gx - ex, syg = gy - ey;
   const IbbLink k = ibb_link<q>(L, C.gp_nb(qo), sxg, syg);
   if (ibb_far(k)) return ibb_far_value<q>(L, k, C.own(qo), C.own(q));
   if (!ibb_near(k)) return C.in(qo);  // neither branch fires: slot keeps its value
@@ -299,8 +322,7 @@ __device__ __forceinline__ double pull_one(const Ctx& C, const LatticeView& L, c
   // 0 < delta < 1/2: the reference reads f[NN][opp q], NN = P + e_q, *in place* (main.c:1181,1213).
   double f2;
   const int nxg = gx + ex, nyg = gy + ey;
-  const bool n_interior = !EDGE || (nxg >= 1 && nxg <= L.lx - 2 && nyg >= 1 && nyg <= L.ly - 2);
-  if (!n_interior) {
+  if (!nn_interior<q, EDGE>(L, gx, gy)) {
     f2 = C.own(q);  // edge wall node: its slot opp q was set by the edge copy to f*[P][q]
   } else {
     const int oN = C.o_nb(q);
@@ -315,6 +337,66 @@ __device__ __forceinline__ double pull_one(const Ctx& C, const LatticeView& L, c
     }
   }
   return ibb_near_value<q>(L, k, C.own(qo), f2);
+}
+
+template <int q, bool EDGE = true, class Ctx>
+__device__ __forceinline__ double pull_one(const Ctx& C, const LatticeView& L, const GrainFluidView& G,
+                                           int gx, int gy) {
+  double out;
+  if (!pull_classify<q, EDGE>(C, L, gx, gy, out)) return out;
+  return ibb_eval<q, EDGE>(C, L, gx, gy);
+}
+
+// The same bounce-back value with the direction as a RUN-TIME argument, for the compacted evaluation of
+// the marching kernel (one lane per link, any direction). Formula for formula the arithmetic of
+// ibb_eval<q>: (x + ex - xc) * ex etc. are the same IEEE operations whether ex is a template constant
+// or a variable; the division by aa in {1, 2} is exact either way.
+struct RtLink {
+  int q;                 // 1..8
+  int gx, gy;            // P
+  double own_qo, own_q;  // f*[P][opp q], f*[P][q]
+  double in_q, in_qo;    // f*[P + e_q][opp q], f*[P - e_q][q]
+  bool nn_int, hazard;   // NN interior; NN solid and q <= 4 (its own update precedes S's)
+};
+__device__ __forceinline__ double link_delta_rt(int x, int y, int ex, int ey, double xc, double yc, double r2) {
+  const int aai = (ex < 0 ? -ex : ex) + (ey < 0 ? -ey : ey);
+  const double aa = (double)aai;
+  const double bb = (x + ex - xc) * ex + (y + ey - yc) * ey;
+  const double cc = (x + ex - xc) * (x + ex - xc) + (y + ey - yc) * (y + ey - yc) - r2;
+  const double t = bb - sqrt(fabs(bb * bb - aa * cc));
+  return aai == 2 ? t * 0.5 : t;  // == t / aa exactly
+}
+// wc_diag = Wq(1) / L.c, wc_axis = Wq(2) / L.c (what ibb_*_value<q> form as Wq(q) / L.c)
+template <class RecFn>
+__device__ __forceinline__ double ibb_eval_rt(const LatticeView& L, const RtLink& k, double wc_diag,
+                                              double wc_axis, RecFn rec_of) {
+  const int q = k.q;
+  const int ex = (q >= 1 && q <= 3) ? -1 : ((q >= 5 && q <= 7) ? 1 : 0);
+  const int ey = (q == 1 || q >= 7) ? 1 : ((q >= 3 && q <= 5) ? -1 : 0);
+  const double wc = (q & 1) ? wc_diag : wc_axis;
+  const int sx = k.gx - ex, sy = k.gy - ey;
+  const GP g = rec_of(-ex, -ey);  // record of the grain that owns S = P - e_q
+  IbbLink a;
+  a.d = link_delta_rt(sx, sy, ex, ey, g.xc, g.yc, g.r2);
+  a.uw = ex * wall_ux(L, g, sy) + ey * wall_uy(L, g, sx);
+  if (a.d >= 0.5) return k.own_qo / (2 * a.d) + (2 * a.d - 1) * k.own_q / (2 * a.d) + 3 * wc * a.uw / a.d;
+  if (!(a.d > 0. && a.d < 0.5)) return k.in_qo;
+  double f2;
+  if (!k.nn_int) {
+    f2 = k.own_q;
+  } else {
+    f2 = k.in_q;
+    if (k.hazard) {
+      const int nx = k.gx + ex, ny = k.gy + ey;
+      const GP gn = rec_of(ex, ey);  // record of the grain that owns NN = P + e_q
+      IbbLink b;
+      b.d = link_delta_rt(nx, ny, -ex, -ey, gn.xc, gn.yc, gn.r2);
+      b.uw = (-ex) * wall_ux(L, gn, ny) + (-ey) * wall_uy(L, gn, nx);
+      if (b.d >= 0.5) f2 = k.own_q / (2 * b.d) + (2 * b.d - 1) * k.own_qo / (2 * b.d) + 3 * wc * b.uw / b.d;
+      else if (b.d > 0. && b.d < 0.5) f2 = 2 * b.d * k.own_q + (1 - 2 * b.d) * k.in_qo + 6 * wc * b.uw;
+    }
+  }
+  return 2 * a.d * k.own_qo + (1 - 2 * a.d) * f2 + 6 * wc * a.uw;
 }
 
 // context over the LDS tile
@@ -514,6 +596,32 @@ struct RegCtx {
   __device__ __forceinline__ bool act_nb(int d) const { return (act >> d) & 1u; }
 };
 
+// All nine pulls of a node except the interpolated bounce-back links: the others are stored right away,
+// the bounce-back links are only flagged: bit q of `ibb` = link (P, q) needs ibb_eval; `nnm` / `hzm` =
+// that link's NN is interior / is a solid node whose own update precedes S's (q <= 4).
+template <bool EDGE, class Ctx>
+__device__ __forceinline__ void classify_store_row(const Ctx& C, const LatticeView& L, int gx, int y,
+                                                   double* __restrict__ fout, long node, unsigned& ibb,
+                                                   unsigned& nnm, unsigned& hzm) {
+  fout[node] = C.own(0);
+#define LBM_CLASSIFY(Q)                                                   \
+  {                                                                       \
+    double o_;                                                            \
+    if (pull_classify<Q, EDGE>(C, L, gx, y, o_)) {                        \
+      ibb |= 1u << Q;                                                     \
+      if (nn_interior<Q, EDGE>(L, gx, y)) {                               \
+        nnm |= 1u << Q;                                                   \
+        if (Q <= 4 && C.o_nb(Q) != -1) hzm |= 1u << Q;                    \
+      }                                                                   \
+    } else {                                                              \
+      fout[Q * L.plane + node] = o_;                                      \
+    }                                                                     \
+  }
+  LBM_CLASSIFY(1) LBM_CLASSIFY(2) LBM_CLASSIFY(3) LBM_CLASSIFY(4)
+  LBM_CLASSIFY(5) LBM_CLASSIFY(6) LBM_CLASSIFY(7) LBM_CLASSIFY(8)
+#undef LBM_CLASSIFY
+}
+
 template <bool EDGE, class Ctx>
 __device__ __forceinline__ void store_row(double* __restrict__ fout, const LatticeView& L,
                                           const GrainFluidView& G, const Ctx& C, long node, int gx, int y) {
@@ -563,6 +671,13 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
   // in the order it was requested; no other global load exists inside the loop.
   __shared__ double2 sRec[4 * REC_RING * 4 * 64];
   const RecRing ring{sRec + (threadIdx.x >> 6) * (REC_RING * 4 * 64)};
+  // wave-private scratch for the compacted bounce-back evaluation: 64 link slots
+  __shared__ double sPay[4 * 64 * 4];
+  __shared__ int sDesc[4 * 64];
+  double* const pay = sPay + (threadIdx.x >> 6) * (64 * 4);
+  int* const desc = sDesc + (threadIdx.x >> 6) * 64;
+  const double wc_diag = Wq(1) / L.c, wc_axis = Wq(2) / L.c;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   auto row_ok = [&](int xl) { return yin && xl >= 0 && xl < L.nxl; };
   const int ycl = y < 0 ? 0 : (y >= L.ly ? L.ly - 1 : y);
   auto node_of = [&](int xl) {  // clamped: always a valid address
@@ -670,10 +785,53 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
       const long node = (long)x * L.sy + y;
       // wave-uniform: is every producing lane of this row at least two nodes away from all edges?
       const bool deep = deep_y && gx >= 2 && gx <= L.lx - 3;
-      if (deep) {
-        if (writer) store_row<false>(fout, L, G, C, node, gx, y);
-      } else {
-        if (writer) store_row<true>(fout, L, G, C, node, gx, y);
+      // (a) everything but the interpolated bounce-back links: computed and stored
+      unsigned ibb = 0, nnm = 0, hzm = 0;
+      if (writer) {
+        if (deep) classify_store_row<false>(C, L, gx, y, fout, node, ibb, nnm, hzm);
+        else classify_store_row<true>(C, L, gx, y, fout, node, ibb, nnm, hzm);
+      }
+      // (b) the bounce-back links of the whole row (typically ~20, spread over all eight directions
+      // and a few lanes) are compacted into dense lanes through LDS and evaluated in ONE pass with the
+      // direction as data, instead of ~3.5 direction-specific divergent passes of ~130 instructions.
+      // slot of link (lane, q) = number of links in directions < q + number in direction q on lower lanes
+      int T = 0;
+#pragma unroll
+      for (int q = 1; q < 9; ++q) T += __popcll(__ballot((ibb >> q) & 1u));
+      for (int base = 0; base < T; base += 64) {  // wave-uniform; a second round only if > 64 links
+        int before = 0;
+#pragma unroll
+        for (int q = 1; q < 9; ++q) {
+          const unsigned long long b = __ballot((ibb >> q) & 1u);
+          const int t = before + __popcll(b & lt_mask) - base;
+          before += __popcll(b);
+          if (((ibb >> q) & 1u) && t >= 0 && t < 64) {
+            desc[t] = lane | (q << 8) | (((nnm >> q) & 1u) << 12) | (((hzm >> q) & 1u) << 13);
+            pay[t * 4 + 0] = C.Fo[OPPq(q)];
+            pay[t * 4 + 1] = C.Fo[q];
+            pay[t * 4 + 2] = C.In[q];
+            pay[t * 4 + 3] = C.In[OPPq(q)];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();  // LDS operations of one wave execute in order
+        if (base + lane < T) {
+          const int d = desc[lane];
+          const int src = d & 63;
+          RtLink k;
+          k.q = (d >> 8) & 15;
+          k.gx = gx;
+          k.gy = y - lane + src;
+          k.own_qo = pay[lane * 4 + 0];
+          k.own_q = pay[lane * 4 + 1];
+          k.in_q = pay[lane * 4 + 2];
+          k.in_qo = pay[lane * 4 + 3];
+          k.nn_int = (d >> 12) & 1;
+          k.hazard = (d >> 13) & 1;
+          // the result goes straight to the population it belongs to: node of lane `src`, plane q
+          fout[k.q * L.plane + (node - lane + src)] =
+              ibb_eval_rt(L, k, wc_diag, wc_axis, [&](int dx, int dy) { return ring.get(x + dx, src + dy); });
+        }
+        __builtin_amdgcn_wave_barrier();
       }
     }
     // row x-1 is no longer needed: its ring slot takes the owner records of row x+3; then request
