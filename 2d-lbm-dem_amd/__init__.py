@@ -78,6 +78,7 @@ def load_library():
     L.lbmdem_free_host.argtypes = [C.c_void_p]
     L.lbmdem_free_host.restype = None
     L.lbmdem_run.argtypes = [C.c_void_p, C.c_long]
+    L.lbmdem_run_dem.argtypes = [C.c_void_p, C.c_long]
     L.lbmdem_set_nbsteps.argtypes = [C.c_void_p, C.c_long]
     L.lbmdem_derive.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]
     L.lbmdem_create.argtypes = [C.POINTER(Config), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
@@ -207,6 +208,10 @@ class LbmDem:
     def renderScene(self, n=1):
         """n x renderScene() (main.c:1697-1765)."""
         _chk(self._L.lbmdem_run(self._h, int(n)))
+
+    def run_dem(self, n=1):
+        """n x (Verlet rebuild when due; DEM sub-step) -- renderScene without its fluid step."""
+        _chk(self._L.lbmdem_run_dem(self._h, int(n)))
 
     def lbm_step(self):
         """reinit_obst_density + obst_construction + collision_streaming + forces_fluid (main.c:1711-1717)."""

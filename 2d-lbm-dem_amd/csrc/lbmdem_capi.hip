@@ -415,6 +415,17 @@ int lbmdem_run(lbmdem_handle* h, long n_dem_steps) {
   return LBMDEM_OK;
 }
 
+int lbmdem_run_dem(lbmdem_handle* h, long n_dem_steps) {
+  CHECK_H(h);
+  for (long k = 0; k < n_dem_steps; ++k) {
+    int rc = LBMDEM_OK;
+    if (h->nbsteps % h->cfg.phys.updateVerlet == 0) rc = lbmdem_verlet_rebuild(h);  // main.c:1721-1724
+    if (rc == LBMDEM_OK) rc = lbmdem_dem_substep(h);                                // main.c:1733-1764
+    if (rc != LBMDEM_OK) return rc;
+  }
+  return LBMDEM_OK;
+}
+
 int lbmdem_set_force_mode(lbmdem_handle* h, int mode) {
   if (!h || (mode != 0 && mode != 1)) return fail(LBMDEM_EINVAL, "bad force mode");
   h->force_mode = mode;

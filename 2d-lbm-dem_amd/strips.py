@@ -48,6 +48,7 @@ class StripRunner:
     def __init__(self, backend, comm, rank: int, world: int):
         self.b, self.comm, self.rank, self.world = backend, comm, rank, world
         self.has_lo, self.has_hi = rank > 0, rank < world - 1
+        self.always_reduce = False  # bench.py --strips with one rank: still go through the collective
 
     # -- one fluid step, split so that an in-process test can interleave several ranks -------------
     def fluid_compute(self):
@@ -82,18 +83,22 @@ class StripRunner:
             self.comm.exchange(self.halo_post())
             self.halo_finish()
         buf = self.forces_post()
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             self.comm.all_reduce_bits(buf)
             self.forces_finish()
 
     def render_scene(self, n: int = 1):
+        """n x renderScene(). The DEM sub-steps between two fluid steps need no communication (the DEM
+        state is replicated), so they go down to the backend in one call."""
         b = self.b
-        for _ in range(n):
-            if b.nbsteps % b.npDEM == 0:          # main.c:1710
+        step = b.nbsteps
+        while n > 0:
+            if step % b.npDEM == 0:               # main.c:1710
                 self.lbm_step()
-            if b.nbsteps % b.updateVerlet == 0:   # main.c:1721
-                b.initVerlet()
-            b.dem_substep()                       # main.c:1733-1764
+            k = min(n, b.npDEM - step % b.npDEM)
+            b.run_dem(k)                          # main.c:1721-1724, 1733-1764, k times
+            step += k
+            n -= k
 
 
 class TorchComm:
@@ -145,6 +150,7 @@ class GpuStripBackend:
     def forces_fluid(self): self.sim.forces_fluid()
     def initVerlet(self): self.sim.initVerlet()
     def dem_substep(self): self.sim.dem_substep()
+    def run_dem(self, k): self.sim.run_dem(k)
 
     def halo_pack(self, side):
         self.sim.halo_pack(side, self.send[side].data_ptr())
@@ -180,4 +186,6 @@ def make_gpu_runner(pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2, force
         raise pkg.LbmDemError(-1, f"strips of {strip[1] - strip[0]} rows are narrower than the halo ({halo})")
     backend = GpuStripBackend(pkg, torch, lx, ly, r, x1, x2, strip, halo if world > 1 else 0, local_rank,
                               force_mode)
-    return _GpuRunner(backend, TorchComm(dist), rank, world)
+    runner = _GpuRunner(backend, TorchComm(dist), rank, world)
+    runner.always_reduce = world == 1
+    return runner

@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-mode", type=int, default=0, help="0 = parity hydro-force kernel, 1 = fast")
+    ap.add_argument("--strips", action="store_true",
+                    help="use the strip-decomposition driver (torch.distributed) even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,7 +132,7 @@ def main():
     (r, x1, x2), sample_mm = make_sample(w)
     lx, ly = w["lx"], w["ly"]
 
-    if world == 1:
+    if world == 1 and not args.strips:
         sim = pkg.LbmDem(lx, ly, r, x1, x2, device=local_rank)
         sim.set_force_mode(args.force_mode)
         npdem = sim.cfg.npDEM
@@ -144,6 +146,8 @@ def main():
         runner = None
     else:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         strips = pkg.strips_module()
         runner = strips.make_gpu_runner(pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2,
@@ -169,7 +173,7 @@ def main():
     elapsed = t1 - t0
     kernel_ms, launches = sim.profile_read()
     sim.profile_enable(False)
-    if world > 1:
+    if world > 1 or args.strips:
         import torch.distributed as dist
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -212,7 +216,7 @@ def main():
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, sample_mm, npdem)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.strips:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -103,6 +103,9 @@ int lbmdem_dem_substep(lbmdem_handle* h);
  * nbsteps % npDEM == 0, a Verlet rebuild when nbsteps % updateVerlet == 0, then a DEM sub-step.
  * Device-resident; returns without synchronising. */
 int lbmdem_run(lbmdem_handle* h, long n_dem_steps);
+/* The same without the fluid steps: n x (Verlet rebuild when due; DEM sub-step). For drivers that run the
+ * fluid step themselves (strip decomposition: halo exchange and force combine sit between its phases). */
+int lbmdem_run_dem(lbmdem_handle* h, long n_dem_steps);
 
 /* hydrodynamic-force kernel choice: 0 = parity (one thread per grain, reference summation order,
  * bit-exact); 1 = fast (wave per grain, shuffle reduction; differs in the last bits). Default 0. */

@@ -71,6 +71,12 @@ class OracleStripBackend:
     def initVerlet(self): self.o.verlet_rebuild()
     def dem_substep(self): self.o.dem_substep()
 
+    def run_dem(self, k):
+        for _ in range(k):
+            if self.o.nbsteps % self.updateVerlet == 0:
+                self.o.verlet_rebuild()
+            self.o.dem_substep()
+
 
 class LoopbackComm:
     """Placeholder comm for runners that are stepped in lock-step inside one process."""

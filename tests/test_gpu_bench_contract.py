@@ -1,0 +1,41 @@
+"""GPU: bench.py's output contract, single process and through the torch.distributed launcher (one
+rank: the same strip-driver + RCCL plumbing the multi-GPU runs use)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _last_json(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-400:]
+    return json.loads(lines[0])
+
+
+def test_single_process_line():
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-500:]
+    d = _last_json(out.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 4 and d["dtype"] == "f64"
+    assert d["unit"] == "MLUPS" and d["value"] > 1000 and d["vs_baseline"] is None and d["data"] == "synthetic"
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_launcher_path_one_rank():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "1", "--steps", "3",
+           "--warmup", "1", "--strips", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-800:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 1 and d["value"] > 1000
