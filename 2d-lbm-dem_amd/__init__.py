@@ -93,6 +93,8 @@ def load_library():
     L.lbmdem_download_grain_pressure.argtypes = [C.c_void_p, C.c_void_p]
     L.lbmdem_download_vtk_fields.argtypes = [C.c_void_p] + [C.c_void_p] * 5
     L.lbmdem_write_vtk.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.lbmdem_checkpoint_save.argtypes = [C.c_void_p, C.c_char_p]
+    L.lbmdem_checkpoint_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     L.lbmdem_set_force_mode.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_profile_enable.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -181,6 +183,20 @@ class LbmDem:
         self.cfg = cfg
         self.lx, self.ly, self.n = int(lx), int(ly), len(r)
         _chk(L.lbmdem_create(C.byref(cfg), _vp(r), _vp(x1), _vp(x2), C.byref(self._h)))
+
+    def checkpoint_save(self, path):
+        _chk(self._L.lbmdem_checkpoint_save(self._h, os.fsencode(path)))
+
+    @classmethod
+    def checkpoint_load(cls, path, device=0):
+        """Restart: a new simulation continuing bit-identically from a checkpoint."""
+        L = load_library()
+        self = cls.__new__(cls)
+        self._L, self._h = L, C.c_void_p()
+        _chk(L.lbmdem_checkpoint_load(os.fsencode(path), int(device), C.byref(self._h)))
+        self.cfg = self.config()
+        self.lx, self.ly, self.n = self.cfg.lx, self.cfg.ly, self.cfg.nbgrains
+        return self
 
     @classmethod
     def from_sample(cls, path, lx, ly, **kw):

@@ -671,6 +671,97 @@ int lbmdem_write_vtk(lbmdem_handle* h, const char* dir, int nfile) {
   return LBMDEM_OK;
 }
 
+// ---- checkpoint / restart ------------------------------------------------------------------------
+
+namespace {
+struct CkptHeader {
+  char magic[8];       // "LBMDEMC1"
+  lbmdem_config cfg;   // incl. the wall positions VerletWall may have moved
+  long nbsteps;
+  int verlet_ok, nnbr; // symmetric list length
+  long plane;          // sanity: nxl * sy of the writer
+};
+bool wr(FILE* fp, const void* p, size_t n) { return fwrite(p, 1, n, fp) == n; }
+bool rd(FILE* fp, void* p, size_t n) { return fread(p, 1, n, fp) == n; }
+}  // namespace
+
+int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) {
+  CHECK_H(h);
+  if (!path) return fail(LBMDEM_EINVAL, "null path");
+  if (h->obst_pending) return fail(LBMDEM_EINVAL, "checkpoint between obst_construction and collide_stream");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int n = h->n;
+  std::vector<int> off(n + 1, 0);
+  if (h->verlet_ok) HIP_TRY(hipMemcpy(off.data(), h->V.offsets, sizeof(int) * (n + 1), hipMemcpyDeviceToHost));
+  CkptHeader H;
+  memset(&H, 0, sizeof H);
+  memcpy(H.magic, "LBMDEMC1", 8);
+  H.cfg = h->cfg; H.nbsteps = h->nbsteps; H.verlet_ok = h->verlet_ok ? 1 : 0; H.nnbr = off[n]; H.plane = h->L.plane;
+  FILE* fp = fopen(path, "wb");
+  if (!fp) return fail(LBMDEM_EINVAL, "cannot open '%s' for writing", path);
+  bool ok = wr(fp, &H, sizeof H);
+  auto dump = [&](const void* dev, size_t bytes) {
+    if (!ok || bytes == 0) return;
+    std::vector<char> buf(bytes);
+    if (hipMemcpy(buf.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; return; }
+    ok = wr(fp, buf.data(), bytes);
+  };
+  dump(h->r, sizeof(double) * n);
+  dump(h->kin[h->kcur].x1, sizeof(double) * 9 * n);
+  dump(h->fhf, sizeof(double) * 3 * n);
+  dump(h->gp, sizeof(double) * n);
+  dump(h->V.offsets, sizeof(int) * (n + 1));
+  dump(h->V.nbr, sizeof(int) * (size_t)H.nnbr);
+  dump(h->V.wallflags, n);
+  dump(h->obst[h->ocur], sizeof(int) * (size_t)h->L.plane);
+  for (int q = 0; q < 9 && ok; ++q)  // plane by plane: bounded host staging
+    dump(h->f[h->fcur] + (size_t)q * h->L.plane, sizeof(double) * (size_t)h->L.plane);
+  ok = (fclose(fp) == 0) && ok;
+  if (!ok) return fail(LBMDEM_EHIP, "writing checkpoint '%s' failed", path);
+  return LBMDEM_OK;
+}
+
+int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) {
+  if (!path || !out) return fail(LBMDEM_EINVAL, "null argument");
+  *out = nullptr;
+  FILE* fp = fopen(path, "rb");
+  if (!fp) return fail(LBMDEM_EINVAL, "cannot open checkpoint '%s'", path);
+  CkptHeader H;
+  if (!rd(fp, &H, sizeof H) || memcmp(H.magic, "LBMDEMC1", 8) != 0) { fclose(fp); return fail(LBMDEM_EINVAL, "'%s' is not a checkpoint", path); }
+  const int n = H.cfg.nbgrains;
+  std::vector<double> r(n), kin(9 * (size_t)n);
+  if (!rd(fp, r.data(), sizeof(double) * n) || !rd(fp, kin.data(), sizeof(double) * 9 * n)) { fclose(fp); return fail(LBMDEM_EINVAL, "checkpoint truncated"); }
+  lbmdem_config cfg = H.cfg;
+  cfg.device = device;
+  lbmdem_handle* h = nullptr;
+  int rc = lbmdem_create(&cfg, r.data(), kin.data(), kin.data() + n, &h);  // x1, x2 are the first two columns
+  if (rc != LBMDEM_OK) { fclose(fp); return rc; }
+  bool ok = h->L.plane == H.plane && H.nnbr >= 0 && H.nnbr <= h->V.cap;
+  auto fill = [&](void* dev, size_t bytes) {
+    if (!ok || bytes == 0) return;
+    std::vector<char> buf(bytes);
+    ok = rd(fp, buf.data(), bytes) && hipMemcpy(dev, buf.data(), bytes, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  if (ok) ok = hipMemcpy(h->kin[0].x1, kin.data(), sizeof(double) * 9 * n, hipMemcpyHostToDevice) == hipSuccess;
+  h->kcur = 0;
+  fill(h->fhf, sizeof(double) * 3 * n);
+  fill(h->gp, sizeof(double) * n);
+  fill(h->V.offsets, sizeof(int) * (n + 1));
+  fill(h->V.nbr, sizeof(int) * (size_t)H.nnbr);
+  fill(h->V.wallflags, n);
+  fill(h->obst[0], sizeof(int) * (size_t)h->L.plane);
+  h->ocur = 0; h->obst_pending = false;
+  for (int q = 0; q < 9 && ok; ++q) fill(h->f[0] + (size_t)q * h->L.plane, sizeof(double) * (size_t)h->L.plane);
+  h->fcur = 0;
+  fclose(fp);
+  if (!ok) { lbmdem_destroy(h); return fail(LBMDEM_EINVAL, "checkpoint '%s' is truncated or from a different decomposition", path); }
+  h->cfg = cfg;  // wall positions as saved
+  h->nbsteps = H.nbsteps;
+  h->verlet_ok = H.verlet_ok != 0;
+  *out = h;
+  return LBMDEM_OK;
+}
+
 long lbmdem_nbsteps(lbmdem_handle* h) { return h ? h->nbsteps : -1; }
 
 int lbmdem_set_nbsteps(lbmdem_handle* h, long n) {

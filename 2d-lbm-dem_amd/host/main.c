@@ -6,7 +6,8 @@
  *
  * The reference fixes the lattice size and the run length at compile time (-Dlx -Dly,
  * `#define duration 1.5`, main.c:27-32,47); here the same defaults apply and can be overridden at
- * run time: --lx N --ly N --scale S --duration SECONDS --steps N_DEM_STEPS --device K.
+ * run time: --lx N --ly N --scale S --duration SECONDS --steps N_DEM_STEPS --device K, and (absent in
+ * the reference, which cannot resume) --checkpoint FILE (written at the end) / --restart FILE.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -23,6 +24,7 @@ int main(int argc, char** argv) {
   double scale = 1., duration = 1.5;   /* main.c:24-26,47 */
   long max_steps = -1;
   const char* sample = NULL;
+  const char *ckpt_out = NULL, *ckpt_in = NULL;
   printf("2D LBM-DEM code\n");
   for (int a = 1; a < argc; ++a) {
     if (!strcmp(argv[a], "--lx") && a + 1 < argc) lx = atoi(argv[++a]);
@@ -31,6 +33,8 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[a], "--duration") && a + 1 < argc) duration = atof(argv[++a]);
     else if (!strcmp(argv[a], "--steps") && a + 1 < argc) max_steps = atol(argv[++a]);
     else if (!strcmp(argv[a], "--device") && a + 1 < argc) device = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "--checkpoint") && a + 1 < argc) ckpt_out = argv[++a];
+    else if (!strcmp(argv[a], "--restart") && a + 1 < argc) ckpt_in = argv[++a];
     else if (argv[a][0] != '-' && !sample) sample = argv[a];
     else { sample = NULL; break; }
   }
@@ -68,15 +72,22 @@ int main(int argc, char** argv) {
     printf("dtLB=%le,  dtmax=%le,   dt=%le,   npDEM=%d,   c=%lf\n", cfg.dtLB, dtmax, cfg.dt, cfg.npDEM, cfg.c);
   }
   lbmdem_handle* h = NULL;
-  DIE(lbmdem_create(&cfg, r, x1, x2, &h), "create");
+  long nbsteps = 0;
+  if (ckpt_in) {
+    DIE(lbmdem_checkpoint_load(ckpt_in, device, &h), "checkpoint_load");
+    DIE(lbmdem_get_config(h, &cfg), "get_config");
+    nbsteps = lbmdem_nbsteps(h);
+    printf("Restarted from %s at step %ld\n", ckpt_in, nbsteps);
+  } else {
+    DIE(lbmdem_create(&cfg, r, x1, x2, &h), "create");
+  }
   time_t now = time(NULL);
   printf("Current local time and date: %s", asctime(localtime(&now)));
 
   /* main loop, main.c:1879-1890: advance to the next console cadence (updateVerlet steps) at a time */
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
-  long nbsteps = 0;
-  int nFile = 0; /* main.c:147 */
+  int nFile = (int)(nbsteps / cfg.phys.stepFilm); /* main.c:147 */
   const int chunk = cfg.phys.updateVerlet;
   const int stepConsole = 400; /* main.c:140 */
   do {
@@ -110,6 +121,7 @@ int main(int argc, char** argv) {
   } while (nbsteps * cfg.dt <= duration && (max_steps < 0 || nbsteps < max_steps));
   DIE(lbmdem_sync(h), "sync");
   clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (ckpt_out) DIE(lbmdem_checkpoint_save(h, ckpt_out), "checkpoint_save");
   double sum = 0;
   DIE(lbmdem_total_density(h, &sum), "total_density");
   fprintf(stderr, "final_density: %f\n", sum);

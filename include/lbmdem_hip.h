@@ -138,6 +138,13 @@ int lbmdem_download_vtk_fields(lbmdem_handle* h, float* grain_pressure, float* g
  * <dir>/{grain_pressure,grain_velocity,grain_acceleration,fluid_pressure,fluid_velocity}_NNNNNN.vtk,
  * byte-identical to the reference's. Single-domain handles only. */
 int lbmdem_write_vtk(lbmdem_handle* h, const char* dir, int nfile);
+/* Checkpoint / restart (absent in the reference, which cannot resume a run: SURVEY.md section 5). The file
+ * holds exactly the state that defines the continuation at a renderScene() boundary -- populations,
+ * current obstacle map, grain kinematics, hydrodynamic forces, Verlet lists, wall positions, step
+ * counter -- in the device layout of the strip that wrote it. A run restarted from it is bit-identical
+ * to the uninterrupted run. load creates a new handle on `device`. */
+int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path);
+int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out);
 long lbmdem_nbsteps(lbmdem_handle* h);
 int lbmdem_set_nbsteps(lbmdem_handle* h, long n);
 int lbmdem_get_config(lbmdem_handle* h, lbmdem_config* out);

@@ -41,3 +41,19 @@ def test_run_matches_oracle_and_writes_a_frame(po, tmp_path):
     assert frames == ["fluid_pressure_000000.vtk", "fluid_velocity_000000.vtk", "grain_acceleration_000000.vtk",
                       "grain_pressure_000000.vtk", "grain_velocity_000000.vtk"]
     assert os.path.getsize(tmp_path / "fluid_velocity_000000.vtk") > 256 * 200 * 12
+
+
+def test_checkpoint_and_restart_from_the_command_line(po, tmp_path):
+    c = gu.CASES["G4_coupled_256x200"]
+    sample = tmp_path / "packing.data"
+    po.write_sample(str(sample), c["r_mm"], c["x_mm"], c["y_mm"])
+    base = [EXE, str(sample), "--lx", "256", "--ly", "200"]
+    full = subprocess.run(base + ["--steps", "150"], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    a = subprocess.run(base + ["--steps", "67", "--checkpoint", "half.ckpt"], capture_output=True, text=True,
+                       cwd=tmp_path, timeout=300)
+    b = subprocess.run(base + ["--steps", "150", "--restart", "half.ckpt"], capture_output=True, text=True,
+                       cwd=tmp_path, timeout=300)
+    assert full.returncode == 0 and a.returncode == 0 and b.returncode == 0, (a.stderr[-300:], b.stderr[-300:])
+    assert "Restarted from half.ckpt at step 67" in b.stdout
+    fd = lambda out: re.search(r"final_density: ([0-9.]+)", out.stderr).group(1)
+    assert fd(full) == fd(b)

@@ -294,3 +294,30 @@ print("ok")
         env = dict(os.environ, LBMDEM_CS_VARIANT=variant)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
         assert out.returncode == 0 and "ok" in out.stdout, (variant, out.stdout[-300:], out.stderr[-600:])
+
+
+def test_checkpoint_restart_is_bit_identical(pkg, po, tmp_path):
+    """Save at a renderScene boundary that is neither a fluid step nor a Verlet rebuild, restart, and
+    demand the same bits as the uninterrupted run (and as the oracle)."""
+    lx, ly = 160, 120
+    r, x1, x2 = small_packing(lx, ly, 40, 17)
+    sim, ora = make_pair(pkg, po, lx, ly, r, x1, x2)
+    rng = np.random.default_rng(6)
+    k = np.zeros((len(r), 9)); k[:, 0], k[:, 1] = x1, x2; k[:, 3:6] = rng.normal(0, 1, (len(r), 3)) * [0.03, 0.03, 20.0]
+    sim.kinematics = k; ora.set_kinematics(k)
+    n1, n2 = 2 * sim.cfg.npDEM + 5, 9 * sim.cfg.npDEM + 3     # crosses the Verlet rebuild at step 100
+    sim.renderScene(n1)
+    ck = str(tmp_path / "state.ckpt")
+    sim.checkpoint_save(ck)
+    sim.renderScene(n2)
+    res = pkg.LbmDem.checkpoint_load(ck)
+    assert res.nbsteps == n1 and res.cfg.Mdx == sim.config().Mdx
+    res.renderScene(n2)
+    ora.steps(n1 + n2)
+    for s in (sim, res):
+        assert np.array_equal(s.f, ora.get_f())
+        assert np.array_equal(s.kinematics, ora.get_grains()[:, :9])
+        assert np.array_equal(s.fhf, ora.get_fhf())
+        assert np.array_equal(s.grain_pressure, ora.get_grains()[:, po.COL["p"]])
+    with pytest.raises(pkg.LbmDemError):
+        pkg.LbmDem.checkpoint_load(str(tmp_path / "missing.ckpt"))
