@@ -93,6 +93,9 @@ def load_library():
     L.lbmdem_download_grain_pressure.argtypes = [C.c_void_p, C.c_void_p]
     L.lbmdem_download_vtk_fields.argtypes = [C.c_void_p] + [C.c_void_p] * 5
     L.lbmdem_write_vtk.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.lbmdem_set_diagnostics.argtypes = [C.c_void_p, C.c_int]
+    L.lbmdem_download_grain_table.argtypes = [C.c_void_p, C.c_void_p]
+    L.lbmdem_write_dem.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p]
     L.lbmdem_checkpoint_save.argtypes = [C.c_void_p, C.c_char_p]
     L.lbmdem_checkpoint_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     L.lbmdem_set_force_mode.argtypes = [C.c_void_p, C.c_int]
@@ -322,6 +325,21 @@ class LbmDem:
         out = np.zeros(self.n)
         _chk(self._L.lbmdem_download_grain_pressure(self._h, _vp(out)))
         return out
+
+    def set_diagnostics(self, always=True):
+        _chk(self._L.lbmdem_set_diagnostics(self._h, int(bool(always))))
+
+    def grain_table(self):
+        """(n, 30) in the reference's struct order (main.c:182-197); fr, ice, slip, rw are 0."""
+        out = np.zeros((self.n, 30))
+        _chk(self._L.lbmdem_download_grain_table(self._h, _vp(out)))
+        return out
+
+    def write_DEM(self, directory=".", nFile=0):
+        """write_DEM (main.c:340-438): DEM%06d.dat + a line of stats.data. -> (KE, PE, SE, IFR)"""
+        e = np.zeros(4)
+        _chk(self._L.lbmdem_write_dem(self._h, os.fsencode(directory), int(nFile), _vp(e)))
+        return tuple(e)
 
     def write_vtk(self, directory=".", nFile=0):
         """write_vtk (main.c:237-338): five binary legacy-VTK files, byte-identical to the reference's."""

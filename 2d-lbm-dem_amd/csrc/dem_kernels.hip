@@ -24,7 +24,7 @@
 
 namespace {
 
-struct Force3 { double f1, f2, f3, fn; };  // fn: normal force, accumulated into the grain pressure p
+struct Force3 { double f1, f2, f3, fn, ft, xij, yij; };  // fn, ft, branch vector: for the diagnostics
 
 __device__ __forceinline__ double maxt(double x, double y) { return (x < y) ? 0. : y; }  // main.c:211-216
 
@@ -50,7 +50,7 @@ __device__ __forceinline__ GrainState advance(const Kin& K, const double* __rest
 template <bool FILM>
 __device__ __forceinline__ Force3 contact(const GrainState& A, const GrainState& B, const DemParams& P,
                                           bool& touched) {
-  Force3 F = {0., 0., 0., 0.};
+  Force3 F = {0., 0., 0., 0., 0., 0., 0.};
   const double xij = A.x1 - B.x1;
   const double yij = A.x2 - B.x2;
   const double dist = sqrt(xij * xij + yij * yij);
@@ -80,15 +80,22 @@ __device__ __forceinline__ Force3 contact(const GrainState& A, const GrainState&
   F.f1 = fn * xn - ft * yn;
   F.f2 = fn * yn + ft * xn;
   F.fn = fn;
+  F.ft = ft;
+  F.xij = xij;
+  F.yij = yij;
   return F;
 }
 
-template <bool FILM>
+// Per-grain contact diagnostics of one sub-step (the fields write_DEM prints, main.c:413-420), in the
+// reference's accumulation order. Only produced when DIAG (the sub-step before an output).
+struct DiagOut { double *s, *f1, *f2, *ifm, *M11, *M12, *M21, *M22; int *z, *zz; };
+
+template <bool FILM, bool DIAG>
 __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, const double* __restrict__ m,
                               const double* __restrict__ It, const double* __restrict__ fhf,
                               const int* __restrict__ offsets, const int* __restrict__ nbr,
                               const unsigned char* __restrict__ wallflags, double* __restrict__ pout,
-                              DemParams P) {
+                              DiagOut D, DemParams P) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
   const GrainState me = advance(in, r, i, P);
@@ -100,6 +107,8 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
   // contact in the same order as the accelerations; a separated pair (dn >= 0) adds nothing
   double pr = 0.0;
   bool touched;
+  double ds = 0., df1 = 0., df2 = 0., difm = 0., dM11 = 0., dM12 = 0., dM21 = 0., dM22 = 0.;
+  int dz = 0, dzz = 0;
   const int k0 = offsets[i], k1 = offsets[i + 1];
   for (int k = k0; k < k1; ++k) {
     const int j = nbr[k];
@@ -108,10 +117,21 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
       const Force3 F = contact<FILM>(me, other, P, touched);
       a1 = a1 + F.f1; a2 = a2 + F.f2; a3 = a3 + F.f3;
       if (touched) pr += F.fn;
+      if (DIAG && touched) {  // this grain is the `i` of force_grains(i, j): main.c:776-799 / 1397-1416
+        ds += F.ft;
+        dz += 1;
+        dM11 += F.f1 * F.xij; dM12 += F.f1 * F.yij; dM21 += F.f2 * F.xij; dM22 += F.f2 * F.yij;
+        if (!FILM) {
+          df1 += F.f1; df2 += F.f2;
+          dzz += 1;
+          if (F.fn == 0) difm = 0; else difm += fabs(F.ft / (P.mu * F.fn));
+        }
+      }
     } else {      // main.c:1446-1448
       const Force3 F = contact<FILM>(other, me, P, touched);
       a1 = a1 - F.f1; a2 = a2 - F.f2; a3 = a3 + F.f3;
       if (touched) pr += F.fn;
+      if (DIAG && touched) ds += F.ft;  // the `j` side only receives p and s
     }
   }
   // walls: bottom, top, left, right (main.c:1455-1508)
@@ -127,6 +147,7 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
       if (fabs(ft) > ftest) ft = (ft < 0.0) ? ftest : -ftest;
       a1 = a1 + ft; a2 = a2 + fn; a3 = a3 + (-(ft * me.r * P.murf));
       pr += fn;
+      if (DIAG) { ds += ft; df1 += ft; dz += 1; dM12 += ft * P.dt; dM22 += fn * P.dt; }  // main.c:830-838
     }
   }
   if (wf & 2u) {
@@ -142,7 +163,9 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
       if (ft > ftmax) ft = ftmax;
       if (vt > 0) ft = -ft;
       a1 = a1 + ft; a2 = a2 + fn; a3 = a3 + ft * me.r * P.murf;
+      if (DIAG) { dM12 += ft * fabs(P.dt); dM22 += fn * fabs(P.dt); }  // main.c:875-882
       pr += fn;
+      if (DIAG) { ds += ft; dz += 1; }
     }
   }
   if (wf & 4u) {
@@ -155,7 +178,9 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
       double ft = P.mum * fn;
       if (vt > 0) ft = -ft;
       a1 = a1 + fn; a2 = a2 + ft; a3 = a3 + ft * me.r * P.murf;
+      if (DIAG) { dM11 += fn * fabs(P.dt); dM21 += ft * fabs(P.dt); }  // main.c:907-915
       pr += fn;
+      if (DIAG) { ds += ft; df1 += fn; dz += 1; }
     }
   }
   if (wf & 8u) {
@@ -169,6 +194,7 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
       if (fn > 0.) fn = 0.;
       a1 = a1 + fn; a2 = a2 + (-ft); a3 = a3 + ft * me.r * P.murf;
       pr += fn;
+      if (DIAG) { df1 += fn; dM11 += fn * fabs(P.dt); dM21 += (-ft) * fabs(P.dt); dz += 1; }  // main.c:938-949
     }
   }
   // main.c:1511-1515 (mw = 0: SURVEY.md hard part 5)
@@ -183,6 +209,11 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
   out.v3[i] = me.v3 + P.dt * a3 / 2.;
   out.a1[i] = a1; out.a2[i] = a2; out.a3[i] = a3;
   pout[i] = pr;
+  if (DIAG) {
+    D.s[i] = ds; D.f1[i] = df1; D.f2[i] = df2; D.ifm[i] = difm;
+    D.M11[i] = dM11; D.M12[i] = dM12; D.M21[i] = dM21; D.M22[i] = dM22;
+    D.z[i] = dz; D.zz[i] = dzz;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -355,12 +386,19 @@ void launch_verlet_rebuild(VerletDevice& V, const Kin& K, const double* r, const
 
 void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const double* m,
                         const double* It, const double* fhf, const VerletDevice& V, double* pout,
-                        const DemParams& P, int film, hipStream_t st) {
+                        const DemParams& P, int film, double* diag, hipStream_t st) {
   const int nb = (P.n + 127) / 128;
-  if (film)
-    hipLaunchKernelGGL(k_dem_substep<true>, dim3(nb), dim3(128), 0, st, in, out, r, m, It, fhf, V.offsets,
-                       V.nbr, V.wallflags, pout, P);
-  else
-    hipLaunchKernelGGL(k_dem_substep<false>, dim3(nb), dim3(128), 0, st, in, out, r, m, It, fhf, V.offsets,
-                       V.nbr, V.wallflags, pout, P);
+  const int n = P.n;
+  DiagOut D{};
+  if (diag) {  // [8][n] doubles then [2][n] ints
+    D.s = diag; D.f1 = diag + n; D.f2 = diag + 2 * n; D.ifm = diag + 3 * n;
+    D.M11 = diag + 4 * n; D.M12 = diag + 5 * n; D.M21 = diag + 6 * n; D.M22 = diag + 7 * n;
+    D.z = reinterpret_cast<int*>(diag + 8 * (size_t)n); D.zz = D.z + n;
+  }
+#define LBM_DEM_LAUNCH(FILM, DIAG)                                                                        \
+  hipLaunchKernelGGL((k_dem_substep<FILM, DIAG>), dim3(nb), dim3(128), 0, st, in, out, r, m, It, fhf,    \
+                     V.offsets, V.nbr, V.wallflags, pout, D, P)
+  if (film) { if (diag) LBM_DEM_LAUNCH(true, true); else LBM_DEM_LAUNCH(true, false); }
+  else { if (diag) LBM_DEM_LAUNCH(false, true); else LBM_DEM_LAUNCH(false, false); }
+#undef LBM_DEM_LAUNCH
 }

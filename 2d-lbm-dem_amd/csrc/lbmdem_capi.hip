@@ -57,6 +57,9 @@ struct lbmdem_handle {
   double *xc = nullptr, *yc = nullptr, *r2 = nullptr, *rbl0 = nullptr;
   double* pk = nullptr;   // [n][8] packed fluid-side grain records
   double* gp = nullptr;   // [n] grain pressure g.p of the last DEM sub-step (main.c:187,776)
+  double* diag = nullptr; // [8][n] doubles s f1 f2 ifm M11 M12 M21 M22, then [2][n] ints z zz
+  bool diag_always = false;
+  bool diag_valid = false; // the last sub-step produced diagnostics
   double* fhf = nullptr;  // [3][n]
   unsigned char* owner = nullptr;
   double rmax = 0.0;
@@ -247,7 +250,7 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
   CREATE_TRY(hipMalloc((void**)&h->obst[0], sizeof(int) * (size_t)L.plane));
   CREATE_TRY(hipMalloc((void**)&h->obst[1], sizeof(int) * (size_t)L.plane));
   // grains: 18 kinematic + r m It rLB xc yc r2 rbl0 + 3 fhf + 8 packed + p = 38 columns
-  const size_t cols = 18 + 8 + 3 + 8 + 1;
+  const size_t cols = 18 + 8 + 3 + 8 + 1 + 9;
   CREATE_TRY(hipMalloc((void**)&h->gbuf, sizeof(double) * cols * n));
   CREATE_TRY(hipMemset(h->gbuf, 0, sizeof(double) * cols * n));
   {
@@ -263,6 +266,7 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
     h->fhf = p0 + 8 * n;
     h->pk = p0 + 11 * (size_t)n;
     h->gp = p0 + 19 * (size_t)n;
+    h->diag = p0 + 20 * (size_t)n;
   }
   CREATE_TRY(hipMalloc((void**)&h->owner, n));
   CREATE_TRY(hipMemset(h->owner, 1, n));
@@ -395,8 +399,12 @@ int lbmdem_dem_substep(lbmdem_handle* h) {
   CHECK_H(h);
   if (!h->verlet_ok) return fail(LBMDEM_EINVAL, "lbmdem_dem_substep before the first lbmdem_verlet_rebuild");
   const int film = (h->nbsteps % h->cfg.phys.stepFilm == 0) ? 1 : 0;  // main.c:1342
+  // contact diagnostics are only needed by write_DEM, which renderScene calls when the step counter
+  // reaches a multiple of stepStrob = 4000 (main.c:142,1773): produce them in exactly that sub-step
+  const bool want_diag = h->diag_always || ((h->nbsteps + 1) % 4000 == 0);
   launch_dem_substep(h->kin[h->kcur], h->kin[1 - h->kcur], h->r, h->m, h->It, h->fhf, h->V, h->gp,
-                     dem_params(h), film, h->stream);
+                     dem_params(h), film, want_diag ? h->diag : nullptr, h->stream);
+  h->diag_valid = want_diag;
   HIP_TRY(hipGetLastError());
   h->kcur = 1 - h->kcur;
   h->nbsteps++;
@@ -671,6 +679,105 @@ int lbmdem_write_vtk(lbmdem_handle* h, const char* dir, int nfile) {
   return LBMDEM_OK;
 }
 
+int lbmdem_set_diagnostics(lbmdem_handle* h, int always) {
+  if (!h) return fail(LBMDEM_EINVAL, "null handle");
+  h->diag_always = always != 0;
+  return LBMDEM_OK;
+}
+
+// 30 columns per grain in the reference's struct order (main.c:182-197):
+// x1 x2 x3 v1 v2 v3 a1 a2 a3 r m mw It p s f1 f2 ifm fm fr ifr M11 M12 M21 M22 ice slip rw z zz
+int lbmdem_download_grain_table(lbmdem_handle* h, double* t) {
+  CHECK_H(h);
+  if (!t) return fail(LBMDEM_EINVAL, "null buffer");
+  if (!h->diag_valid) return fail(LBMDEM_EINVAL, "no contact diagnostics for the last sub-step (lbmdem_set_diagnostics, or "
+                                                 "the sub-step that reaches a multiple of 4000)");
+  const int n = h->n;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::vector<double> kin(9 * (size_t)n), rr(n), mm(n), it(n), gp(n), dg(9 * (size_t)n);
+  HIP_TRY(hipMemcpy(kin.data(), h->kin[h->kcur].x1, sizeof(double) * 9 * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(rr.data(), h->r, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(mm.data(), h->m, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(it.data(), h->It, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(gp.data(), h->gp, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(dg.data(), h->diag, sizeof(double) * 9 * n, hipMemcpyDeviceToHost));
+  const int* zi = reinterpret_cast<const int*>(dg.data() + 8 * (size_t)n);
+  const lbmdem_config& c = h->cfg;
+  for (int i = 0; i < n; ++i) {
+    double* o = t + (size_t)i * 30;
+    for (int k = 0; k < 9; ++k) o[k] = kin[(size_t)k * n + i];
+    o[9] = rr[i]; o[10] = mm[i]; o[11] = 0.0; o[12] = it[i];
+    o[13] = gp[i]; o[14] = dg[i]; o[15] = dg[(size_t)n + i]; o[16] = dg[2 * (size_t)n + i];
+    o[17] = dg[3 * (size_t)n + i];
+    const int z = zi[i], zz = zi[n + i];
+    o[18] = (z == 0) ? 0. : o[17] / z;  // fm, main.c:409-412
+    o[19] = 0.0;                        // fr   -- order-dependent carry, not reproduced
+    // ifr, main.c:388-390
+    o[20] = fabs(((o[10] * c.phys.G + o[16]) * (c.dt * o[4] + c.dt2 * o[7] / 2.)) + (o[15] * (c.dt * o[3] + c.dt2 * o[6] / 2.)));
+    o[21] = dg[4 * (size_t)n + i]; o[22] = dg[5 * (size_t)n + i]; o[23] = dg[6 * (size_t)n + i]; o[24] = dg[7 * (size_t)n + i];
+    o[25] = 0.0; o[26] = 0.0; o[27] = 0.0;  // ice, slip, rw -- not reproduced
+    o[28] = z; o[29] = zz;
+  }
+  return LBMDEM_OK;
+}
+
+// write_DEM, main.c:340-438: DEM%06d.dat (28 tab-separated columns per grain) and one line appended to
+// stats.data. The four columns that depend on the reference's serial carries (fr, ice, slip, rw) and
+// the four statistics summed from them (WF, INCE, TSLIP, TRW) are written as 0.
+int lbmdem_write_dem(lbmdem_handle* h, const char* dir, int nfile, double* energies4) {
+  CHECK_H(h);
+  const int n = h->n;
+  std::vector<double> t(30 * (size_t)n), hf(3 * (size_t)n);
+  int rc = lbmdem_download_grain_table(h, t.data());
+  if (rc != LBMDEM_OK) return rc;
+  rc = lbmdem_download_fhf(h, hf.data());
+  if (rc != LBMDEM_OK) return rc;
+  const lbmdem_config& c = h->cfg;
+  const lbmdem_physics& p = c.phys;
+  char path[4096];
+  snprintf(path, sizeof path, "%s/DEM%.6i.dat", (dir && *dir) ? dir : ".", nfile);
+  FILE* fp = fopen(path, "w");
+  if (!fp) return fail(LBMDEM_EINVAL, "cannot open '%s' for writing", path);
+  auto G = [&](int i, int col) { return t[(size_t)i * 30 + col]; };
+  double xfront = G(0, 0) + G(0, 9), height = G(0, 1) + G(0, 9), xgrainmax = G(0, 0);
+  double energie_x = 0., energie_y = 0., energie_teta = 0., energy_p = 0., SE = 0., IFR = 0., zmean = 0;
+  double N[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < n; i++) {
+    const double x1 = G(i, 0), x2 = G(i, 1), v1 = G(i, 3), v2 = G(i, 4), v3 = G(i, 5), r = G(i, 9), m = G(i, 10),
+                 It = G(i, 12), pp = G(i, 13), ss = G(i, 14);
+    const int z = (int)G(i, 28), zz = (int)G(i, 29);
+    zmean += z;
+    if (z >= 0 && z <= 5) N[z] += 1;
+    energie_x += 0.5 * m * v1 * v1;
+    energie_y += 0.5 * m * v2 * v2;
+    energie_teta += 0.5 * It * v3 * v3;
+    energy_p += m * p.G * x2;
+    SE += 0.5 * (((pp * pp) / p.kg) + ((ss * ss) / p.kt));
+    IFR += G(i, 20);
+    const double ESE = 0.5 * (((pp * pp) / p.kg) + ((ss * ss) / p.kt));
+    if (x1 + r > xgrainmax) xgrainmax = x1 + r;
+    if (x2 + r > height) height = x2 + r;
+    if (zz > 0 && x1 + r >= xfront) xfront = x1 + r;
+    fprintf(fp,
+            "%i\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%le\t%i\n",
+            i, r, x1, x2, G(i, 2), v1, v2, v3, G(i, 6), G(i, 7), G(i, 8), hf[3 * (size_t)i], hf[3 * (size_t)i + 1],
+            hf[3 * (size_t)i + 2], pp, ss, ESE, G(i, 19), G(i, 20), G(i, 25), G(i, 26), G(i, 27), G(i, 18), G(i, 21),
+            G(i, 22), G(i, 23), G(i, 24), z);
+  }
+  fclose(fp);
+  const double energie_cin = energie_x + energie_y + energie_teta;
+  zmean = zmean / n;
+  snprintf(path, sizeof path, "%s/stats.data", (dir && *dir) ? dir : ".");
+  fp = fopen(path, "a");
+  if (!fp) return fail(LBMDEM_EINVAL, "cannot open '%s' for appending", path);
+  fprintf(fp, "%le %le %le %le %le %le %le %le %le %le %le %le %le %le %le %le %le %le %le %le %le %le\n",
+          h->nbsteps * c.dt - p.dtt, xfront, xgrainmax, height, zmean, energie_x, energie_y, energie_teta, energie_cin,
+          N[0] / n, N[1] / n, N[2] / n, N[3] / n, N[4] / n, N[5] / n, energy_p, SE, 0.0, IFR, 0.0, 0.0, 0.0);
+  fclose(fp);
+  if (energies4) { energies4[0] = energie_cin; energies4[1] = energy_p; energies4[2] = SE; energies4[3] = IFR; }
+  return LBMDEM_OK;
+}
+
 // ---- checkpoint / restart ------------------------------------------------------------------------
 
 namespace {
@@ -681,8 +788,8 @@ struct CkptHeader {
   int verlet_ok, nnbr; // symmetric list length
   long plane;          // sanity: nxl * sy of the writer
 };
-bool wr(FILE* fp, const void* p, size_t n) { return fwrite(p, 1, n, fp) == n; }
-bool rd(FILE* fp, void* p, size_t n) { return fread(p, 1, n, fp) == n; }
+static bool wr(FILE* fp, const void* p, size_t n) { return fwrite(p, 1, n, fp) == n; }
+static bool rd(FILE* fp, void* p, size_t n) { return fread(p, 1, n, fp) == n; }
 }  // namespace
 
 int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) {

@@ -115,4 +115,4 @@ void launch_verlet_rebuild(VerletDevice& V, const Kin& K, const double* r, const
                            hipStream_t st);
 void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const double* m,
                         const double* It, const double* fhf, const VerletDevice& V, double* pout,
-                        const DemParams& P, int film, hipStream_t st);
+                        const DemParams& P, int film, double* diag, hipStream_t st);

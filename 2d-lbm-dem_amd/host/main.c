@@ -83,11 +83,23 @@ int main(int argc, char** argv) {
   }
   time_t now = time(NULL);
   printf("Current local time and date: %s", asctime(localtime(&now)));
+  if (!ckpt_in) { /* stats.data header, main.c:1867-1877 */
+    FILE* st = fopen("stats.data", "w");
+    if (st) {
+      fprintf(st, "#1_t 2_xfront 3_xgrainmax 4_height 5_zmean 6_energie_x 7_energie_y "
+                  "8_energie_teta 9_energie_cin 10_N0 11_N1 12_N2 13_N3 14_N4 15_N5 "
+                  "16_energy_Potential 17_Strain_Energy 18_Frictional_Work "
+                  "19_Internal_Friction 20_Inelastic_Collision 21_Slip "
+                  "22_Rotational_Work\n");
+      fclose(st);
+    }
+  }
 
   /* main loop, main.c:1879-1890: advance to the next console cadence (updateVerlet steps) at a time */
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
   int nFile = (int)(nbsteps / cfg.phys.stepFilm); /* main.c:147 */
+  double energies[4] = {0, 0, 0, 0}; /* KE, PE, SE, IFR of the last write_DEM (main.c:1885-1889) */
   const int chunk = cfg.phys.updateVerlet;
   const int stepConsole = 400; /* main.c:140 */
   do {
@@ -113,10 +125,14 @@ int main(int argc, char** argv) {
         DIE(lbmdem_write_vtk(h, ".", nFile), "write_vtk");
         nFile++;
       }
+      /* write_DEM every stepStrob = 4000 DEM steps (main.c:142,1773-1776; write_forces' PostScript
+       * picture is not produced) */
+      if (nbsteps % 4000 == 0) DIE(lbmdem_write_dem(h, ".", nFile, energies), "write_dem");
     }
     if (nbsteps % chunk == 0) {
       now = time(NULL);
-      printf("steps %li steps %le Time %s \n", nbsteps, nbsteps * cfg.dt, asctime(localtime(&now)));
+      printf("steps %li steps %le KE %le PE %le SE %le WF %le INCE %le SLIP %le RW %le Time %s \n", nbsteps,
+             nbsteps * cfg.dt, energies[0], energies[1], energies[2], 0., 0., 0., 0., asctime(localtime(&now)));
     }
   } while (nbsteps * cfg.dt <= duration && (max_steps < 0 || nbsteps < max_steps));
   DIE(lbmdem_sync(h), "sync");

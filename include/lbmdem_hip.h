@@ -138,6 +138,17 @@ int lbmdem_download_vtk_fields(lbmdem_handle* h, float* grain_pressure, float* g
  * <dir>/{grain_pressure,grain_velocity,grain_acceleration,fluid_pressure,fluid_velocity}_NNNNNN.vtk,
  * byte-identical to the reference's. Single-domain handles only. */
 int lbmdem_write_vtk(lbmdem_handle* h, const char* dir, int nfile);
+/* Contact diagnostics of the last DEM sub-step (what write_DEM prints, main.c:340-438). They are produced
+ * in the sub-step that brings the step counter to a multiple of stepStrob = 4000 (main.c:142,1773), or in
+ * every sub-step after lbmdem_set_diagnostics(h, 1). Table: 30 doubles per grain in the reference's struct
+ * order (main.c:182-197): x1 x2 x3 v1 v2 v3 a1 a2 a3 r m mw It p s f1 f2 ifm fm fr ifr M11 M12 M21 M22 ice
+ * slip rw z zz. fr, ice, slip, rw depend on carries through the reference's serial contact loop
+ * (main.c:130-131) and are reported as 0. */
+int lbmdem_set_diagnostics(lbmdem_handle* h, int always);
+int lbmdem_download_grain_table(lbmdem_handle* h, double* table30);
+/* write_DEM (main.c:340-438): <dir>/DEM%06d.dat and one line appended to <dir>/stats.data; energies4 (may be
+ * NULL) receives energie_cin, energy_p, SE, IFR for the console line of main.c:1885-1889. */
+int lbmdem_write_dem(lbmdem_handle* h, const char* dir, int nfile, double* energies4);
 /* Checkpoint / restart (absent in the reference, which cannot resume a run: SURVEY.md section 5). The file
  * holds exactly the state that defines the continuation at a renderScene() boundary -- populations,
  * current obstacle map, grain kinematics, hydrodynamic forces, Verlet lists, wall positions, step

@@ -133,6 +133,17 @@ REF_API void ref_steps(long n) {
   for (long k = 0; k < n; ++k) renderScene();
 }
 
+/* the same inside `dir`: renderScene writes DEM%06d.dat/.ps, stats.data (every 4000 steps) and the VTK
+ * frames (every 8000) into the cwd (main.c:1767-1776) */
+REF_API int ref_steps_in_dir(long n, const char* dir) {
+  char cwd[4096];
+  if (!getcwd(cwd, sizeof cwd)) return -1;
+  if (chdir(dir) != 0) return -2;
+  for (long k = 0; k < n; ++k) renderScene();
+  if (chdir(cwd) != 0) return -3;
+  return 0;
+}
+
 /* individual phases, for LBM-only vectors */
 REF_API void ref_reinit_obst_density(void) { reinit_obst_density(); }
 REF_API void ref_obst_construction(void) { obst_construction(); }

@@ -65,6 +65,13 @@ def cases():
     # G4: ~600-grain packing, fully coupled, 20 fluid steps
     r, x, y = samples.row_packing(256, 200, 600, seed=77)
     c["G4_coupled_256x200"] = dict(kind="coupled", lx=256, ly=200, r_mm=r, x_mm=x, y_mm=y, fluid_steps=20)
+    # G6: output files. G4's packing plus four grains pressed into the DEM walls, 4000 renderScene calls:
+    # the reference then writes DEM000000.dat and appends a line to stats.data (main.c:1773-1776)
+    r, x, y = samples.row_packing(256, 200, 600, seed=77)
+    r = np.concatenate([r, [0.6, 0.7, 0.8, 0.9]])
+    x = np.concatenate([x, [0.6 - 0.002, 60.0, 256 - 0.8 + 0.002, 80.0]])
+    y = np.concatenate([y, [90.0, 0.7 - 0.003, 40.0, 200 - 0.9 + 0.003]])
+    c["G6_output_256x200"] = dict(kind="output", lx=256, ly=200, r_mm=r, x_mm=x, y_mm=y, steps=4000)
     # G5: DEM-focused: 240 renderScene calls on a tiny lattice with random initial grain velocities:
     # film law at step 0, Verlet rebuilds at 0/100/200, grain-grain contacts, and four extra grains
     # pressed 2-3 um into the left/bottom/right/top DEM walls (the right/top walls sit at 1e-3*lx,
@@ -193,11 +200,35 @@ def make_vtk_fixture():
     assert R.L.ref_write_vtk(os.fsencode(out), 3) == 0
 
 
+def make_dem_output_fixture():
+    """tests/golden/dem_G6_4000steps/{DEM000000.dat, stats.data}: what the reference's write_DEM
+    (main.c:340-438) writes for case G6 at step 4000, plus the grain table at that moment."""
+    import ctypes
+    import pyoracle as po
+    c = cases()["G6_output_256x200"]
+    tmp = tempfile.NamedTemporaryFile("w", suffix=".data", delete=False)
+    tmp.close()
+    po.write_sample(tmp.name, c["r_mm"], c["x_mm"], c["y_mm"])
+    R = po.Reference(c["lx"], c["ly"], tmp.name)
+    os.unlink(tmp.name)
+    out = os.path.join(HERE, "dem_G6_4000steps")
+    os.makedirs(out, exist_ok=True)
+    for f in os.listdir(out):
+        os.unlink(os.path.join(out, f))
+    assert R.L.ref_steps_in_dir(ctypes.c_long(c["steps"]), os.fsencode(out)) == 0
+    os.unlink(os.path.join(out, "DEM000000.ps"))   # write_forces' PostScript picture: not reproduced
+    np.savez_compressed(os.path.join(out, "inputs_and_table.npz"), r_mm=np.asarray(c["r_mm"], float),
+                        x_mm=np.asarray(c["x_mm"], float), y_mm=np.asarray(c["y_mm"], float),
+                        grains=R.get_grains())
+
+
 def main():
     import pyoracle as po
     if not po.reference_available():
         raise SystemExit("the reference is not present here; golden vectors can only be made in the build container")
     for name, case in cases().items():
+        if case["kind"] == "output":
+            continue
         q = mp.Queue()
         p = mp.Process(target=_generate, args=(name, case, q))
         p.start()
@@ -205,9 +236,10 @@ def main():
         p.join()
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **pack(name, case, res))
         print("wrote", name, {k: getattr(v, "shape", None) for k, v in pack(name, case, res).items()})
-    p = mp.Process(target=make_vtk_fixture)
-    p.start()
-    p.join()
+    for target in (make_vtk_fixture, make_dem_output_fixture):
+        p = mp.Process(target=target)
+        p.start()
+        p.join()
 
 
 if __name__ == "__main__":
