@@ -131,14 +131,22 @@ __device__ __forceinline__ double link_delta(int x, int y, double xc, double yc,
 // small kernels
 // ---------------------------------------------------------------------------------------------
 
-// obst = -1 in the interior, nbgrains on the four lattice edges (main.c:669-683, 997-999)
+// obst = -1 in the interior, nbgrains on the four lattice edges (main.c:669-683, 997-999); 16-byte stores
+// (the row pitch is a multiple of 16 elements)
 __global__ void k_obst_fill(int* __restrict__ obst, LatticeView L) {
-  const long total = (long)L.nxl * L.sy;
-  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (long)gridDim.x * blockDim.x) {
-    const int xl = (int)(k / L.sy), y = (int)(k % L.sy);
+  const long total4 = (long)L.nxl * L.sy / 4;
+  int4* o4 = reinterpret_cast<int4*>(obst);
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < total4; k += (long)gridDim.x * blockDim.x) {
+    const long e = k * 4;
+    const int xl = (int)(e / L.sy), y0 = (int)(e % L.sy);
     const int gx = L.gx0 + xl;
-    const bool edge = (gx == 0 || gx == L.lx - 1 || y == 0 || y >= L.ly - 1);
-    obst[k] = edge ? L.n : -1;
+    const bool xedge = (gx == 0 || gx == L.lx - 1);
+    int4 v;
+    v.x = (xedge || y0 == 0 || y0 >= L.ly - 1) ? L.n : -1;
+    v.y = (xedge || y0 + 1 >= L.ly - 1) ? L.n : -1;
+    v.z = (xedge || y0 + 2 >= L.ly - 1) ? L.n : -1;
+    v.w = (xedge || y0 + 3 >= L.ly - 1) ? L.n : -1;
+    o4[k] = v;
   }
 }
 
@@ -501,12 +509,14 @@ __global__ __launch_bounds__(256) void k_collide_stream(const double* __restrict
 //
 // One WAVEFRONT owns a window of 64 consecutive y (62 produce output, the two edge lanes only feed
 // their neighbours) and walks along x over LX rows. Each lane keeps the f* of its column for three
-// consecutive rows in registers (27 doubles); row x+1 is loaded, re-initialised/collided and rotated
-// in while row x is produced. The six diagonal/vertical neighbours a pull needs live in the adjacent
-// lanes and are fetched with cross-lane shuffles; the obstacle ids of the 3x3 neighbourhood are read
-// directly (they are 4-byte, cached). No LDS, no barriers: waves are independent, every load of a
-// row is a full 512-byte coalesced request, and the next row's loads are in flight while the
-// current one is computed. Redundant work: 2 of 64 lanes and 2 of LX+2 rows.
+// consecutive rows in registers; row x+1 is re-initialised/collided and rotated in while row x is
+// produced. The six diagonal/vertical neighbours a pull needs live in the adjacent lanes and are
+// fetched with cross-lane shuffles; the obstacle ids of the 3x3 neighbourhood are read directly (they
+// are 4-byte, cached). No barriers: waves are independent, every load of a row is a full 512-byte
+// coalesced request, and the loads of the next two rows are in flight while the current one is
+// computed. LDS is used only wave-privately: a ring of grain records (RecRing) and the scratch of the
+// compacted bounce-back evaluation. Redundant work: 2 of 64 lanes and 3 of LX+3 rows.
+// DESIGN.md section 4 lists what was measured on the way (in-order vmcnt, no loads under branches, ...).
 
 struct Ids3 { int m, c, p; };  // obstacle ids at (y-1, y, y+1) of one row
 
@@ -620,20 +630,6 @@ __device__ __forceinline__ void classify_store_row(const Ctx& C, const LatticeVi
   LBM_CLASSIFY(1) LBM_CLASSIFY(2) LBM_CLASSIFY(3) LBM_CLASSIFY(4)
   LBM_CLASSIFY(5) LBM_CLASSIFY(6) LBM_CLASSIFY(7) LBM_CLASSIFY(8)
 #undef LBM_CLASSIFY
-}
-
-template <bool EDGE, class Ctx>
-__device__ __forceinline__ void store_row(double* __restrict__ fout, const LatticeView& L,
-                                          const GrainFluidView& G, const Ctx& C, long node, int gx, int y) {
-  fout[node] = C.own(0);
-  fout[1 * L.plane + node] = pull_one<1, EDGE>(C, L, G, gx, y);
-  fout[2 * L.plane + node] = pull_one<2, EDGE>(C, L, G, gx, y);
-  fout[3 * L.plane + node] = pull_one<3, EDGE>(C, L, G, gx, y);
-  fout[4 * L.plane + node] = pull_one<4, EDGE>(C, L, G, gx, y);
-  fout[5 * L.plane + node] = pull_one<5, EDGE>(C, L, G, gx, y);
-  fout[6 * L.plane + node] = pull_one<6, EDGE>(C, L, G, gx, y);
-  fout[7 * L.plane + node] = pull_one<7, EDGE>(C, L, G, gx, y);
-  fout[8 * L.plane + node] = pull_one<8, EDGE>(C, L, G, gx, y);
 }
 
 __device__ __forceinline__ double shfl_up1(double v) { return __shfl_up(v, 1, 64); }
@@ -1233,7 +1229,7 @@ inline int grid_for(long total, int block = 256, int cap = 256 * 8) {
 // ---------------------------------------------------------------------------------------------
 
 void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st) {
-  hipLaunchKernelGGL(k_obst_fill, dim3(grid_for((long)L.nxl * L.sy)), dim3(256), 0, st, obst, L);
+  hipLaunchKernelGGL(k_obst_fill, dim3(grid_for((long)L.nxl * L.sy / 4)), dim3(256), 0, st, obst, L);
 }
 
 void launch_grain_geom(int n, const double* x1, const double* x2, const double* r, const double* rLB,
