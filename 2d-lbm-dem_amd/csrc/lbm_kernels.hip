@@ -639,7 +639,8 @@ template <int LX, int MINW>
 __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict__ fin, double* __restrict__ fout,
                                                   const int* __restrict__ ob_old,
                                                   const int* __restrict__ ob_new, LatticeView L,
-                                                  GrainFluidView G, int nstrips, int nwork, int xcd_remap) {
+                                                  GrainFluidView G, int nstrips, int nwork, int xcd_remap,
+                                                  int seg_rows) {
   const int lane = threadIdx.x & 63;
   int blk = blockIdx.x;
   if (xcd_remap) {  // XCD k (blocks b % 8 == k) walks the k-th contiguous eighth of the work list
@@ -653,8 +654,11 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
   const bool yin = y >= 0 && y < L.ly;
   const bool writer = lane >= 1 && lane <= 62 && yin;
   const bool deep_y = strip * 62 >= 2 && strip * 62 + 61 <= L.ly - 3;  // producing lanes 1..62
-  const int xs = L.xo0 + seg * LX;
-  const int xe = xs + LX < L.xo1 ? xs + LX : L.xo1;
+  // rows per wave: the template value, or (LX == 0) a run-time value chosen so that one round of resident
+  // waves covers the lattice
+  const int rows_per_wave = LX > 0 ? LX : seg_rows;
+  const int xs = L.xo0 + seg * rows_per_wave;
+  const int xe = xs + rows_per_wave < L.xo1 ? xs + rows_per_wave : L.xo1;
 
   // Software pipeline. In iteration x (producing row x) the wave issues, in this order,
   //   (1) small gathers: new ids of row x+4, previous-map id of row x+4, the record of the grain that
@@ -1270,12 +1274,23 @@ template <int LX, int MINW>
 static void launch_march(const double* fin, double* fout, const int* obst_old, const int* obst_new,
                          const LatticeView& L, const GrainFluidView& G, int remap, hipStream_t st) {
   const int rows = L.xo1 - L.xo0;
-  const int nstrips = (L.ly + 61) / 62, nseg = (rows + LX - 1) / LX;
+  const int nstrips = (L.ly + 61) / 62;
+  int seg_rows = LX;
+  if (LX == 0) {
+    // one balanced round: 256 CUs x 2 workgroups x 4 waves are resident (VGPR- and LDS-limited); give
+    // every y-strip the same number of equal x-segments
+    const int resident = 256 * 2 * 4;
+    int nseg = resident / nstrips;
+    if (nseg < 1) nseg = 1;
+    seg_rows = (rows + nseg - 1) / nseg;
+    if (seg_rows < 8) seg_rows = 8;
+  }
+  const int nseg = (rows + seg_rows - 1) / seg_rows;
   const int nwork = nstrips * nseg;
   int grid = (nwork + 3) / 4;
   if (remap) grid = ((grid + 7) / 8) * 8;
   hipLaunchKernelGGL((k_cs_march<LX, MINW>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, L, G,
-                     nstrips, nwork, remap);
+                     nstrips, nwork, remap, seg_rows);
 }
 
 void launch_collide_stream(const double* fin, double* fout, const int* obst_old, const int* obst_new,
@@ -1293,6 +1308,7 @@ void launch_collide_stream(const double* fin, double* fout, const int* obst_old,
     case 17: launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
     case 18: launch_march<8, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
     case 19: launch_march<64, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
+    case 20: launch_march<0, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;  // one balanced round
     default: launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
   }
 }

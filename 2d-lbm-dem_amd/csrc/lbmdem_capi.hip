@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <new>
 #include <vector>
 
 #define REF_PI 3.14159265358979 /* main.c:42 */
@@ -141,7 +142,7 @@ int lbmdem_derive(lbmdem_config* cfg, int lx, int ly, double scale, int nbgrains
   return LBMDEM_OK;
 }
 
-int lbmdem_read_sample(const char* path, int* nbgrains, double** r_out, double** x1_out, double** x2_out) {
+int lbmdem_read_sample(const char* path, int* nbgrains, double** r_out, double** x1_out, double** x2_out) try {
   if (!path || !nbgrains || !r_out || !x1_out || !x2_out) return fail(LBMDEM_EINVAL, "null argument");
   FILE* fp = fopen(path, "r");
   if (!fp) return fail(LBMDEM_EINVAL, "cannot open sample '%s'", path);
@@ -172,6 +173,10 @@ int lbmdem_read_sample(const char* path, int* nbgrains, double** r_out, double**
   fclose(fp);
   *nbgrains = n; *r_out = r; *x1_out = x1; *x2_out = x2;
   return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
 }
 
 void lbmdem_free_host(void* p) { free(p); }
@@ -187,7 +192,7 @@ static int paint_into(lbmdem_handle* h, int* obst) {
 }
 
 int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, const double* x2,
-                  lbmdem_handle** out) {
+                  lbmdem_handle** out) try {
   if (!cfg || !r || !x1 || !x2 || !out) return fail(LBMDEM_EINVAL, "lbmdem_create: null argument");
   *out = nullptr;
   if (cfg->lx < 3 || cfg->ly < 3 || cfg->nbgrains < 1) return fail(LBMDEM_EINVAL, "bad lattice/grain count");
@@ -307,6 +312,10 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
 #undef CREATE_TRY
   *out = h;
   return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
 }
 
 int lbmdem_destroy(lbmdem_handle* h) {
@@ -337,7 +346,7 @@ int lbmdem_obst_construction(lbmdem_handle* h) {
   return rc;
 }
 
-int lbmdem_collide_stream(lbmdem_handle* h) {
+int lbmdem_collide_stream(lbmdem_handle* h) try {
   CHECK_H(h);
   const int* ob_old = h->obst[h->ocur];
   const int* ob_new = h->obst_pending ? h->obst[1 - h->ocur] : h->obst[h->ocur];
@@ -358,6 +367,10 @@ int lbmdem_collide_stream(lbmdem_handle* h) {
   h->fcur = 1 - h->fcur;
   if (h->obst_pending) { h->ocur = 1 - h->ocur; h->obst_pending = false; }
   return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
 }
 
 int lbmdem_forces_fluid(lbmdem_handle* h) {
@@ -440,6 +453,9 @@ int lbmdem_set_force_mode(lbmdem_handle* h, int mode) {
   return LBMDEM_OK;
 }
 
+// No C++ exception may cross the C ABI: every entry point that allocates host memory (std::vector, new) is a
+// function-try-block that turns std::bad_alloc into LBMDEM_ENOMEM.
+
 // ---- state transfer ---------------------------------------------------------------------------
 
 int lbmdem_upload_f(lbmdem_handle* h, const double* f_aos) {
@@ -517,7 +533,7 @@ int lbmdem_total_density(lbmdem_handle* h, double* sum) {
   return LBMDEM_OK;
 }
 
-int lbmdem_upload_kinematics(lbmdem_handle* h, const double* k9) {
+int lbmdem_upload_kinematics(lbmdem_handle* h, const double* k9) try {
   CHECK_H(h);
   if (!k9) return fail(LBMDEM_EINVAL, "null buffer");
   const int n = h->n;
@@ -527,9 +543,13 @@ int lbmdem_upload_kinematics(lbmdem_handle* h, const double* k9) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(h->kin[h->kcur].x1, soa.data(), sizeof(double) * 9 * n, hipMemcpyHostToDevice));
   return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
 }
 
-int lbmdem_download_kinematics(lbmdem_handle* h, double* k9) {
+int lbmdem_download_kinematics(lbmdem_handle* h, double* k9) try {
   CHECK_H(h);
   if (!k9) return fail(LBMDEM_EINVAL, "null buffer");
   const int n = h->n;
@@ -539,9 +559,13 @@ int lbmdem_download_kinematics(lbmdem_handle* h, double* k9) {
   for (int i = 0; i < n; ++i)
     for (int c = 0; c < 9; ++c) k9[(size_t)i * 9 + c] = soa[(size_t)c * n + i];
   return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
 }
 
-int lbmdem_download_fhf(lbmdem_handle* h, double* fhf3) {
+int lbmdem_download_fhf(lbmdem_handle* h, double* fhf3) try {
   CHECK_H(h);
   if (!fhf3) return fail(LBMDEM_EINVAL, "null buffer");
   const int n = h->n;
@@ -551,10 +575,14 @@ int lbmdem_download_fhf(lbmdem_handle* h, double* fhf3) {
   for (int i = 0; i < n; ++i)
     for (int c = 0; c < 3; ++c) fhf3[(size_t)i * 3 + c] = soa[(size_t)c * n + i];
   return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
 }
 
 int lbmdem_download_verlet(lbmdem_handle* h, int* cumul, int* neighbours, int cap, int* npairs,
-                           int* wallflags) {
+                           int* wallflags) try {
   CHECK_H(h);
   if (!h->verlet_ok) return fail(LBMDEM_EINVAL, "no Verlet list built yet");
   const int n = h->n;
@@ -586,6 +614,10 @@ int lbmdem_download_verlet(lbmdem_handle* h, int* cumul, int* neighbours, int ca
   }
   if (neighbours && cnt > cap) return fail(LBMDEM_EINVAL, "neighbours[] too small: need %d", cnt);
   return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
 }
 
 int lbmdem_download_grain_pressure(lbmdem_handle* h, double* p) {
@@ -657,7 +689,7 @@ static int write_vtk_file(const char* path, int nx, int ny, const char* name, in
   return LBMDEM_OK;
 }
 
-int lbmdem_write_vtk(lbmdem_handle* h, const char* dir, int nfile) {
+int lbmdem_write_vtk(lbmdem_handle* h, const char* dir, int nfile) try {
   CHECK_H(h);
   const LatticeView& L = h->L;
   if (L.xo0 != 0 || L.xo1 != L.lx || L.gx0 != 0)
@@ -677,6 +709,10 @@ int lbmdem_write_vtk(lbmdem_handle* h, const char* dir, int nfile) {
     if (rc != LBMDEM_OK) return rc;
   }
   return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
 }
 
 int lbmdem_set_diagnostics(lbmdem_handle* h, int always) {
@@ -687,7 +723,7 @@ int lbmdem_set_diagnostics(lbmdem_handle* h, int always) {
 
 // 30 columns per grain in the reference's struct order (main.c:182-197):
 // x1 x2 x3 v1 v2 v3 a1 a2 a3 r m mw It p s f1 f2 ifm fm fr ifr M11 M12 M21 M22 ice slip rw z zz
-int lbmdem_download_grain_table(lbmdem_handle* h, double* t) {
+int lbmdem_download_grain_table(lbmdem_handle* h, double* t) try {
   CHECK_H(h);
   if (!t) return fail(LBMDEM_EINVAL, "null buffer");
   if (!h->diag_valid) return fail(LBMDEM_EINVAL, "no contact diagnostics for the last sub-step (lbmdem_set_diagnostics, or "
@@ -719,12 +755,16 @@ int lbmdem_download_grain_table(lbmdem_handle* h, double* t) {
     o[28] = z; o[29] = zz;
   }
   return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
 }
 
 // write_DEM, main.c:340-438: DEM%06d.dat (28 tab-separated columns per grain) and one line appended to
 // stats.data. The four columns that depend on the reference's serial carries (fr, ice, slip, rw) and
 // the four statistics summed from them (WF, INCE, TSLIP, TRW) are written as 0.
-int lbmdem_write_dem(lbmdem_handle* h, const char* dir, int nfile, double* energies4) {
+int lbmdem_write_dem(lbmdem_handle* h, const char* dir, int nfile, double* energies4) try {
   CHECK_H(h);
   const int n = h->n;
   std::vector<double> t(30 * (size_t)n), hf(3 * (size_t)n);
@@ -776,6 +816,10 @@ int lbmdem_write_dem(lbmdem_handle* h, const char* dir, int nfile, double* energ
   fclose(fp);
   if (energies4) { energies4[0] = energie_cin; energies4[1] = energy_p; energies4[2] = SE; energies4[3] = IFR; }
   return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
 }
 
 // ---- checkpoint / restart ------------------------------------------------------------------------
@@ -792,7 +836,7 @@ static bool wr(FILE* fp, const void* p, size_t n) { return fwrite(p, 1, n, fp) =
 static bool rd(FILE* fp, void* p, size_t n) { return fread(p, 1, n, fp) == n; }
 }  // namespace
 
-int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) {
+int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) try {
   CHECK_H(h);
   if (!path) return fail(LBMDEM_EINVAL, "null path");
   if (h->obst_pending) return fail(LBMDEM_EINVAL, "checkpoint between obst_construction and collide_stream");
@@ -826,9 +870,13 @@ int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) {
   ok = (fclose(fp) == 0) && ok;
   if (!ok) return fail(LBMDEM_EHIP, "writing checkpoint '%s' failed", path);
   return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
 }
 
-int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) {
+int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) try {
   if (!path || !out) return fail(LBMDEM_EINVAL, "null argument");
   *out = nullptr;
   FILE* fp = fopen(path, "rb");
@@ -867,6 +915,10 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) {
   h->verlet_ok = H.verlet_ok != 0;
   *out = h;
   return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
 }
 
 long lbmdem_nbsteps(lbmdem_handle* h) { return h ? h->nbsteps : -1; }

@@ -321,3 +321,18 @@ def test_checkpoint_restart_is_bit_identical(pkg, po, tmp_path):
         assert np.array_equal(s.grain_pressure, ora.get_grains()[:, po.COL["p"]])
     with pytest.raises(pkg.LbmDemError):
         pkg.LbmDem.checkpoint_load(str(tmp_path / "missing.ckpt"))
+
+
+def test_long_horizon_8200_steps_still_bit_exact(pkg, po):
+    """8200 renderScene calls (683 fluid steps, 82 Verlet rebuilds, the film-law step at nbsteps = 8000):
+    the coupled system is chaotic, so this only holds if every step is reproduced exactly."""
+    import golden_util as gu
+    r, x1, x2 = gu.inputs_m("G4_coupled_256x200")
+    sim, ora = make_pair(pkg, po, 256, 200, r, x1, x2)
+    for n in (4100, 4100):
+        sim.renderScene(n); ora.steps(n)
+        assert np.array_equal(sim.kinematics, ora.get_grains()[:, :9]), sim.nbsteps
+        assert np.array_equal(sim.fhf, ora.get_fhf()), sim.nbsteps
+    assert np.array_equal(sim.f, ora.get_f())
+    assert np.array_equal(sim.obst, ora.get_obst())
+    assert ora.act_anomalies() == 0
