@@ -95,3 +95,33 @@ def test_strips_equal_single_domain_at_1024(pkg):
     for R in runners:
         assert np.array_equal(R.b.sim.kinematics, single.kinematics)
         assert np.array_equal(R.b.sim.fhf, single.fhf)
+
+
+def test_c2_1024_fluid_only_rho_u(pkg, po):
+    """BASELINE config 2 shape: 1024 x 1024, fluid only. The reference cannot run with 0 grains
+    (main.c:220 reads g[0]) and has no lid (its lid terms are commented out, main.c:1125-1130), so the
+    case is: one small grain in a corner, all four edges resting walls, f = equilibrium of a smooth
+    vortex field u = U (sin 2pi x cos 2pi y, -cos 2pi x sin 2pi y), U = 0.02 in lattice units.
+    10 fluid steps; every population, and rho, u, must equal the oracle's."""
+    lx = ly = 1024
+    r, x1, x2 = np.array([0.5e-3]), np.array([1.2e-3]), np.array([1.1e-3])
+    sim = pkg.LbmDem(lx, ly, r, x1, x2)
+    ora = po.Oracle(lx, ly, r, x1, x2)
+    X = (np.arange(lx) / lx)[:, None]; Y = (np.arange(ly) / ly)[None, :]
+    U = 0.02
+    ux = U * np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y)
+    uy = -U * np.cos(2 * np.pi * X) * np.sin(2 * np.pi * Y)
+    ex = np.array([0, -1, -1, -1, 0, 1, 1, 1, 0.0]); ey = np.array([0, 1, 0, -1, -1, -1, 0, 1, 1.0])
+    w = np.array([4 / 9, 1 / 36, 1 / 9, 1 / 36, 1 / 9, 1 / 36, 1 / 9, 1 / 36, 1 / 9])
+    eu = ux[..., None] * ex + uy[..., None] * ey
+    f0 = w * (1 + 3 * eu + 4.5 * eu ** 2 - 1.5 * (ux ** 2 + uy ** 2)[..., None])
+    sim.f = f0; ora.set_f(f0)
+    for _ in range(10):
+        sim.lbm_step(); ora.lbm_steps(1)
+    fc = ora.get_f()
+    assert np.array_equal(sim.f, fc)
+    rho, jx, jy = sim.macro()
+    assert np.allclose(rho, fc.sum(-1), rtol=1e-14, atol=0)
+    assert np.allclose(jx, (fc * ex).sum(-1), rtol=0, atol=1e-15)
+    assert np.allclose(jy, (fc * ey).sum(-1), rtol=0, atol=1e-15)
+    assert np.abs(jx).max() > 0.5 * U      # the vortex is still there
