@@ -177,6 +177,14 @@ ORA_API ora_sim* ora_create(int lx, int ly, double scale, int n, const double* r
   return s;
 }
 
+/* test-only: another reduced-radius factor (the reference's is the global reductionR = 0.85, main.c:94);
+ * recomputes rLB (main.c:1858-1860) and repaints the initial obstacle map (main.c:1861) */
+ORA_API void ora_set_reduction(ora_sim* s, double reductionR) {
+  s->reductionR = reductionR;
+  for (int i = 0; i < s->n; ++i) s->rLB[i] = s->reductionR * s->r[i] / s->dx;
+  paint_initial_obstacles(s);
+}
+
 ORA_API void ora_destroy(ora_sim* s) {
   if (!s) return;
   free(s->f); free(s->delta); free(s->obst); free(s->act);

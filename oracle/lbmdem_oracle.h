@@ -37,6 +37,8 @@ void ora_free(void* p);
 ora_sim* ora_create(int lx, int ly, double scale, int n, const double* r, const double* x1,
                     const double* x2);
 void ora_destroy(ora_sim* s);
+/* test-only: change reductionR (main.c:94) right after ora_create */
+void ora_set_reduction(ora_sim* s, double reductionR);
 
 /* one renderScene() (main.c:1697-1777, file output excluded) = one DEM sub-step, with the
  * reference's cadences: LBM step every npDEM calls, Verlet rebuild every 100, film law every 8000 */

@@ -114,6 +114,7 @@ class Oracle:
     def verlet_rebuild(self): self._call("ora_verlet_rebuild")
     def dem_substep(self): self._call("ora_dem_substep")
     def set_threads(self, n): self._call("ora_set_threads", C.c_int(n))
+    def set_reduction(self, v): self._call("ora_set_reduction", C.c_double(v))
     def set_nbsteps(self, n): self._call("ora_set_nbsteps", C.c_long(n))
     @property
     def nbsteps(self): return int(self._call("ora_nbsteps"))

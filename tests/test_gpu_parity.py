@@ -336,3 +336,26 @@ def test_long_horizon_8200_steps_still_bit_exact(pkg, po):
     assert np.array_equal(sim.f, ora.get_f())
     assert np.array_equal(sim.obst, ora.get_obst())
     assert ora.act_anomalies() == 0
+
+
+@pytest.mark.parametrize("reduction", [1.0, 1.08, 0.6])
+def test_other_reduction_factors(pkg, po, reduction):
+    """reductionR (main.c:94) other than 0.85. For >= 1 the reduced disc is not inside the grain, the
+    second paint condition d2 <= R2 decides (main.c:1027-1028), neighbouring discs overlap, and the
+    library routes the fused step to the LDS-tile kernel."""
+    lx, ly = 160, 120
+    r, x1, x2 = small_packing(lx, ly, 40, 23)
+    phys = pkg.Physics()
+    pkg.load_library().lbmdem_physics_defaults(__import__("ctypes").byref(phys))
+    phys.reductionR = reduction
+    sim = pkg.LbmDem(lx, ly, r, x1, x2, physics=phys)
+    ora = po.Oracle(lx, ly, r, x1, x2); ora.set_reduction(reduction)
+    rng = np.random.default_rng(12)
+    k = np.zeros((len(r), 9)); k[:, 0], k[:, 1] = x1, x2; k[:, 3:6] = rng.normal(0, 1, (len(r), 3)) * [0.03, 0.03, 20.0]
+    sim.kinematics = k; ora.set_kinematics(k)
+    assert np.array_equal(sim.obst, ora.get_obst())
+    n = 2 * sim.cfg.npDEM + 1
+    sim.renderScene(n); ora.steps(n)
+    if ora.act_anomalies() != 0:
+        pytest.skip("three reduced discs overlap at a node in this configuration (documented limit)")
+    assert_same_state(sim, ora, f"reductionR={reduction}")
