@@ -32,6 +32,7 @@ static const double WQ[NQ] = {4. / 9, 1. / 36, 1. / 9, 1. / 36, 1. / 9, 1. / 36,
 struct ora_sim {
   int lx, ly, n;
   int threads;
+  double scale;
   /* fluid constants (main.c:74-94) */
   double rho_moy, tau, s2, s3, s5, s7, s8, s9, nu, reductionR;
   /* DEM constants (main.c:97-118) */
@@ -113,12 +114,34 @@ static int* ialloc(size_t n) { return (int*)calloc(n ? n : 1, sizeof(int)); }
 
 static void paint_initial_obstacles(ora_sim* s);
 
+/* main.c:1836-1860: walls, gravity, dx, dtLB, npDEM, c, dt, rLB */
+static void derive_run_constants(ora_sim* s) {
+  const int lx = s->lx, ly = s->ly, n = s->n;
+  s->Mgx = 0.;
+  s->Mdx = 1.e-3 * lx / 10;
+  s->Mhy = 1.e-3 * ly / 10;
+  s->Mby = 0.;
+  s->xG = -s->G * sin(s->angleG);
+  s->yG = -s->G * cos(s->angleG);
+  s->dx = (1. / s->scale) * (s->Mdx - s->Mgx) / (lx - 1);
+  double rMin = s->r[0];
+  for (int i = 1; i <= n - 1; i++) rMin = fmin(rMin, s->r[i]);
+  double dtmax = (1 / s->iterDEM) * REF_PI * rMin * sqrt(REF_PI * RHO_S / s->kg);
+  s->dtLB = s->dx * s->dx * (s->tau - 0.5) / (3 * s->nu);
+  s->npDEM = (int)(s->dtLB / dtmax + 1);
+  s->c = s->dx / s->dtLB;
+  s->dt = s->dtLB / s->npDEM;
+  s->dt2 = s->dt * s->dt;
+  for (int i = 0; i < n; ++i) s->rLB[i] = s->reductionR * s->r[i] / s->dx;
+}
+
 ORA_API ora_sim* ora_create(int lx, int ly, double scale, int n, const double* r, const double* x1,
                             const double* x2) {
   if (lx < 3 || ly < 3 || n < 1) return NULL;
   ora_sim* s = (ora_sim*)calloc(1, sizeof *s);
   if (!s) return NULL;
   s->lx = lx; s->ly = ly; s->n = n; s->threads = 0;
+  s->scale = scale;
   s->rho_moy = 1000; s->tau = 0.504;
   s->s2 = 1.5; s->s3 = 1.4; s->s5 = 1.5; s->s7 = 1.5; s->s8 = 1.9841; s->s9 = 1.9841;
   s->nu = 1e-6; s->reductionR = 0.85;
@@ -155,26 +178,23 @@ ORA_API ora_sim* ora_create(int lx, int ly, double scale, int n, const double* r
   /* main.c:1834 */
   for (size_t k = 0; k < nn; ++k)
     for (int q = 0; q < NQ; ++q) s->f[k * NQ + q] = WQ[q];
-  /* main.c:1836-1854 */
-  s->Mgx = 0.;
-  s->Mdx = 1.e-3 * lx / 10;
-  s->Mhy = 1.e-3 * ly / 10;
-  s->Mby = 0.;
-  s->xG = -s->G * sin(s->angleG);
-  s->yG = -s->G * cos(s->angleG);
-  s->dx = (1. / scale) * (s->Mdx - s->Mgx) / (lx - 1);
-  double rMin = s->r[0];
-  for (int i = 1; i <= n - 1; i++) rMin = fmin(rMin, s->r[i]);
-  double dtmax = (1 / s->iterDEM) * REF_PI * rMin * sqrt(REF_PI * RHO_S / s->kg);
-  s->dtLB = s->dx * s->dx * (s->tau - 0.5) / (3 * s->nu);
-  s->npDEM = (int)(s->dtLB / dtmax + 1);
-  s->c = s->dx / s->dtLB;
-  s->dt = s->dtLB / s->npDEM;
-  s->dt2 = s->dt * s->dt;
-  /* main.c:1858-1860 */
-  for (int i = 0; i < n; ++i) s->rLB[i] = s->reductionR * s->r[i] / s->dx;
+  derive_run_constants(s);
   paint_initial_obstacles(s);
   return s;
+}
+
+/* test-only: replace every physics constant (same order as lbmdem_physics in include/lbmdem_hip.h:
+ * rho_moy tau s2 s3 s5 s7 s8 s9 nu reductionR G angleG km kg kt ktm nug num nugt mu mum mumb murf distVerlet
+ * dtt iterDEM freq amp t, then updateVerlet, stepFilm) right after ora_create and re-derive the run */
+ORA_API void ora_set_physics(ora_sim* s, const double* p, int updateVerlet, int stepFilm) {
+  s->rho_moy = p[0]; s->tau = p[1]; s->s2 = p[2]; s->s3 = p[3]; s->s5 = p[4]; s->s7 = p[5]; s->s8 = p[6];
+  s->s9 = p[7]; s->nu = p[8]; s->reductionR = p[9]; s->G = p[10]; s->angleG = p[11]; s->km = p[12];
+  s->kg = p[13]; s->kt = p[14]; s->ktm = p[15]; s->nug = p[16]; s->num = p[17]; s->nugt = p[18];
+  s->mu = p[19]; s->mum = p[20]; s->mumb = p[21]; s->murf = p[22]; s->distVerlet = p[23]; s->dtt = p[24];
+  s->iterDEM = p[25]; s->freq = p[26]; s->amp = p[27]; s->t = p[28];
+  s->updateVerlet = updateVerlet; s->stepFilm = stepFilm;
+  derive_run_constants(s);
+  paint_initial_obstacles(s);
 }
 
 /* test-only: another reduced-radius factor (the reference's is the global reductionR = 0.85, main.c:94);

@@ -37,6 +37,8 @@ void ora_free(void* p);
 ora_sim* ora_create(int lx, int ly, double scale, int n, const double* r, const double* x1,
                     const double* x2);
 void ora_destroy(ora_sim* s);
+/* test-only: all physics constants in the order of lbmdem_physics (29 doubles), + the two cadences */
+void ora_set_physics(ora_sim* s, const double* p29, int updateVerlet, int stepFilm);
 /* test-only: change reductionR (main.c:94) right after ora_create */
 void ora_set_reduction(ora_sim* s, double reductionR);
 

@@ -115,6 +115,10 @@ class Oracle:
     def dem_substep(self): self._call("ora_dem_substep")
     def set_threads(self, n): self._call("ora_set_threads", C.c_int(n))
     def set_reduction(self, v): self._call("ora_set_reduction", C.c_double(v))
+
+    def set_physics(self, p29, updateVerlet, stepFilm):
+        p = np.ascontiguousarray(p29, dtype=np.float64); assert p.shape == (29,)
+        self._call("ora_set_physics", _vp(p), C.c_int(updateVerlet), C.c_int(stepFilm))
     def set_nbsteps(self, n): self._call("ora_set_nbsteps", C.c_long(n))
     @property
     def nbsteps(self): return int(self._call("ora_nbsteps"))

@@ -359,3 +359,41 @@ def test_other_reduction_factors(pkg, po, reduction):
     if ora.act_anomalies() != 0:
         pytest.skip("three reduced discs overlap at a node in this configuration (documented limit)")
     assert_same_state(sim, ora, f"reductionR={reduction}")
+
+
+@pytest.mark.parametrize("dtt", [0.0, 5e-5])
+def test_every_physics_constant_is_plumbed_through(pkg, po, dtt):
+    """All 29 physics constants + the two cadences perturbed away from the reference's values
+    (main.c:74-118,143,163-165): gravity at an angle, other relaxation rates, stiffnesses, friction,
+    Verlet distance and cadence, a film step every 7 sub-steps ... The HIP path (constants passed through
+    lbmdem_config) must still equal the oracle bit for bit -- nothing may be hard-coded in a kernel."""
+    import ctypes
+    lx, ly = 160, 120
+    r, x1, x2 = small_packing(lx, ly, 40, 29)
+    phys = pkg.Physics()
+    pkg.load_library().lbmdem_physics_defaults(ctypes.byref(phys))
+    names = [f[0] for f in pkg.Physics._fields_ if f[1] is ctypes.c_double]
+    assert len(names) == 29
+    rng = np.random.default_rng(77)
+    for nme in names:
+        v = getattr(phys, nme)
+        setattr(phys, nme, v * (1 + 0.1 * rng.uniform(-1, 1)) if v != 0 else 0.0)
+    # dtt > 0: VerletWall keeps the right/top DEM walls at the lattice edge until nbsteps*dt >= dtt
+    # (main.c:1555-1561), so grains near those edges feel them during the first rebuild periods
+    phys.tau = 0.52; phys.angleG = 0.3; phys.t = 0.013; phys.reductionR = 0.8; phys.dtt = dtt
+    phys.updateVerlet, phys.stepFilm = 17, 7
+    sim = pkg.LbmDem(lx, ly, r, x1, x2, physics=phys)
+    ora = po.Oracle(lx, ly, r, x1, x2)
+    ora.set_physics([getattr(phys, nme) for nme in names], phys.updateVerlet, phys.stepFilm)
+    s = ora.scalars()
+    for key in ("dx", "dtLB", "dt", "c", "npDEM", "xG", "yG"):
+        assert getattr(sim.cfg, key) == s[key], key
+    k = np.zeros((len(r), 9)); k[:, 0], k[:, 1] = x1, x2; k[:, 3:6] = rng.normal(0, 1, (len(r), 3)) * [0.03, 0.03, 20.0]
+    sim.kinematics = k; ora.set_kinematics(k)
+    n = 5 * sim.cfg.npDEM + 3
+    assert dtt == 0.0 or n * sim.cfg.dt > dtt > 17 * sim.cfg.dt   # the wall move happens inside the run
+    sim.renderScene(n); ora.steps(n)
+    assert ora.act_anomalies() == 0
+    assert_same_state(sim, ora, "perturbed physics")
+    assert sim.config().Mdx == ora.scalars()["Mdx"] and sim.config().Mhy == ora.scalars()["Mhy"]
+    assert np.array_equal(sim.grain_pressure, ora.get_grains()[:, po.COL["p"]])
