@@ -397,3 +397,19 @@ def test_every_physics_constant_is_plumbed_through(pkg, po, dtt):
     assert_same_state(sim, ora, "perturbed physics")
     assert sim.config().Mdx == ora.scalars()["Mdx"] and sim.config().Mhy == ora.scalars()["Mhy"]
     assert np.array_equal(sim.grain_pressure, ora.get_grains()[:, po.COL["p"]])
+
+
+@pytest.mark.parametrize("scale", [0.75, 1.25, 1.75])
+def test_scale_macro_values_of_the_jube_sweep(pkg, po, scale):
+    """The reference's JUBE benchmark sweeps -Dscale over 0.75 ... 1.75 (benchmark.xml:8): dx, and with it
+    every lattice-unit quantity, changes."""
+    lx, ly = 200, 150
+    r, x, y = samples.row_packing(int(lx / scale), int(ly / scale), 30, seed=41)
+    r, x1, x2 = samples.to_metres(r, x, y)
+    sim = pkg.LbmDem(lx, ly, r, x1, x2, scale=scale)
+    ora = po.Oracle(lx, ly, r, x1, x2, scale=scale)
+    assert sim.cfg.dx == ora.scalars()["dx"] and sim.cfg.npDEM == ora.scalars()["npDEM"]
+    n = 3 * sim.cfg.npDEM + 1
+    sim.renderScene(n); ora.steps(n)
+    assert ora.act_anomalies() == 0
+    assert_same_state(sim, ora, f"scale={scale}")
