@@ -86,56 +86,12 @@ __device__ __forceinline__ Force3 contact(const GrainState& A, const GrainState&
   return F;
 }
 
-// Per-grain contact diagnostics of one sub-step (the fields write_DEM prints, main.c:413-420), in the
-// reference's accumulation order. Only produced when DIAG (the sub-step before an output).
-struct DiagOut { double *s, *f1, *f2, *ifm, *M11, *M12, *M21, *M22; int *z, *zz; };
-
-template <bool FILM, bool DIAG>
-__global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, const double* __restrict__ m,
-                              const double* __restrict__ It, const double* __restrict__ fhf,
-                              const int* __restrict__ offsets, const int* __restrict__ nbr,
-                              const unsigned char* __restrict__ wallflags, double* __restrict__ pout,
-                              DiagOut D, DemParams P) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P.n) return;
-  const GrainState me = advance(in, r, i, P);
-  const double x3 = in.x3[i] + P.dt * in.v3[i] + P.dt2 * in.a3[i] / 2.;
-
-  // acceleration_grains: start from the hydrodynamic force (main.c:1429-1431)
-  double a1 = fhf[i], a2 = fhf[P.n + i], a3 = fhf[2 * P.n + i];
-  // grain pressure g.p (main.c:1734, 776-777, 830, 880, 912, 938): reset every sub-step, += fn per
-  // contact in the same order as the accelerations; a separated pair (dn >= 0) adds nothing
-  double pr = 0.0;
-  bool touched;
-  double ds = 0., df1 = 0., df2 = 0., difm = 0., dM11 = 0., dM12 = 0., dM21 = 0., dM22 = 0.;
-  int dz = 0, dzz = 0;
-  const int k0 = offsets[i], k1 = offsets[i + 1];
-  for (int k = k0; k < k1; ++k) {
-    const int j = nbr[k];
-    const GrainState other = advance(in, r, j, P);
-    if (i < j) {  // main.c:1443-1445
-      const Force3 F = contact<FILM>(me, other, P, touched);
-      a1 = a1 + F.f1; a2 = a2 + F.f2; a3 = a3 + F.f3;
-      if (touched) pr += F.fn;
-      if (DIAG && touched) {  // this grain is the `i` of force_grains(i, j): main.c:776-799 / 1397-1416
-        ds += F.ft;
-        dz += 1;
-        dM11 += F.f1 * F.xij; dM12 += F.f1 * F.yij; dM21 += F.f2 * F.xij; dM22 += F.f2 * F.yij;
-        if (!FILM) {
-          df1 += F.f1; df2 += F.f2;
-          dzz += 1;
-          if (F.fn == 0) difm = 0; else difm += fabs(F.ft / (P.mu * F.fn));
-        }
-      }
-    } else {      // main.c:1446-1448
-      const Force3 F = contact<FILM>(other, me, P, touched);
-      a1 = a1 - F.f1; a2 = a2 - F.f2; a3 = a3 + F.f3;
-      if (touched) pr += F.fn;
-      if (DIAG && touched) ds += F.ft;  // the `j` side only receives p and s
-    }
-  }
-  // walls: bottom, top, left, right (main.c:1455-1508)
-  const unsigned wf = wallflags[i];
+// The four wall laws applied to one grain, in the reference's order bottom, top, left, right
+// (main.c:1455-1508); wf = the grain's wall candidate flags (VerletWall, main.c:1563-1593).
+template <bool DIAG>
+__device__ __forceinline__ void walls(const GrainState& me, unsigned wf, const DemParams& P, double& a1,
+                                      double& a2, double& a3, double& pr, double& ds, double& df1, int& dz,
+                                      double& dM11, double& dM12, double& dM21, double& dM22) {
   if (wf & 1u) {
     const double dn = me.x2 - me.r - P.Mby;
     if (dn < 0) {  // force_WallB, main.c:809-828
@@ -197,6 +153,58 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
       if (DIAG) { df1 += fn; dM11 += fn * fabs(P.dt); dM21 += (-ft) * fabs(P.dt); dz += 1; }  // main.c:938-949
     }
   }
+}
+
+// Per-grain contact diagnostics of one sub-step (the fields write_DEM prints, main.c:413-420), in the
+// reference's accumulation order. Only produced when DIAG (the sub-step before an output).
+struct DiagOut { double *s, *f1, *f2, *ifm, *M11, *M12, *M21, *M22; int *z, *zz; };
+
+template <bool FILM, bool DIAG>
+__global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, const double* __restrict__ m,
+                              const double* __restrict__ It, const double* __restrict__ fhf,
+                              const int* __restrict__ offsets, const int* __restrict__ nbr,
+                              const unsigned char* __restrict__ wallflags, double* __restrict__ pout,
+                              DiagOut D, DemParams P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  const GrainState me = advance(in, r, i, P);
+  const double x3 = in.x3[i] + P.dt * in.v3[i] + P.dt2 * in.a3[i] / 2.;
+
+  // acceleration_grains: start from the hydrodynamic force (main.c:1429-1431)
+  double a1 = fhf[i], a2 = fhf[P.n + i], a3 = fhf[2 * P.n + i];
+  // grain pressure g.p (main.c:1734, 776-777, 830, 880, 912, 938): reset every sub-step, += fn per
+  // contact in the same order as the accelerations; a separated pair (dn >= 0) adds nothing
+  double pr = 0.0;
+  bool touched;
+  double ds = 0., df1 = 0., df2 = 0., difm = 0., dM11 = 0., dM12 = 0., dM21 = 0., dM22 = 0.;
+  int dz = 0, dzz = 0;
+  const int k0 = offsets[i], k1 = offsets[i + 1];
+  for (int k = k0; k < k1; ++k) {
+    const int j = nbr[k];
+    const GrainState other = advance(in, r, j, P);
+    if (i < j) {  // main.c:1443-1445
+      const Force3 F = contact<FILM>(me, other, P, touched);
+      a1 = a1 + F.f1; a2 = a2 + F.f2; a3 = a3 + F.f3;
+      if (touched) pr += F.fn;
+      if (DIAG && touched) {  // this grain is the `i` of force_grains(i, j): main.c:776-799 / 1397-1416
+        ds += F.ft;
+        dz += 1;
+        dM11 += F.f1 * F.xij; dM12 += F.f1 * F.yij; dM21 += F.f2 * F.xij; dM22 += F.f2 * F.yij;
+        if (!FILM) {
+          df1 += F.f1; df2 += F.f2;
+          dzz += 1;
+          if (F.fn == 0) difm = 0; else difm += fabs(F.ft / (P.mu * F.fn));
+        }
+      }
+    } else {      // main.c:1446-1448
+      const Force3 F = contact<FILM>(other, me, P, touched);
+      a1 = a1 - F.f1; a2 = a2 - F.f2; a3 = a3 + F.f3;
+      if (touched) pr += F.fn;
+      if (DIAG && touched) ds += F.ft;  // the `j` side only receives p and s
+    }
+  }
+  // walls: bottom, top, left, right (main.c:1455-1508)
+  walls<DIAG>(me, wallflags[i], P, a1, a2, a3, pr, ds, df1, dz, dM11, dM12, dM21, dM22);
   // main.c:1511-1515 (mw = 0: SURVEY.md hard part 5)
   const double mi = m[i], mw = 0.0;
   a1 = a1 / mi + ((mi - mw) / mi) * P.xG;
@@ -214,6 +222,96 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
     D.M11[i] = dM11; D.M12[i] = dM12; D.M21[i] = dM21; D.M22[i] = dM22;
     D.z[i] = dz; D.zz[i] = dzz;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The sub-step, one lane per CONTACT CANDIDATE
+// ---------------------------------------------------------------------------------------------
+//
+// k_dem_substep spends its time in arithmetic, not in memory: one thread walks all partners of its
+// grain, ~150 dependent fp64 instructions each (a square root and two divisions), twice because
+// lanes with i < j and i > j take different branches -- ~14 000 cycles of one wave per SIMD while
+// three quarters of the chip's issue slots idle. Here the Verlet list itself is the parallel axis:
+//   phase 1  one lane per list entry (grain i, partner j): the contact force in the canonical
+//            (lower, higher) frame (operands selected, not branched), signed for i, staged in LDS;
+//   phase 2  one lane per grain adds its entries in list order (ascending partner = the reference's
+//            accumulation order, main.c:1442-1448), applies the wall laws and the second half kick.
+// A workgroup owns DEM_GRAINS consecutive grains and therefore a contiguous slice of the list.
+// x - y == x + (-y) in IEEE arithmetic, so `a1 + (i < j ? f1 : -f1)` is bit for bit the reference's
+// `a1 + f1` / `a1 - f1`.
+constexpr int DEM_GRAINS = 64;    // grains per workgroup
+constexpr int DEM_ENTRIES = 512;  // list entries staged per round (8 per grain; denser lists take more rounds)
+
+template <bool FILM>
+__global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const double* __restrict__ r,
+                                                     const double* __restrict__ m,
+                                                     const double* __restrict__ It,
+                                                     const double* __restrict__ fhf,
+                                                     const int* __restrict__ offsets,
+                                                     const int* __restrict__ nbr, const int* __restrict__ own,
+                                                     const unsigned char* __restrict__ wallflags,
+                                                     double* __restrict__ pout, DemParams P) {
+  __shared__ double sF1[DEM_ENTRIES], sF2[DEM_ENTRIES], sF3[DEM_ENTRIES], sFn[DEM_ENTRIES];
+  __shared__ unsigned char sTouched[DEM_ENTRIES];
+  const int tid = threadIdx.x;
+  const int g0 = blockIdx.x * DEM_GRAINS;
+  const int g1 = g0 + DEM_GRAINS < P.n ? g0 + DEM_GRAINS : P.n;
+  const int e0 = offsets[g0], e1 = offsets[g1];
+  // phase-2 lanes: everything that does not depend on the partners is requested now
+  const int i = g0 + tid;
+  const bool mine = tid < DEM_GRAINS && i < P.n;
+  GrainState me{};
+  double x3 = 0., a1 = 0., a2 = 0., a3 = 0., pr = 0.0, mi = 1., Iti = 1.;
+  int k0 = 0, k1 = 0;
+  unsigned wf = 0;
+  if (mine) {
+    me = advance(in, r, i, P);
+    x3 = in.x3[i] + P.dt * in.v3[i] + P.dt2 * in.a3[i] / 2.;
+    a1 = fhf[i]; a2 = fhf[P.n + i]; a3 = fhf[2 * P.n + i];  // main.c:1429-1431
+    k0 = offsets[i]; k1 = offsets[i + 1];
+    wf = wallflags[i];
+    mi = m[i]; Iti = It[i];
+  }
+  for (int base = e0; base < e1; base += DEM_ENTRIES) {
+    const int lim = base + DEM_ENTRIES < e1 ? base + DEM_ENTRIES : e1;
+    for (int e = base + tid; e < lim; e += 256) {
+      const int gi = own[e], gj = nbr[e];
+      const GrainState a = advance(in, r, gi, P), b = advance(in, r, gj, P);
+      const bool lower = gi < gj;
+      bool touched;
+      const Force3 F = contact<FILM>(lower ? a : b, lower ? b : a, P, touched);  // main.c:1443-1448
+      const int s = e - base;
+      sF1[s] = lower ? F.f1 : -F.f1;
+      sF2[s] = lower ? F.f2 : -F.f2;
+      sF3[s] = F.f3;
+      sFn[s] = F.fn;
+      sTouched[s] = touched ? 1 : 0;
+    }
+    __syncthreads();
+    if (mine) {
+      const int lo = k0 > base ? k0 : base, hi = k1 < lim ? k1 : lim;
+      for (int k = lo; k < hi; ++k) {
+        const int s = k - base;
+        a1 = a1 + sF1[s]; a2 = a2 + sF2[s]; a3 = a3 + sF3[s];
+        if (sTouched[s]) pr += sFn[s];
+      }
+    }
+    __syncthreads();
+  }
+  if (!mine) return;
+  double ds = 0., df1 = 0., dM11 = 0., dM12 = 0., dM21 = 0., dM22 = 0.;
+  int dz = 0;
+  walls<false>(me, wf, P, a1, a2, a3, pr, ds, df1, dz, dM11, dM12, dM21, dM22);
+  const double mw = 0.0;
+  a1 = a1 / mi + ((mi - mw) / mi) * P.xG;
+  a2 = (a2 / mi) + ((mi - mw) / mi) * P.yG;
+  a3 = a3 / Iti;
+  out.x1[i] = me.x1; out.x2[i] = me.x2; out.x3[i] = x3;
+  out.v1[i] = me.v1 + P.dt * a1 / 2.;
+  out.v2[i] = me.v2 + P.dt * a2 / 2.;
+  out.v3[i] = me.v3 + P.dt * a3 / 2.;
+  out.a1[i] = a1; out.a2[i] = a2; out.a3[i] = a3;
+  pout[i] = pr;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -259,8 +357,8 @@ __global__ void k_verlet_scan(int n, const double* __restrict__ x1, const double
                               const double* __restrict__ r, double ox, double oy, double cs, int ncx, int ncy,
                               const int* __restrict__ cell_start, const int* __restrict__ cell_end,
                               const int* __restrict__ sorted, double dV, int* __restrict__ counts,
-                              const int* __restrict__ offsets, int* __restrict__ nbr, long cap,
-                              int* __restrict__ overflow) {
+                              const int* __restrict__ offsets, int* __restrict__ nbr, int* __restrict__ own,
+                              long cap, int* __restrict__ overflow) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double xi = x1[i], yi = x2[i], ri = r[i];
@@ -280,7 +378,7 @@ __global__ void k_verlet_scan(int n, const double* __restrict__ x1, const double
                                  : verlet_pair(x1[j], x2[j], r[j], xi, yi, ri, dV);
         if (!hit) continue;
         if (MODE) {
-          if ((long)base + cnt < cap) nbr[base + cnt] = j; else *overflow = 1;
+          if ((long)base + cnt < cap) { nbr[base + cnt] = j; own[base + cnt] = i; } else *overflow = 1;
         }
         ++cnt;
       }
@@ -313,6 +411,13 @@ __global__ void k_wall_flags(int n, const double* __restrict__ x1, const double*
   flags[i] = (unsigned char)f;
 }
 
+// owner of every list entry, from the offsets (after a checkpoint load; k_verlet_scan<1> writes it directly)
+__global__ void k_fill_own(int n, const int* __restrict__ offsets, int* __restrict__ own) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int k = offsets[i]; k < offsets[i + 1]; ++k) own[k] = i;
+}
+
 __global__ void k_set_last_offset(int n, const int* __restrict__ counts, int* __restrict__ offsets) {
   if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n] = offsets[n - 1] + counts[n - 1];
 }
@@ -338,7 +443,7 @@ int verlet_alloc(VerletDevice& V, int n, double cs, double ox, double oy, double
   A((void**)&V.vals_in, sizeof(int) * n); A((void**)&V.vals_out, sizeof(int) * n);
   A((void**)&V.cell_start, sizeof(int) * ncell); A((void**)&V.cell_end, sizeof(int) * ncell);
   A((void**)&V.counts, sizeof(int) * n); A((void**)&V.offsets, sizeof(int) * (n + 1));
-  A((void**)&V.nbr, sizeof(int) * V.cap); A((void**)&V.wallflags, n);
+  A((void**)&V.nbr, sizeof(int) * V.cap); A((void**)&V.own, sizeof(int) * V.cap); A((void**)&V.wallflags, n);
   A((void**)&V.overflow, sizeof(int));
   if (e != hipSuccess) return -1;
   V.sort_tmp_bytes = 0;
@@ -356,7 +461,7 @@ int verlet_alloc(VerletDevice& V, int n, double cs, double ox, double oy, double
 
 void verlet_free(VerletDevice& V) {
   void* ps[] = {V.keys_in, V.keys_out, V.vals_in, V.vals_out, V.cell_start, V.cell_end, V.sort_tmp,
-                V.scan_tmp, V.counts, V.offsets, V.nbr, V.wallflags, V.overflow};
+                V.scan_tmp, V.counts, V.offsets, V.nbr, V.own, V.wallflags, V.overflow};
   for (void* p : ps) if (p) (void)hipFree(p);
   V = VerletDevice{};
 }
@@ -375,20 +480,35 @@ void launch_verlet_rebuild(VerletDevice& V, const Kin& K, const double* r, const
   hipLaunchKernelGGL(k_cell_bounds, dim3(nb), dim3(256), 0, st, n, V.keys_out, V.cell_start, V.cell_end);
   hipLaunchKernelGGL(k_verlet_scan<0>, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, r, V.ox, V.oy, V.cs, V.ncx,
                      V.ncy, V.cell_start, V.cell_end, V.vals_out, P.distVerlet, V.counts, V.offsets, V.nbr,
-                     V.cap, V.overflow);
+                     V.own, V.cap, V.overflow);
   (void)hipcub::DeviceScan::ExclusiveSum(V.scan_tmp, V.scan_tmp_bytes, V.counts, V.offsets, n, st);
   hipLaunchKernelGGL(k_set_last_offset, dim3(1), dim3(1), 0, st, n, V.counts, V.offsets);
   hipLaunchKernelGGL(k_verlet_scan<1>, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, r, V.ox, V.oy, V.cs, V.ncx,
                      V.ncy, V.cell_start, V.cell_end, V.vals_out, P.distVerlet, V.counts, V.offsets, V.nbr,
-                     V.cap, V.overflow);
+                     V.own, V.cap, V.overflow);
   hipLaunchKernelGGL(k_wall_flags, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, r, P, V.wallflags);
+}
+
+void launch_fill_own(const VerletDevice& V, int n, hipStream_t st) {
+  hipLaunchKernelGGL(k_fill_own, dim3((n + 255) / 256), dim3(256), 0, st, n, V.offsets, V.own);
 }
 
 void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const double* m,
                         const double* It, const double* fhf, const VerletDevice& V, double* pout,
                         const DemParams& P, int film, double* diag, hipStream_t st) {
-  const int nb = (P.n + 127) / 128;
   const int n = P.n;
+  static const int variant = getenv("LBMDEM_DEM_VARIANT") ? atoi(getenv("LBMDEM_DEM_VARIANT")) : 1;
+  if (!diag && variant == 1) {  // one lane per list entry
+    const int nbe = (n + DEM_GRAINS - 1) / DEM_GRAINS;
+    if (film)
+      hipLaunchKernelGGL(k_dem_entries<true>, dim3(nbe), dim3(256), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
+                         V.own, V.wallflags, pout, P);
+    else
+      hipLaunchKernelGGL(k_dem_entries<false>, dim3(nbe), dim3(256), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
+                         V.own, V.wallflags, pout, P);
+    return;
+  }
+  const int nb = (P.n + 127) / 128;
   DiagOut D{};
   if (diag) {  // [8][n] doubles then [2][n] ints
     D.s = diag; D.f1 = diag + n; D.f2 = diag + 2 * n; D.ifm = diag + 3 * n;
@@ -402,3 +522,4 @@ void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const do
   else { if (diag) LBM_DEM_LAUNCH(false, true); else LBM_DEM_LAUNCH(false, false); }
 #undef LBM_DEM_LAUNCH
 }
+

@@ -56,6 +56,24 @@ __device__ __forceinline__ double wall_uy(const LatticeView& L, const GP& g, int
   return g.v2 + (x * L.dx + L.Mgx - g.x1) * g.v3;
 }
 
+// Correctly rounded a / b from y = RN(1 / b) (Markstein's theorem; Muller et al., Handbook of Floating-
+// Point Arithmetic, section 4.7): q = RN(a * y) is a faithful quotient, r = a - b * q is exact in an fma,
+// and RN(q + r * y) = RN(a / b) -- for every a, provided the significand of b is not all ones and
+// nothing under- or overflows (the callers check b; |a / b| here is a velocity ratio or a moment, far
+// from 1e-290). r == 0 means q is already the exact quotient (this also keeps the sign of a zero).
+// One division costs ~30 fp64 instructions on gfx950; this costs 3 + a select. The fused kernel is
+// issue-bound, not bandwidth-bound, so instructions are what counts.
+__device__ __forceinline__ double exact_div(double a, double b, double y) {
+  const double q = a * y;
+  const double r = __builtin_fma(-b, q, a);
+  return r == 0.0 ? q : __builtin_fma(r, y, q);
+}
+__device__ __forceinline__ bool significand_all_ones(double v) {
+  return (__double_as_longlong(v) & 0xFFFFFFFFFFFFFll) == 0xFFFFFFFFFFFFFll;
+}
+// numerators for which exact_div cannot underflow (divisors here are O(1) .. O(1e8))
+__device__ __forceinline__ bool div_safe(double a) { return a == 0.0 || (fabs(a) > 1e-200 && fabs(a) < 1e200); }
+
 // main.c:1082-1116, in registers
 __device__ __forceinline__ void mrt_collide(const LatticeView& L, double (&f)[9]) {
   const double a = 1. / 36;
@@ -74,12 +92,26 @@ __device__ __forceinline__ void mrt_collide(const LatticeView& L, double (&f)[9]
   const double j_x2 = j_x * j_x;
   const double j_y2 = j_y * j_y;
 
-  const double eO = e - L.s2 * (e + 2 * rho - 3 * (j_x2 + j_y2) / rho);
-  const double epsO = eps - L.s3 * (eps - rho + 3 * (j_x2 + j_y2) / rho);
+  // three quotients by the same rho: one true division (the reciprocal) + three exact_div
+  double d1, d2, d3;  // 3 * (j_x2 + j_y2) / rho, (j_x2 - j_y2) / rho, j_x * j_y / rho
+  const double n1 = 3 * (j_x2 + j_y2), n2 = j_x2 - j_y2, n3 = j_x * j_y;
+  if (L.recip_ok && !significand_all_ones(rho) && rho > 1e-8 && rho < 1e8 && div_safe(n1) && div_safe(n2) &&
+      div_safe(n3)) {
+    const double y = 1.0 / rho;
+    d1 = exact_div(n1, rho, y);
+    d2 = exact_div(n2, rho, y);
+    d3 = exact_div(n3, rho, y);
+  } else {
+    d1 = 3 * (j_x2 + j_y2) / rho;
+    d2 = (j_x2 - j_y2) / rho;
+    d3 = j_x * j_y / rho;
+  }
+  const double eO = e - L.s2 * (e + 2 * rho - d1);
+  const double epsO = eps - L.s3 * (eps - rho + d1);
   const double q_xO = q_x - L.s5 * (q_x + j_x);
   const double q_yO = q_y - L.s7 * (q_y + j_y);
-  const double p_xxO = p_xx - L.s8 * (p_xx - (j_x2 - j_y2) / rho);
-  const double p_xyO = p_xy - L.s9 * (p_xy - j_x * j_y / rho);
+  const double p_xxO = p_xx - L.s8 * (p_xx - d2);
+  const double p_xyO = p_xy - L.s9 * (p_xy - d3);
 
   f[0] = a * (4 * rho - 4 * eO + 4 * epsO);
   f[2] = a * (4 * rho - eO - 2 * epsO - 6 * j_x + 6 * q_xO + 9 * p_xxO);
@@ -100,12 +132,21 @@ __device__ __forceinline__ void mrt_collide(const LatticeView& L, double (&f)[9]
 __device__ __forceinline__ void grain_equilibrium(const LatticeView& L, const GP& g, int x, int y,
                                                   double (&f)[9]) {
   const double ux = wall_ux(L, g, y), uy = wall_uy(L, g, x);
-  const double u_squ = (ux * ux + uy * uy) / (L.c * L.c);
+  double u_squ, e1, e2, e3, e4;
+  if (L.recip_ok && div_safe(ux * ux) && div_safe(uy * uy)) {  // divisions by the run constants c and c*c
+    u_squ = exact_div(ux * ux + uy * uy, L.c * L.c, L.rcc);
+    e1 = exact_div(-ux + uy, L.c, L.rc);
+    e2 = exact_div(-ux, L.c, L.rc);
+    e3 = exact_div(-ux + (-uy), L.c, L.rc);
+    e4 = exact_div(-uy, L.c, L.rc);
+  } else {
+    u_squ = (ux * ux + uy * uy) / (L.c * L.c);
+    e1 = (-ux + uy) / L.c;     // q = 1: (-1, 1)
+    e2 = (-ux) / L.c;          // q = 2: (-1, 0)
+    e3 = (-ux + (-uy)) / L.c;  // q = 3: (-1,-1)
+    e4 = (-uy) / L.c;          // q = 4: ( 0,-1)
+  }
   const double k = 1.5 * u_squ;
-  const double e1 = (-ux + uy) / L.c;     // q = 1: (-1, 1)
-  const double e2 = (-ux) / L.c;          // q = 2: (-1, 0)
-  const double e3 = (-ux + (-uy)) / L.c;  // q = 3: (-1,-1)
-  const double e4 = (-uy) / L.c;          // q = 4: ( 0,-1)
   f[0] = Wq(0) * (1. + 0.0 - k);          // eu = 0: 1. + 3*0 + 4.5*0*0 == 1.
   f[1] = Wq(1) * (1. + 3 * e1 + 4.5 * e1 * e1 - k);
   f[5] = Wq(5) * (1. + 3 * (-e1) + 4.5 * e1 * e1 - k);
@@ -635,7 +676,7 @@ __device__ __forceinline__ void classify_store_row(const Ctx& C, const LatticeVi
 __device__ __forceinline__ double shfl_up1(double v) { return __shfl_up(v, 1, 64); }
 __device__ __forceinline__ double shfl_dn1(double v) { return __shfl_down(v, 1, 64); }
 
-template <int LX, int MINW>
+template <int LX, int MINW, int WW>
 __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict__ fin, double* __restrict__ fout,
                                                   const int* __restrict__ ob_old,
                                                   const int* __restrict__ ob_new, LatticeView L,
@@ -650,10 +691,12 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
   const int w = blk * 4 + (threadIdx.x >> 6);
   if (w >= nwork) return;  // whole wave
   const int strip = w % nstrips, seg = w / nstrips;
-  const int y = strip * 62 - 1 + lane;
+  // WW producing lanes in the middle of the window, (64 - WW) / 2 feeding lanes on either side
+  constexpr int OFF = (64 - WW) / 2;
+  const int y = strip * WW - OFF + lane;
   const bool yin = y >= 0 && y < L.ly;
-  const bool writer = lane >= 1 && lane <= 62 && yin;
-  const bool deep_y = strip * 62 >= 2 && strip * 62 + 61 <= L.ly - 3;  // producing lanes 1..62
+  const bool writer = lane >= OFF && lane < OFF + WW && yin;
+  const bool deep_y = strip * WW >= 2 && strip * WW + WW - 1 <= L.ly - 3;  // the producing lanes
   // rows per wave: the template value, or (LX == 0) a run-time value chosen so that one round of resident
   // waves covers the lattice
   const int rows_per_wave = LX > 0 ? LX : seg_rows;
@@ -1270,26 +1313,31 @@ static int cs_variant() {
   return v;
 }
 
-template <int LX, int MINW>
+template <int LX, int MINW, int WW = 62>
 static void launch_march(const double* fin, double* fout, const int* obst_old, const int* obst_new,
                          const LatticeView& L, const GrainFluidView& G, int remap, hipStream_t st) {
   const int rows = L.xo1 - L.xo0;
-  const int nstrips = (L.ly + 61) / 62;
+  const int nstrips = (L.ly + WW - 1) / WW;
   int seg_rows = LX;
   if (LX == 0) {
-    // one balanced round: 256 CUs x 2 workgroups x 4 waves are resident (VGPR- and LDS-limited); give
-    // every y-strip the same number of equal x-segments
-    const int resident = 256 * 2 * 4;
-    int nseg = resident / nstrips;
-    if (nseg < 1) nseg = 1;
-    seg_rows = (rows + nseg - 1) / nseg;
-    if (seg_rows < 8) seg_rows = 8;
+    // run-time segment length: LBMDEM_CS_ROWS, or one balanced round: 256 CUs x 2 workgroups x 4 waves are
+    // resident (VGPR- and LDS-limited); give every y-strip the same number of equal x-segments
+    static const int env_rows = getenv("LBMDEM_CS_ROWS") ? atoi(getenv("LBMDEM_CS_ROWS")) : 0;
+    if (env_rows > 0) {
+      seg_rows = env_rows;
+    } else {
+      const int resident = 256 * 2 * 4;
+      int nseg = resident / nstrips;
+      if (nseg < 1) nseg = 1;
+      seg_rows = (rows + nseg - 1) / nseg;
+      if (seg_rows < 8) seg_rows = 8;
+    }
   }
   const int nseg = (rows + seg_rows - 1) / seg_rows;
   const int nwork = nstrips * nseg;
   int grid = (nwork + 3) / 4;
   if (remap) grid = ((grid + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_cs_march<LX, MINW>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, L, G,
+  hipLaunchKernelGGL((k_cs_march<LX, MINW, WW>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, L, G,
                      nstrips, nwork, remap, seg_rows);
 }
 
@@ -1309,6 +1357,8 @@ void launch_collide_stream(const double* fin, double* fout, const int* obst_old,
     case 18: launch_march<8, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
     case 19: launch_march<64, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
     case 20: launch_march<0, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;  // one balanced round
+    case 21: launch_march<32, 2, 56>(fin, fout, obst_old, obst_new, L, G, remap, st); break;  // stores start on 64-byte boundaries
+    case 22: launch_march<32, 2, 48>(fin, fout, obst_old, obst_new, L, G, remap, st); break;  // ... on 128-byte boundaries
     default: launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
   }
 }

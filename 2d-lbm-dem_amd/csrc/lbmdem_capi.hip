@@ -232,6 +232,18 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
   const lbmdem_physics& p = cfg->phys;
   L.s2 = p.s2; L.s3 = p.s3; L.s5 = p.s5; L.s7 = p.s7; L.s8 = p.s8; L.s9 = p.s9;
   L.reduced_lt1 = p.reductionR < 1.0 ? 1 : 0;
+  {
+    const double cc = cfg->c * cfg->c;
+    L.rc = 1.0 / cfg->c;
+    L.rcc = 1.0 / cc;
+    auto all_ones = [](double v) {
+      uint64_t b;
+      memcpy(&b, &v, sizeof b);
+      return (b & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull;
+    };
+    L.recip_ok = (!all_ones(cfg->c) && !all_ones(cc) && cfg->c > 1e-4 && cfg->c < 1e4) ? 1 : 0;
+    if (const char* e = getenv("LBMDEM_TRUE_DIVISIONS")) if (atoi(e)) L.recip_ok = 0;  // A/B switch
+  }
   // force scaling, main.c:1329-1331
   h->fscale12 = p.rho_moy * 9 * p.nu * p.nu / (cfg->dx * (p.tau - 0.5) * (p.tau - 0.5));
   h->fscale3 = cfg->dx * p.rho_moy * 9 * p.nu * p.nu / (cfg->dx * (p.tau - 0.5) * (p.tau - 0.5));
@@ -913,6 +925,10 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
   h->cfg = cfg;  // wall positions as saved
   h->nbsteps = H.nbsteps;
   h->verlet_ok = H.verlet_ok != 0;
+  if (h->verlet_ok) {  // the entry -> grain map is derived from the offsets
+    launch_fill_own(h->V, n, h->stream);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { lbmdem_destroy(h); return fail(LBMDEM_EHIP, "k_fill_own failed"); }
+  }
   *out = h;
   return LBMDEM_OK;
 } catch (const std::bad_alloc&) {

@@ -24,6 +24,10 @@ struct LatticeView {
   double dx, c, Mgx, Mby;
   double s2, s3, s5, s7, s8, s9;
   int reduced_lt1;  // phys.reductionR < 1: reduced discs lie strictly inside the grains (always, in the reference)
+  // x / c and x / (c*c) as correctly rounded quotients from the reciprocals (exact_div in lbm_kernels.hip);
+  // recip_ok = 0 when a divisor's significand is all ones (the one case the construction does not cover)
+  double rc, rcc;
+  int recip_ok;
 };
 
 // Grain state used by the fluid kernels. xc, yc, r2, rbl0 are the lattice-unit centre, squared
@@ -105,6 +109,7 @@ struct VerletDevice {
   int* counts;   // n
   int* offsets;  // n + 1
   int* nbr;      // cap
+  int* own;      // cap: the grain each entry belongs to
   long cap;
   unsigned char* wallflags;  // n
   int* overflow;             // device flag
@@ -113,6 +118,7 @@ int verlet_alloc(VerletDevice& V, int n, double cs, double ox, double oy, double
 void verlet_free(VerletDevice& V);
 void launch_verlet_rebuild(VerletDevice& V, const Kin& K, const double* r, const DemParams& P,
                            hipStream_t st);
+void launch_fill_own(const VerletDevice& V, int n, hipStream_t st);
 void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const double* m,
                         const double* It, const double* fhf, const VerletDevice& V, double* pout,
                         const DemParams& P, int film, double* diag, hipStream_t st);

@@ -413,3 +413,32 @@ def test_scale_macro_values_of_the_jube_sweep(pkg, po, scale):
     sim.renderScene(n); ora.steps(n)
     assert ora.act_anomalies() == 0
     assert_same_state(sim, ora, f"scale={scale}")
+
+
+def test_long_verlet_lists_take_several_staging_rounds(pkg, po):
+    """The sub-step kernel gives one lane to every Verlet-list entry and stages a workgroup's entries
+    (64 grains) in rounds of 512. A wide Verlet distance makes every grain a candidate partner of ~25
+    others, so a workgroup needs several rounds and grains have entries in more than one of them; the
+    film law (other kernel instantiation) and the ordinary law both run."""
+    import ctypes
+    lx, ly = 400, 300
+    r, x1, x2 = small_packing(lx, ly, 260, 5)
+    phys = pkg.Physics()
+    pkg.load_library().lbmdem_physics_defaults(ctypes.byref(phys))
+    names = [f[0] for f in pkg.Physics._fields_ if f[1] is ctypes.c_double]
+    phys.distVerlet = 4e-3
+    phys.updateVerlet, phys.stepFilm = 9, 5
+    sim = pkg.LbmDem(lx, ly, r, x1, x2, physics=phys)
+    ora = po.Oracle(lx, ly, r, x1, x2)
+    ora.set_physics([getattr(phys, nme) for nme in names], phys.updateVerlet, phys.stepFilm)
+    rng = np.random.default_rng(3)
+    k = np.zeros((len(r), 9)); k[:, 0], k[:, 1] = x1, x2; k[:, 3:6] = rng.normal(0, 1, (len(r), 3)) * [0.05, 0.05, 10.0]
+    sim.kinematics = k; ora.set_kinematics(k)
+    ora.verlet_rebuild()
+    cnt = np.bincount(np.asarray(ora.pairs()).ravel(), minlength=len(r))   # symmetric list lengths
+    per_group = [int(cnt[g:g + 64].sum()) for g in range(0, len(r), 64)]
+    assert max(per_group) > 2 * 512, per_group     # more than two rounds somewhere
+    n = 2 * sim.cfg.npDEM + 5
+    sim.renderScene(n); ora.steps(n)
+    assert_same_state(sim, ora, "long lists")
+    assert np.array_equal(sim.grain_pressure, ora.get_grains()[:, po.COL["p"]])
