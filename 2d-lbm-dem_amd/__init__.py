@@ -96,6 +96,7 @@ def load_library():
     L.lbmdem_set_diagnostics.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_download_grain_table.argtypes = [C.c_void_p, C.c_void_p]
     L.lbmdem_write_dem.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p]
+    L.lbmdem_write_forces.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.lbmdem_checkpoint_save.argtypes = [C.c_void_p, C.c_char_p]
     L.lbmdem_checkpoint_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     L.lbmdem_set_force_mode.argtypes = [C.c_void_p, C.c_int]
@@ -340,6 +341,10 @@ class LbmDem:
         e = np.zeros(4)
         _chk(self._L.lbmdem_write_dem(self._h, os.fsencode(directory), int(nFile), _vp(e)))
         return tuple(e)
+
+    def write_forces(self, directory=".", nFile=0):
+        """write_forces (main.c:440-478): DEM%06d.ps, grains + one line per overlapping pair."""
+        _chk(self._L.lbmdem_write_forces(self._h, os.fsencode(directory), int(nFile)))
 
     def write_vtk(self, directory=".", nFile=0):
         """write_vtk (main.c:237-338): five binary legacy-VTK files, byte-identical to the reference's."""

@@ -834,6 +834,94 @@ int lbmdem_write_dem(lbmdem_handle* h, const char* dir, int nfile, double* energ
   return fail(LBMDEM_EINVAL, "unexpected C++ exception");
 }
 
+int lbmdem_write_forces(lbmdem_handle* h, const char* dir, int nfile) try {
+  CHECK_H(h);
+  const int n = h->n;
+  std::vector<double> t(30 * (size_t)n);
+  int rc = lbmdem_download_grain_table(h, t.data());
+  if (rc != LBMDEM_OK) return rc;
+  auto X1 = [&](int i) { return t[(size_t)i * 30 + 0]; };
+  auto X2 = [&](int i) { return t[(size_t)i * 30 + 1]; };
+  auto R = [&](int i) { return t[(size_t)i * 30 + 9]; };
+  auto FM = [&](int i) { return t[(size_t)i * 30 + 18]; };
+  char path[4096];
+  snprintf(path, sizeof path, "%s/DEM%.6i.ps", (dir && *dir) ? dir : ".", nfile);
+  FILE* fp = fopen(path, "w");
+  if (!fp) return fail(LBMDEM_EINVAL, "cannot open '%s' for writing", path);
+  const double margin = 10 * R(0), hrx1 = h->cfg.lx, hry2 = h->cfg.ly;  // main.c:449
+  fprintf(fp, "%%!PS-Adobe-3.0 EPSF-3.0 \n");
+  fprintf(fp, "%%%%BoundingBox: %f %f %f %f \n", -margin, -margin, hrx1 + margin, hry2 + margin);
+  fprintf(fp, "%%%%Creator: lbmdem-hip \n");
+  fprintf(fp, "%%%%Title: DEM Grains & Forces \n");
+  fprintf(fp, "0.1 setlinewidth 0.0 setgray \n");
+  for (int i = 0; i < n; i++)
+    fprintf(fp, "newpath %le %le %le 0.0 setlinewidth %.2f setgray 0 360 arc gsave fill grestore\n", X1(i) * 10000,
+            X2(i) * 10000, R(i) * 10000, (0.8 - FM(i) / 2));
+  // overlapping pairs, dn < -1e-10 (main.c:462-466), found on a uniform grid of cell size 2 r_max: any pair
+  // with dn < 0 has its centres closer than that, i.e. in adjacent cells
+  double xmin = X1(0), xmax = X1(0), ymin = X2(0), ymax = X2(0), rmax = R(0);
+  for (int i = 1; i < n; i++) {
+    if (X1(i) < xmin) xmin = X1(i);
+    if (X1(i) > xmax) xmax = X1(i);
+    if (X2(i) < ymin) ymin = X2(i);
+    if (X2(i) > ymax) ymax = X2(i);
+    if (R(i) > rmax) rmax = R(i);
+  }
+  const double cs = 2 * rmax > 0 ? 2 * rmax : 1.0;
+  long ncx = (long)((xmax - xmin) / cs) + 1, ncy = (long)((ymax - ymin) / cs) + 1;
+  while (ncx * ncy > 4L * n + 64) {  // far-flung grains: coarsen (still correct, cells only get larger)
+    if (ncx >= ncy) ncx = (ncx + 1) / 2; else ncy = (ncy + 1) / 2;
+  }
+  const double csx = (xmax - xmin) / ncx > cs ? (xmax - xmin) / ncx * (1 + 1e-12) : cs;
+  const double csy = (ymax - ymin) / ncy > cs ? (ymax - ymin) / ncy * (1 + 1e-12) : cs;
+  auto cell = [&](double v, double lo, double c, long nc) {
+    long k = (long)((v - lo) / c);
+    return k < 0 ? 0 : (k >= nc ? nc - 1 : k);
+  };
+  std::vector<int> start((size_t)(ncx * ncy) + 1, 0), order(n);
+  for (int i = 0; i < n; i++) start[(size_t)(cell(X2(i), ymin, csy, ncy) * ncx + cell(X1(i), xmin, csx, ncx)) + 1]++;
+  for (size_t k = 1; k < start.size(); k++) start[k] += start[k - 1];
+  {
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    for (int i = 0; i < n; i++) order[(size_t)fill[(size_t)(cell(X2(i), ymin, csy, ncy) * ncx + cell(X1(i), xmin, csx, ncx))]++] = i;
+  }
+  std::vector<int> js;
+  for (int i = 0; i < n; i++) {
+    js.clear();
+    const long cx = cell(X1(i), xmin, csx, ncx), cy = cell(X2(i), ymin, csy, ncy);
+    for (long yy = cy - 1; yy <= cy + 1; ++yy) {
+      if (yy < 0 || yy >= ncy) continue;
+      for (long xx = cx - 1; xx <= cx + 1; ++xx) {
+        if (xx < 0 || xx >= ncx) continue;
+        for (int k = start[(size_t)(yy * ncx + xx)]; k < start[(size_t)(yy * ncx + xx) + 1]; ++k) {
+          const int j = order[(size_t)k];
+          if (j == i) continue;
+          const double dn = (sqrt((X1(i) - X1(j)) * (X1(i) - X1(j)) + (X2(i) - X2(j)) * (X2(i) - X2(j)))) - R(i) - R(j);
+          if (dn < -1e-10) js.push_back(j);
+        }
+      }
+    }
+    for (size_t a = 1; a < js.size(); ++a) {  // ascending j: the reference's inner loop order
+      const int v = js[a];
+      size_t b = a;
+      while (b > 0 && js[b - 1] > v) { js[b] = js[b - 1]; --b; }
+      js[b] = v;
+    }
+    for (int j : js) {
+      fprintf(fp, "%le setlinewidth \n 0.0 setgray \n", 1.);
+      fprintf(fp, "1 setlinecap \n newpath \n");
+      fprintf(fp, "%le %le moveto \n %le %le lineto\n", X1(i) * 10000, X2(i) * 10000, X1(j) * 10000, X2(j) * 10000);
+      fprintf(fp, "stroke \n");
+    }
+  }
+  fclose(fp);
+  return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
+}
+
 // ---- checkpoint / restart ------------------------------------------------------------------------
 
 namespace {

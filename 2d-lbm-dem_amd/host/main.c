@@ -125,9 +125,11 @@ int main(int argc, char** argv) {
         DIE(lbmdem_write_vtk(h, ".", nFile), "write_vtk");
         nFile++;
       }
-      /* write_DEM every stepStrob = 4000 DEM steps (main.c:142,1773-1776; write_forces' PostScript
-       * picture is not produced) */
-      if (nbsteps % 4000 == 0) DIE(lbmdem_write_dem(h, ".", nFile, energies), "write_dem");
+      /* write_DEM and write_forces every stepStrob = 4000 DEM steps (main.c:142,1773-1776) */
+      if (nbsteps % 4000 == 0) {
+        DIE(lbmdem_write_dem(h, ".", nFile, energies), "write_dem");
+        DIE(lbmdem_write_forces(h, ".", nFile), "write_forces");
+      }
     }
     if (nbsteps % chunk == 0) {
       now = time(NULL);

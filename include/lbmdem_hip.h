@@ -149,6 +149,13 @@ int lbmdem_download_grain_table(lbmdem_handle* h, double* table30);
 /* write_DEM (main.c:340-438): <dir>/DEM%06d.dat and one line appended to <dir>/stats.data; energies4 (may be
  * NULL) receives energie_cin, energy_p, SE, IFR for the console line of main.c:1885-1889. */
 int lbmdem_write_dem(lbmdem_handle* h, const char* dir, int nfile, double* energies4);
+/* write_forces (main.c:440-478): <dir>/DEM%06d.ps, a PostScript picture of the grains (grey level from g.fm)
+ * and one line per overlapping pair, in the reference's order (i outer, j inner, both directions). The
+ * reference reads g[nbgrains], one element past its array, and its three "%%%Word" header formats are
+ * undefined conversions; this writer emits the nbgrains real grains and the headers the format strings
+ * evidently mean. Every other line is character-identical to the reference's file. The pair search is a
+ * host-side uniform grid (same pairs as the reference's O(N^2) loop). */
+int lbmdem_write_forces(lbmdem_handle* h, const char* dir, int nfile);
 /* Checkpoint / restart (absent in the reference, which cannot resume a run: SURVEY.md section 5). The file
  * holds exactly the state that defines the continuation at a renderScene() boundary -- populations,
  * current obstacle map, grain kinematics, hydrodynamic forces, Verlet lists, wall positions, step

@@ -35,6 +35,13 @@ def test_dem_file_and_stats_line_match_the_reference(pkg, tmp_path):
         for k in range(28):
             if k not in UNPINNED_DEM_COLS:
                 assert cg[k] == cw[k], (cg[0], k, cg[k], cw[k])
+    # write_forces (main.c:440-478): every well-defined line of the reference's PostScript file
+    sim.write_forces(str(tmp_path), 0)
+    got = open(tmp_path / "DEM000000.ps", "rb").read().split(b"\n")
+    want = open(os.path.join(REF_DIR, "DEM000000.ps"), "rb").read().split(b"\n")
+    assert got[1].startswith(b"%%BoundingBox: ") and got[2].startswith(b"%%Creator") and got[3].startswith(b"%%Title")
+    assert [got[0]] + got[4:] == want      # the fixture has the three undefined header lines removed
+    assert sum(l.startswith(b"stroke") for l in got) >= 20
     sg = open(tmp_path / "stats.data").read().split()
     sw = open(os.path.join(REF_DIR, "stats.data")).read().split()
     assert len(sg) == len(sw) == 22

@@ -44,6 +44,7 @@ def test_run_matches_oracle_and_writes_a_frame(po, tmp_path):
     # write_DEM at steps 4000 and 8000 (main.c:1773): nFile is 0 at 4000 and 1 at 8000 (incremented by the
     # VTK frame written just before)
     assert (tmp_path / "DEM000000.dat").exists() and (tmp_path / "DEM000001.dat").exists()
+    assert (tmp_path / "DEM000000.ps").exists() and (tmp_path / "DEM000001.ps").exists()   # write_forces
     stats = open(tmp_path / "stats.data").read().splitlines()
     assert stats[0].startswith("#1_t 2_xfront") and len(stats) == 3 and len(stats[1].split()) == 22
     assert re.search(r"steps 8000 steps .* KE [0-9.e+-]+ PE [0-9.e+-]+ SE", out.stdout)
