@@ -97,6 +97,7 @@ def load_library():
     L.lbmdem_download_grain_table.argtypes = [C.c_void_p, C.c_void_p]
     L.lbmdem_write_dem.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p]
     L.lbmdem_write_forces.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.lbmdem_collide_stream_part.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_checkpoint_save.argtypes = [C.c_void_p, C.c_char_p]
     L.lbmdem_checkpoint_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     L.lbmdem_set_force_mode.argtypes = [C.c_void_p, C.c_int]
@@ -243,6 +244,14 @@ class LbmDem:
     def collision_streaming(self):
         """reinit_obst_density (with the previous obstacle map) + collision_streaming."""
         _chk(self._L.lbmdem_collide_stream(self._h))
+
+    def collision_streaming_edges(self):
+        """First part of a split collision_streaming: the owned rows a neighbouring strip needs."""
+        _chk(self._L.lbmdem_collide_stream_part(self._h, 1))
+
+    def collision_streaming_interior(self):
+        """Second part: all other owned rows (runs while the halo rows travel)."""
+        _chk(self._L.lbmdem_collide_stream_part(self._h, 2))
 
     def forces_fluid(self):
         _chk(self._L.lbmdem_forces_fluid(self._h))

@@ -49,6 +49,12 @@ struct lbmdem_handle {
   int* obst[2] = {nullptr, nullptr};
   int ocur = 0;           // map the current f was produced with ("old" for the next collide_stream)
   bool obst_pending = false;  // obst[1 - ocur] holds a newer map not yet consumed by collide_stream
+  // collide_stream in two parts (lbmdem_collide_stream_part): after EDGES the interior rows of f[fcur] are
+  // still missing; the operands of the launch are kept for INTERIOR
+  bool cs_interior_pending = false;
+  const double* cs_fin = nullptr;
+  const int *cs_ob_old = nullptr, *cs_ob_new = nullptr;
+  int cs_lo_end = 0, cs_hi_begin = 0;  // interior = local rows [cs_lo_end, cs_hi_begin)
   // grains
   int n = 0;
   double* gbuf = nullptr;  // one allocation, carved below
@@ -353,28 +359,40 @@ int lbmdem_destroy(lbmdem_handle* h) {
 
 int lbmdem_obst_construction(lbmdem_handle* h) {
   CHECK_H(h);
+  if (h->cs_interior_pending) return fail(LBMDEM_EINVAL, "lbmdem_collide_stream_part(LBMDEM_CS_INTERIOR) has not been called after LBMDEM_CS_EDGES");
   int rc = paint_into(h, h->obst[1 - h->ocur]);
   if (rc == LBMDEM_OK) h->obst_pending = true;
   return rc;
 }
 
+static int prof_begin(lbmdem_handle* h, hipEvent_t* e1) {
+  *e1 = nullptr;
+  if (!h->prof) return LBMDEM_OK;
+  if (h->ev_used == h->ev0.size()) {
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    h->ev0.push_back(a); h->ev1.push_back(b);
+  }
+  hipEvent_t e0 = h->ev0[h->ev_used];
+  *e1 = h->ev1[h->ev_used];
+  ++h->ev_used;
+  HIP_TRY(hipEventRecord(e0, h->stream));
+  return LBMDEM_OK;
+}
+
+#define CHECK_NOT_SPLIT(h) do { if ((h)->cs_interior_pending) return fail(LBMDEM_EINVAL, "lbmdem_collide_stream_part(LBMDEM_CS_INTERIOR) has not been called after LBMDEM_CS_EDGES"); } while (0)
+
 int lbmdem_collide_stream(lbmdem_handle* h) try {
   CHECK_H(h);
+  CHECK_NOT_SPLIT(h);
   const int* ob_old = h->obst[h->ocur];
   const int* ob_new = h->obst_pending ? h->obst[1 - h->ocur] : h->obst[h->ocur];
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (h->prof) {
-    if (h->ev_used == h->ev0.size()) {
-      hipEvent_t a, b;
-      HIP_TRY(hipEventCreate(&a));
-      HIP_TRY(hipEventCreate(&b));
-      h->ev0.push_back(a); h->ev1.push_back(b);
-    }
-    e0 = h->ev0[h->ev_used]; e1 = h->ev1[h->ev_used]; ++h->ev_used;
-    HIP_TRY(hipEventRecord(e0, h->stream));
-  }
+  hipEvent_t e1 = nullptr;
+  int rc = prof_begin(h, &e1);
+  if (rc != LBMDEM_OK) return rc;
   launch_collide_stream(h->f[h->fcur], h->f[1 - h->fcur], ob_old, ob_new, h->L, gview(h), h->stream);
-  if (h->prof) HIP_TRY(hipEventRecord(e1, h->stream));
+  if (e1) HIP_TRY(hipEventRecord(e1, h->stream));
   HIP_TRY(hipGetLastError());
   h->fcur = 1 - h->fcur;
   if (h->obst_pending) { h->ocur = 1 - h->ocur; h->obst_pending = false; }
@@ -385,8 +403,62 @@ int lbmdem_collide_stream(lbmdem_handle* h) try {
   return fail(LBMDEM_EINVAL, "unexpected C++ exception");
 }
 
+int lbmdem_collide_stream_part(lbmdem_handle* h, int part) try {
+  CHECK_H(h);
+  const LatticeView& L = h->L;
+  if (part == LBMDEM_CS_EDGES) {
+    CHECK_NOT_SPLIT(h);
+    const int H = h->cfg.halo;
+    const bool has_lo = L.gx0 + L.xo0 > 0, has_hi = L.gx0 + L.xo1 < L.lx;  // interior cuts
+    int lo_end = has_lo ? L.xo0 + H : L.xo0;
+    if (lo_end > L.xo1) lo_end = L.xo1;
+    int hi_begin = has_hi ? L.xo1 - H : L.xo1;
+    if (hi_begin < lo_end) hi_begin = lo_end;
+    h->cs_fin = h->f[h->fcur];
+    h->cs_ob_old = h->obst[h->ocur];
+    h->cs_ob_new = h->obst_pending ? h->obst[1 - h->ocur] : h->obst[h->ocur];
+    h->cs_lo_end = lo_end; h->cs_hi_begin = hi_begin;
+    hipEvent_t e1 = nullptr;  // the interval of this step's fused kernels ends in INTERIOR
+    int rc = prof_begin(h, &e1);
+    if (rc != LBMDEM_OK) return rc;
+    LatticeView Ls = L;
+    if (lo_end > L.xo0) {
+      Ls.xo0 = L.xo0; Ls.xo1 = lo_end;
+      launch_collide_stream(h->cs_fin, h->f[1 - h->fcur], h->cs_ob_old, h->cs_ob_new, Ls, gview(h), h->stream);
+    }
+    if (L.xo1 > hi_begin) {
+      Ls.xo0 = hi_begin; Ls.xo1 = L.xo1;
+      launch_collide_stream(h->cs_fin, h->f[1 - h->fcur], h->cs_ob_old, h->cs_ob_new, Ls, gview(h), h->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    h->fcur = 1 - h->fcur;
+    if (h->obst_pending) { h->ocur = 1 - h->ocur; h->obst_pending = false; }
+    h->cs_interior_pending = true;
+    return LBMDEM_OK;
+  }
+  if (part == LBMDEM_CS_INTERIOR) {
+    if (!h->cs_interior_pending) return fail(LBMDEM_EINVAL, "LBMDEM_CS_INTERIOR without a preceding LBMDEM_CS_EDGES");
+    if (h->cs_hi_begin > h->cs_lo_end) {
+      LatticeView Ls = L;
+      Ls.xo0 = h->cs_lo_end; Ls.xo1 = h->cs_hi_begin;
+      // the grain records are those of EDGES: nothing moves the grains between the two parts
+      launch_collide_stream(h->cs_fin, h->f[h->fcur], h->cs_ob_old, h->cs_ob_new, Ls, gview(h), h->stream);
+    }
+    if (h->prof && h->ev_used > 0) HIP_TRY(hipEventRecord(h->ev1[h->ev_used - 1], h->stream));
+    HIP_TRY(hipGetLastError());
+    h->cs_interior_pending = false;
+    return LBMDEM_OK;
+  }
+  return fail(LBMDEM_EINVAL, "part must be LBMDEM_CS_EDGES or LBMDEM_CS_INTERIOR");
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
+}
+
 int lbmdem_forces_fluid(lbmdem_handle* h) {
   CHECK_H(h);
+  CHECK_NOT_SPLIT(h);
   const int* ob = h->obst_pending ? h->obst[1 - h->ocur] : h->obst[h->ocur];
   if (h->force_mode == 0)
     launch_forces_parity(h->f[h->fcur], ob, h->L, gview(h), h->fscale12, h->fscale3, h->fhf, h->owner, h->stream);
@@ -422,6 +494,7 @@ int lbmdem_verlet_rebuild(lbmdem_handle* h) {
 
 int lbmdem_dem_substep(lbmdem_handle* h) {
   CHECK_H(h);
+  CHECK_NOT_SPLIT(h);
   if (!h->verlet_ok) return fail(LBMDEM_EINVAL, "lbmdem_dem_substep before the first lbmdem_verlet_rebuild");
   const int film = (h->nbsteps % h->cfg.phys.stepFilm == 0) ? 1 : 0;  // main.c:1342
   // contact diagnostics are only needed by write_DEM, which renderScene calls when the step counter
@@ -486,6 +559,7 @@ int lbmdem_upload_f(lbmdem_handle* h, const double* f_aos) {
 
 int lbmdem_download_f(lbmdem_handle* h, double* f_aos) {
   CHECK_H(h);
+  CHECK_NOT_SPLIT(h);
   if (!f_aos) return fail(LBMDEM_EINVAL, "null buffer");
   const LatticeView& L = h->L;
   const int rows = L.xo1 - L.xo0;
@@ -514,6 +588,7 @@ int lbmdem_download_obst(lbmdem_handle* h, int* obst) {
 
 int lbmdem_download_macro(lbmdem_handle* h, double* rho, double* ux, double* uy) {
   CHECK_H(h);
+  CHECK_NOT_SPLIT(h);
   if (!rho || !ux || !uy) return fail(LBMDEM_EINVAL, "null buffer");
   const LatticeView& L = h->L;
   const int rows = L.xo1 - L.xo0;
@@ -533,6 +608,7 @@ int lbmdem_download_macro(lbmdem_handle* h, double* rho, double* ux, double* uy)
 
 int lbmdem_total_density(lbmdem_handle* h, double* sum) {
   CHECK_H(h);
+  CHECK_NOT_SPLIT(h);
   if (!sum) return fail(LBMDEM_EINVAL, "null buffer");
   const int nb = 1024;
   launch_density_partial(h->f[h->fcur], h->L, h->dpartial, nb, h->stream);
@@ -643,6 +719,7 @@ int lbmdem_download_grain_pressure(lbmdem_handle* h, double* p) {
 int lbmdem_download_vtk_fields(lbmdem_handle* h, float* grain_pressure, float* grain_velocity,
                                float* grain_acceleration, float* fluid_pressure, float* fluid_velocity) {
   CHECK_H(h);
+  CHECK_NOT_SPLIT(h);
   if (!grain_pressure || !grain_velocity || !grain_acceleration || !fluid_pressure || !fluid_velocity)
     return fail(LBMDEM_EINVAL, "null buffer");
   const LatticeView& L = h->L;
@@ -938,6 +1015,7 @@ static bool rd(FILE* fp, void* p, size_t n) { return fread(p, 1, n, fp) == n; }
 
 int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) try {
   CHECK_H(h);
+  CHECK_NOT_SPLIT(h);
   if (!path) return fail(LBMDEM_EINVAL, "null path");
   if (h->obst_pending) return fail(LBMDEM_EINVAL, "checkpoint between obst_construction and collide_stream");
   HIP_TRY(hipStreamSynchronize(h->stream));

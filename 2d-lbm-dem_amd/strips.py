@@ -6,9 +6,10 @@ multi-GPU design of BASELINE.json's north_star, one process per GPU:
 * **Fluid**: the lattice is cut along x (the reference's slow axis, which this framework keeps as the
   slow device axis -- a strip is one contiguous slab per population plane and a halo row is
   contiguous). Rank k owns rows [x_k, x_{k+1}); it keeps `halo` extra rows on each interior side.
-  After the fused collide+stream kernel has produced the owned rows, the `halo` outermost owned rows
-  travel to the neighbour's halo (one send + one receive per neighbour per fluid step, point to
-  point over xGMI: RCCL through torch.distributed's batched isend/irecv). halo = 2 + the largest
+  The fused collide+stream kernel first produces the `halo` owned rows next to each cut; they travel
+  to the neighbour's halo (one send + one receive per neighbour per fluid step, point to point over
+  xGMI: RCCL through torch.distributed's batched isend/irecv, issued on a side stream) WHILE the
+  kernel produces the interior rows -- the exchange is off the critical path. halo = 2 + the largest
   grain radius in nodes, so that (a) the next collide+stream finds the f row and the two obstacle
   rows it reads beyond the cut and (b) the owner of a grain sees every node of the grain's bounding
   box and computes its hydrodynamic force in the reference's serial order -- results do not depend
@@ -77,11 +78,23 @@ class StripRunner:
     def forces_finish(self):
         self.b.fhf_import()
 
+    # -- the same with the halo exchange overlapped with the interior rows -----------------------------
+    def fluid_edges(self):
+        self.b.obst_construction()
+        self.b.collision_streaming_edges()
+
+    def fluid_interior(self):
+        self.b.collision_streaming_interior()
+
     def lbm_step(self):
-        self.fluid_compute()
         if self.world > 1:
-            self.comm.exchange(self.halo_post())
+            self.fluid_edges()
+            pending = self.comm.exchange_begin(self.halo_post())   # rows next to the cuts are on their way
+            self.fluid_interior()                                  # ... while the bulk is computed
+            self.comm.exchange_end(pending)
             self.halo_finish()
+        else:
+            self.fluid_compute()
         buf = self.forces_post()
         if self.world > 1 or self.always_reduce:
             self.comm.all_reduce_bits(buf)
@@ -107,16 +120,40 @@ class TorchComm:
 
     def __init__(self, dist, group=None):
         self.dist, self.group = dist, group
+        self._side = None   # stream the point-to-point transfers are issued on (device tensors only)
 
-    def exchange(self, ops):
+    def _p2p(self, ops):
         d = self.dist
         p2p = []
         for peer, send, recv in ops:
             p2p.append(d.P2POp(d.isend, send, peer, self.group))
             p2p.append(d.P2POp(d.irecv, recv, peer, self.group))
-        if p2p:
-            for req in d.batch_isend_irecv(p2p):
-                req.wait()
+        return p2p
+
+    def exchange(self, ops):
+        self.exchange_end(self.exchange_begin(ops))
+
+    def exchange_begin(self, ops):
+        """Start the neighbour transfers; they depend on what has been enqueued so far (the packed edge
+        rows) but not on what the caller enqueues next (the interior rows)."""
+        p2p = self._p2p(ops)
+        if not p2p:
+            return []
+        if ops[0][1].is_cuda:
+            import torch
+            dev = ops[0][1].device
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ready)
+                return self.dist.batch_isend_irecv(p2p)
+        return self.dist.batch_isend_irecv(p2p)
+
+    def exchange_end(self, pending):
+        for req in pending:
+            req.wait()   # device tensors: the CURRENT stream waits for the transfer, not the host
 
     def all_reduce_bits(self, int64_tensor):
         self.dist.all_reduce(int64_tensor, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -147,6 +184,8 @@ class GpuStripBackend:
 
     def obst_construction(self): self.sim.obst_construction()
     def collision_streaming(self): self.sim.collision_streaming()
+    def collision_streaming_edges(self): self.sim.collision_streaming_edges()
+    def collision_streaming_interior(self): self.sim.collision_streaming_interior()
     def forces_fluid(self): self.sim.forces_fluid()
     def initVerlet(self): self.sim.initVerlet()
     def dem_substep(self): self.sim.dem_substep()

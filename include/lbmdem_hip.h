@@ -185,6 +185,15 @@ int lbmdem_profile_read(lbmdem_handle* h, double* mean_ms, long* launches);
  * (9 * halo * ly doubles, plane-major), exchanged by the caller (RCCL send/recv via
  * torch.distributed) and unpacked into the neighbour's halo rows. side: 0 = low x, 1 = high x. */
 long lbmdem_halo_doubles(lbmdem_handle* h);
+/* collide_stream in two parts, so that the halo exchange overlaps the bulk of the kernel:
+ *   LBMDEM_CS_EDGES     the owned rows within `halo` of an interior cut (what the neighbours need); the
+ *                       new lattice becomes current, halo_pack may follow immediately;
+ *   LBMDEM_CS_INTERIOR  the remaining owned rows. Must follow EDGES before anything else reads the
+ *                       lattice (forces_fluid, downloads, the next collide_stream fail until then).
+ * EDGES + INTERIOR == lbmdem_collide_stream, row for row (every row is computed from the old lattice). */
+#define LBMDEM_CS_EDGES 1
+#define LBMDEM_CS_INTERIOR 2
+int lbmdem_collide_stream_part(lbmdem_handle* h, int part);
 int lbmdem_halo_pack(lbmdem_handle* h, int side, void* dev_buf);
 int lbmdem_halo_unpack(lbmdem_handle* h, int side, const void* dev_buf);
 /* Device pointer to the 3*n hydrodynamic-force table (fhf1[n], fhf2[n], fhf3[n]) and to the

@@ -37,6 +37,23 @@ class OracleStripBackend:
         f[:self.xb] = np.nan         # rows this rank does not own are NOT computed on the GPU path
         f[self.xe:] = np.nan
 
+    # split form: after `edges` only the H rows next to each cut exist; the interior is withheld (NaN)
+    # until `interior` -- a halo_pack that read anything else would ship NaNs
+    def collision_streaming_edges(self):
+        self.collision_streaming()
+        f = self.o.f_view()
+        lo = self.xb + self.H if self.xb > 0 else self.xb
+        hi = self.xe - self.H if self.xe < self.lx else self.xe
+        self._held = (lo, hi, f[lo:hi].copy()) if hi > lo else None
+        if self._held:
+            f[lo:hi] = np.nan
+
+    def collision_streaming_interior(self):
+        if self._held:
+            lo, hi, rows = self._held
+            self.o.f_view()[lo:hi] = rows
+        self._held = None
+
     def halo_pack(self, side):
         f = self.o.f_view()
         rows = f[self.xb:self.xb + self.H] if side == 0 else f[self.xe - self.H:self.xe]
@@ -81,6 +98,8 @@ class OracleStripBackend:
 class LoopbackComm:
     """Placeholder comm for runners that are stepped in lock-step inside one process."""
     def exchange(self, ops): raise RuntimeError("lock-step driver delivers the halos")
+    def exchange_begin(self, ops): raise RuntimeError("lock-step driver delivers the halos")
+    def exchange_end(self, pending): raise RuntimeError("lock-step driver delivers the halos")
     def all_reduce_bits(self, t): raise RuntimeError("lock-step driver combines the forces")
 
 
@@ -90,13 +109,14 @@ def lockstep_render(runners, n):
     b0 = runners[0].b
     for _ in range(n):
         if b0.nbsteps % b0.npDEM == 0:
-            for R in runners: R.fluid_compute()
-            posts = [R.halo_post() for R in runners]
+            for R in runners: R.fluid_edges()
+            posts = [R.halo_post() for R in runners]       # packed before any interior row exists
             for rk, ops in enumerate(posts):
                 for peer, send, _ in ops:
                     dst = [rv for (p2, _, rv) in posts[peer] if p2 == rk]
                     assert len(dst) == 1
                     dst[0].copy_(send)
+            for R in runners: R.fluid_interior()
             for R in runners: R.halo_finish()
             bufs = [R.forces_post() for R in runners]
             total = bufs[0].clone()

@@ -47,3 +47,75 @@ def test_strips_on_one_gpu_bit_exact(pkg, po, world):
 def test_strip_needs_enough_halo(pkg):
     with pytest.raises(pkg.LbmDemError):
         pkg.LbmDem(128, 64, [0.8e-3], [3e-3], [3e-3], strip=(0, 64), halo=3)
+
+
+def test_split_collide_stream_equals_the_single_launch(pkg):
+    """lbmdem_collide_stream_part: EDGES then INTERIOR produce the rows of one lbmdem_collide_stream; the
+    lattice may not be read in between."""
+    lx, ly = 256, 128
+    r, x, y = samples.row_packing(lx, ly, 150, seed=13)
+    r, x1, x2 = samples.to_metres(r, x, y)
+    cfg = pkg.derive(lx, ly, r)
+    halo = pkg.strips_module().halo_rows(float(r.max()), cfg.dx)
+    outs = []
+    for split in (False, True):
+        sim = pkg.LbmDem(lx, ly, r, x1, x2, strip=(64, 160), halo=halo)      # cuts on both sides
+        for _ in range(3):
+            sim.obst_construction()
+            if split:
+                sim.collision_streaming_edges()
+                with pytest.raises(pkg.LbmDemError):
+                    sim.forces_fluid()
+                with pytest.raises(pkg.LbmDemError):
+                    sim.collision_streaming()
+                sim.collision_streaming_interior()
+            else:
+                sim.collision_streaming()
+            sim.forces_fluid()
+            sim.run_dem(cfg.npDEM)
+        got = np.full((lx, ly, 9), np.nan)
+        sim.download_f_into(got)
+        outs.append((got[64:160].copy(), sim.fhf, sim.kinematics))
+        with pytest.raises(pkg.LbmDemError):
+            sim.collision_streaming_interior()          # nothing pending
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert not np.isnan(outs[0][0]).any()
+
+
+_SELF_EXCHANGE = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+import __graft_entry__ as ge
+strips = ge.load_package().strips_module()
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1,
+                        device_id=torch.device("cuda", 0))
+torch.cuda.set_device(0)
+comm = strips.TorchComm(dist)
+send = torch.arange(300000, dtype=torch.float64, device="cuda")
+recv = torch.zeros_like(send)
+big = torch.randn(2048, 2048, device="cuda")
+for it in range(5):
+    send.mul_(1.5).add_(it)                       # produced on the main stream just before the exchange
+    pending = comm.exchange_begin([(0, send, recv)])
+    for _ in range(6):
+        big = (big @ big) * 1e-3                  # the "interior rows": main stream stays busy
+    comm.exchange_end(pending)
+    chk = recv.clone()                            # main stream, ordered after the transfer
+    assert torch.equal(chk, send), it
+assert comm._side is not None
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("SELF-EXCHANGE-OK")
+"""
+
+
+def test_torchcomm_overlapped_exchange_over_rccl(tmp_path):
+    """TorchComm.exchange_begin/end (side stream, event dependency on the producer, current stream waits on
+    completion) with the real RCCL backend: a one-rank group sending to itself while the main stream is
+    busy. (More than one rank per GPU is refused by RCCL; the two-rank protocol runs under gloo in
+    tests/test_strips_gloo.py.)"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _SELF_EXCHANGE], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "SELF-EXCHANGE-OK" in out.stdout, out.stderr[-2000:]
