@@ -9,9 +9,9 @@ the Verlet rebuilds that fall inside (renderScene x npDEM, main.c:1697-1765). No
 
 Workload at N=1: BASELINE.json configs[3], 4096 x 4096 lattice with 50 000 grains (a deterministic
 synthetic row packing of the same shape as bin/50000.data: radii 0.5-0.9 mm, ~34 % solid nodes;
-/root/reference does not exist on the GPU box). At N>1: the lattice is strip-decomposed along x, one
-process per GPU; scaling is STRONG on configs[4] (8192 x 4096, 50 000 grains) when --gpus > 1, as
-BASELINE.json's north_star asks.
+/root/reference does not exist on the GPU box). At N>1: the SAME lattice is strip-decomposed along x, one
+process per GPU (strong scaling of the case BASELINE.json's metric names: "4096^2 / 50k grains; 1/2/4/8
+MI355X"). `--workload configs4` runs BASELINE.json configs[4] (8192 x 4096, 50 000 grains) instead.
 
 Output: one JSON line on rank 0. `value` = lattice-node updates of the whole job per second / 1e6
 with all state resident in HBM. `roofline` prices the dominant kernel (k_collide_stream) from HIP
@@ -40,12 +40,12 @@ TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")   # PMC-
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def workload(ngpus):
-    if ngpus == 1:
-        return dict(name="4096x4096 D2Q9 MRT + 50000 grains (synthetic row packing, seed 1234)",
-                    lx=4096, ly=4096, n=50000, fill_lx=4096)
-    return dict(name="8192x4096 D2Q9 MRT + 50000 grains (synthetic row packing, seed 1234), x-strips",
-                lx=8192, ly=4096, n=50000, fill_lx=8192)
+def workload(which):
+    if which == "configs4":
+        return dict(name="8192x4096 D2Q9 MRT + 50000 grains (synthetic row packing, seed 1234)",
+                    lx=8192, ly=4096, n=50000, fill_lx=8192)
+    return dict(name="4096x4096 D2Q9 MRT + 50000 grains (synthetic row packing, seed 1234)",
+                lx=4096, ly=4096, n=50000, fill_lx=4096)
 
 
 def make_sample(w):
@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-mode", type=int, default=0, help="0 = parity hydro-force kernel, 1 = fast")
+    ap.add_argument("--workload", choices=["metric", "configs4"], default="metric",
+                    help="metric = 4096x4096/50k grains (BASELINE.json's metric, every N); configs4 = 8192x4096/50k")
     ap.add_argument("--strips", action="store_true",
                     help="use the strip-decomposition driver (torch.distributed) even with one rank")
     args = ap.parse_args()
@@ -142,7 +144,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     pkg = ge.load_package()
-    w = workload(args.gpus)
+    w = workload(args.workload)
     (r, x1, x2), sample_mm = make_sample(w)
     lx, ly = w["lx"], w["ly"]
 
@@ -204,18 +206,21 @@ def main():
         rows = cfgd.x_end - cfgd.x_begin
         achieved = BYTES_PER_LUP * rows * ly / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic = None
-        if args.gpus == 1 and "LBMDEM_CS_VARIANT" not in os.environ and os.path.exists(TRAFFIC_FILE):
+        if args.gpus == 1 and args.workload == "metric" and "LBMDEM_CS_VARIANT" not in os.environ \
+                and os.path.exists(TRAFFIC_FILE):
             traffic = round(json.load(open(TRAFFIC_FILE))["traffic_bytes_per_launch"])   # same workload + kernel
         out = {
             "metric": "MLUPS (D2Q9 collide+stream, coupled LBM-DEM step) on 4096^2 / 50k grains",
             "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak" if args.gpus == 1 else "strong", "vs_baseline": None, "dtype": "f64",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": w["name"], "lx": lx, "ly": ly, "grains": int(len(r)), "npDEM": int(npdem),
                        "step": "1 fluid step + npDEM DEM sub-steps (+ Verlet rebuild every 100 DEM steps)",
                        "force_kernel": "parity" if args.force_mode == 0 else "fast",
-                       "decomposition": "none" if args.gpus == 1 else f"{args.gpus} x-strips, halo exchange per fluid step"},
+                       "decomposition": "none" if args.gpus == 1 else
+                       f"{args.gpus} x-strips; halo exchange overlapped with the interior rows, one bit-exact "
+                       f"all-reduce of the hydrodynamic forces per fluid step; DEM state replicated"},
             "dem_steps_per_s": round(args.steps * npdem / elapsed, 1),
             "collide_stream_kernel_ms": round(kernel_ms, 4),
             "collide_stream_kernel_mlups": round(1e-6 * rows * ly / (kernel_ms * 1e-3), 1) if kernel_ms > 0 else None,
