@@ -25,6 +25,9 @@ int main(int argc, char** argv) {
   long max_steps = -1;
   const char* sample = NULL;
   const char *ckpt_out = NULL, *ckpt_in = NULL;
+  /* device-resident kernel arguments: ~1.2 us less per launch (the HIP runtime reads this when it
+   * initialises, i.e. at the first lbmdem_* call below); an explicit setting of the caller wins */
+  setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
   printf("2D LBM-DEM code\n");
   for (int a = 1; a < argc; ++a) {
     if (!strcmp(argv[a], "--lx") && a + 1 < argc) lx = atoi(argv[++a]);
