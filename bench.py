@@ -46,11 +46,18 @@ def workload(which):
     if which == "configs4":
         return dict(name="8192x4096 D2Q9 MRT + 50000 grains (synthetic row packing, seed 1234)",
                     lx=8192, ly=4096, n=50000, fill_lx=8192)
+    if which == "real50k":
+        return dict(name="4096x4096 D2Q9 MRT + the reference's bin/50000.data (49987 grains, unscaled)",
+                    lx=4096, ly=4096, n=49987, fill_lx=4096, real=True)
     return dict(name="4096x4096 D2Q9 MRT + 50000 grains (synthetic row packing, seed 1234)",
                 lx=4096, ly=4096, n=50000, fill_lx=4096)
 
 
 def make_sample(w):
+    if w.get("real"):   # the reference's own bin/50000.data as its reader parsed it (fixture: tests/golden/make_golden.py)
+        g = np.load(os.path.join(ROOT, "tests", "golden", "real_50000_4096x4096.npz"))
+        r, x1, x2 = g["r"], g["x1"], g["x2"]
+        return (r, x1, x2), (r * 1e3, x1 * 1e3, x2 * 1e3)
     r, x, y = samples.row_packing(w["fill_lx"], w["ly"], w["n"], seed=1234)
     return samples.to_metres(r, x, y), (r, x, y)
 
@@ -127,8 +134,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-mode", type=int, default=0, help="0 = parity hydro-force kernel, 1 = fast")
-    ap.add_argument("--workload", choices=["metric", "configs4"], default="metric",
-                    help="metric = 4096x4096/50k grains (BASELINE.json's metric, every N); configs4 = 8192x4096/50k")
+    ap.add_argument("--workload", choices=["metric", "configs4", "real50k"], default="metric",
+                    help="metric = 4096x4096 / 50k-grain synthetic packing (BASELINE.json's metric, every N); "
+                         "configs4 = 8192x4096/50k; real50k = 4096x4096 with the reference's bin/50000.data geometry")
     ap.add_argument("--strips", action="store_true",
                     help="use the strip-decomposition driver (torch.distributed) even with one rank")
     args = ap.parse_args()

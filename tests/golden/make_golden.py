@@ -231,6 +231,54 @@ def make_dem_output_fixture():
                         grains=R.get_grains())
 
 
+# ---- the reference's own sample inputs at BASELINE.json's sizes ----------------------------------------
+
+REAL_CASES = {
+    # name: (sample file under /root/reference/bin, lx, ly, fluid steps at which the state is hashed)
+    "real_a08d83_600x500": ("a08d83.data", 600, 500, (1, 10, 20)),             # SURVEY.md section 8c known answers
+    "real_7000_2048x2048": ("a08_a4b4r18_7000.data", 2048, 2048, (1, 2)),      # BASELINE.json configs[2]
+    "real_50000_4096x4096": ("50000.data", 4096, 4096, (1, 2)),                # BASELINE.json configs[3]
+}
+
+
+def _real_case(name, q):
+    """Runs in its own process: the reference on one of its shipped samples; returns the parsed grains
+    (exactly the doubles the reference works with) and SHA-256 digests of its state."""
+    import pyoracle as po
+    fname, lx, ly, dumps = REAL_CASES[name]
+    po.build_ref(lx, ly)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)
+    R = po.Reference(lx, ly, os.path.join(po.REF_ROOT, "bin", fname))
+    g0 = R.get_grains()
+    s = R.scalars()
+    out = dict(r=g0[:, po.COL["r"]].copy(), x1=g0[:, 0].copy(), x2=g0[:, 1].copy(),
+               npDEM=np.int64(s["npDEM"]), dx=np.float64(s["dx"]), c=np.float64(s["c"]), dumps=np.array(dumps))
+    done = 0
+    for k in dumps:
+        R.steps((k - done) * int(s["npDEM"]))
+        done = k
+        g = R.get_grains()
+        out[f"sha_f_{k}"] = sha(R.get_f())
+        out[f"sha_obst_{k}"] = sha(R.get_obst().astype(np.int32))
+        out[f"sha_fhf_{k}"] = sha(R.get_fhf())
+        out[f"sha_kin_{k}"] = sha(g[:, :9])
+        out[f"mass_{k}"] = np.float64(R.total_density())
+        out[f"grain0_{k}"] = g[0, :9].copy()
+    q.put(out)
+
+
+def make_real_fixtures():
+    for name in REAL_CASES:
+        q = mp.Queue()
+        p = mp.Process(target=_real_case, args=(name, q))
+        p.start()
+        res = q.get()
+        p.join()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
+        print("wrote", name, {k: str(v)[:20] for k, v in res.items() if k.startswith(("sha_f", "mass"))})
+
+
 def main():
     import pyoracle as po
     if not po.reference_available():
@@ -245,6 +293,7 @@ def main():
         p.join()
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **pack(name, case, res))
         print("wrote", name, {k: getattr(v, "shape", None) for k, v in pack(name, case, res).items()})
+    make_real_fixtures()
     for target in (make_vtk_fixture, make_dem_output_fixture):
         p = mp.Process(target=target)
         p.start()

@@ -81,3 +81,30 @@ class GpuAdapter:
     def lbm_steps(self, n):
         for _ in range(n):
             self.sim.lbm_step()
+
+
+# ---- the reference's own shipped samples (tests/golden/real_*.npz: parsed grains + SHA-256 of its state) ----
+REAL_CASES = mg.REAL_CASES
+
+
+def check_real_case(name, make_sim, state_of, dumps=None):
+    """Run `name` on a backend and compare the SHA-256 of f, obst, fhf and the kinematics with what the
+    unmodified reference produced from its own sample file. make_sim(lx, ly, r, x1, x2) -> sim with
+    .steps(n); state_of(sim) -> (f[lx][ly][9], obst int32, fhf[n][3], kin[n][9], total mass)."""
+    g = load(name)
+    _, lx, ly, all_dumps = REAL_CASES[name]
+    sim = make_sim(lx, ly, g["r"], g["x1"], g["x2"])
+    npdem = int(g["npDEM"])
+    done = 0
+    for k in (dumps or all_dumps):
+        sim.steps((k - done) * npdem)
+        done = k
+        f, obst, fhf, kin, mass = state_of(sim)
+        assert np.array_equal(kin[0], g[f"grain0_{k}"]), (name, k, "grain 0")
+        assert sha(kin) == str(g[f"sha_kin_{k}"]), (name, k, "kinematics")
+        assert sha(fhf) == str(g[f"sha_fhf_{k}"]), (name, k, "hydrodynamic forces")
+        assert sha(obst.astype(np.int32)) == str(g[f"sha_obst_{k}"]), (name, k, "obstacle map")
+        assert sha(f) == str(g[f"sha_f_{k}"]), (name, k, "populations")
+        if mass is not None:
+            assert mass == float(g[f"mass_{k}"]), (name, k, "total density")
+    return sim

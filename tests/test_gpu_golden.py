@@ -14,6 +14,18 @@ def test_hip_matches_reference_dump(pkg, name):
     gu.compare(name, res, grain_cols=list(range(9)))
 
 
+@pytest.mark.parametrize("name", sorted(gu.REAL_CASES))
+def test_hip_on_the_reference_s_own_samples(pkg, name):
+    """The reference's shipped inputs at BASELINE.json's sizes -- a08d83 @ 600x500, a08_a4b4r18_7000 @ 2048^2
+    (configs[2]), 50000.data @ 4096^2 (configs[3], 49 987 grains) -- through the C ABI: populations, obstacle
+    map, hydrodynamic forces and grain kinematics after whole coupled steps hash (SHA-256 of the host-layout
+    buffers) to what the unmodified reference produced."""
+    class Sim:
+        def __init__(self, lx, ly, r, x1, x2): self.s = pkg.LbmDem(lx, ly, r, x1, x2)
+        def steps(self, n): self.s.renderScene(n)
+    gu.check_real_case(name, Sim, lambda s: (s.s.f, s.s.obst, s.s.fhf, s.s.kinematics, None))
+
+
 def test_vtk_files_byte_identical_to_the_reference(pkg, tmp_path):
     """write_vtk (main.c:237-338): the five binary legacy-VTK files for case G5 after 25 renderScene
     calls must equal, byte for byte, the files the reference wrote (tests/golden/vtk_G5_25steps/)."""

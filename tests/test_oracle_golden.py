@@ -20,6 +20,19 @@ def test_oracle_matches_reference_dump(po, name):
     assert np.array_equal(np.array([s[k] for k in po.SCALARS], float), g["scalars"])
 
 
+@pytest.mark.parametrize("name,dumps", [("real_a08d83_600x500", None), ("real_7000_2048x2048", None),
+                                        ("real_50000_4096x4096", (1,))])
+def test_oracle_on_the_reference_s_own_samples(po, name, dumps):
+    """The reference's shipped inputs at BASELINE.json's sizes (a08d83 @ 600x500; a08_a4b4r18_7000 @ 2048^2 =
+    configs[2]; 50000.data @ 4096^2 = configs[3]): the state after whole coupled steps must hash to what the
+    unmodified reference produced (tests/golden/real_*.npz). The serial total density too (same order)."""
+    class Sim:
+        def __init__(self, lx, ly, r, x1, x2): self.o = po.Oracle(lx, ly, r, x1, x2)
+        def steps(self, n): self.o.steps(n)
+    gu.check_real_case(name, Sim, lambda s: (s.o.get_f(), s.o.get_obst(), s.o.get_fhf(), s.o.get_grains()[:, :9],
+                                             s.o.total_density()), dumps)
+
+
 def test_known_answer_scalars_of_the_real_samples(po):
     """Derived run constants the survey measured on the reference for its own sample geometry
     (SURVEY.md section 8c / BASELINE.md section 2): they depend only on lx, scale and the smallest radius."""
