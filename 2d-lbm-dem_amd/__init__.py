@@ -345,14 +345,15 @@ class LbmDem:
         _chk(self._L.lbmdem_set_diagnostics(self._h, int(bool(always))))
 
     def grain_table(self):
-        """(n, 30) in the reference's struct order (main.c:182-197); fr, ice, slip, rw are 0."""
+        """(n, 30) in the reference's struct order (main.c:182-197)."""
         out = np.zeros((self.n, 30))
         _chk(self._L.lbmdem_download_grain_table(self._h, _vp(out)))
         return out
 
     def write_DEM(self, directory=".", nFile=0):
-        """write_DEM (main.c:340-438): DEM%06d.dat + a line of stats.data. -> (KE, PE, SE, IFR)"""
-        e = np.zeros(4)
+        """write_DEM (main.c:340-438): DEM%06d.dat + a line of stats.data.
+        -> (KE, PE, SE, IFR, WF, INCE, TSLIP, TRW)"""
+        e = np.zeros(8)
         _chk(self._L.lbmdem_write_dem(self._h, os.fsencode(directory), int(nFile), _vp(e)))
         return tuple(e)
 

@@ -16,7 +16,9 @@
 //    in the (i < j) frame -> the same pair set. The list is kept symmetric (CSR, partners ascending).
 //
 // Diagnostics that depend on the serial contact order (slip, rw, fr, ice through pft/pff/pf/ic,
-// main.c:130-131) are not produced here; they never feed back into x, v, a (SURVEY.md hard part 7).
+// main.c:130-131; they never feed back into x, v, a -- SURVEY.md hard part 7) are replayed in the reference's
+// order by a separate small pipeline in the sub-steps that feed write_DEM: see "Order-dependent contact
+// diagnostics" below.
 
 #include "lbmdem_internal.h"
 
@@ -24,7 +26,7 @@
 
 namespace {
 
-struct Force3 { double f1, f2, f3, fn, ft, xij, yij; };  // fn, ft, branch vector: for the diagnostics
+struct Force3 { double f1, f2, f3, fn, ft, xij, yij, vt; };  // fn, ft, branch vector, vt: for the diagnostics
 
 __device__ __forceinline__ double maxt(double x, double y) { return (x < y) ? 0. : y; }  // main.c:211-216
 
@@ -50,7 +52,7 @@ __device__ __forceinline__ GrainState advance(const Kin& K, const double* __rest
 template <bool FILM>
 __device__ __forceinline__ Force3 contact(const GrainState& A, const GrainState& B, const DemParams& P,
                                           bool& touched) {
-  Force3 F = {0., 0., 0., 0., 0., 0., 0.};
+  Force3 F = {0., 0., 0., 0., 0., 0., 0., 0.};
   const double xij = A.x1 - B.x1;
   const double yij = A.x2 - B.x2;
   const double dist = sqrt(xij * xij + yij * yij);
@@ -83,6 +85,7 @@ __device__ __forceinline__ Force3 contact(const GrainState& A, const GrainState&
   F.ft = ft;
   F.xij = xij;
   F.yij = yij;
+  F.vt = vt;
   return F;
 }
 
@@ -157,7 +160,7 @@ __device__ __forceinline__ void walls(const GrainState& me, unsigned wf, const D
 
 // Per-grain contact diagnostics of one sub-step (the fields write_DEM prints, main.c:413-420), in the
 // reference's accumulation order. Only produced when DIAG (the sub-step before an output).
-struct DiagOut { double *s, *f1, *f2, *ifm, *M11, *M12, *M21, *M22; int *z, *zz; };
+struct DiagOut { double *s, *f1, *f2, *ifm, *M11, *M12, *M21, *M22; int *z, *zz; DiagExtra X; };
 
 template <bool FILM, bool DIAG>
 __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, const double* __restrict__ m,
@@ -186,6 +189,11 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
       const Force3 F = contact<FILM>(me, other, P, touched);
       a1 = a1 + F.f1; a2 = a2 + F.f2; a3 = a3 + F.f3;
       if (touched) pr += F.fn;
+      if (DIAG) {  // what the carry pass needs of this contact (launch_diag_extra)
+        D.X.e_touched[k] = touched ? 1 : 0;
+        D.X.e_ft[k] = F.ft; D.X.e_f3[k] = F.f3;
+        D.X.e_avt[k] = fabs(F.vt * P.dt); D.X.e_av3[k] = fabs(me.v3 * P.dt);
+      }
       if (DIAG && touched) {  // this grain is the `i` of force_grains(i, j): main.c:776-799 / 1397-1416
         ds += F.ft;
         dz += 1;
@@ -201,8 +209,10 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
       a1 = a1 - F.f1; a2 = a2 - F.f2; a3 = a3 + F.f3;
       if (touched) pr += F.fn;
       if (DIAG && touched) ds += F.ft;  // the `j` side only receives p and s
+      if (DIAG) D.X.e_touched[k] = 0;
     }
   }
+  if (DIAG) D.X.a1gc[i] = a1;
   // walls: bottom, top, left, right (main.c:1455-1508)
   walls<DIAG>(me, wallflags[i], P, a1, a2, a3, pr, ds, df1, dz, dM11, dM12, dM21, dM22);
   // main.c:1511-1515 (mw = 0: SURVEY.md hard part 5)
@@ -312,6 +322,175 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const doub
   out.v3[i] = me.v3 + P.dt * a3 / 2.;
   out.a1[i] = a1; out.a2[i] = a2; out.a3[i] = a3;
   pout[i] = pr;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Order-dependent contact diagnostics: fr, ice, slip, rw
+// ---------------------------------------------------------------------------------------------
+//
+// The reference updates four file-scope "previous contact" variables while it walks the contacts serially
+// (pft, pff, pf, ic: main.c:130-131) and each contact's contribution to slip / rw / fr reads them:
+//     slip_i += |ft| (|vt dt| + |ft - pft| / kt);  pft = ft        (force_grains, main.c:782-786)
+// so a contribution depends on the contact evaluated just before it -- of whatever grain -- and the
+// chain runs on through the four wall loops and into the next sub-step. Reproduced in three steps:
+//   k_diag_scan   the sub-step kernel has left (touched, ft, f3, |vt dt|, |v3 dt|) per list entry; the
+//                 entries with own < partner, in list order, ARE the reference's contact order. One
+//                 workgroup turns "value of the previous touched entry" into a scan (chunk, last-defined
+//                 across chunks, chunk again) and stores every entry's contribution;
+//   k_diag_accum  one thread per grain adds its contributions in list order (the film law credits both
+//                 partners, main.c:1401-1408: the upper one finds the pair's entry by bisection);
+//   k_diag_walls  the four wall loops (main.c:1455-1508) replayed by ONE thread in the reference's order
+//                 with the carries, `ic`, and the reference's own indexing of g[] by the list POSITION in
+//                 the two `fr` updates of acceleration_grains (main.c:1462-1465, 1490-1493) -- a few hundred
+//                 wall candidates, once per 4000 sub-steps.
+// carry[] = {pft, pff, pf} persists on the device; the sub-step before a table sub-step runs the same pipeline so
+// that the table starts from the right carries (exact whenever that sub-step has a contact of each kind).
+
+__global__ __launch_bounds__(1024) void k_diag_scan(DiagExtra X, const int* __restrict__ offsets, int n, double kt) {
+  __shared__ double sFt[1024], sF3[1024];
+  __shared__ unsigned char sHas[1024];
+  const int t = threadIdx.x;
+  const int E = offsets[n];
+  const int chunk = (E + 1023) / 1024;
+  const int b = t * chunk, e = b + chunk < E ? b + chunk : E;
+  bool has = false;
+  double lft = 0., lf3 = 0.;
+  for (int k = b; k < e; ++k)
+    if (X.e_touched[k]) { has = true; lft = X.e_ft[k]; lf3 = X.e_f3[k]; }
+  sHas[t] = has; sFt[t] = lft; sF3[t] = lf3;
+  __syncthreads();
+  double pft = X.carry[0], pff = X.carry[1];
+  for (int u = t - 1; u >= 0; --u)
+    if (sHas[u]) { pft = sFt[u]; pff = sF3[u]; break; }
+  for (int k = b; k < e; ++k) {
+    if (!X.e_touched[k]) continue;
+    const double ft = X.e_ft[k], f3 = X.e_f3[k];
+    X.e_dslip[k] = fabs(ft) * (X.e_avt[k] + (fabs(ft - pft)) / kt);
+    X.e_drw[k] = fabs(f3) * (X.e_av3[k] + (fabs(f3 - pff)) / kt);
+    pft = ft; pff = f3;
+  }
+  __syncthreads();
+  if (t == 0) {
+    for (int u = 1023; u >= 0; --u)
+      if (sHas[u]) { X.carry[0] = sFt[u]; X.carry[1] = sF3[u]; break; }
+  }
+}
+
+template <bool FILM>
+__global__ void k_diag_accum(DiagExtra X, const int* __restrict__ offsets, const int* __restrict__ nbr, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double slip = 0., rw = 0.;
+  for (int k = offsets[i]; k < offsets[i + 1]; ++k) {
+    const int j = nbr[k];
+    int e = k;
+    if (j < i) {  // the pair's entry lives in j's list
+      if (!FILM) continue;   // force_grains credits the lower grain only
+      int lo = offsets[j], hi = offsets[j + 1] - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (nbr[mid] < i) lo = mid + 1; else hi = mid;
+      }
+      e = lo;
+    }
+    if (X.e_touched[e]) { slip += X.e_dslip[e]; rw += X.e_drw[e]; }
+  }
+  X.slip[i] = slip; X.rw[i] = rw; X.fr[i] = 0.; X.ice[i] = 0.;
+}
+
+// wall candidate lists in grain order (VerletWall, main.c:1563-1593): wave w builds list w
+__global__ __launch_bounds__(256) void k_diag_wall_lists(DiagExtra X, const unsigned char* __restrict__ wallflags, int n) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int cnt = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const bool f = i < n && ((wallflags[i] >> w) & 1u);
+    const unsigned long long b = __ballot(f);
+    if (f) X.wlist[(size_t)w * n + cnt + __popcll(b & lt)] = i;
+    cnt += __popcll(b);
+  }
+  if (lane == 0) X.wcount[w] = cnt;
+}
+
+__global__ void k_diag_walls(DiagExtra X, Kin in, const double* __restrict__ r, DemParams P) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const int n = P.n;
+  double pft = X.carry[0], pff = X.carry[1], pf = X.carry[2], ic = 0.0;  // ic: reset every sub-step (main.c:1743)
+  const int *LB = X.wlist, *LT = X.wlist + n, *LL = X.wlist + 2 * (size_t)n, *LR = X.wlist + 3 * (size_t)n;
+  // g[k].v1 and g[k].a1 of the reference at this point: drifted velocity, force sum so far (k = list position)
+  auto v1_of = [&](int g) { return in.v1[g] + P.dt * in.a1[g] / 2.; };
+  for (int k = 0; k < X.wcount[0]; ++k) {  // bottom: main.c:1455-1468, force_WallB 809-845
+    const int i = LB[k];
+    const GrainState me = advance(in, r, i, P);
+    const double dn = me.x2 - me.r - P.Mby;
+    if (!(dn < 0)) continue;
+    const double vn = me.v2, vt = me.v1;
+    double fn = -P.km * dn - P.num * vn;
+    if (fn < 0) fn = 0.;
+    double ft = P.ktm * vt;
+    const double ftest = P.mumb * fn;
+    if (fabs(ft) > ftest) ft = (ft < 0.0) ? ftest : -ftest;
+    const double f1 = ft, f3 = -(ft * me.r * P.murf);
+    X.rw[i] += fabs(f3) * (fabs(me.v3 * P.dt) + (fabs(f3 - pff)) / P.kt);
+    X.fr[i] += fabs(ft) * (fabs(vt * P.dt) + (fabs(ft - pft)) / P.kt);
+    pff = f3; pft = ft;
+    X.a1gc[i] = X.a1gc[i] + f1;
+    X.fr[i] += fabs(f1) * (fabs(P.dt * v1_of(k)) + fabs(P.dt2 * X.a1gc[k]) + (fabs(f1 - pf)) / P.kt);
+    pf = f1;
+  }
+  for (int k = 0; k < X.wcount[1]; ++k) {  // top: main.c:1470-1480, force_WallT 846-887
+    const int i = LT[k];
+    const GrainState me = advance(in, r, i, P);
+    const double dn = -me.x2 - me.r + P.Mhy;
+    if (!(dn < 0)) continue;
+    const double vn = me.v2;
+    double fn = P.km * dn - P.num * vn;
+    ic += P.num * vn * vn * P.dt;
+    if (fn > 0.) fn = 0.;
+    const double vt = me.v1 + me.v3 * me.r - P.wallT_vel;
+    double ft = fabs(P.ktm * vt);
+    double ftmax;
+    if (vt >= 0) ftmax = P.mumb * fn - P.nugt * vt; else ftmax = P.mumb * fn + P.nugt * vt;
+    if (ft > ftmax) ft = ftmax;
+    if (vt > 0) ft = -ft;
+    X.a1gc[i] = X.a1gc[i] + ft;
+  }
+  for (int k = 0; k < X.wcount[2]; ++k) {  // left: main.c:1482-1496, force_WallL 888-921
+    const int i = LL[k];
+    const GrainState me = advance(in, r, i, P);
+    const double dn = me.x1 - me.r - P.Mgx;
+    if (!(dn < 0)) continue;
+    const double vn = me.v1;
+    double fn = -P.km * dn + P.num * vn;
+    ic += P.num * vn * vn * P.dt;
+    if (fn < 0.) fn = 0.;
+    const double vt = me.v2;
+    double ft = P.mum * fn;
+    if (vt > 0) ft = -ft;
+    const double f1 = fn, f2 = ft, f3 = ft * me.r * P.murf;
+    X.ice[i] += ic;
+    X.rw[i] += fabs(f3) * fabs(me.v3 * P.dt);
+    X.fr[i] += fabs(ft) * (fabs(vt * P.dt) + (fabs(ft - pft)) / P.kt);
+    pft = ft;
+    X.a1gc[i] = X.a1gc[i] + f1;
+    X.fr[i] += fabs(f2) * (fabs(P.dt * v1_of(k)) + fabs(P.dt2 * X.a1gc[k]) + (fabs(f2 - pf)) / P.kt);
+    pf = f2;
+  }
+  for (int k = 0; k < X.wcount[3]; ++k) {  // right: main.c:1498-1508, force_WallR 923-951
+    const int i = LR[k];
+    const GrainState me = advance(in, r, i, P);
+    const double dn = -me.x1 - me.r + P.Mdx;
+    if (!(dn < 0)) continue;
+    const double vn = me.v1;
+    const double fn = P.km * dn - P.num * vn;
+    const double vt = me.v2;
+    double ft = P.mum * fn;
+    if (vt > 0) ft = -ft;
+    pft = ft;
+    X.a1gc[i] = X.a1gc[i] + ((fn > 0.) ? 0. : fn);
+  }
+  X.carry[0] = pft; X.carry[1] = pff; X.carry[2] = pf;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -489,13 +668,49 @@ void launch_verlet_rebuild(VerletDevice& V, const Kin& K, const double* r, const
   hipLaunchKernelGGL(k_wall_flags, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, r, P, V.wallflags);
 }
 
+int diag_extra_alloc(DiagExtra& X, int n, long cap) {
+  X = DiagExtra{};
+  double* d = nullptr;
+  const size_t nd = 5 * (size_t)n + 6 * (size_t)cap + 4;
+  if (hipMalloc((void**)&d, sizeof(double) * nd) != hipSuccess) return -1;
+  if (hipMemset(d, 0, sizeof(double) * nd) != hipSuccess) return -1;
+  X.fr = d; X.ice = d + n; X.slip = d + 2 * (size_t)n; X.rw = d + 3 * (size_t)n; X.a1gc = d + 4 * (size_t)n;
+  double* e = d + 5 * (size_t)n;
+  X.e_ft = e; X.e_f3 = e + cap; X.e_avt = e + 2 * cap; X.e_av3 = e + 3 * cap; X.e_dslip = e + 4 * cap; X.e_drw = e + 5 * cap;
+  X.carry = e + 6 * cap;
+  if (hipMalloc((void**)&X.e_touched, (size_t)cap) != hipSuccess) return -1;
+  if (hipMemset(X.e_touched, 0, (size_t)cap) != hipSuccess) return -1;
+  if (hipMalloc((void**)&X.wlist, sizeof(int) * (4 * (size_t)n + 4)) != hipSuccess) return -1;
+  X.wcount = X.wlist + 4 * (size_t)n;
+  return 0;
+}
+
+void diag_extra_free(DiagExtra& X) {
+  if (X.fr) (void)hipFree(X.fr);
+  if (X.e_touched) (void)hipFree(X.e_touched);
+  if (X.wlist) (void)hipFree(X.wlist);
+  X = DiagExtra{};
+}
+
+void launch_diag_extra(const DiagExtra& X, const Kin& in, const double* r, const VerletDevice& V,
+                       const DemParams& P, int film, hipStream_t st) {
+  const int n = P.n;
+  hipLaunchKernelGGL(k_diag_scan, dim3(1), dim3(1024), 0, st, X, V.offsets, n, P.kt);
+  if (film)
+    hipLaunchKernelGGL(k_diag_accum<true>, dim3((n + 255) / 256), dim3(256), 0, st, X, V.offsets, V.nbr, n);
+  else
+    hipLaunchKernelGGL(k_diag_accum<false>, dim3((n + 255) / 256), dim3(256), 0, st, X, V.offsets, V.nbr, n);
+  hipLaunchKernelGGL(k_diag_wall_lists, dim3(1), dim3(256), 0, st, X, V.wallflags, n);
+  hipLaunchKernelGGL(k_diag_walls, dim3(1), dim3(1), 0, st, X, in, r, P);
+}
+
 void launch_fill_own(const VerletDevice& V, int n, hipStream_t st) {
   hipLaunchKernelGGL(k_fill_own, dim3((n + 255) / 256), dim3(256), 0, st, n, V.offsets, V.own);
 }
 
 void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const double* m,
                         const double* It, const double* fhf, const VerletDevice& V, double* pout,
-                        const DemParams& P, int film, double* diag, hipStream_t st) {
+                        const DemParams& P, int film, double* diag, const DiagExtra* X, hipStream_t st) {
   const int n = P.n;
   static const int variant = getenv("LBMDEM_DEM_VARIANT") ? atoi(getenv("LBMDEM_DEM_VARIANT")) : 1;
   if (!diag && variant == 1) {  // one lane per list entry
@@ -514,6 +729,7 @@ void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const do
     D.s = diag; D.f1 = diag + n; D.f2 = diag + 2 * n; D.ifm = diag + 3 * n;
     D.M11 = diag + 4 * n; D.M12 = diag + 5 * n; D.M21 = diag + 6 * n; D.M22 = diag + 7 * n;
     D.z = reinterpret_cast<int*>(diag + 8 * (size_t)n); D.zz = D.z + n;
+    D.X = *X;
   }
 #define LBM_DEM_LAUNCH(FILM, DIAG)                                                                        \
   hipLaunchKernelGGL((k_dem_substep<FILM, DIAG>), dim3(nb), dim3(128), 0, st, in, out, r, m, It, fhf,    \

@@ -66,6 +66,8 @@ struct lbmdem_handle {
   double* gp = nullptr;   // [n] grain pressure g.p of the last DEM sub-step (main.c:187,776)
   double* diag = nullptr; // [8][n] doubles s f1 f2 ifm M11 M12 M21 M22, then [2][n] ints z zz
   bool diag_always = false;
+  DiagExtra dx{};          // buffers of the order-dependent diagnostics fr, ice, slip, rw (allocated on first use)
+  bool dx_ready = false;
   bool diag_valid = false; // the last sub-step produced diagnostics
   double* fhf = nullptr;  // [3][n]
   unsigned char* owner = nullptr;
@@ -348,6 +350,7 @@ int lbmdem_destroy(lbmdem_handle* h) {
   if (h->owner) (void)hipFree(h->owner);
   if (h->dpartial) (void)hipFree(h->dpartial);
   verlet_free(h->V);
+  diag_extra_free(h->dx);
   for (hipEvent_t e : h->ev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev1) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -499,10 +502,20 @@ int lbmdem_dem_substep(lbmdem_handle* h) {
   const int film = (h->nbsteps % h->cfg.phys.stepFilm == 0) ? 1 : 0;  // main.c:1342
   // contact diagnostics are only needed by write_DEM, which renderScene calls when the step counter
   // reaches a multiple of stepStrob = 4000 (main.c:142,1773): produce them in exactly that sub-step
-  const bool want_diag = h->diag_always || ((h->nbsteps + 1) % 4000 == 0);
+  const bool want_table = h->diag_always || ((h->nbsteps + 1) % 4000 == 0);
+  // fr, ice, slip, rw read "previous contact" carries that thread from sub-step to sub-step (main.c:130-131):
+  // the sub-step before a table sub-step runs the diagnostic pipeline too, to hand over the right carries
+  const bool want_diag = want_table || ((h->nbsteps + 2) % 4000 == 0);
+  if (want_diag && !h->dx_ready) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (diag_extra_alloc(h->dx, h->n, h->V.cap) != 0) return fail(LBMDEM_ENOMEM, "diagnostic buffers: hipMalloc failed");
+    h->dx_ready = true;
+  }
+  const DemParams P = dem_params(h);
   launch_dem_substep(h->kin[h->kcur], h->kin[1 - h->kcur], h->r, h->m, h->It, h->fhf, h->V, h->gp,
-                     dem_params(h), film, want_diag ? h->diag : nullptr, h->stream);
-  h->diag_valid = want_diag;
+                     P, film, want_diag ? h->diag : nullptr, want_diag ? &h->dx : nullptr, h->stream);
+  if (want_diag) launch_diag_extra(h->dx, h->kin[h->kcur], h->r, h->V, P, film, h->stream);
+  h->diag_valid = want_table;
   HIP_TRY(hipGetLastError());
   h->kcur = 1 - h->kcur;
   h->nbsteps++;
@@ -819,7 +832,8 @@ int lbmdem_download_grain_table(lbmdem_handle* h, double* t) try {
                                                  "the sub-step that reaches a multiple of 4000)");
   const int n = h->n;
   HIP_TRY(hipStreamSynchronize(h->stream));
-  std::vector<double> kin(9 * (size_t)n), rr(n), mm(n), it(n), gp(n), dg(9 * (size_t)n);
+  std::vector<double> kin(9 * (size_t)n), rr(n), mm(n), it(n), gp(n), dg(9 * (size_t)n), ex(4 * (size_t)n);
+  HIP_TRY(hipMemcpy(ex.data(), h->dx.fr, sizeof(double) * 4 * n, hipMemcpyDeviceToHost));  // fr, ice, slip, rw
   HIP_TRY(hipMemcpy(kin.data(), h->kin[h->kcur].x1, sizeof(double) * 9 * n, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(rr.data(), h->r, sizeof(double) * n, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(mm.data(), h->m, sizeof(double) * n, hipMemcpyDeviceToHost));
@@ -836,11 +850,11 @@ int lbmdem_download_grain_table(lbmdem_handle* h, double* t) try {
     o[17] = dg[3 * (size_t)n + i];
     const int z = zi[i], zz = zi[n + i];
     o[18] = (z == 0) ? 0. : o[17] / z;  // fm, main.c:409-412
-    o[19] = 0.0;                        // fr   -- order-dependent carry, not reproduced
+    o[19] = ex[i];                      // fr
     // ifr, main.c:388-390
     o[20] = fabs(((o[10] * c.phys.G + o[16]) * (c.dt * o[4] + c.dt2 * o[7] / 2.)) + (o[15] * (c.dt * o[3] + c.dt2 * o[6] / 2.)));
     o[21] = dg[4 * (size_t)n + i]; o[22] = dg[5 * (size_t)n + i]; o[23] = dg[6 * (size_t)n + i]; o[24] = dg[7 * (size_t)n + i];
-    o[25] = 0.0; o[26] = 0.0; o[27] = 0.0;  // ice, slip, rw -- not reproduced
+    o[25] = ex[(size_t)n + i]; o[26] = ex[2 * (size_t)n + i]; o[27] = ex[3 * (size_t)n + i];  // ice, slip, rw
     o[28] = z; o[29] = zz;
   }
   return LBMDEM_OK;
@@ -851,9 +865,8 @@ int lbmdem_download_grain_table(lbmdem_handle* h, double* t) try {
 }
 
 // write_DEM, main.c:340-438: DEM%06d.dat (28 tab-separated columns per grain) and one line appended to
-// stats.data. The four columns that depend on the reference's serial carries (fr, ice, slip, rw) and
-// the four statistics summed from them (WF, INCE, TSLIP, TRW) are written as 0.
-int lbmdem_write_dem(lbmdem_handle* h, const char* dir, int nfile, double* energies4) try {
+// stats.data. energies8 (may be NULL): KE, PE, SE, IFR, WF, INCE, TSLIP, TRW.
+int lbmdem_write_dem(lbmdem_handle* h, const char* dir, int nfile, double* energies8) try {
   CHECK_H(h);
   const int n = h->n;
   std::vector<double> t(30 * (size_t)n), hf(3 * (size_t)n);
@@ -870,6 +883,7 @@ int lbmdem_write_dem(lbmdem_handle* h, const char* dir, int nfile, double* energ
   auto G = [&](int i, int col) { return t[(size_t)i * 30 + col]; };
   double xfront = G(0, 0) + G(0, 9), height = G(0, 1) + G(0, 9), xgrainmax = G(0, 0);
   double energie_x = 0., energie_y = 0., energie_teta = 0., energy_p = 0., SE = 0., IFR = 0., zmean = 0;
+  double WF = 0., INCE = 0., TSLIP = 0., TRW = 0.;
   double N[6] = {0, 0, 0, 0, 0, 0};
   for (int i = 0; i < n; i++) {
     const double x1 = G(i, 0), x2 = G(i, 1), v1 = G(i, 3), v2 = G(i, 4), v3 = G(i, 5), r = G(i, 9), m = G(i, 10),
@@ -882,7 +896,11 @@ int lbmdem_write_dem(lbmdem_handle* h, const char* dir, int nfile, double* energ
     energie_teta += 0.5 * It * v3 * v3;
     energy_p += m * p.G * x2;
     SE += 0.5 * (((pp * pp) / p.kg) + ((ss * ss) / p.kt));
+    WF += G(i, 19);
     IFR += G(i, 20);
+    TSLIP += G(i, 26);
+    TRW += G(i, 27);
+    INCE += G(i, 25);
     const double ESE = 0.5 * (((pp * pp) / p.kg) + ((ss * ss) / p.kt));
     if (x1 + r > xgrainmax) xgrainmax = x1 + r;
     if (x2 + r > height) height = x2 + r;
@@ -901,9 +919,12 @@ int lbmdem_write_dem(lbmdem_handle* h, const char* dir, int nfile, double* energ
   if (!fp) return fail(LBMDEM_EINVAL, "cannot open '%s' for appending", path);
   fprintf(fp, "%le %le %le %le %le %le %le %le %le %le %le %le %le %le %le %le %le %le %le %le %le %le\n",
           h->nbsteps * c.dt - p.dtt, xfront, xgrainmax, height, zmean, energie_x, energie_y, energie_teta, energie_cin,
-          N[0] / n, N[1] / n, N[2] / n, N[3] / n, N[4] / n, N[5] / n, energy_p, SE, 0.0, IFR, 0.0, 0.0, 0.0);
+          N[0] / n, N[1] / n, N[2] / n, N[3] / n, N[4] / n, N[5] / n, energy_p, SE, WF, IFR, INCE, TSLIP, TRW);
   fclose(fp);
-  if (energies4) { energies4[0] = energie_cin; energies4[1] = energy_p; energies4[2] = SE; energies4[3] = IFR; }
+  if (energies8) {
+    energies8[0] = energie_cin; energies8[1] = energy_p; energies8[2] = SE; energies8[3] = IFR;
+    energies8[4] = WF; energies8[5] = INCE; energies8[6] = TSLIP; energies8[7] = TRW;
+  }
   return LBMDEM_OK;
 } catch (const std::bad_alloc&) {
   return fail(LBMDEM_ENOMEM, "host memory allocation failed");

@@ -118,7 +118,27 @@ int verlet_alloc(VerletDevice& V, int n, double cs, double ox, double oy, double
 void verlet_free(VerletDevice& V);
 void launch_verlet_rebuild(VerletDevice& V, const Kin& K, const double* r, const DemParams& P,
                            hipStream_t st);
+// Buffers of the order-dependent contact diagnostics fr, ice, slip, rw (main.c:782-789, 840-843, 851, 893,
+// 916-919, 942, 1462-1466, 1490-1494): they depend on "previous contact" carries (pft, pff, pf, ic,
+// main.c:130-131) that thread through the reference's serial contact loop. Only used by the rare sub-steps
+// that produce write_DEM's table (see launch_diag_extra).
+struct DiagExtra {
+  double *fr, *ice, *slip, *rw;          // [n] results
+  double* a1gc;                          // [n] a1 after the grain contacts; the wall pass keeps adding (= g[].a1 then)
+  double *e_ft, *e_f3, *e_avt, *e_av3;   // [cap] per list entry with own < partner: ft, f3, |vt dt|, |v3_own dt|
+  double *e_dslip, *e_drw;               // [cap] its contribution to slip / rw once the carries are known
+  unsigned char* e_touched;              // [cap] 1 = entry with own < partner and dn < 0
+  int* wlist;                            // [4][n] wall candidate lists (bottom, top, left, right), grains ascending
+  int* wcount;                           // [4]
+  double* carry;                         // pft, pff, pf: persist from sub-step to sub-step
+};
+int diag_extra_alloc(DiagExtra& X, int n, long cap);
+void diag_extra_free(DiagExtra& X);
+// after the DIAG sub-step kernel: carries scanned over the contacts in the reference's order, per-grain sums,
+// then the four wall loops replayed serially
+void launch_diag_extra(const DiagExtra& X, const Kin& in, const double* r, const VerletDevice& V,
+                       const DemParams& P, int film, hipStream_t st);
 void launch_fill_own(const VerletDevice& V, int n, hipStream_t st);
 void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const double* m,
                         const double* It, const double* fhf, const VerletDevice& V, double* pout,
-                        const DemParams& P, int film, double* diag, hipStream_t st);
+                        const DemParams& P, int film, double* diag, const DiagExtra* X, hipStream_t st);

@@ -102,7 +102,7 @@ int main(int argc, char** argv) {
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
   int nFile = (int)(nbsteps / cfg.phys.stepFilm); /* main.c:147 */
-  double energies[4] = {0, 0, 0, 0}; /* KE, PE, SE, IFR of the last write_DEM (main.c:1885-1889) */
+  double energies[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* KE, PE, SE, IFR, WF, INCE, TSLIP, TRW of the last write_DEM (main.c:1885-1889) */
   const int chunk = cfg.phys.updateVerlet;
   const int stepConsole = 400; /* main.c:140 */
   do {
@@ -137,7 +137,7 @@ int main(int argc, char** argv) {
     if (nbsteps % chunk == 0) {
       now = time(NULL);
       printf("steps %li steps %le KE %le PE %le SE %le WF %le INCE %le SLIP %le RW %le Time %s \n", nbsteps,
-             nbsteps * cfg.dt, energies[0], energies[1], energies[2], 0., 0., 0., 0., asctime(localtime(&now)));
+             nbsteps * cfg.dt, energies[0], energies[1], energies[2], energies[4], energies[5], energies[6], energies[7], asctime(localtime(&now)));
     }
   } while (nbsteps * cfg.dt <= duration && (max_steps < 0 || nbsteps < max_steps));
   DIE(lbmdem_sync(h), "sync");

@@ -142,13 +142,15 @@ int lbmdem_write_vtk(lbmdem_handle* h, const char* dir, int nfile);
  * in the sub-step that brings the step counter to a multiple of stepStrob = 4000 (main.c:142,1773), or in
  * every sub-step after lbmdem_set_diagnostics(h, 1). Table: 30 doubles per grain in the reference's struct
  * order (main.c:182-197): x1 x2 x3 v1 v2 v3 a1 a2 a3 r m mw It p s f1 f2 ifm fm fr ifr M11 M12 M21 M22 ice
- * slip rw z zz. fr, ice, slip, rw depend on carries through the reference's serial contact loop
- * (main.c:130-131) and are reported as 0. */
+ * slip rw z zz. fr, ice, slip, rw read "previous contact" carries that thread through the reference's serial
+ * contact loop and from sub-step to sub-step (pft, pff, pf, ic: main.c:130-131); the library replays them in
+ * the reference's order, starting one sub-step before a table sub-step (exact when that sub-step has a contact
+ * of each kind, which a packed bed always has; always exact after lbmdem_set_diagnostics(h, 1) from step 0). */
 int lbmdem_set_diagnostics(lbmdem_handle* h, int always);
 int lbmdem_download_grain_table(lbmdem_handle* h, double* table30);
-/* write_DEM (main.c:340-438): <dir>/DEM%06d.dat and one line appended to <dir>/stats.data; energies4 (may be
- * NULL) receives energie_cin, energy_p, SE, IFR for the console line of main.c:1885-1889. */
-int lbmdem_write_dem(lbmdem_handle* h, const char* dir, int nfile, double* energies4);
+/* write_DEM (main.c:340-438): <dir>/DEM%06d.dat and one line appended to <dir>/stats.data; energies8 (may be
+ * NULL) receives energie_cin, energy_p, SE, IFR, WF, INCE, TSLIP, TRW for the console line of main.c:1885-1889. */
+int lbmdem_write_dem(lbmdem_handle* h, const char* dir, int nfile, double* energies8);
 /* write_forces (main.c:440-478): <dir>/DEM%06d.ps, a PostScript picture of the grains (grey level from g.fm)
  * and one line per overlapping pair, in the reference's order (i outer, j inner, both directions). The
  * reference reads g[nbgrains], one element past its array, and its three "%%%Word" header formats are

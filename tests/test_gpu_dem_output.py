@@ -1,8 +1,7 @@
 """GPU: write_DEM (main.c:340-438) -- DEM%06d.dat and stats.data -- against the files the reference wrote
 (tests/golden/dem_G6_4000steps/), and the per-grain contact diagnostics against the oracle (which is
-pinned to the reference for all 30 grain fields). The four fields that depend on the reference's serial
-carries through the contact loop (fr, ice, slip, rw) and the statistics summed from them are written as 0
-and excluded here."""
+pinned to the reference for all 30 grain fields), including the four that depend on the reference's serial
+"previous contact" carries through the contact loop (fr, ice, slip, rw)."""
 import os
 
 import numpy as np
@@ -12,8 +11,8 @@ import golden_util as gu
 
 pytestmark = pytest.mark.gpu
 REF_DIR = os.path.join(gu.HERE, "golden", "dem_G6_4000steps")
-UNPINNED_DEM_COLS = {17, 19, 20, 21}          # 0-based: fr, ice, slip, rw
-UNPINNED_STATS_COLS = {17, 19, 20, 21}        # WF, INCE, TSLIP, TRW
+UNPINNED_DEM_COLS = set()
+UNPINNED_STATS_COLS = set()
 
 
 def _inputs():
@@ -52,7 +51,8 @@ def test_dem_file_and_stats_line_match_the_reference(pkg, tmp_path):
 
 def test_grain_table_matches_reference_dump_and_oracle(pkg, po):
     r, x1, x2, ref_table = _inputs()
-    cols = [po.COL[c] for c in "x1 x2 x3 v1 v2 v3 a1 a2 a3 r m It p s f1 f2 ifm M11 M12 M21 M22 z zz".split()]
+    cols = [po.COL[c] for c in "x1 x2 x3 v1 v2 v3 a1 a2 a3 r m It p s f1 f2 ifm M11 M12 M21 M22 z zz "
+                               "fr ice slip rw".split()]
     sim = pkg.LbmDem(256, 200, r, x1, x2)
     ora = po.Oracle(256, 200, r, x1, x2)
     sim.set_diagnostics(True)
@@ -69,5 +69,36 @@ def test_grain_table_matches_reference_dump_and_oracle(pkg, po):
     tg = sim.grain_table()                   # produced automatically by the sub-step reaching 4000
     for c in cols + [po.COL["fm"]]:
         assert np.array_equal(tg[:, c], ref_table[:, c]), c
+    assert (ref_table[:, po.COL["slip"]] != 0).sum() >= 5   # the carry chain is exercised at that step
     with pytest.raises(pkg.LbmDemError):
         sim.renderScene(1); sim.grain_table()
+
+
+def test_order_dependent_diagnostics_with_walls_and_film(pkg, po):
+    """fr, ice, slip, rw against the oracle while grains are pressed into all four walls (bottom and left
+    feed `fr` through the list-position-indexed update of main.c:1462/1490, top and left feed `ic`), with the
+    film law every 5th sub-step (it credits both partners of a contact) and Verlet rebuilds in between."""
+    import ctypes
+    import golden_util as gu
+    c = gu.ALL_CASES["G5_dem_64x48"]
+    r, x1, x2 = gu.inputs_m("G5_dem_64x48")
+    phys = pkg.Physics()
+    pkg.load_library().lbmdem_physics_defaults(ctypes.byref(phys))
+    names = [f[0] for f in pkg.Physics._fields_ if f[1] is ctypes.c_double]
+    phys.updateVerlet, phys.stepFilm = 13, 5
+    sim = pkg.LbmDem(c["lx"], c["ly"], r, x1, x2, physics=phys)
+    ora = po.Oracle(c["lx"], c["ly"], r, x1, x2)
+    ora.set_physics([getattr(phys, nme) for nme in names], phys.updateVerlet, phys.stepFilm)
+    k = gu.mg.dem_initial_kinematics(c)
+    sim.kinematics = k; ora.set_kinematics(k)
+    sim.set_diagnostics(True)
+    cols = [po.COL[n] for n in "fr ice slip rw p s z".split()]
+    seen = {n: 0 for n in "fr ice slip rw".split()}
+    for n in (1, 1, 1, 2, 3, 7, 11, 30, 60):
+        sim.renderScene(n); ora.steps(n)
+        tg, to = sim.grain_table(), ora.get_grains()
+        for cc in cols:
+            assert np.array_equal(tg[:, cc], to[:, cc]), (sim.nbsteps, cc)
+        for nme in seen:
+            seen[nme] = max(seen[nme], int((to[:, po.COL[nme]] != 0).sum()))
+    assert all(v > 0 for v in seen.values()), seen
