@@ -1024,7 +1024,7 @@ int lbmdem_write_forces(lbmdem_handle* h, const char* dir, int nfile) try {
 
 namespace {
 struct CkptHeader {
-  char magic[8];       // "LBMDEMC1"
+  char magic[8];       // "LBMDEMC2"
   lbmdem_config cfg;   // incl. the wall positions VerletWall may have moved
   long nbsteps;
   int verlet_ok, nnbr; // symmetric list length
@@ -1045,7 +1045,7 @@ int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) try {
   if (h->verlet_ok) HIP_TRY(hipMemcpy(off.data(), h->V.offsets, sizeof(int) * (n + 1), hipMemcpyDeviceToHost));
   CkptHeader H;
   memset(&H, 0, sizeof H);
-  memcpy(H.magic, "LBMDEMC1", 8);
+  memcpy(H.magic, "LBMDEMC2", 8);
   H.cfg = h->cfg; H.nbsteps = h->nbsteps; H.verlet_ok = h->verlet_ok ? 1 : 0; H.nnbr = off[n]; H.plane = h->L.plane;
   FILE* fp = fopen(path, "wb");
   if (!fp) return fail(LBMDEM_EINVAL, "cannot open '%s' for writing", path);
@@ -1081,7 +1081,7 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
   FILE* fp = fopen(path, "rb");
   if (!fp) return fail(LBMDEM_EINVAL, "cannot open checkpoint '%s'", path);
   CkptHeader H;
-  if (!rd(fp, &H, sizeof H) || memcmp(H.magic, "LBMDEMC1", 8) != 0) { fclose(fp); return fail(LBMDEM_EINVAL, "'%s' is not a checkpoint", path); }
+  if (!rd(fp, &H, sizeof H) || memcmp(H.magic, "LBMDEMC2", 8) != 0) { fclose(fp); return fail(LBMDEM_EINVAL, "'%s' is not a checkpoint", path); }
   const int n = H.cfg.nbgrains;
   std::vector<double> r(n), kin(9 * (size_t)n);
   if (!rd(fp, r.data(), sizeof(double) * n) || !rd(fp, kin.data(), sizeof(double) * 9 * n)) { fclose(fp); return fail(LBMDEM_EINVAL, "checkpoint truncated"); }

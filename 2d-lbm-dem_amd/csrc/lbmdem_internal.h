@@ -10,16 +10,17 @@
 // Device-side views (passed by value to kernels)
 // ---------------------------------------------------------------------------------------------
 
-// Local lattice slab: global rows [gx0, gx0 + nxl), all ly columns. Device layout is SoA planes
-// f[q][xl][y] with y contiguous (pitch sy) -- the reference's fast axis (main.c:56) is kept as the
-// fast axis so that an x-strip is one contiguous slab per plane and halo rows are contiguous.
+// Local lattice slab: global rows [gx0, gx0 + nxl), all ly columns. Device layout of the populations:
+// f[xl][y / 16][q][y % 16] (row pitch sy, a multiple of 16; see fbase() in lbm_kernels.hip) -- the reference's
+// fast axis (main.c:56) is kept as the fast axis so that an x-strip is one contiguous slab and halo rows
+// are contiguous. The obstacle map is plain obst[xl][y] with the same pitch.
 struct LatticeView {
   int lx, ly;    // global lattice size
   int gx0;       // global x of local row 0
   int nxl;       // local rows (owned + halo)
   int xo0, xo1;  // owned local rows [xo0, xo1)
   int sy;        // row pitch in elements
-  long plane;    // nxl * sy
+  long plane;    // nxl * sy: nodes of the slab (a lattice is 9 * plane doubles)
   int n;         // nbgrains; also the obst code of the lattice-edge walls (main.c:676,681)
   double dx, c, Mgx, Mby;
   double s2, s3, s5, s7, s8, s9;

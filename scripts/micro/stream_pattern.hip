@@ -6,7 +6,15 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 // A: one wave = 64-wide window (62 writers, offset -1), marches LX rows, prefetch 1 row ahead
-template <int LX, int USE, int OFF, int WORK = 0, int MINW = 1>
+// LAYOUT 0: nine planes f[q][x][y]; 1: tiles of 16 y-nodes, f[x][y/16][q][y%16] (the nine 128-byte lines of a tile
+// are contiguous: a wave-row touches 2 DRAM regions instead of 18)
+template <int LAYOUT>
+__device__ __forceinline__ long fidx(int q, int x, int y, int ly, long plane) {
+  if (LAYOUT == 0) return q * plane + (long)x * ly + y;
+  return ((((long)x * (ly >> 4) + (y >> 4)) * 9 + q) << 4) + (y & 15);
+}
+
+template <int LX, int USE, int OFF, int WORK = 0, int MINW = 1, int LAYOUT = 0>
 __global__ __launch_bounds__(256, MINW) void k_march(const double* __restrict__ fin, double* __restrict__ fout, int lx, int ly,
                                                long plane, int nstrips, int nwork, int remap) {
   const int lane = threadIdx.x & 63;
@@ -20,14 +28,14 @@ __global__ __launch_bounds__(256, MINW) void k_march(const double* __restrict__ 
   const bool writer = lane >= OFF && lane < OFF + USE && yin;
   const int xs = seg * LX, xe = min(xs + LX, lx);
   double cur[9], nxt[9];
-  for (int q = 0; q < 9; ++q) cur[q] = yin ? fin[q * plane + (long)xs * ly + y] : 0.0;
+  for (int q = 0; q < 9; ++q) cur[q] = yin ? fin[fidx<LAYOUT>(q, xs, y, ly, plane)] : 0.0;
   for (int x = xs; x < xe; ++x) {
     const int xn = x + 1 < lx ? x + 1 : x;
-    for (int q = 0; q < 9; ++q) nxt[q] = yin ? fin[q * plane + (long)xn * ly + y] : 0.0;
+    for (int q = 0; q < 9; ++q) nxt[q] = yin ? fin[fidx<LAYOUT>(q, xn, y, ly, plane)] : 0.0;
     // synthetic VALU load: WORK x 9 dependent-per-q fp64 FMAs (independent across q)
     for (int k = 0; k < WORK; ++k)
       for (int q = 0; q < 9; ++q) cur[q] = cur[q] * 1.0000001 + 0.5;
-    if (writer) for (int q = 0; q < 9; ++q) fout[q * plane + (long)x * ly + y] = cur[q] + 1.0;
+    if (writer) for (int q = 0; q < 9; ++q) fout[fidx<LAYOUT>(q, x, y, ly, plane)] = cur[q] + 1.0;
     for (int q = 0; q < 9; ++q) cur[q] = nxt[q];
   }
 }
@@ -74,5 +82,14 @@ int main() {
   MARCHW(16, 112, 8, "march LX16 62/64 +1008 FMA/row 8 waves/SIMD");
   MARCHW(16, 56, 2, "march LX16 62/64 +504 FMA/row  (minw 2)");
   MARCHW(16, 112, 2, "march LX16 62/64 +1008 FMA/row (minw 2)");
+  // layout comparison at the occupancy of the real kernel: SHM bytes of dynamic LDS per workgroup limit the CU to 2 workgroups
+#define MARCHL(LX, LAYOUT, SHM, NAME) { const int ns = (ly + 61) / 62, nseg = (lx + LX - 1) / LX, nw = ns * nseg; int g = ((nw + 3) / 4 + 7) / 8 * 8; \
+    rep(NAME, timeit([&] { hipLaunchKernelGGL((k_march<LX, 62, 1, 0, 1, LAYOUT>), dim3(g), dim3(256), SHM, 0, a, b, lx, ly, plane, ns, nw, 1); })); }
+  MARCHL(32, 0, 0, "march LX32 62/64 planes            full occupancy");
+  MARCHL(32, 1, 0, "march LX32 62/64 16-node tiles     full occupancy");
+  MARCHL(32, 0, 76800, "march LX32 62/64 planes            2 workgroups/CU");
+  MARCHL(32, 1, 76800, "march LX32 62/64 16-node tiles     2 workgroups/CU");
+  MARCHL(16, 0, 76800, "march LX16 62/64 planes            2 workgroups/CU");
+  MARCHL(16, 1, 76800, "march LX16 62/64 16-node tiles     2 workgroups/CU");
   return 0;
 }
