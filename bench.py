@@ -38,7 +38,7 @@ import __graft_entry__ as ge  # noqa: E402
 import samples  # noqa: E402
 
 BYTES_PER_LUP = 148.0   # 9x8 B read + 9x8 B write + 4 B obstacle id
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")   # PMC-measured HBM bytes per launch
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")   # PMC-measured HBM bytes per launch
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -239,7 +239,7 @@ def main():
                          "traffic": traffic, "bytes_per_lup": BYTES_PER_LUP, "launches_timed": launches,
                          "note": "achieved = algorithmic 148 B/LUP x lattice nodes per launch / mean HIP-event "
                                  "duration; traffic = HBM bytes per launch from rocprofv3 FETCH_SIZE + WRITE_SIZE "
-                                 "(separate passes, calibrated; profiles/r01_f_pmc_traffic.json)"},
+                                 "(separate passes, calibrated; profiles/r01_g_pmc_traffic.json)"},
             "total_mass": mass,
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
