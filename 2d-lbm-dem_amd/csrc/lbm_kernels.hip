@@ -208,32 +208,27 @@ __global__ void k_obst_fill(int* __restrict__ obst, LatticeView L) {
   }
 }
 
-// per-grain lattice geometry (main.c:1009-1013) + the packed record the fluid kernels read
-__global__ void k_grain_geom(int n, const double* __restrict__ x1, const double* __restrict__ x2,
-                             const double* __restrict__ r, const double* __restrict__ rLB,
-                             const double* __restrict__ v1, const double* __restrict__ v2,
-                             const double* __restrict__ v3, double Mgx, double Mby, double dx,
-                             double* __restrict__ xc, double* __restrict__ yc, double* __restrict__ r2,
-                             double* __restrict__ rbl0, double* __restrict__ pk) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double cx = (x1[i] - Mgx) / dx, cy = (x2[i] - Mby) / dx, rr = rLB[i] * rLB[i];
-  xc[i] = cx;
-  yc[i] = cy;
-  r2[i] = rr;
-  rbl0[i] = r[i] / dx;
-  double* o = pk + (long)i * 8;
-  o[0] = x1[i]; o[1] = x2[i]; o[2] = v1[i]; o[3] = v2[i]; o[4] = v3[i]; o[5] = cx; o[6] = cy; o[7] = rr;
-}
-
-// Rasterise the reduced discs (main.c:1016-1032). One wavefront per grain, lanes sweep the
-// bounding box with y fastest (coalesced). Overlaps resolve to the highest grain index, which is
-// what the reference's ascending serial paint produces (main.c:1028) -> atomicMax.
-__global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, GrainFluidView G) {
+// Rasterise the reduced discs (main.c:1016-1032). One wavefront per grain: every lane derives the grain's
+// lattice geometry (main.c:1009-1013: centre, squared reduced radius, unreduced radius in nodes), lane 0 stores
+// it -- also as one packed 64-byte record {x1, x2, v1, v2, v3, xc, yc, r2} for the fluid kernels -- and the lanes
+// sweep the bounding box with y fastest (coalesced). Overlaps resolve to the highest grain index, which is what
+// the reference's ascending serial paint produces (main.c:1028) -> atomicMax.
+__global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const double* __restrict__ x1,
+                             const double* __restrict__ x2, const double* __restrict__ r,
+                             const double* __restrict__ rLB, const double* __restrict__ v1,
+                             const double* __restrict__ v2, const double* __restrict__ v3,
+                             double* __restrict__ oxc, double* __restrict__ oyc, double* __restrict__ or2,
+                             double* __restrict__ orbl0, double* __restrict__ pk) {
   const int lane = threadIdx.x & 63;
   const int i = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  if (i >= L.n) return;
-  const double xc = G.xc[i], yc = G.yc[i], r2 = G.r2[i], rbl0 = G.rbl0[i];
+  if (i >= n) return;
+  const double gx1 = x1[i], gx2 = x2[i];
+  const double xc = (gx1 - L.Mgx) / L.dx, yc = (gx2 - L.Mby) / L.dx, r2 = rLB[i] * rLB[i], rbl0 = r[i] / L.dx;
+  if (lane == 0) {
+    oxc[i] = xc; oyc[i] = yc; or2[i] = r2; orbl0[i] = rbl0;
+    double* o = pk + (long)i * 8;
+    o[0] = gx1; o[1] = gx2; o[2] = v1[i]; o[3] = v2[i]; o[4] = v3[i]; o[5] = xc; o[6] = yc; o[7] = r2;
+  }
   const double R2 = rbl0 * rbl0;
   int xi = (int)(xc - rbl0), xf = (int)(xc + rbl0);
   if (xi < 1) xi = 1;
@@ -1301,17 +1296,12 @@ void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st) {
   hipLaunchKernelGGL(k_obst_fill, dim3(grid_for((long)L.nxl * L.sy / 4)), dim3(256), 0, st, obst, L);
 }
 
-void launch_grain_geom(int n, const double* x1, const double* x2, const double* r, const double* rLB,
-                       const double* v1, const double* v2, const double* v3, double Mgx, double Mby,
-                       double dx, double* xc, double* yc, double* r2, double* rbl0, double* pk,
-                       hipStream_t st) {
-  hipLaunchKernelGGL(k_grain_geom, dim3((n + 255) / 256), dim3(256), 0, st, n, x1, x2, r, rLB, v1, v2, v3, Mgx,
-                     Mby, dx, xc, yc, r2, rbl0, pk);
-}
-
-void launch_obst_paint(int* obst, const LatticeView& L, const GrainFluidView& G, hipStream_t st) {
-  const long threads = (long)L.n * 64;
-  hipLaunchKernelGGL(k_obst_paint, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, obst, L, G);
+void launch_obst_paint(int* obst, const LatticeView& L, int n, const double* x1, const double* x2, const double* r,
+                       const double* rLB, const double* v1, const double* v2, const double* v3, double* xc,
+                       double* yc, double* r2, double* rbl0, double* pk, hipStream_t st) {
+  const long threads = (long)n * 64;
+  hipLaunchKernelGGL(k_obst_paint, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, obst, L, n, x1, x2, r,
+                     rLB, v1, v2, v3, xc, yc, r2, rbl0, pk);
 }
 
 template <int TX, int TY>

@@ -192,9 +192,8 @@ void lbmdem_free_host(void* p) { free(p); }
 static int paint_into(lbmdem_handle* h, int* obst) {
   const Kin& K = h->kin[h->kcur];
   launch_obst_fill(obst, h->L, h->stream);
-  launch_grain_geom(h->n, K.x1, K.x2, h->r, h->rLB, K.v1, K.v2, K.v3, h->cfg.Mgx, h->cfg.Mby, h->cfg.dx,
-                    h->xc, h->yc, h->r2, h->rbl0, h->pk, h->stream);
-  launch_obst_paint(obst, h->L, gview(h), h->stream);
+  launch_obst_paint(obst, h->L, h->n, K.x1, K.x2, h->r, h->rLB, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0, h->pk,
+                    h->stream);
   HIP_TRY(hipGetLastError());
   return LBMDEM_OK;
 }

@@ -64,11 +64,10 @@ struct Kin {
 
 // lbm_kernels.hip
 void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st);
-void launch_grain_geom(int n, const double* x1, const double* x2, const double* r, const double* rLB,
-                       const double* v1, const double* v2, const double* v3, double Mgx, double Mby,
-                       double dx, double* xc, double* yc, double* r2, double* rbl0, double* pk,
-                       hipStream_t st);
-void launch_obst_paint(int* obst, const LatticeView& L, const GrainFluidView& G, hipStream_t st);
+// fills xc, yc, r2, rbl0, pk (per-grain lattice geometry, main.c:1009-1013) and paints the reduced discs
+void launch_obst_paint(int* obst, const LatticeView& L, int n, const double* x1, const double* x2, const double* r,
+                       const double* rLB, const double* v1, const double* v2, const double* v3, double* xc,
+                       double* yc, double* r2, double* rbl0, double* pk, hipStream_t st);
 void launch_collide_stream(const double* fin, double* fout, const int* obst_old, const int* obst_new,
                            const LatticeView& L, const GrainFluidView& G, hipStream_t st);
 void launch_forces_parity(const double* f, const int* obst, const LatticeView& L,
