@@ -121,6 +121,8 @@ class TorchComm:
     def __init__(self, dist, group=None):
         self.dist, self.group = dist, group
         self._side = None   # stream the point-to-point transfers are issued on (device tensors only)
+        self._ready = None  # event: "the packed rows are enqueued"
+        self._p2p_cache = (None, None)   # the P2POp list is rebuilt only when the buffers change (they do not)
 
     def _p2p(self, ops):
         d = self.dist
@@ -136,7 +138,10 @@ class TorchComm:
     def exchange_begin(self, ops):
         """Start the neighbour transfers; they depend on what has been enqueued so far (the packed edge
         rows) but not on what the caller enqueues next (the interior rows)."""
-        p2p = self._p2p(ops)
+        key = tuple((peer, send.data_ptr(), recv.data_ptr()) for peer, send, recv in ops)
+        if self._p2p_cache[0] != key:
+            self._p2p_cache = (key, self._p2p(ops))
+        p2p = self._p2p_cache[1]
         if not p2p:
             return []
         if ops[0][1].is_cuda:
@@ -144,10 +149,10 @@ class TorchComm:
             dev = ops[0][1].device
             if self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(dev))
+                self._ready = torch.cuda.Event()
+            self._ready.record(torch.cuda.current_stream(dev))
             with torch.cuda.stream(self._side):
-                self._side.wait_event(ready)
+                self._side.wait_event(self._ready)
                 return self.dist.batch_isend_irecv(p2p)
         return self.dist.batch_isend_irecv(p2p)
 
