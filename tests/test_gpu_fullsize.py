@@ -125,3 +125,39 @@ def test_c2_1024_fluid_only_rho_u(pkg, po):
     assert np.allclose(jx, (fc * ex).sum(-1), rtol=0, atol=1e-15)
     assert np.allclose(jy, (fc * ey).sum(-1), rtol=0, atol=1e-15)
     assert np.abs(jx).max() > 0.5 * U      # the vortex is still there
+
+
+def test_real_7000_grain_sample_30_coupled_steps_vs_oracle(pkg, po):
+    """The reference's a08_a4b4r18_7000.data (6 355 grains, the packing with genuine bounce-back order hazards) on
+    2048 x 2048 for 30 coupled steps = 360 DEM sub-steps with three Verlet rebuilds: every bit of f, obst, fhf
+    and the kinematics equals the oracle's (which is pinned to the reference on this very sample)."""
+    import golden_util as gu
+    g = gu.load("real_7000_2048x2048")
+    lx = ly = 2048
+    sim = pkg.LbmDem(lx, ly, g["r"], g["x1"], g["x2"])
+    ora = po.Oracle(lx, ly, g["r"], g["x1"], g["x2"], fast=False)
+    n = 30 * int(g["npDEM"])
+    sim.renderScene(n); ora.steps(n)
+    assert ora.act_anomalies() == 0
+    assert np.array_equal(sim.kinematics, ora.get_grains()[:, :9])
+    assert np.array_equal(sim.fhf, ora.get_fhf())
+    assert np.array_equal(sim.obst, ora.get_obst())
+    assert np.array_equal(sim.f, ora.get_f())
+
+
+def test_real_50000_grain_sample_six_coupled_steps_vs_oracle(pkg, po):
+    """BASELINE.json configs[3] on the reference's own bin/50000.data (49 987 grains, 4096 x 4096): six coupled
+    steps (72 DEM sub-steps incl. the film step and a Verlet build) against the oracle, every bit."""
+    import golden_util as gu
+    g = gu.load("real_50000_4096x4096")
+    lx = ly = 4096
+    sim = pkg.LbmDem(lx, ly, g["r"], g["x1"], g["x2"])
+    ora = po.Oracle(lx, ly, g["r"], g["x1"], g["x2"], fast=False)
+    n = 6 * int(g["npDEM"])
+    sim.renderScene(n); ora.steps(n)
+    assert ora.act_anomalies() == 0
+    assert np.array_equal(sim.kinematics, ora.get_grains()[:, :9])
+    assert np.array_equal(sim.fhf, ora.get_fhf())
+    assert np.array_equal(sim.obst, ora.get_obst())
+    got = sim.f
+    assert np.array_equal(got, ora.get_f())
