@@ -14,7 +14,7 @@ __device__ __forceinline__ long fidx(int q, int x, int y, int ly, long plane) {
   return ((((long)x * (ly >> 4) + (y >> 4)) * 9 + q) << 4) + (y & 15);
 }
 
-template <int LX, int USE, int OFF, int WORK = 0, int MINW = 1, int LAYOUT = 0>
+template <int LX, int USE, int OFF, int WORK = 0, int MINW = 1, int LAYOUT = 0, int SYNC = 0>
 __global__ __launch_bounds__(256, MINW) void k_march(const double* __restrict__ fin, double* __restrict__ fout, int lx, int ly,
                                                long plane, int nstrips, int nwork, int remap) {
   const int lane = threadIdx.x & 63;
@@ -35,6 +35,16 @@ __global__ __launch_bounds__(256, MINW) void k_march(const double* __restrict__ 
     // synthetic VALU load: WORK x 9 dependent-per-q fp64 FMAs (independent across q)
     for (int k = 0; k < WORK; ++k)
       for (int q = 0; q < 9; ++q) cur[q] = cur[q] * 1.0000001 + 0.5;
+    if (SYNC) {  // the four waves of a workgroup exchange their seam columns through LDS once per row
+      __shared__ double seam[4][2][3];
+      const int wv = threadIdx.x >> 6;
+      if (lane == 0) { seam[wv][0][0] = cur[1]; seam[wv][0][1] = cur[2]; seam[wv][0][2] = cur[3]; }
+      if (lane == 63) { seam[wv][1][0] = cur[5]; seam[wv][1][1] = cur[6]; seam[wv][1][2] = cur[7]; }
+      __syncthreads();
+      if (lane == 0 && wv > 0) cur[0] += seam[wv - 1][1][0] * 1e-30;
+      if (lane == 63 && wv < 3) cur[0] += seam[wv + 1][0][0] * 1e-30;
+      __syncthreads();
+    }
     if (writer) for (int q = 0; q < 9; ++q) fout[fidx<LAYOUT>(q, x, y, ly, plane)] = cur[q] + 1.0;
     for (int q = 0; q < 9; ++q) cur[q] = nxt[q];
   }
@@ -91,5 +101,12 @@ int main() {
   MARCHL(32, 1, 76800, "march LX32 62/64 16-node tiles     2 workgroups/CU");
   MARCHL(16, 0, 76800, "march LX16 62/64 planes            2 workgroups/CU");
   MARCHL(16, 1, 76800, "march LX16 62/64 16-node tiles     2 workgroups/CU");
+  // aligned 64-lane windows (idea: seam columns through LDS), with and without a workgroup barrier per row
+#define MARCHS(LX, SYNC, SHM, NAME) { const int ns = ly / 64, nseg = (lx + LX - 1) / LX, nw = ns * nseg; int g = ((nw + 3) / 4 + 7) / 8 * 8; \
+    rep(NAME, timeit([&] { hipLaunchKernelGGL((k_march<LX, 64, 0, 0, 1, 1, SYNC>), dim3(g), dim3(256), SHM, 0, a, b, lx, ly, plane, ns, nw, 1); })); }
+  MARCHS(32, 0, 76800, "march LX32 64/64 tiles aligned          2 workgroups/CU");
+  MARCHS(32, 1, 76800, "march LX32 64/64 tiles aligned + 2 barriers/row  2 wg/CU");
+  MARCHS(16, 0, 76800, "march LX16 64/64 tiles aligned          2 workgroups/CU");
+  MARCHS(16, 1, 76800, "march LX16 64/64 tiles aligned + 2 barriers/row  2 wg/CU");
   return 0;
 }
