@@ -205,6 +205,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
+    # informative: the DEM side alone (sub-steps incl. the Verlet rebuilds that fall inside), after the timed region
+    dem_only = None
+    if world == 1 and not args.strips:
+        nsub = 100 * npdem
+        sim.run_dem(npdem); sync()
+        t0 = time.perf_counter(); sim.run_dem(nsub); sync(); t1 = time.perf_counter()
+        dem_only = nsub / (t1 - t0)
+
     mass = sim.final_density()
     if not np.isfinite(mass):
         raise SystemExit("non-finite lattice mass after the timed run")
@@ -232,6 +240,7 @@ def main():
                        f"{args.gpus} x-strips; halo exchange overlapped with the interior rows, one bit-exact "
                        f"all-reduce of the hydrodynamic forces per fluid step; DEM state replicated"},
             "dem_steps_per_s": round(args.steps * npdem / elapsed, 1),
+            "dem_only_steps_per_s": round(dem_only, 1) if dem_only else None,
             "collide_stream_kernel_ms": round(kernel_ms, 4),
             "collide_stream_kernel_mlups": round(1e-6 * rows * ly / (kernel_ms * 1e-3), 1) if kernel_ms > 0 else None,
             "roofline": {"bound": "hbm", "kernel": "k_cs_march (fused reinit+collide+IBB+stream)", "achieved": round(achieved, 1),
