@@ -206,12 +206,20 @@ def main():
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
     # informative: the DEM side alone (sub-steps incl. the Verlet rebuilds that fall inside), after the timed region
-    dem_only = None
+    dem_only = lbm_only_ms = None
     if world == 1 and not args.strips:
         nsub = 100 * npdem
         sim.run_dem(npdem); sync()
         t0 = time.perf_counter(); sim.run_dem(nsub); sync(); t1 = time.perf_counter()
         dem_only = nsub / (t1 - t0)
+        # ... and the fluid side alone: obstacle map + fused kernel + hydrodynamic forces (SURVEY 8d, item ii)
+        nl = 20
+        sim.lbm_step(); sync()
+        t0 = time.perf_counter()
+        for _ in range(nl):
+            sim.lbm_step()
+        sync(); t1 = time.perf_counter()
+        lbm_only_ms = 1e3 * (t1 - t0) / nl
 
     mass = sim.final_density()
     if not np.isfinite(mass):
@@ -241,6 +249,8 @@ def main():
                        f"all-reduce of the hydrodynamic forces per fluid step; DEM state replicated"},
             "dem_steps_per_s": round(args.steps * npdem / elapsed, 1),
             "dem_only_steps_per_s": round(dem_only, 1) if dem_only else None,
+            "lbm_step_only_ms": round(lbm_only_ms, 4) if lbm_only_ms else None,
+            "lbm_step_only_mlups": round(1e-3 * lx * ly / lbm_only_ms, 1) if lbm_only_ms else None,
             "collide_stream_kernel_ms": round(kernel_ms, 4),
             "collide_stream_kernel_mlups": round(1e-6 * rows * ly / (kernel_ms * 1e-3), 1) if kernel_ms > 0 else None,
             "roofline": {"bound": "hbm", "kernel": "k_cs_march (fused reinit+collide+IBB+stream)", "achieved": round(achieved, 1),
