@@ -21,7 +21,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblbmdem_hip.so")
+# LBMDEM_HIP_LIBRARY: load another build of the same ABI (e.g. the `make AB=1` experiment build)
+LIB_PATH = os.environ.get("LBMDEM_HIP_LIBRARY") or os.path.join(_HERE, "liblbmdem_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lbmdem_hip.h")
 
 
@@ -106,6 +107,7 @@ def load_library():
     L.lbmdem_checkpoint_save.argtypes = [C.c_void_p, C.c_char_p]
     L.lbmdem_checkpoint_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     L.lbmdem_set_force_mode.argtypes = [C.c_void_p, C.c_int]
+    L.lbmdem_force_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lbmdem_profile_enable.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.lbmdem_halo_pack.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -391,6 +393,13 @@ class LbmDem:
     # ---- plumbing -------------------------------------------------------------------------------
     def set_force_mode(self, mode):
         _chk(self._L.lbmdem_set_force_mode(self._h, int(mode)))
+
+    def force_stats(self):
+        """(grains summed from the fused kernel's link table, grains gathered from the lattice) of the last
+        forces_fluid call."""
+        a, b = C.c_int(0), C.c_int(0)
+        _chk(self._L.lbmdem_force_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_stream(self, hip_stream_ptr):
         """Enqueue on a caller-owned hipStream_t; 0/None = the HIP default stream."""

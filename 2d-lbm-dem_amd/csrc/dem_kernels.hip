@@ -712,7 +712,11 @@ void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const do
                         const double* It, const double* fhf, const VerletDevice& V, double* pout,
                         const DemParams& P, int film, double* diag, const DiagExtra* X, hipStream_t st) {
   const int n = P.n;
+#ifdef LBMDEM_AB
   static const int variant = getenv("LBMDEM_DEM_VARIANT") ? atoi(getenv("LBMDEM_DEM_VARIANT")) : 1;
+#else
+  const int variant = 1;
+#endif
   if (!diag && variant == 1) {  // one lane per list entry
     const int nbe = (n + DEM_GRAINS - 1) / DEM_GRAINS;
     if (film)

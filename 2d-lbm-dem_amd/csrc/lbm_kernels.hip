@@ -151,7 +151,7 @@ __device__ __forceinline__ void grain_equilibrium(const LatticeView& L, const GP
   const double ux = wall_ux(L, g, y), uy = wall_uy(L, g, x);
   double u_squ, e1, e2, e3, e4;
   if (L.recip_ok && div_safe(ux * ux) && div_safe(uy * uy)) {  // divisions by the run constants c and c*c
-    u_squ = exact_div(ux * ux + uy * uy, L.c * L.c, L.rcc);
+    u_squ = exact_div(ux * ux + uy * uy, L.cc, L.rcc);
     e1 = exact_div(-ux + uy, L.c, L.rc);
     e2 = exact_div(-ux, L.c, L.rc);
     e3 = exact_div(-ux + (-uy), L.c, L.rc);
@@ -218,7 +218,8 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
                              const double* __restrict__ rLB, const double* __restrict__ v1,
                              const double* __restrict__ v2, const double* __restrict__ v3,
                              double* __restrict__ oxc, double* __restrict__ oyc, double* __restrict__ or2,
-                             double* __restrict__ orbl0, double* __restrict__ pk) {
+                             double* __restrict__ orbl0, double* __restrict__ pk,
+                             unsigned char* __restrict__ touched) {
   const int lane = threadIdx.x & 63;
   const int i = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (i >= n) return;
@@ -245,8 +246,17 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
   for (int k = lane; k < total; k += 64) {
     const int x = xi + k / ny, y = yi + k % ny;
     const double d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc);
-    if (d2 <= R2 && d2 <= r2) atomicMax(&obst[(long)(x - L.gx0) * L.sy + y], i);
+    if (d2 <= R2 && d2 <= r2) {
+      // the previous owner of the node, if any: both discs are then flagged as overlapping (the force kernel
+      // derives the footprint of unflagged grains from the disc test alone, without reading the map)
+      const int old = atomicMax(&obst[(long)(x - L.gx0) * L.sy + y], i);
+      if (old >= 0 && old < n && old != i) { touched[i] = 1; touched[old] = 1; }
+    }
   }
+}
+
+__global__ void k_fill_u64(unsigned long long* __restrict__ p, long count, unsigned long long v) {
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (long)gridDim.x * blockDim.x) p[k] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -428,6 +438,13 @@ __device__ __forceinline__ double link_delta_rt(int x, int y, int ex, int ey, do
   return aai == 2 ? t * 0.5 : t;  // == t / aa exactly
 }
 // wc_diag = Wq(1) / L.c, wc_axis = Wq(2) / L.c (what ibb_*_value<q> form as Wq(q) / L.c)
+// Lattice line through node (x, y) parallel to e = (ex, ey), numbered relative to the grain centre (xc, yc):
+// the index of a link's slot in the ForceSlots table. Producer (fused kernel) and consumer (force kernel) both
+// call this with the same doubles.
+__device__ __forceinline__ int slot_line(int x, int y, int ex, int ey, double xc, double yc) {
+  return ey * (x - (int)xc) - ex * (y - (int)yc);
+}
+
 template <class RecFn>
 __device__ __forceinline__ double ibb_eval_rt(const LatticeView& L, const RtLink& k, double wc_diag,
                                               double wc_axis, RecFn rec_of) {
@@ -636,6 +653,12 @@ struct RecRing {
     p[128] = make_double2(g.v3, g.xc);
     p[192] = make_double2(g.yc, g.r2);
   }
+  // only the lattice-unit centre (xc, yc) of that record
+  __device__ __forceinline__ void get_centre(int row, int lane, double& xc, double& yc) const {
+    const double* p = reinterpret_cast<const double*>(base + (row & (REC_RING - 1)) * 4 * 64 + lane);
+    xc = p[2 * 128 + 1];
+    yc = p[2 * 192];
+  }
   __device__ __forceinline__ GP get(int row, int lane) const {
     const double2* p = base + (row & (REC_RING - 1)) * 4 * 64 + lane;
     const double2 a = p[0], b = p[64], c = p[128], d = p[192];
@@ -686,6 +709,10 @@ __device__ __forceinline__ void classify_store_row(const Ctx& C, const LatticeVi
 #undef LBM_CLASSIFY
 }
 
+// number of set bits of `m` below this lane
+__device__ __forceinline__ unsigned mbcnt(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
 __device__ __forceinline__ double shfl_up1(double v) { return __shfl_up(v, 1, 64); }
 __device__ __forceinline__ double shfl_dn1(double v) { return __shfl_down(v, 1, 64); }
 
@@ -693,8 +720,8 @@ template <int LX, int MINW, int WW>
 __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict__ fin, double* __restrict__ fout,
                                                   const int* __restrict__ ob_old,
                                                   const int* __restrict__ ob_new, LatticeView L,
-                                                  GrainFluidView G, int nstrips, int nwork, int xcd_remap,
-                                                  int seg_rows) {
+                                                  GrainFluidView G, ForceSlots S, int nstrips, int nwork,
+                                                  int xcd_remap, int seg_rows) {
   const int lane = threadIdx.x & 63;
   int blk = blockIdx.x;
   if (xcd_remap) {  // XCD k (blocks b % 8 == k) walks the k-th contiguous eighth of the work list
@@ -730,10 +757,11 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
   // wave-private scratch for the compacted bounce-back evaluation: 64 link slots
   __shared__ double sPay[4 * 64 * 4];
   __shared__ int sDesc[4 * 64];
+  __shared__ int sGid[4 * 64];
   double* const pay = sPay + (threadIdx.x >> 6) * (64 * 4);
   int* const desc = sDesc + (threadIdx.x >> 6) * 64;
-  const double wc_diag = Wq(1) / L.c, wc_axis = Wq(2) / L.c;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  int* const gid = sGid + (threadIdx.x >> 6) * 64;
+  const double wc_diag = L.wc_diag, wc_axis = L.wc_axis;  // kernel arguments: scalar registers
   auto row_ok = [&](int xl) { return yin && xl >= 0 && xl < L.nxl; };
   const int ycl = y < 0 ? 0 : (y >= L.ly ? L.ly - 1 : y);
   auto node_of = [&](int xl) {  // clamped: always a valid address
@@ -859,10 +887,11 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
 #pragma unroll
         for (int q = 1; q < 9; ++q) {
           const unsigned long long b = __ballot((ibb >> q) & 1u);
-          const int t = before + __popcll(b & lt_mask) - base;
+          const int t = before + (int)mbcnt(b) - base;
           before += __popcll(b);
           if (((ibb >> q) & 1u) && t >= 0 && t < 64) {
             desc[t] = lane | (q << 8) | (((nnm >> q) & 1u) << 12) | (((hzm >> q) & 1u) << 13);
+            gid[t] = C.onb[OPPq(q)];  // the grain that owns S = P - e_q
             pay[t * 4 + 0] = C.Fo[OPPq(q)];
             pay[t * 4 + 1] = C.Fo[q];
             pay[t * 4 + 2] = C.In[q];
@@ -884,8 +913,20 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
           k.nn_int = (d >> 12) & 1;
           k.hazard = (d >> 13) & 1;
           // the result goes straight to the population it belongs to: node of lane `src`, plane q
-          fout[fidx(k.q, node - lane + src)] =
+          const double out =
               ibb_eval_rt(L, k, wc_diag, wc_axis, [&](int dx, int dy) { return ring.get(x + dx, src + dy); });
+          fout[fidx(k.q, node - lane + src)] = out;
+          // ... and the link's momentum-exchange sum f_new[S][opp q] + f_new[P][q] (main.c:1313-1316; the first
+          // is f*[P][opp q], streamed unchanged into the solid node) to the owning grain's slot table
+          if (S.tab != nullptr) {
+            const int ex = (k.q >= 1 && k.q <= 3) ? -1 : ((k.q >= 5 && k.q <= 7) ? 1 : 0);
+            const int ey = (k.q == 1 || k.q >= 7) ? 1 : ((k.q >= 3 && k.q <= 5) ? -1 : 0);
+            double cx, cy;
+            ring.get_centre(x - ex, src - ey, cx, cy);
+            const int rel = slot_line(k.gx - ex, k.gy - ey, ex, ey, cx, cy) + S.half;
+            if ((unsigned)rel < (unsigned)S.spd)
+              S.tab[((long)gid[lane] * 8 + (k.q - 1)) * S.spd + rel] = k.own_qo + out;
+          }
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -947,149 +988,455 @@ constexpr int FORCE_TILE = 40;       // footprint edge staged in LDS (bounding b
 constexpr int FORCE_BN_CAP = 512;    // boundary nodes kept per grain before a flush
 constexpr int FORCE_TERMS_CAP = 128; // terms replayed per batch
 
+struct ForceLds {
+  double sT[FORCE_TERMS_CAP * 4 + 2];             // [term][fnx, fny, -p1, p2], then a zero slot
+  unsigned char sIn[FORCE_TILE * FORCE_TILE];     // 1 = node belongs to grain i
+  unsigned short sBnK[FORCE_BN_CAP];              // boundary node: index in the bounding box
+  unsigned char sBnM[FORCE_BN_CAP];               //                link mask (bit q-1)
+};
+
+// Phase B for up to 64 boundary nodes, one per lane (in scan order): `mask` = the node's links (bit q-1),
+// fx/fy[q-1] = fnx, fny of link q, (wx, wy) = (x - xc, y - yc). Terms go to LDS in scan order, three lanes
+// replay the additions. `h` is the running accumulator of lanes 0..2. One-wave workgroup: barriers are cheap.
+__device__ __forceinline__ void force_replay(ForceLds& sh, int lane, unsigned mask, const double (&fx)[8],
+                                             const double (&fy)[8], double wx, double wy, double& h) {
+  const int zero_slot = FORCE_TERMS_CAP * 4;
+  const int a_off = lane < 3 ? lane : 0;  // fnx | fny | -p1
+  const int cnt = __popc(mask);
+  int pos = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(pos, off, 64);
+    if (lane >= off) pos += v;
+  }
+  const int nterms = __shfl(pos, 63, 64);
+  pos -= cnt;
+  for (int lo = 0; lo < nterms; lo += FORCE_TERMS_CAP) {  // wave-uniform
+    __syncthreads();  // the previous batch has been consumed
+    int p = pos;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (mask & (1u << q)) {
+        if (p >= lo && p < lo + FORCE_TERMS_CAP) {
+          double* t = &sh.sT[(p - lo) * 4];
+          t[0] = fx[q];
+          t[1] = fy[q];
+          t[2] = fx[q] * (-wy);
+          t[3] = fy[q] * wx;
+        }
+        ++p;
+      }
+    }
+    const int nb = nterms - lo < FORCE_TERMS_CAP ? nterms - lo : FORCE_TERMS_CAP;
+    // pad the batch to a multiple of 8 with zero terms: (h + 0.0) + 0.0 == h exactly
+    const int nb8 = (nb + 7) & ~7;
+    if (lane < 4 * (nb8 - nb)) sh.sT[nb * 4 + lane] = 0.0;
+    __syncthreads();
+    if (lane < 3) {
+      const int b_off = lane == 2 ? 3 : -1;
+      for (int t = 0; t < nb8; t += 8) {
+        double a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {  // loads do not depend on h: issue them ahead of the chain
+          a[u] = sh.sT[(t + u) * 4 + a_off];
+          b[u] = sh.sT[b_off >= 0 ? (t + u) * 4 + b_off : zero_slot];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) h = (h + a[u]) + b[u];
+      }
+    }
+  }
+}
+
+// The ordered sums of one grain gathered from the obstacle map and the lattice (phases A0, A1, A2, B above).
+// Returns h (lanes 0..2).
+__device__ __forceinline__ double force_gather(ForceLds& sh, const double* __restrict__ f,
+                                               const int* __restrict__ obst, const LatticeView& L, int i, double xc,
+                                               double yc, int xi, int xf, int yi, int yf, int lane) {
+  double h = 0.0;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const int nx = xf - xi + 1, ny = yf - yi + 1;
+  const int total = nx * ny;
+  const int tx = nx + 2, ty = ny + 2;
+  const bool staged = tx <= FORCE_TILE && ty <= FORCE_TILE && total <= 65535;
+  __syncthreads();
+  if (staged) {  // A0
+    for (int k = lane; k < tx * ty; k += 64) {
+      const int x = xi - 1 + k / ty, y = yi - 1 + k % ty;  // in-bounds: the box is clamped to [1, l-2]
+      sh.sIn[k] = obst[(long)(x - L.gx0) * L.sy + y] == i ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  // boundary-node list is consumed whenever it fills up or the scan ends
+  int nbn = 0;
+  for (int base = 0; base < total || nbn > 0; base += 64) {
+    // A1: classify 64 bounding-box nodes
+    if (base < total) {
+      const int k = base + lane;
+      unsigned m = 0;
+      if (k < total) {
+        const int bx = k / ny, by = k % ny;
+        if (staged) {
+          const unsigned char* c = &sh.sIn[(bx + 1) * ty + (by + 1)];
+          if (c[0]) {
+#pragma unroll
+            for (int q = 1; q < 9; ++q)
+              if (!c[EXq(q) * ty + EYq(q)]) m |= 1u << (q - 1);
+          }
+        } else {
+          const int x = xi + bx, y = yi + by;
+          if (obst[(long)(x - L.gx0) * L.sy + y] == i) {
+#pragma unroll
+            for (int q = 1; q < 9; ++q)
+              if (obst[(long)(x + EXq(q) - L.gx0) * L.sy + (y + EYq(q))] != i) m |= 1u << (q - 1);
+          }
+        }
+      }
+      const unsigned long long bal = __ballot(m != 0);
+      if (m != 0) {
+        const int slot = nbn + __popcll(bal & lt_mask);
+        sh.sBnK[slot] = (unsigned short)k;
+        sh.sBnM[slot] = (unsigned char)m;
+      }
+      nbn += __popcll(bal);
+    }
+    const bool last = base + 64 >= total;
+    if (!(last || nbn > FORCE_BN_CAP - 64)) continue;  // wave-uniform: keep collecting
+    __syncthreads();
+    // A2 + B over the collected boundary nodes, 64 at a time
+    for (int b0 = 0; b0 < nbn; b0 += 64) {
+      const int bi = b0 + lane;
+      unsigned mask = 0;
+      double fx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      double wx = 0.0, wy = 0.0;
+      if (bi < nbn) {
+        const int k = sh.sBnK[bi];
+        mask = sh.sBnM[bi];
+        const int x = xi + k / ny, y = yi + k % ny;
+        const long nodeP = (long)(x - L.gx0) * L.sy + y;
+        wx = x - xc;
+        wy = y - yc;
+#pragma unroll
+        for (int q = 1; q < 9; ++q) {
+          if (mask & (1u << (q - 1))) {
+            const int qo = OPPq(q);
+            const long nodeN = (long)(x + EXq(q) - L.gx0) * L.sy + (y + EYq(q));
+            const double s = f[fidx(qo, nodeP)] + f[fidx(q, nodeN)];
+            fx[q - 1] = s * EXq(qo);
+            fy[q - 1] = s * EYq(qo);
+          }
+        }
+      }
+      force_replay(sh, lane, mask, fx, fy, wx, wy, h);
+    }
+    __syncthreads();
+    nbn = 0;
+    if (last) break;
+  }
+  return h;
+}
+
 __global__ __launch_bounds__(64) void k_forces_parity(const double* __restrict__ f,
                                                       const int* __restrict__ obst, LatticeView L,
                                                       GrainFluidView G, double scale12, double scale3,
                                                       double* __restrict__ fhf,
                                                       unsigned char* __restrict__ owner) {
-  __shared__ double sT[FORCE_TERMS_CAP * 4 + 2];      // [term][fnx, fny, -p1, p2], then a zero slot
-  __shared__ unsigned char sIn[FORCE_TILE * FORCE_TILE];  // 1 = node belongs to grain i
-  __shared__ unsigned short sBnK[FORCE_BN_CAP];       // boundary node: index in the bounding box
-  __shared__ unsigned char sBnM[FORCE_BN_CAP];        //                link mask (bit q-1)
+  __shared__ ForceLds sh;
   const int lane = threadIdx.x;
   const int i = blockIdx.x;
   const double xc = G.xc[i], yc = G.yc[i];
   const bool own = grain_owned(L, xc);
   double h = 0.0;  // lanes 0,1,2 hold h1,h2,h3
-  const int zero_slot = FORCE_TERMS_CAP * 4;
-  if (lane == 0) sT[zero_slot] = 0.0;
-  const int a_off = lane < 3 ? lane : 0;  // fnx | fny | -p1
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  if (lane == 0) sh.sT[FORCE_TERMS_CAP * 4] = 0.0;
   int xi, xf, yi, yf;
-  if (own && grain_box(L, G, i, xi, xf, yi, yf)) {
-    const int nx = xf - xi + 1, ny = yf - yi + 1;
-    const int total = nx * ny;
-    const int tx = nx + 2, ty = ny + 2;
-    const bool staged = tx <= FORCE_TILE && ty <= FORCE_TILE && total <= 65535;
-    if (staged) {  // A0
-      for (int k = lane; k < tx * ty; k += 64) {
-        const int x = xi - 1 + k / ty, y = yi - 1 + k % ty;  // in-bounds: the box is clamped to [1, l-2]
-        sIn[k] = obst[(long)(x - L.gx0) * L.sy + y] == i ? 1 : 0;
-      }
-      __syncthreads();
-    }
-    // boundary-node list is consumed whenever it fills up or the scan ends
-    int nbn = 0;
-    for (int base = 0; base < total || nbn > 0; base += 64) {
-      // A1: classify 64 bounding-box nodes
-      if (base < total) {
-        const int k = base + lane;
-        unsigned m = 0;
-        if (k < total) {
-          const int bx = k / ny, by = k % ny;
-          if (staged) {
-            const unsigned char* c = &sIn[(bx + 1) * ty + (by + 1)];
-            if (c[0]) {
-#pragma unroll
-              for (int q = 1; q < 9; ++q)
-                if (!c[EXq(q) * ty + EYq(q)]) m |= 1u << (q - 1);
-            }
-          } else {
-            const int x = xi + bx, y = yi + by;
-            if (obst[(long)(x - L.gx0) * L.sy + y] == i) {
-#pragma unroll
-              for (int q = 1; q < 9; ++q)
-                if (obst[(long)(x + EXq(q) - L.gx0) * L.sy + (y + EYq(q))] != i) m |= 1u << (q - 1);
-            }
-          }
-        }
-        const unsigned long long bal = __ballot(m != 0);
-        if (m != 0) {
-          const int slot = nbn + __popcll(bal & lt_mask);
-          sBnK[slot] = (unsigned short)k;
-          sBnM[slot] = (unsigned char)m;
-        }
-        nbn += __popcll(bal);
-      }
-      const bool last = base + 64 >= total;
-      if (!(last || nbn > FORCE_BN_CAP - 64)) continue;  // wave-uniform: keep collecting
-      __syncthreads();
-      // A2 + B over the collected boundary nodes, 64 at a time
-      for (int b0 = 0; b0 < nbn; b0 += 64) {
-        const int bi = b0 + lane;
-        unsigned mask = 0;
-        double fx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        double wx = 0.0, wy = 0.0;
-        if (bi < nbn) {
-          const int k = sBnK[bi];
-          mask = sBnM[bi];
-          const int x = xi + k / ny, y = yi + k % ny;
-          const long nodeP = (long)(x - L.gx0) * L.sy + y;
-          wx = x - xc;
-          wy = y - yc;
-#pragma unroll
-          for (int q = 1; q < 9; ++q) {
-            if (mask & (1u << (q - 1))) {
-              const int qo = OPPq(q);
-              const long nodeN = (long)(x + EXq(q) - L.gx0) * L.sy + (y + EYq(q));
-              const double s = f[fidx(qo, nodeP)] + f[fidx(q, nodeN)];
-              fx[q - 1] = s * EXq(qo);
-              fy[q - 1] = s * EYq(qo);
-            }
-          }
-        }
-        const int cnt = __popc(mask);
-        int pos = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const int v = __shfl_up(pos, off, 64);
-          if (lane >= off) pos += v;
-        }
-        const int nterms = __shfl(pos, 63, 64);
-        pos -= cnt;
-        for (int lo = 0; lo < nterms; lo += FORCE_TERMS_CAP) {  // wave-uniform
-          __syncthreads();  // the previous batch has been consumed (one-wave workgroup: cheap)
-          int p = pos;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            if (mask & (1u << q)) {
-              if (p >= lo && p < lo + FORCE_TERMS_CAP) {
-                double* t = &sT[(p - lo) * 4];
-                t[0] = fx[q];
-                t[1] = fy[q];
-                t[2] = fx[q] * (-wy);
-                t[3] = fy[q] * wx;
-              }
-              ++p;
-            }
-          }
-          const int nb = nterms - lo < FORCE_TERMS_CAP ? nterms - lo : FORCE_TERMS_CAP;
-          // pad the batch to a multiple of 8 with zero terms: (h + 0.0) + 0.0 == h exactly
-          const int nb8 = (nb + 7) & ~7;
-          if (lane < 4 * (nb8 - nb)) sT[nb * 4 + lane] = 0.0;
-          __syncthreads();
-          if (lane < 3) {
-            const int b_off = lane == 2 ? 3 : -1;
-            for (int t = 0; t < nb8; t += 8) {
-              double a[8], b[8];
-#pragma unroll
-              for (int u = 0; u < 8; ++u) {  // loads do not depend on h: issue them ahead of the chain
-                a[u] = sT[(t + u) * 4 + a_off];
-                b[u] = sT[b_off >= 0 ? (t + u) * 4 + b_off : zero_slot];
-              }
-#pragma unroll
-              for (int u = 0; u < 8; ++u) h = (h + a[u]) + b[u];
-            }
-          }
-        }
-      }
-      __syncthreads();
-      nbn = 0;
-      if (last) break;
-    }
-  }
+  if (own && grain_box(L, G, i, xi, xf, yi, yf)) h = force_gather(sh, f, obst, L, i, xc, yc, xi, xf, yi, yf, lane);
   if (lane == 0 && owner) owner[i] = own ? 1 : 0;
   if (lane < 3) fhf[lane * L.n + i] = own ? h * (lane == 2 ? scale3 : scale12) : 0.0;
+}
+
+// The same sums from the ForceSlots table the fused kernel filled while it evaluated the bounce-back links, without
+// touching the lattice. One wavefront serves GW grains.
+//
+// Phase A, per grain, all lanes. For a grain whose disc overlaps no other disc (rasteriser flag) and is not cut by
+// the lattice-edge clamp, the grain's nodes are exactly those passing the paint test, so every lattice line
+// parallel to a direction e that meets the disc carries exactly two boundary links: from its last in-disc node
+// forwards (direction q(e)) and from its first in-disc node backwards (the opposite direction). One lane takes
+// one line: the chord ends come from the line/circle intersection (one square root), then the exact paint test
+// around them decides. A slot must hold a sum iff that link exists -- an empty slot where the geometry has a
+// link means the link ends in a non-fluid node (another grain, a lattice-edge wall) or belongs to another
+// rank's rows: the grain is then GATHERED from obst and f like in k_forces_parity. The links are ranked in the
+// reference's scan order (x outer, y, q; main.c:1305-1309) through an LDS bitmap over (node, q), and the
+// addends of the three accumulators are stored in that order. Addends that are exact zeros by construction
+// (fnx of a vertical link, ...) are left out: h + (+-0.0) == h for the accumulators, which are never -0.0.
+// Phase B: lanes 3g, 3g+1, 3g+2 replay the additions of grain g's three accumulators (the serial part is
+// shared by the GW grains of the wave). The wave also resets the tables to empty for the next step.
+// PASSES = passes over the four line families: 2 when two families fit a wave (spd <= 32), else 4.
+struct DiscTest {
+  double xc, yc, R2, r2;
+  __device__ __forceinline__ bool in(int x, int y) const {  // the paint test of k_obst_paint (main.c:1024-1028)
+    const double d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc);
+    return d2 <= R2 && d2 <= r2;
+  }
+};
+
+constexpr unsigned long long M_DIAG = 0x5555555555555555ull;  // bits of q = 1, 3, 5, 7 in a bitmap word
+constexpr unsigned long long M_XDIR = 0x2222222222222222ull;  // q = 2, 6 (ey = 0)
+constexpr unsigned long long M_YDIR = 0x8888888888888888ull;  // q = 4, 8 (ex = 0)
+
+template <int GW, int PASSES>
+__global__ __launch_bounds__(64) void k_forces_table(const double* __restrict__ f, const int* __restrict__ obst,
+                                                     LatticeView L, GrainFluidView G, ForceSlots S, int cap1, int cap3,
+                                                     int nw64, double scale12, double scale3,
+                                                     double* __restrict__ fhf, unsigned char* __restrict__ owner) {
+  extern __shared__ double sDyn[];
+  // per grain: addends of fhf1 [cap1] | fhf2 [cap1] | fhf3 [cap3]
+  // then the bitmap [nw64] and the three per-word prefix counts [3][nw64]
+  const int per_grain = 2 * cap1 + cap3;
+  const size_t lists_doubles = (size_t)GW * per_grain;
+  unsigned long long* const bm = reinterpret_cast<unsigned long long*>(sDyn + lists_doubles);
+  int* const pw = reinterpret_cast<int*>(bm + nw64);
+  const int lane = threadIdx.x;
+  const int g0 = blockIdx.x * GW;
+  const int spd = S.spd, HB = S.hb;
+  const int B = 2 * HB + 1;
+  constexpr int FPP = 4 / PASSES;   // line families per pass
+  constexpr int LPF = 64 / FPP;     // lanes per family
+  const int rel = lane & (LPF - 1);
+  const bool lane_has_line = rel < spd;
+  const int c = rel - S.half;       // slot_line() of this lane's line for the family's forward direction
+
+  // line families: direction e, its q, the opposite q
+  auto fam_ex = [](int fm) { return fm == 1 ? 0 : 1; };                  // (1,0) (0,1) (1,1) (1,-1)
+  auto fam_ey = [](int fm) { return fm == 0 ? 0 : (fm == 3 ? -1 : 1); };
+  auto fam_q = [](int fm) { return fm == 0 ? 6 : (fm == 1 ? 8 : (fm == 2 ? 7 : 5)); };
+
+  unsigned long long fw[GW][PASSES], bw[GW][PASSES];  // slots of the forward / backward link of the lane's lines
+  int n1[GW], n2[GW], n3[GW];                           // addends per accumulator; n1 < 0: gather
+  bool own[GW];
+  // ---- tables of all GW grains: fetch, reset (one round of global latency for the whole wave)
+#pragma unroll
+  for (int g = 0; g < GW; ++g) {
+    const int i = g0 + g;
+    bool local = false;
+    if (i < L.n) {
+      const double xc = G.xc[i], rbl0 = G.rbl0[i];
+      local = xc + rbl0 + 2.0 >= (double)L.gx0 && xc - rbl0 - 2.0 <= (double)(L.gx0 + L.nxl);
+    }
+    unsigned long long* tg = reinterpret_cast<unsigned long long*>(S.tab) + (long)(i < L.n ? i : 0) * 8 * spd;
+#pragma unroll
+    for (int j = 0; j < PASSES; ++j) {
+      const int fm = j * FPP + lane / LPF;
+      const int q = fam_q(fm), qo = q - 4;
+      fw[g][j] = bw[g][j] = LBMDEM_SLOT_EMPTY;
+      if (local && lane_has_line) {
+        const int kf = (q - 1) * spd + rel;
+        fw[g][j] = tg[kf];
+        tg[kf] = LBMDEM_SLOT_EMPTY;
+        const int rb = S.half - c;  // the same line seen from the opposite direction
+        if (rb >= 0 && rb < spd) {
+          const int kb = (qo - 1) * spd + rb;
+          bw[g][j] = tg[kb];
+          tg[kb] = LBMDEM_SLOT_EMPTY;
+        }
+      }
+    }
+  }
+  // ---- phase A
+#pragma unroll
+  for (int g = 0; g < GW; ++g) {
+    const int i = g0 + g;
+    n1[g] = n2[g] = n3[g] = 0;
+    own[g] = false;
+    if (i >= L.n) continue;
+    const double xc = G.xc[i], yc = G.yc[i], rbl0 = G.rbl0[i], r2 = G.r2[i];
+    own[g] = grain_owned(L, xc);
+    const bool was_touched = S.touched[i] != 0;
+    if (was_touched && lane == 0) S.touched[i] = 0;  // the rasteriser sets it again while it applies
+    int xi, xf, yi, yf;
+    if (!own[g] || !grain_box(L, G, i, xi, xf, yi, yf)) continue;
+    // the clamp of the paint box to [1, l-2] must not cut the reduced disc: centre at least rLB (+ a margin) inside
+    const double m_lo_x = xc - 1.000001, m_hi_x = (double)(L.lx - 2) - 0.000001 - xc;
+    const double m_lo_y = yc - 1.000001, m_hi_y = (double)(L.ly - 2) - 0.000001 - yc;
+    const double m_min = fmin(fmin(m_lo_x, m_hi_x), fmin(m_lo_y, m_hi_y));
+    const bool unclamped = m_min > 0.0 && m_min * m_min >= r2;
+    if (was_touched || !unclamped) { n1[g] = -1; continue; }
+    const DiscTest D{xc, yc, rbl0 * rbl0, r2};
+    const int X0 = (int)xc, Y0 = (int)yc;
+    for (int w = lane; w < nw64; w += 64) bm[w] = 0ull;
+    __builtin_amdgcn_wave_barrier();
+    bool bad = false;
+    int keyf[PASSES], keyb[PASSES];  // -1: no link; else ((bx * B + by) * 8 + q - 1) | bx << 20 | by << 26
+#pragma unroll
+    for (int j = 0; j < PASSES; ++j) {
+      const int fm = j * FPP + lane / LPF;
+      const int ex = fam_ex(fm), ey = fam_ey(fm), q = fam_q(fm);
+      // a node of the line slot_line() == c, and the line's nodes: (px0 + m ex, py0 + m ey)
+      const int px0 = X0 + ey * c, py0 = Y0 - (ey == 0 ? ex * c : 0);
+      const double ax = px0 - xc, ay = py0 - yc;
+      const double inv_ee = (ex != 0 && ey != 0) ? 0.5 : 1.0;
+      const double ee = (ex != 0 && ey != 0) ? 2.0 : 1.0;
+      const double be = ax * ex + ay * ey;
+      double disc = be * be - ee * (ax * ax + ay * ay - r2);
+      const bool far = disc < -4.0;
+      if (disc < 0.0) disc = 0.0;
+      const double sq = sqrt(disc);
+      const double mf = (sq - be) * inv_ee, mb = (-sq - be) * inv_ee;  // chord ends, in steps of e
+      const double ff = floor(mf), cb = ceil(mb);
+      // a chord end within rounding distance of a lattice node: let the gather path decide
+      const bool shaky = (mf - ff < 1e-7) || (ff + 1.0 - mf < 1e-7) || (cb - mb < 1e-7) || (mb - (cb - 1.0) < 1e-7);
+      const int kf = (int)ff, kb = (int)cb;
+      const bool f0 = D.in(px0 + kf * ex, py0 + kf * ey), f1 = D.in(px0 + (kf + 1) * ex, py0 + (kf + 1) * ey);
+      const bool b0 = D.in(px0 + kb * ex, py0 + kb * ey), b1 = D.in(px0 + (kb - 1) * ex, py0 + (kb - 1) * ey);
+      const bool has = f0 && !f1 && b0 && !b1 && kb <= kf;      // the line carries a chord of in-disc nodes
+      const bool none = !f0 && !f1 && !b0 && !b1;                // ... or none
+      const bool meets = has && !far && lane_has_line;
+      const bool ffill = fw[g][j] != LBMDEM_SLOT_EMPTY, bfill = bw[g][j] != LBMDEM_SLOT_EMPTY;
+      if (lane_has_line && !far && ((!has && !none) || (has && shaky))) bad = true;
+      if (meets != ffill || meets != bfill) bad = true;
+      keyf[j] = keyb[j] = -1;
+      if (meets) {
+        const int bxf = px0 + kf * ex - (X0 - HB), byf = py0 + kf * ey - (Y0 - HB);
+        const int bxb = px0 + kb * ex - (X0 - HB), byb = py0 + kb * ey - (Y0 - HB);
+        if (bxf < 0 || bxf >= B || byf < 0 || byf >= B || bxb < 0 || bxb >= B || byb < 0 || byb >= B) bad = true;
+        else {
+          const int kyf = (bxf * B + byf) * 8 + (q - 1);
+          const int kyb = (bxb * B + byb) * 8 + (q - 5);   // the opposite direction
+          atomicOr(&bm[kyf >> 6], 1ull << (kyf & 63));
+          atomicOr(&bm[kyb >> 6], 1ull << (kyb & 63));
+          keyf[j] = kyf | (bxf << 20) | (byf << 26);        // B <= 63, B * B * 8 < 2^20
+          keyb[j] = kyb | (bxb << 20) | (byb << 26);
+        }
+      }
+    }
+    if (__any(bad)) { n1[g] = -1; continue; }
+    __builtin_amdgcn_wave_barrier();
+    // per-word exclusive prefixes of the three addend counts
+    {
+      const int wpl = (nw64 + 63) >> 6;  // words per lane, contiguous
+      int cd = 0, cx = 0, cy = 0;
+      for (int u = 0; u < wpl; ++u) {
+        const int w = lane * wpl + u;
+        if (w < nw64) {
+          const unsigned long long v = bm[w];
+          cd += __popcll(v & M_DIAG); cx += __popcll(v & M_XDIR); cy += __popcll(v & M_YDIR);
+        }
+      }
+      // one scan for the three counts: 10 bits each (a grain has < 1024 addends per accumulator: cap3 check below)
+      const int mine3 = (cd + cx) | ((cd + cy) << 10) | ((2 * cd + cx + cy) << 20);
+      int incl = mine3;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+      }
+      const int excl = incl - mine3;
+      int r1 = excl & 1023, r2_ = (excl >> 10) & 1023, r3 = (excl >> 20) & 1023;
+      const int tot = __shfl(incl, 63, 64);
+      for (int u = 0; u < wpl; ++u) {
+        const int w = lane * wpl + u;
+        if (w < nw64) {
+          const unsigned long long v = bm[w];
+          pw[w] = r1; pw[nw64 + w] = r2_; pw[2 * nw64 + w] = r3;
+          const int d = __popcll(v & M_DIAG), x = __popcll(v & M_XDIR), y = __popcll(v & M_YDIR);
+          r1 += d + x; r2_ += d + y; r3 += 2 * d + x + y;
+        }
+      }
+      n1[g] = tot & 1023; n2[g] = (tot >> 10) & 1023; n3[g] = (tot >> 20) & 1023;
+    }
+    if (n1[g] > cap1 || n2[g] > cap1 || n3[g] > cap3) { n1[g] = -1; continue; }
+    __builtin_amdgcn_wave_barrier();
+    double* const l1 = sDyn + (size_t)g * per_grain;
+    double* const l2 = l1 + cap1;
+    double* const l3 = l2 + cap1;
+    auto emit = [&](int keyp, unsigned long long slot) {
+      const int key = keyp & 0xFFFFF;
+      const int q = (key & 7) + 1;
+      const int x = X0 - HB + ((keyp >> 20) & 63), y = Y0 - HB + ((keyp >> 26) & 63);
+      const int w = key >> 6;
+      const unsigned long long below = bm[w] & ((1ull << (key & 63)) - 1ull);
+      const int bd = __popcll(below & M_DIAG), bx = __popcll(below & M_XDIR), by = __popcll(below & M_YDIR);
+      const int r1 = pw[w] + bd + bx, r2_ = pw[nw64 + w] + bd + by, r3 = pw[2 * nw64 + w] + 2 * bd + bx + by;
+      const int qo = q <= 4 ? q + 4 : q - 4;
+      const int exo = (qo >= 1 && qo <= 3) ? -1 : ((qo >= 5 && qo <= 7) ? 1 : 0);
+      const int eyo = (qo == 1 || qo >= 7) ? 1 : ((qo >= 3 && qo <= 5) ? -1 : 0);
+      const double sum = __longlong_as_double((long long)slot);
+      const double fnx = sum * exo, fny = sum * eyo;  // main.c:1315-1316
+      const double wx = x - xc, wy = y - yc;
+      int r3b = r3;
+      if (exo != 0) { l1[r1] = fnx; l3[r3b++] = fnx * (-wy); }   // - fnx * (y - yc)
+      if (eyo != 0) { l2[r2_] = fny; l3[r3b] = fny * wx; }        // + fny * (x - xc)
+    };
+#pragma unroll
+    for (int j = 0; j < PASSES; ++j) {
+      if (keyf[j] >= 0) {
+        emit(keyf[j], fw[g][j]);
+        emit(keyb[j], bw[g][j]);
+      }
+    }
+    // pad every list to a multiple of 8 addends with zeros
+    if (lane < 8) {
+      if (n1[g] + lane < ((n1[g] + 7) & ~7)) l1[n1[g] + lane] = 0.0;
+      if (n2[g] + lane < ((n2[g] + 7) & ~7)) l2[n2[g] + lane] = 0.0;
+      if (n3[g] + lane < ((n3[g] + 7) & ~7)) l3[n3[g] + lane] = 0.0;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- phase B: lane 3g + a replays accumulator a of grain g
+  {
+    const int g = lane / 3, a = lane - 3 * g;
+    int mine = 0, longest = 0;
+    bool replayed = false, mine_own = false;
+#pragma unroll
+    for (int gg = 0; gg < GW; ++gg) {
+      const int na = a == 0 ? n1[gg] : (a == 1 ? n2[gg] : n3[gg]);
+      if (gg == g) {
+        replayed = n1[gg] >= 0;
+        mine_own = own[gg];
+        if (replayed) mine = (na + 7) & ~7;
+      }
+      if (n1[gg] >= 0 && n3[gg] > longest) longest = n3[gg];  // fhf3 has the longest list
+    }
+    longest = (longest + 7) & ~7;
+    const double* tl = sDyn + (size_t)(g < GW ? g : 0) * per_grain + (a == 0 ? 0 : (a == 1 ? cap1 : 2 * cap1));
+    double h = 0.0;
+    for (int t = 0; t < longest; t += 8) {  // wave-uniform trip count
+      if (t < mine) {
+        double2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const double2*>(tl + t)[u];  // issued ahead of the chain
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { h = h + v[u].x; h = h + v[u].y; }
+      }
+    }
+    if (g < GW && g0 + g < L.n && replayed)
+      fhf[a * L.n + g0 + g] = mine_own ? h * (a == 2 ? scale3 : scale12) : 0.0;
+  }
+  // ---- the grains the table could not serve go to the queue of the gather kernel that follows
+#pragma unroll
+  for (int g = 0; g < GW; ++g) {
+    const int i = g0 + g;
+    if (i < L.n && lane == 0) {
+      if (owner) owner[i] = own[g] ? 1 : 0;
+      if (n1[g] < 0) S.queue[atomicAdd(S.gathered, 1)] = i;
+    }
+  }
+}
+
+// The queued grains, gathered from obst and f: one wavefront per grain, a fixed grid strides over the queue.
+__global__ __launch_bounds__(64) void k_forces_gather_queue(const double* __restrict__ f, const int* __restrict__ obst,
+                                                            LatticeView L, GrainFluidView G, ForceSlots S,
+                                                            double scale12, double scale3, double* __restrict__ fhf) {
+  __shared__ ForceLds sh;
+  const int lane = threadIdx.x;
+  const int count = *S.gathered;
+  if (lane == 0) sh.sT[FORCE_TERMS_CAP * 4] = 0.0;
+  for (int k = blockIdx.x; k < count; k += gridDim.x) {  // wave-uniform
+    const int i = S.queue[k];
+    int xi, xf, yi, yf;
+    grain_box(L, G, i, xi, xf, yi, yf);
+    const double h = force_gather(sh, f, obst, L, i, G.xc[i], G.yc[i], xi, xf, yi, yf, lane);
+    if (lane < 3) fhf[lane * L.n + i] = h * (lane == 2 ? scale3 : scale12);
+  }
 }
 
 // Fast kernel: one wavefront per grain, lanes take bounding-box nodes, cross-lane shuffle reduction.
@@ -1298,10 +1645,16 @@ void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st) {
 
 void launch_obst_paint(int* obst, const LatticeView& L, int n, const double* x1, const double* x2, const double* r,
                        const double* rLB, const double* v1, const double* v2, const double* v3, double* xc,
-                       double* yc, double* r2, double* rbl0, double* pk, hipStream_t st) {
+                       double* yc, double* r2, double* rbl0, double* pk, unsigned char* touched, hipStream_t st) {
   const long threads = (long)n * 64;
   hipLaunchKernelGGL(k_obst_paint, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, obst, L, n, x1, x2, r,
-                     rLB, v1, v2, v3, xc, yc, r2, rbl0, pk);
+                     rLB, v1, v2, v3, xc, yc, r2, rbl0, pk, touched);
+}
+
+void launch_slots_clear(const ForceSlots& S, int n, hipStream_t st) {
+  const long count = (long)n * 8 * S.spd;
+  hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(count)), dim3(256), 0, st, reinterpret_cast<unsigned long long*>(S.tab),
+                     count, (unsigned long long)LBMDEM_SLOT_EMPTY);
 }
 
 template <int TX, int TY>
@@ -1315,7 +1668,8 @@ static void launch_cs(const double* fin, double* fout, const int* obst_old, cons
                      L, G, tiles_y, ntiles, remap);
 }
 
-// tuning knob for experiments: LBMDEM_CS_VARIANT = tile shape (0..3) + 8 * xcd_remap
+#ifdef LBMDEM_AB
+// A/B builds only (make AB=1): LBMDEM_CS_VARIANT = kernel shape + 8 * xcd_remap
 static int cs_variant() {
   static int v = -1;
   if (v < 0) {
@@ -1324,61 +1678,106 @@ static int cs_variant() {
   }
   return v;
 }
+#endif
 
 template <int LX, int MINW, int WW = 62>
 static void launch_march(const double* fin, double* fout, const int* obst_old, const int* obst_new,
-                         const LatticeView& L, const GrainFluidView& G, int remap, hipStream_t st) {
+                         const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, int remap,
+                         hipStream_t st) {
   const int rows = L.xo1 - L.xo0;
   const int nstrips = (L.ly + WW - 1) / WW;
   int seg_rows = LX;
   if (LX == 0) {
-    // run-time segment length: LBMDEM_CS_ROWS, or one balanced round: 256 CUs x 2 workgroups x 4 waves are
-    // resident (VGPR- and LDS-limited); give every y-strip the same number of equal x-segments
+    // run-time segment length: one balanced round: 256 CUs x 2 workgroups x 4 waves are resident (VGPR- and
+    // LDS-limited); give every y-strip the same number of equal x-segments
+    const int resident = 256 * 2 * 4;
+    int nseg = resident / nstrips;
+    if (nseg < 1) nseg = 1;
+    seg_rows = (rows + nseg - 1) / nseg;
+    if (seg_rows < 8) seg_rows = 8;
+#ifdef LBMDEM_AB
     static const int env_rows = getenv("LBMDEM_CS_ROWS") ? atoi(getenv("LBMDEM_CS_ROWS")) : 0;
-    if (env_rows > 0) {
-      seg_rows = env_rows;
-    } else {
-      const int resident = 256 * 2 * 4;
-      int nseg = resident / nstrips;
-      if (nseg < 1) nseg = 1;
-      seg_rows = (rows + nseg - 1) / nseg;
-      if (seg_rows < 8) seg_rows = 8;
-    }
+    if (env_rows > 0) seg_rows = env_rows;
+#endif
   }
   const int nseg = (rows + seg_rows - 1) / seg_rows;
   const int nwork = nstrips * nseg;
   int grid = (nwork + 3) / 4;
   if (remap) grid = ((grid + 7) / 8) * 8;
   hipLaunchKernelGGL((k_cs_march<LX, MINW, WW>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, L, G,
-                     nstrips, nwork, remap, seg_rows);
+                     S, nstrips, nwork, remap, seg_rows);
 }
 
+// The marching kernel assumes reductionR < 1 (always true in the reference); other configurations run the
+// LDS-tile kernel, which does not fill the slot table.
+bool collide_stream_fills_slots(const LatticeView& L) { return L.reduced_lt1 != 0; }
+
 void launch_collide_stream(const double* fin, double* fout, const int* obst_old, const int* obst_new,
-                           const LatticeView& L, const GrainFluidView& G, hipStream_t st) {
+                           const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, hipStream_t st) {
+#ifdef LBMDEM_AB
   int v = cs_variant();
   const int remap = (v >> 3) & 1;
-  if (!L.reduced_lt1 && (v & ~8) >= 16) v = 1;  // marching kernel assumes reductionR < 1
+  if (!L.reduced_lt1 && (v & ~8) >= 16) v = 1;
   switch (v & ~8) {
-    case 0: launch_cs<8, 64>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
-    case 1: launch_cs<4, 64>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
-    case 2: launch_cs<4, 128>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
-    case 3: launch_cs<2, 128>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
-    case 4: launch_cs<16, 32>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
-    case 16: launch_march<16, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
-    case 17: launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
-    case 18: launch_march<8, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
-    case 19: launch_march<64, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
-    case 20: launch_march<0, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;  // one balanced round
-    case 21: launch_march<32, 2, 56>(fin, fout, obst_old, obst_new, L, G, remap, st); break;  // stores start on 64-byte boundaries
-    case 22: launch_march<32, 2, 48>(fin, fout, obst_old, obst_new, L, G, remap, st); break;  // ... on 128-byte boundaries
-    default: launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, remap, st); break;
+    case 0: launch_cs<8, 64>(fin, fout, obst_old, obst_new, L, G, remap, st); return;
+    case 1: launch_cs<4, 64>(fin, fout, obst_old, obst_new, L, G, remap, st); return;
+    case 2: launch_cs<4, 128>(fin, fout, obst_old, obst_new, L, G, remap, st); return;
+    case 16: launch_march<16, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;
+    case 19: launch_march<64, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;
+    case 20: launch_march<0, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;  // one balanced round
+    case 21: launch_march<32, 2, 56>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;  // 64-byte aligned stores
+    default: launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;
   }
+#else
+  if (L.reduced_lt1) launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, S, /*xcd remap*/ 1, st);
+  else launch_cs<4, 64>(fin, fout, obst_old, obst_new, L, G, 0, st);
+#endif
 }
 
 void launch_forces_parity(const double* f, const int* obst, const LatticeView& L,
                           const GrainFluidView& G, double scale12, double scale3, double* fhf,
                           unsigned char* owner, hipStream_t st) {
   hipLaunchKernelGGL(k_forces_parity, dim3(L.n), dim3(64), 0, st, f, obst, L, G, scale12, scale3, fhf, owner);
+}
+
+template <int GW, int PASSES>
+static void launch_forces_table_t(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
+                                  const ForceSlots& S, double scale12, double scale3, double* fhf, unsigned char* owner,
+                                  hipStream_t st) {
+  const int HB = S.hb, B = 2 * HB + 1;
+  const int nw64 = (B * B * 8 + 63) / 64;
+  // addends per accumulator: one link per direction and lattice line meeting the disc (<= spd lines for the
+  // diagonal families, <= 2 hb + 1 for the axis families); fhf3 takes two addends per diagonal link
+  const int cap1 = (4 * S.spd + 2 * B + 7) & ~7, cap3 = (8 * S.spd + 4 * B + 7) & ~7;
+  const size_t lists_doubles = (size_t)GW * (2 * cap1 + cap3);
+  const size_t lds = lists_doubles * 8 + (size_t)nw64 * 8 + (size_t)nw64 * 12;
+  hipLaunchKernelGGL((k_forces_table<GW, PASSES>), dim3((L.n + GW - 1) / GW), dim3(64), lds, st, f, obst, L, G, S, cap1,
+                     cap3, nw64, scale12, scale3, fhf, owner);
+  const int grid = L.n < 2048 ? L.n : 2048;
+  hipLaunchKernelGGL(k_forces_gather_queue, dim3(grid), dim3(64), 0, st, f, obst, L, G, S, scale12, scale3, fhf);
+}
+
+void launch_forces_slots(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
+                         const ForceSlots& S, double scale12, double scale3, double* fhf, unsigned char* owner,
+                         hipStream_t st) {
+#ifdef LBMDEM_AB
+  static const int gw = getenv("LBMDEM_FORCE_GW") ? atoi(getenv("LBMDEM_FORCE_GW")) : 3;
+#else
+  const int gw = 3;
+#endif
+  if (S.spd <= 32) {
+    switch (gw) {
+#ifdef LBMDEM_AB
+      case 1: launch_forces_table_t<1, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, st); break;
+      case 2: launch_forces_table_t<2, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, st); break;
+      case 4: launch_forces_table_t<4, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, st); break;
+      case 6: launch_forces_table_t<6, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, st); break;
+#endif
+      default: launch_forces_table_t<3, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, st); break;
+    }
+  } else {
+    launch_forces_table_t<2, 4>(f, obst, L, G, S, scale12, scale3, fhf, owner, st);
+  }
 }
 
 void launch_forces_fast(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,

@@ -55,6 +55,7 @@ struct lbmdem_handle {
   const double* cs_fin = nullptr;
   const int *cs_ob_old = nullptr, *cs_ob_new = nullptr;
   int cs_lo_end = 0, cs_hi_begin = 0;  // interior = local rows [cs_lo_end, cs_hi_begin)
+  ForceSlots cs_slots{nullptr, nullptr, 0, 0, 0, nullptr, nullptr};
   // grains
   int n = 0;
   double* gbuf = nullptr;  // one allocation, carved below
@@ -71,6 +72,11 @@ struct lbmdem_handle {
   bool diag_valid = false; // the last sub-step produced diagnostics
   double* fhf = nullptr;  // [3][n]
   unsigned char* owner = nullptr;
+  // link sums handed from the fused kernel to the force kernel (ForceSlots, lbmdem_internal.h)
+  ForceSlots fs{nullptr, nullptr, 0, 0, 0, nullptr, nullptr};
+  bool slots_clean = false;  // every slot is empty
+  bool last_forces_from_table = false;
+  bool slots_valid = false;  // the table was filled by the collide_stream that produced f[fcur] with the current map
   double rmax = 0.0;
   VerletDevice V{};
   bool verlet_ok = false;
@@ -193,7 +199,8 @@ static int paint_into(lbmdem_handle* h, int* obst) {
   const Kin& K = h->kin[h->kcur];
   launch_obst_fill(obst, h->L, h->stream);
   launch_obst_paint(obst, h->L, h->n, K.x1, K.x2, h->r, h->rLB, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0, h->pk,
-                    h->stream);
+                    h->fs.touched, h->stream);
+  h->slots_valid = false;  // the grain geometry the table is indexed with has changed
   HIP_TRY(hipGetLastError());
   return LBMDEM_OK;
 }
@@ -243,13 +250,18 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
     const double cc = cfg->c * cfg->c;
     L.rc = 1.0 / cfg->c;
     L.rcc = 1.0 / cc;
+    L.cc = cc;
+    L.wc_diag = (1. / 36) / cfg->c;
+    L.wc_axis = (1. / 9) / cfg->c;
     auto all_ones = [](double v) {
       uint64_t b;
       memcpy(&b, &v, sizeof b);
       return (b & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull;
     };
     L.recip_ok = (!all_ones(cfg->c) && !all_ones(cc) && cfg->c > 1e-4 && cfg->c < 1e4) ? 1 : 0;
+#ifdef LBMDEM_AB
     if (const char* e = getenv("LBMDEM_TRUE_DIVISIONS")) if (atoi(e)) L.recip_ok = 0;  // A/B switch
+#endif
   }
   // force scaling, main.c:1329-1331
   h->fscale12 = p.rho_moy * 9 * p.nu * p.nu / (cfg->dx * (p.tau - 0.5) * (p.tau - 0.5));
@@ -293,7 +305,29 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
     h->diag = p0 + 20 * (size_t)n;
   }
   CREATE_TRY(hipMalloc((void**)&h->owner, n));
-  CREATE_TRY(hipMemset(h->owner, 1, n));
+  CREATE_TRY(hipMemsetAsync(h->owner, 1, n, h->stream));
+  CREATE_TRY(hipMalloc((void**)&h->fs.queue, sizeof(int) * n));
+  CREATE_TRY(hipMalloc((void**)&h->fs.gathered, sizeof(int)));
+  CREATE_TRY(hipMemsetAsync(h->fs.gathered, 0, sizeof(int), h->stream));
+  CREATE_TRY(hipMalloc((void**)&h->fs.touched, n));
+  CREATE_TRY(hipMemsetAsync(h->fs.touched, 0, n, h->stream));
+  {
+    // lattice lines through a reduced disc, any direction: |ey dx - ex dy| <= sqrt(2) rLB, +2 for the truncated centre
+    const int half = (int)ceil(1.4143 * p.reductionR * rmax / cfg->dx) + 2;
+    const int spd = (2 * half + 1 + 3) & ~3;
+    bool want = spd <= LBMDEM_SPD_MAX && collide_stream_fills_slots(L);
+#ifdef LBMDEM_AB
+    if (const char* e = getenv("LBMDEM_NO_SLOTS")) if (atoi(e)) want = false;  // A/B: forces gathered from the lattice
+#endif
+    if (want) {
+      h->fs.half = half;
+      h->fs.spd = spd;
+      h->fs.hb = (int)ceil(p.reductionR * rmax / cfg->dx) + 1;
+      CREATE_TRY(hipMalloc((void**)&h->fs.tab, sizeof(double) * 8 * (size_t)spd * n));
+      launch_slots_clear(h->fs, n, h->stream);
+      h->slots_clean = true;
+    }
+  }
   CREATE_TRY(hipMalloc((void**)&h->dpartial, sizeof(double) * 1024));
   {
     // per-grain constants on the host, reference arithmetic: main.c:624-626, 1859
@@ -347,6 +381,10 @@ int lbmdem_destroy(lbmdem_handle* h) {
   }
   if (h->gbuf) (void)hipFree(h->gbuf);
   if (h->owner) (void)hipFree(h->owner);
+  if (h->fs.touched) (void)hipFree(h->fs.touched);
+  if (h->fs.tab) (void)hipFree(h->fs.tab);
+  if (h->fs.gathered) (void)hipFree(h->fs.gathered);
+  if (h->fs.queue) (void)hipFree(h->fs.queue);
   if (h->dpartial) (void)hipFree(h->dpartial);
   verlet_free(h->V);
   diag_extra_free(h->dx);
@@ -365,6 +403,18 @@ int lbmdem_obst_construction(lbmdem_handle* h) {
   int rc = paint_into(h, h->obst[1 - h->ocur]);
   if (rc == LBMDEM_OK) h->obst_pending = true;
   return rc;
+}
+
+// The slot table the next fused-kernel launch fills (tab == nullptr: none, e.g. the fast force kernel does not
+// read it). A table that still holds sums nobody consumed is emptied first.
+static ForceSlots slots_for_launch(lbmdem_handle* h) {
+  ForceSlots S = h->fs;
+  if (h->force_mode != 0) S.tab = nullptr;
+  if (S.tab) {
+    if (!h->slots_clean) launch_slots_clear(h->fs, h->n, h->stream);
+    h->slots_clean = false;
+  }
+  return S;
 }
 
 static int prof_begin(lbmdem_handle* h, hipEvent_t* e1) {
@@ -393,8 +443,9 @@ int lbmdem_collide_stream(lbmdem_handle* h) try {
   hipEvent_t e1 = nullptr;
   int rc = prof_begin(h, &e1);
   if (rc != LBMDEM_OK) return rc;
-  launch_collide_stream(h->f[h->fcur], h->f[1 - h->fcur], ob_old, ob_new, h->L, gview(h), h->stream);
+  launch_collide_stream(h->f[h->fcur], h->f[1 - h->fcur], ob_old, ob_new, h->L, gview(h), slots_for_launch(h), h->stream);
   if (e1) HIP_TRY(hipEventRecord(e1, h->stream));
+  h->slots_valid = h->fs.tab != nullptr && h->force_mode == 0;
   HIP_TRY(hipGetLastError());
   h->fcur = 1 - h->fcur;
   if (h->obst_pending) { h->ocur = 1 - h->ocur; h->obst_pending = false; }
@@ -424,13 +475,14 @@ int lbmdem_collide_stream_part(lbmdem_handle* h, int part) try {
     int rc = prof_begin(h, &e1);
     if (rc != LBMDEM_OK) return rc;
     LatticeView Ls = L;
+    h->cs_slots = slots_for_launch(h);
     if (lo_end > L.xo0) {
       Ls.xo0 = L.xo0; Ls.xo1 = lo_end;
-      launch_collide_stream(h->cs_fin, h->f[1 - h->fcur], h->cs_ob_old, h->cs_ob_new, Ls, gview(h), h->stream);
+      launch_collide_stream(h->cs_fin, h->f[1 - h->fcur], h->cs_ob_old, h->cs_ob_new, Ls, gview(h), h->cs_slots, h->stream);
     }
     if (L.xo1 > hi_begin) {
       Ls.xo0 = hi_begin; Ls.xo1 = L.xo1;
-      launch_collide_stream(h->cs_fin, h->f[1 - h->fcur], h->cs_ob_old, h->cs_ob_new, Ls, gview(h), h->stream);
+      launch_collide_stream(h->cs_fin, h->f[1 - h->fcur], h->cs_ob_old, h->cs_ob_new, Ls, gview(h), h->cs_slots, h->stream);
     }
     HIP_TRY(hipGetLastError());
     h->fcur = 1 - h->fcur;
@@ -444,8 +496,9 @@ int lbmdem_collide_stream_part(lbmdem_handle* h, int part) try {
       LatticeView Ls = L;
       Ls.xo0 = h->cs_lo_end; Ls.xo1 = h->cs_hi_begin;
       // the grain records are those of EDGES: nothing moves the grains between the two parts
-      launch_collide_stream(h->cs_fin, h->f[h->fcur], h->cs_ob_old, h->cs_ob_new, Ls, gview(h), h->stream);
+      launch_collide_stream(h->cs_fin, h->f[h->fcur], h->cs_ob_old, h->cs_ob_new, Ls, gview(h), h->cs_slots, h->stream);
     }
+    h->slots_valid = h->cs_slots.tab != nullptr;
     if (h->prof && h->ev_used > 0) HIP_TRY(hipEventRecord(h->ev1[h->ev_used - 1], h->stream));
     HIP_TRY(hipGetLastError());
     h->cs_interior_pending = false;
@@ -462,11 +515,31 @@ int lbmdem_forces_fluid(lbmdem_handle* h) {
   CHECK_H(h);
   CHECK_NOT_SPLIT(h);
   const int* ob = h->obst_pending ? h->obst[1 - h->ocur] : h->obst[h->ocur];
-  if (h->force_mode == 0)
+  if (h->force_mode == 0 && h->slots_valid && !h->obst_pending) {
+    // the link sums were left in the slot table by the fused kernel; the kernel empties the table again
+    HIP_TRY(hipMemsetAsync(h->fs.gathered, 0, sizeof(int), h->stream));
+    launch_forces_slots(h->f[h->fcur], ob, h->L, gview(h), h->fs, h->fscale12, h->fscale3, h->fhf, h->owner, h->stream);
+    h->last_forces_from_table = true;
+    h->slots_valid = false;
+    h->slots_clean = true;
+  } else if (h->force_mode == 0) {
+    h->last_forces_from_table = false;
     launch_forces_parity(h->f[h->fcur], ob, h->L, gview(h), h->fscale12, h->fscale3, h->fhf, h->owner, h->stream);
-  else
+  } else
     launch_forces_fast(h->f[h->fcur], ob, h->L, gview(h), h->fscale12, h->fscale3, h->fhf, h->owner, h->stream);
   HIP_TRY(hipGetLastError());
+  return LBMDEM_OK;
+}
+
+int lbmdem_force_stats(lbmdem_handle* h, int* from_table, int* gathered) {
+  CHECK_H(h);
+  int g = h->n;
+  if (h->last_forces_from_table) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(&g, h->fs.gathered, sizeof(int), hipMemcpyDeviceToHost));
+  }
+  if (from_table) *from_table = h->last_forces_from_table ? h->n - g : 0;
+  if (gathered) *gathered = g;
   return LBMDEM_OK;
 }
 
@@ -563,6 +636,7 @@ int lbmdem_upload_f(lbmdem_handle* h, const double* f_aos) {
   double* tmp = nullptr;
   HIP_TRY(hipMalloc((void**)&tmp, sizeof(double) * cnt));
   hipError_t e = hipMemcpyAsync(tmp, f_aos + (size_t)L.gx0 * L.ly * 9, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream);
+  h->slots_valid = false;  // the populations the link sums were formed from are being replaced
   if (e == hipSuccess) { launch_aos_to_soa(tmp, h->f[h->fcur], L, h->stream); e = hipStreamSynchronize(h->stream); }
   (void)hipFree(tmp);
   HIP_TRY(e);

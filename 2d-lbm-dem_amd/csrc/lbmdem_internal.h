@@ -29,6 +29,8 @@ struct LatticeView {
   // recip_ok = 0 when a divisor's significand is all ones (the one case the construction does not cover)
   double rc, rcc;
   int recip_ok;
+  double cc;                 // c * c
+  double wc_diag, wc_axis;   // w_q / c for the diagonal and the axis directions (main.c:1174,1184)
 };
 
 // Grain state used by the fluid kernels. xc, yc, r2, rbl0 are the lattice-unit centre, squared
@@ -41,6 +43,26 @@ struct GrainFluidView {
   // record, fetched with four 16-byte loads by the fluid kernels
   const double* pk;
 };
+
+// Per-grain table of link momentum-exchange sums, written by the fused fluid kernel where it evaluates the
+// interpolated bounce-back links and consumed by the hydrodynamic-force kernel (main.c:1313-1316:
+// f[P][opp q] + f[N][q] of a link from solid node P of grain i to fluid node N = P + e_q).
+// tab[i][q - 1][rel]: the nodes of a reduced disc on one lattice line form one interval, so grain i has at most
+// ONE link of direction q into a fluid node per lattice line parallel to e_q; rel = c(P) - c(centre) + half with
+// c(x, y) = ey * x - ex * y numbers those lines (centre = the truncated lattice coordinates of the grain centre).
+// A slot holds LBMDEM_SLOT_EMPTY unless the fused kernel of this step wrote it. `touched[i]` = some node of grain
+// i's disc is also covered by another grain's disc (set by the rasteriser). tab == nullptr: feature off.
+struct ForceSlots {
+  double* tab;
+  unsigned char* touched;
+  int spd;   // slots per direction (2 * half + 1 rounded up)
+  int half;
+  int hb;    // >= largest reduced radius in nodes + 1: a grain's nodes lie within +-hb of its truncated centre
+  int* gathered;  // device counter: grains the table could not serve ...
+  int* queue;     // ... and their indices, for the gather kernel that follows
+};
+#define LBMDEM_SLOT_EMPTY 0x7FF8C0DE5107E117ull  /* a quiet NaN no arithmetic produces */
+constexpr int LBMDEM_SPD_MAX = 64;               // larger grains (reduced radius > ~20 nodes): feature off
 
 struct DemParams {
   int n;
@@ -67,9 +89,16 @@ void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st);
 // fills xc, yc, r2, rbl0, pk (per-grain lattice geometry, main.c:1009-1013) and paints the reduced discs
 void launch_obst_paint(int* obst, const LatticeView& L, int n, const double* x1, const double* x2, const double* r,
                        const double* rLB, const double* v1, const double* v2, const double* v3, double* xc,
-                       double* yc, double* r2, double* rbl0, double* pk, hipStream_t st);
+                       double* yc, double* r2, double* rbl0, double* pk, unsigned char* touched, hipStream_t st);
 void launch_collide_stream(const double* fin, double* fout, const int* obst_old, const int* obst_new,
-                           const LatticeView& L, const GrainFluidView& G, hipStream_t st);
+                           const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, hipStream_t st);
+// true when launch_collide_stream(..., S) with S.tab != nullptr fills the table (the marching kernel does)
+bool collide_stream_fills_slots(const LatticeView& L);
+void launch_slots_clear(const ForceSlots& S, int n, hipStream_t st);
+// parity forces from the slot table (resets it to empty); grains whose table is incomplete gather from f
+void launch_forces_slots(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
+                         const ForceSlots& S, double scale12, double scale3, double* fhf, unsigned char* owner,
+                         hipStream_t st);
 void launch_forces_parity(const double* f, const int* obst, const LatticeView& L,
                           const GrainFluidView& G, double scale12, double scale3, double* fhf,
                           unsigned char* owner, hipStream_t st);

@@ -91,6 +91,14 @@ int lbmdem_obst_construction(lbmdem_handle* h); /* main.c:991-1065 (obst only; a
 int lbmdem_collide_stream(lbmdem_handle* h);    /* main.c:966-986 + 1071-1243 */
 int lbmdem_forces_fluid(lbmdem_handle* h);      /* main.c:1285-1333 */
 
+/* Diagnostic for the parity force kernel: the fused collide_stream kernel leaves every bounce-back link's
+ * momentum-exchange sum (main.c:1313-1316) in a per-grain table, and forces_fluid replays them in the reference's
+ * order without touching the lattice; grains with a link that ends in a non-fluid node (another grain, a
+ * lattice-edge wall), with overlapping discs, or cut by a strip boundary are gathered from obst and f instead --
+ * same bits either way. Returns how many grains of the LAST forces_fluid call took each route (from_table = 0
+ * when the table did not describe the current lattice and every grain was gathered). Synchronises. */
+int lbmdem_force_stats(lbmdem_handle* h, int* from_table, int* gathered);
+
 /* initVerlet + VerletWall, main.c:1519-1594 (same pair set; uniform grid + radix sort instead of
  * the O(N^2) scan). Also moves the right/top DEM walls as VerletWall does (main.c:1555-1561). */
 int lbmdem_verlet_rebuild(lbmdem_handle* h);

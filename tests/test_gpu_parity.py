@@ -144,6 +144,7 @@ def test_grains_touching_lattice_edges(pkg, po):
     sim.kinematics = k; ora.set_kinematics(k); sim.f = f0; ora.set_f(f0)
     for _ in range(4):
         sim.lbm_step(); ora.lbm_steps(1)
+    assert sim.force_stats() == (0, 5)     # every grain is cut by the lattice-edge clamp: all gathered
     assert np.array_equal(sim.obst, ora.get_obst())
     assert np.array_equal(sim.f, ora.get_f())
     assert np.array_equal(sim.fhf, ora.get_fhf())
@@ -268,32 +269,60 @@ def test_large_grains_take_the_unstaged_force_path(pkg, po):
     assert np.array_equal(sim.fhf, ora.get_fhf())
 
 
-def test_every_fused_kernel_variant_is_bit_exact(pkg, po):
-    """The LDS-tile kernel (kept as the fallback for reductionR >= 1) and the marching kernel at
-    several segment lengths, selected through LBMDEM_CS_VARIANT, in fresh processes."""
-    import os, subprocess, sys
-    code = r'''
-import sys, numpy as np
-sys.path[:0] = [%r, %r, %r]
-import __graft_entry__ as ge, pyoracle as po, samples
-pkg = ge.load_package()
-lx, ly = 200, 130
-r, x, y = samples.row_packing(lx, ly, 80, seed=3); r, x1, x2 = samples.to_metres(r, x, y)
-sim = pkg.LbmDem(lx, ly, r, x1, x2); ora = po.Oracle(lx, ly, r, x1, x2)
-rng = np.random.default_rng(1)
-k = np.zeros((len(r), 9)); k[:, 0], k[:, 1] = x1, x2; k[:, 3:6] = rng.normal(0, 1, (len(r), 3)) * [0.03, 0.03, 20.0]
-sim.kinematics = k; ora.set_kinematics(k)
-n = 3 * sim.cfg.npDEM + 1
-sim.renderScene(n); ora.steps(n)
-assert np.array_equal(sim.f, ora.get_f()) and np.array_equal(sim.kinematics, ora.get_grains()[:, :9])
-print("ok")
-''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-       os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"),
-       os.path.dirname(os.path.abspath(__file__)))
-    for variant in ("1", "9", "0", "16", "24", "17", "25", "18", "19"):
-        env = dict(os.environ, LBMDEM_CS_VARIANT=variant)
-        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
-        assert out.returncode == 0 and "ok" in out.stdout, (variant, out.stdout[-300:], out.stderr[-600:])
+def test_force_slot_table_and_gather_path_give_the_same_bits(pkg, po):
+    """forces_fluid has two routes to the reference's ordered sums (main.c:1305-1321): the link sums the fused
+    kernel left in the per-grain slot table, and -- whenever that table does not describe the current lattice --
+    the gather from obst and f. Every call sequence must land on the oracle's bits: forces twice in a row (second
+    call: table already consumed), two collision_streaming calls before one forces call (table refilled), a new
+    obstacle map between collision_streaming and forces (table stale), uploaded populations (table stale), and
+    switching the force kernel in between. Grains are driven into each other and against the lattice edges so
+    that discs overlap (rasteriser flag) and links end in non-fluid nodes (empty slots)."""
+    lx, ly = 200, 130
+    r, x, y = samples.row_packing(lx, ly, 80, seed=3)
+    r, x1, x2 = samples.to_metres(r, x, y)
+    sim, ora = make_pair(pkg, po, lx, ly, r, x1, x2)
+    rng = np.random.default_rng(1)
+    k = np.zeros((len(r), 9)); k[:, 0], k[:, 1] = x1, x2; k[:, 3:6] = rng.normal(0, 1, (len(r), 3)) * [0.05, 0.05, 20.0]
+    sim.kinematics = k; ora.set_kinematics(k)
+    n = 3 * sim.cfg.npDEM
+    sim.renderScene(n); ora.steps(n)                       # table route in every fluid step
+    assert np.array_equal(sim.fhf, ora.get_fhf()) and np.array_equal(sim.f, ora.get_f())
+    sim.lbm_step(); ora.lbm_steps(1)
+    from_table, gathered = sim.force_stats()
+    assert from_table + gathered == len(r) and from_table > len(r) // 2, (from_table, gathered)
+    assert np.array_equal(sim.fhf, ora.get_fhf())
+    sim.forces_fluid(); ora.forces_fluid()                 # second call: gather route
+    assert sim.force_stats() == (0, len(r))
+    assert np.array_equal(sim.fhf, ora.get_fhf())
+    # two collision_streaming calls, then forces
+    for _ in range(2):
+        sim.obst_construction(); sim.collision_streaming()
+        ora.reinit(); ora.obst_construction(); ora.collision_streaming()
+    sim.forces_fluid(); ora.forces_fluid()
+    assert np.array_equal(sim.f, ora.get_f()) and np.array_equal(sim.fhf, ora.get_fhf())
+    # uploaded populations between collision_streaming and forces
+    sim.obst_construction(); sim.collision_streaming()
+    ora.reinit(); ora.obst_construction(); ora.collision_streaming()
+    f1 = ora.get_f() * (1 + 1e-3 * rng.standard_normal((lx, ly, 9)))
+    sim.f = f1; ora.set_f(f1)
+    sim.forces_fluid(); ora.forces_fluid()
+    assert np.array_equal(sim.fhf, ora.get_fhf())
+    # fast kernel for one step (does not consume the table), then parity again
+    sim.set_force_mode(1); sim.lbm_step(); ora.lbm_steps(1)
+    sim.set_force_mode(0)
+    sim.forces_fluid()
+    assert np.array_equal(sim.fhf, ora.get_fhf())
+    sim.renderScene(n); ora.steps(n)
+    assert_same_state(sim, ora, "after mixed call sequences")
+    # grains move and a new map is painted AFTER collision_streaming: forces must use the new map with the
+    # current f (the table was filled for the previous map's geometry)
+    sim.obst_construction(); sim.collision_streaming()
+    ora.reinit(); ora.obst_construction(); ora.collision_streaming()
+    k2 = sim.kinematics; k2[:, 0] += 1.5 * sim.cfg.dx; k2[:, 1] -= 0.7 * sim.cfg.dx
+    sim.kinematics = k2; ora.set_kinematics(k2)
+    sim.obst_construction(); ora.obst_construction()
+    sim.forces_fluid(); ora.forces_fluid()
+    assert np.array_equal(sim.obst, ora.get_obst()) and np.array_equal(sim.fhf, ora.get_fhf())
 
 
 def test_checkpoint_restart_is_bit_identical(pkg, po, tmp_path):
