@@ -713,6 +713,16 @@ __device__ __forceinline__ void classify_store_row(const Ctx& C, const LatticeVi
 __device__ __forceinline__ unsigned mbcnt(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
+// inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / row broadcasts (no LDS traffic)
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
 __device__ __forceinline__ double shfl_up1(double v) { return __shfl_up(v, 1, 64); }
 __device__ __forceinline__ double shfl_dn1(double v) { return __shfl_down(v, 1, 64); }
 
@@ -757,10 +767,8 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
   // wave-private scratch for the compacted bounce-back evaluation: 64 link slots
   __shared__ double sPay[4 * 64 * 4];
   __shared__ int sDesc[4 * 64];
-  __shared__ int sGid[4 * 64];
   double* const pay = sPay + (threadIdx.x >> 6) * (64 * 4);
   int* const desc = sDesc + (threadIdx.x >> 6) * 64;
-  int* const gid = sGid + (threadIdx.x >> 6) * 64;
   const double wc_diag = L.wc_diag, wc_axis = L.wc_axis;  // kernel arguments: scalar registers
   auto row_ok = [&](int xl) { return yin && xl >= 0 && xl < L.nxl; };
   const int ycl = y < 0 ? 0 : (y >= L.ly ? L.ly - 1 : y);
@@ -890,8 +898,8 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
           const int t = before + (int)mbcnt(b) - base;
           before += __popcll(b);
           if (((ibb >> q) & 1u) && t >= 0 && t < 64) {
-            desc[t] = lane | (q << 8) | (((nnm >> q) & 1u) << 12) | (((hzm >> q) & 1u) << 13);
-            gid[t] = C.onb[OPPq(q)];  // the grain that owns S = P - e_q
+            // bits 14..31: the grain that owns S = P - e_q (the slot table is only used with < 2^18 grains)
+            desc[t] = lane | (q << 8) | (((nnm >> q) & 1u) << 12) | (((hzm >> q) & 1u) << 13) | (C.onb[OPPq(q)] << 14);
             pay[t * 4 + 0] = C.Fo[OPPq(q)];
             pay[t * 4 + 1] = C.Fo[q];
             pay[t * 4 + 2] = C.In[q];
@@ -925,7 +933,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
             ring.get_centre(x - ex, src - ey, cx, cy);
             const int rel = slot_line(k.gx - ex, k.gy - ey, ex, ey, cx, cy) + S.half;
             if ((unsigned)rel < (unsigned)S.spd)
-              S.tab[((long)gid[lane] * 8 + (k.q - 1)) * S.spd + rel] = k.own_qo + out;
+              S.tab[((long)((unsigned)d >> 14) * 8 + (k.q - 1)) * S.spd + rel] = k.own_qo + out;
           }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1183,20 +1191,26 @@ constexpr unsigned long long M_DIAG = 0x5555555555555555ull;  // bits of q = 1, 
 constexpr unsigned long long M_XDIR = 0x2222222222222222ull;  // q = 2, 6 (ey = 0)
 constexpr unsigned long long M_YDIR = 0x8888888888888888ull;  // q = 4, 8 (ex = 0)
 
+constexpr int FT_WAVES = 4;  // waves per workgroup of k_forces_table
+
 template <int GW, int PASSES>
-__global__ __launch_bounds__(64) void k_forces_table(const double* __restrict__ f, const int* __restrict__ obst,
-                                                     LatticeView L, GrainFluidView G, ForceSlots S, int cap1, int cap3,
-                                                     int nw64, double scale12, double scale3,
-                                                     double* __restrict__ fhf, unsigned char* __restrict__ owner) {
+__global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(LatticeView L, GrainFluidView G, ForceSlots S, int cap1,
+                                                                int cap3, int nw64, double scale12, double scale3,
+                                                                double* __restrict__ fhf,
+                                                                unsigned char* __restrict__ owner) {
   extern __shared__ double sDyn[];
-  // per grain: addends of fhf1 [cap1] | fhf2 [cap1] | fhf3 [cap3]
-  // then the bitmap [nw64] and the three per-word prefix counts [3][nw64]
+  // per grain of the workgroup: addends of fhf1 [cap1] | fhf2 [cap1] | fhf3 [cap3]
+  // then per wave: the bitmap [nw64] and the three per-word prefix counts [3][nw64]; then [FT_WAVES * GW][4] counts
   const int per_grain = 2 * cap1 + cap3;
-  const size_t lists_doubles = (size_t)GW * per_grain;
-  unsigned long long* const bm = reinterpret_cast<unsigned long long*>(sDyn + lists_doubles);
-  int* const pw = reinterpret_cast<int*>(bm + nw64);
-  const int lane = threadIdx.x;
-  const int g0 = blockIdx.x * GW;
+  const int wave = threadIdx.x >> 6;
+  const size_t lists_doubles = (size_t)FT_WAVES * GW * per_grain;
+  unsigned long long* const bm = reinterpret_cast<unsigned long long*>(sDyn + lists_doubles) + (size_t)wave * nw64 * 3;
+  int* const pw = reinterpret_cast<int*>(bm + nw64);  // 3 * nw64 ints = 1.5 * nw64 words: the wave's 3 * nw64 words hold both
+  int* const counts = reinterpret_cast<int*>(reinterpret_cast<unsigned long long*>(sDyn + lists_doubles) +
+                                             (size_t)FT_WAVES * nw64 * 3);
+  const int lane = threadIdx.x & 63;
+  const int gslot0 = wave * GW;                       // this wave's grains within the workgroup
+  const int g0 = (blockIdx.x * FT_WAVES + wave) * GW;
   const int spd = S.spd, HB = S.hb;
   const int B = 2 * HB + 1;
   constexpr int FPP = 4 / PASSES;   // line families per pass
@@ -1295,9 +1309,11 @@ __global__ __launch_bounds__(64) void k_forces_table(const double* __restrict__ 
       if (meets != ffill || meets != bfill) bad = true;
       keyf[j] = keyb[j] = -1;
       if (meets) {
+        // in-disc nodes lie within +-hb of the truncated centre (hb >= largest reduced radius + 1)
         const int bxf = px0 + kf * ex - (X0 - HB), byf = py0 + kf * ey - (Y0 - HB);
         const int bxb = px0 + kb * ex - (X0 - HB), byb = py0 + kb * ey - (Y0 - HB);
-        if (bxf < 0 || bxf >= B || byf < 0 || byf >= B || bxb < 0 || bxb >= B || byb < 0 || byb >= B) bad = true;
+        if ((unsigned)bxf >= (unsigned)B || (unsigned)byf >= (unsigned)B || (unsigned)bxb >= (unsigned)B ||
+            (unsigned)byb >= (unsigned)B) bad = true;
         else {
           const int kyf = (bxf * B + byf) * 8 + (q - 1);
           const int kyb = (bxb * B + byb) * 8 + (q - 5);   // the opposite direction
@@ -1323,15 +1339,10 @@ __global__ __launch_bounds__(64) void k_forces_table(const double* __restrict__ 
       }
       // one scan for the three counts: 10 bits each (a grain has < 1024 addends per accumulator: cap3 check below)
       const int mine3 = (cd + cx) | ((cd + cy) << 10) | ((2 * cd + cx + cy) << 20);
-      int incl = mine3;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-      }
+      const int incl = wave_inclusive_scan(mine3);
       const int excl = incl - mine3;
       int r1 = excl & 1023, r2_ = (excl >> 10) & 1023, r3 = (excl >> 20) & 1023;
-      const int tot = __shfl(incl, 63, 64);
+      const int tot = __builtin_amdgcn_readlane(incl, 63);
       for (int u = 0; u < wpl; ++u) {
         const int w = lane * wpl + u;
         if (w < nw64) {
@@ -1345,7 +1356,7 @@ __global__ __launch_bounds__(64) void k_forces_table(const double* __restrict__ 
     }
     if (n1[g] > cap1 || n2[g] > cap1 || n3[g] > cap3) { n1[g] = -1; continue; }
     __builtin_amdgcn_wave_barrier();
-    double* const l1 = sDyn + (size_t)g * per_grain;
+    double* const l1 = sDyn + (size_t)(gslot0 + g) * per_grain;
     double* const l2 = l1 + cap1;
     double* const l3 = l2 + cap1;
     auto emit = [&](int keyp, unsigned long long slot) {
@@ -1380,24 +1391,43 @@ __global__ __launch_bounds__(64) void k_forces_table(const double* __restrict__ 
       if (n3[g] + lane < ((n3[g] + 7) & ~7)) l3[n3[g] + lane] = 0.0;
     }
   }
-  __builtin_amdgcn_wave_barrier();
-  // ---- phase B: lane 3g + a replays accumulator a of grain g
+  // hand the wave's counts to the replaying wave; queue what the table could not serve
+#pragma unroll
+  for (int g = 0; g < GW; ++g) {
+    const int i = g0 + g;
+    if (lane == 0) {
+      int* cnt = counts + (gslot0 + g) * 4;
+      cnt[0] = n1[g]; cnt[1] = n2[g]; cnt[2] = n3[g]; cnt[3] = own[g] ? 1 : 0;
+      if (i < L.n) {
+        if (owner) owner[i] = own[g] ? 1 : 0;
+        if (n1[g] < 0) S.queue[atomicAdd(S.gathered, 1)] = i;
+      }
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  // ---- phase B, first wave only: lane 3g + a replays accumulator a of grain g of the workgroup (the serial part
+  // is shared by FT_WAVES * GW grains)
   {
+    constexpr int NG = FT_WAVES * GW;
+    static_assert(3 * NG <= 64, "one lane per accumulator");
     const int g = lane / 3, a = lane - 3 * g;
+    const int gi = blockIdx.x * NG + g;
     int mine = 0, longest = 0;
     bool replayed = false, mine_own = false;
-#pragma unroll
-    for (int gg = 0; gg < GW; ++gg) {
-      const int na = a == 0 ? n1[gg] : (a == 1 ? n2[gg] : n3[gg]);
-      if (gg == g) {
-        replayed = n1[gg] >= 0;
-        mine_own = own[gg];
-        if (replayed) mine = (na + 7) & ~7;
-      }
-      if (n1[gg] >= 0 && n3[gg] > longest) longest = n3[gg];  // fhf3 has the longest list
+    if (g < NG) {
+      const int* cnt = counts + g * 4;
+      replayed = cnt[0] >= 0;
+      mine_own = cnt[3] != 0;
+      if (replayed) mine = (cnt[a] + 7) & ~7;
     }
-    longest = (longest + 7) & ~7;
-    const double* tl = sDyn + (size_t)(g < GW ? g : 0) * per_grain + (a == 0 ? 0 : (a == 1 ? cap1 : 2 * cap1));
+    longest = mine;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int v = __shfl_xor(longest, off, 64);
+      longest = v > longest ? v : longest;
+    }
+    const double* tl = sDyn + (size_t)(g < NG ? g : 0) * per_grain + (a == 0 ? 0 : (a == 1 ? cap1 : 2 * cap1));
     double h = 0.0;
     for (int t = 0; t < longest; t += 8) {  // wave-uniform trip count
       if (t < mine) {
@@ -1408,17 +1438,7 @@ __global__ __launch_bounds__(64) void k_forces_table(const double* __restrict__ 
         for (int u = 0; u < 4; ++u) { h = h + v[u].x; h = h + v[u].y; }
       }
     }
-    if (g < GW && g0 + g < L.n && replayed)
-      fhf[a * L.n + g0 + g] = mine_own ? h * (a == 2 ? scale3 : scale12) : 0.0;
-  }
-  // ---- the grains the table could not serve go to the queue of the gather kernel that follows
-#pragma unroll
-  for (int g = 0; g < GW; ++g) {
-    const int i = g0 + g;
-    if (i < L.n && lane == 0) {
-      if (owner) owner[i] = own[g] ? 1 : 0;
-      if (n1[g] < 0) S.queue[atomicAdd(S.gathered, 1)] = i;
-    }
+    if (g < NG && gi < L.n && replayed) fhf[a * L.n + gi] = mine_own ? h * (a == 2 ? scale3 : scale12) : 0.0;
   }
 }
 
@@ -1749,11 +1769,12 @@ static void launch_forces_table_t(const double* f, const int* obst, const Lattic
   // addends per accumulator: one link per direction and lattice line meeting the disc (<= spd lines for the
   // diagonal families, <= 2 hb + 1 for the axis families); fhf3 takes two addends per diagonal link
   const int cap1 = (4 * S.spd + 2 * B + 7) & ~7, cap3 = (8 * S.spd + 4 * B + 7) & ~7;
-  const size_t lists_doubles = (size_t)GW * (2 * cap1 + cap3);
-  const size_t lds = lists_doubles * 8 + (size_t)nw64 * 8 + (size_t)nw64 * 12;
-  hipLaunchKernelGGL((k_forces_table<GW, PASSES>), dim3((L.n + GW - 1) / GW), dim3(64), lds, st, f, obst, L, G, S, cap1,
-                     cap3, nw64, scale12, scale3, fhf, owner);
-  const int grid = L.n < 2048 ? L.n : 2048;
+  const size_t lists_doubles = (size_t)FT_WAVES * GW * (2 * cap1 + cap3);
+  const size_t lds = lists_doubles * 8 + (size_t)FT_WAVES * nw64 * 24 + (size_t)FT_WAVES * GW * 16;
+  const int per_block = FT_WAVES * GW;
+  hipLaunchKernelGGL((k_forces_table<GW, PASSES>), dim3((L.n + per_block - 1) / per_block), dim3(64 * FT_WAVES), lds, st,
+                     L, G, S, cap1, cap3, nw64, scale12, scale3, fhf, owner);
+  const int grid = L.n < 256 ? L.n : 256;
   hipLaunchKernelGGL(k_forces_gather_queue, dim3(grid), dim3(64), 0, st, f, obst, L, G, S, scale12, scale3, fhf);
 }
 
@@ -1761,22 +1782,21 @@ void launch_forces_slots(const double* f, const int* obst, const LatticeView& L,
                          const ForceSlots& S, double scale12, double scale3, double* fhf, unsigned char* owner,
                          hipStream_t st) {
 #ifdef LBMDEM_AB
-  static const int gw = getenv("LBMDEM_FORCE_GW") ? atoi(getenv("LBMDEM_FORCE_GW")) : 3;
+  static const int gw = getenv("LBMDEM_FORCE_GW") ? atoi(getenv("LBMDEM_FORCE_GW")) : 1;
 #else
-  const int gw = 3;
+  const int gw = 1;
 #endif
   if (S.spd <= 32) {
     switch (gw) {
 #ifdef LBMDEM_AB
-      case 1: launch_forces_table_t<1, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, st); break;
       case 2: launch_forces_table_t<2, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, st); break;
-      case 4: launch_forces_table_t<4, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, st); break;
-      case 6: launch_forces_table_t<6, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, st); break;
+      case 3: launch_forces_table_t<3, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, st); break;
+      case 5: launch_forces_table_t<5, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, st); break;
 #endif
-      default: launch_forces_table_t<3, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, st); break;
+      default: launch_forces_table_t<1, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, st); break;
     }
   } else {
-    launch_forces_table_t<2, 4>(f, obst, L, G, S, scale12, scale3, fhf, owner, st);
+    launch_forces_table_t<1, 4>(f, obst, L, G, S, scale12, scale3, fhf, owner, st);
   }
 }
 

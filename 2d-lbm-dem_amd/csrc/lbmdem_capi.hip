@@ -315,7 +315,7 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
     // lattice lines through a reduced disc, any direction: |ey dx - ex dy| <= sqrt(2) rLB, +2 for the truncated centre
     const int half = (int)ceil(1.4143 * p.reductionR * rmax / cfg->dx) + 2;
     const int spd = (2 * half + 1 + 3) & ~3;
-    bool want = spd <= LBMDEM_SPD_MAX && collide_stream_fills_slots(L);
+    bool want = spd <= LBMDEM_SPD_MAX && collide_stream_fills_slots(L) && n < (1 << 18);  // grain id: 18 bits of a link descriptor
 #ifdef LBMDEM_AB
     if (const char* e = getenv("LBMDEM_NO_SLOTS")) if (atoi(e)) want = false;  // A/B: forces gathered from the lattice
 #endif

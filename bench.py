@@ -38,19 +38,20 @@ import __graft_entry__ as ge  # noqa: E402
 import samples  # noqa: E402
 
 BYTES_PER_LUP = 148.0   # 9x8 B read + 9x8 B write + 4 B obstacle id
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")   # PMC-measured HBM bytes per launch
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # PMC-measured HBM bytes per launch (static: measured once, scripts/pmc_traffic.sh)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def workload(which):
     if which == "configs4":
         return dict(name="8192x4096 D2Q9 MRT + 50000 grains (synthetic row packing, seed 1234)",
-                    lx=8192, ly=4096, n=50000, fill_lx=8192)
+                    lx=8192, ly=4096, n=50000, fill_lx=8192, short="8192x4096 / 50k grains", data="synthetic")
     if which == "real50k":
         return dict(name="4096x4096 D2Q9 MRT + the reference's bin/50000.data (49987 grains, unscaled)",
-                    lx=4096, ly=4096, n=49987, fill_lx=4096, real=True)
+                    lx=4096, ly=4096, n=49987, fill_lx=4096, real=True, short="4096^2 / bin/50000.data (49987 grains)",
+                    data="the reference's bin/50000.data geometry (fixture tests/golden/real_50000_4096x4096.npz); lattice at rest")
     return dict(name="4096x4096 D2Q9 MRT + 50000 grains (synthetic row packing, seed 1234)",
-                lx=4096, ly=4096, n=50000, fill_lx=4096)
+                lx=4096, ly=4096, n=50000, fill_lx=4096, short="4096^2 / 50k grains", data="synthetic")
 
 
 def make_sample(w):
@@ -130,8 +131,8 @@ def cpu_baseline(w, sample_mm, npdem):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)     # >= 200 timed steps after 20 warm-up
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-mode", type=int, default=0, help="0 = parity hydro-force kernel, 1 = fast")
     ap.add_argument("--workload", choices=["metric", "configs4", "real50k"], default="metric",
@@ -221,7 +222,28 @@ def main():
         sync(); t1 = time.perf_counter()
         lbm_only_ms = 1e3 * (t1 - t0) / nl
 
+    # informative: the fast (shuffle-tree) force kernel on the same state: drift against the parity kernel's
+    # bits for one and the same lattice, and the coupled-step rate with it (SURVEY hard part 11)
+    fast = None
+    if world == 1 and not args.strips and args.force_mode == 0:
+        sim.forces_fluid(); fp = sim.fhf.copy()
+        sim.set_force_mode(1); sim.forces_fluid(); ff = sim.fhf.copy()
+        scale_f = np.abs(fp).max(axis=0)
+        drift = float((np.abs(ff - fp).max(axis=0) / np.where(scale_f > 0, scale_f, 1.0)).max())
+        nf = max(10, min(50, args.steps))
+        run_steps(2); sync()
+        t0 = time.perf_counter(); run_steps(nf); sync(); t1 = time.perf_counter()
+        sim.set_force_mode(0)
+        fast = {"ms_per_step": round(1e3 * (t1 - t0) / nf, 4), "mlups": round(1e-6 * lx * ly * nf / (t1 - t0), 1),
+                "steps": nf, "max_rel_drift_vs_parity": drift,
+                "note": "force_mode=1: wave-per-grain shuffle-tree sums (last-bit differences); not the headline"}
+
     mass = sim.final_density()
+    if world > 1 or args.strips:   # every rank holds the mass of its own rows
+        import torch.distributed as dist
+        tm = torch.tensor([mass], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tm, op=dist.ReduceOp.SUM)
+        mass = float(tm[0])
     if not np.isfinite(mass):
         raise SystemExit("non-finite lattice mass after the timed run")
 
@@ -232,15 +254,14 @@ def main():
         rows = cfgd.x_end - cfgd.x_begin
         achieved = BYTES_PER_LUP * rows * ly / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic = None
-        if args.gpus == 1 and args.workload == "metric" and "LBMDEM_CS_VARIANT" not in os.environ \
-                and os.path.exists(TRAFFIC_FILE):
+        if args.gpus == 1 and args.workload == "metric" and os.path.exists(TRAFFIC_FILE):
             traffic = round(json.load(open(TRAFFIC_FILE))["traffic_bytes_per_launch"])   # same workload + kernel
         out = {
-            "metric": "MLUPS (D2Q9 collide+stream, coupled LBM-DEM step) on 4096^2 / 50k grains",
+            "metric": f"MLUPS (D2Q9 collide+stream, coupled LBM-DEM step) on {w['short']}",
             "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
+            "data": w["data"],
             "config": {"workload": w["name"], "lx": lx, "ly": ly, "grains": int(len(r)), "npDEM": int(npdem),
                        "step": "1 fluid step + npDEM DEM sub-steps (+ Verlet rebuild every 100 DEM steps)",
                        "force_kernel": "parity" if args.force_mode == 0 else "fast",
@@ -255,10 +276,12 @@ def main():
             "collide_stream_kernel_mlups": round(1e-6 * rows * ly / (kernel_ms * 1e-3), 1) if kernel_ms > 0 else None,
             "roofline": {"bound": "hbm", "kernel": "k_cs_march (fused reinit+collide+IBB+stream)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "bytes_per_lup": BYTES_PER_LUP, "launches_timed": launches,
+                         "traffic": traffic, "traffic_source": "static: " + os.path.relpath(TRAFFIC_FILE, ROOT) if traffic else None,
+                         "bytes_per_lup": BYTES_PER_LUP, "launches_timed": launches,
                          "note": "achieved = algorithmic 148 B/LUP x lattice nodes per launch / mean HIP-event "
                                  "duration; traffic = HBM bytes per launch from rocprofv3 FETCH_SIZE + WRITE_SIZE "
-                                 "(separate passes, calibrated; profiles/r01_g_pmc_traffic.json)"},
+                                 "(separate passes, calibrated on copy kernels; measured once for this kernel and workload, not in this run)"},
+            "fast_force_mode": fast,
             "total_mass": mass,
         }
         if args.gpus == 1 and not args.no_cpu_baseline:

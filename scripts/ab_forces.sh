@@ -1,7 +1,7 @@
 # A/B inside ONE gpurun call (same GPU): per-kernel times from rocprofv3 for the experiment build with
 # several settings. usage: bash scripts/ab_forces.sh "<env1>" "<env2>" ...   (each arg = env assignments, may be empty)
 cd /tmp && export TMPDIR=/tmp
-export LBMDEM_HIP_LIBRARY=$GRAFT_REPO_ROOT/2d-lbm-dem_amd/liblbmdem_hip_ab.so
+export LBMDEM_HIP_LIBRARY=${LBMDEM_HIP_LIBRARY:-$GRAFT_REPO_ROOT/2d-lbm-dem_amd/liblbmdem_hip_ab.so}
 k=0
 for e in "$@"; do
   k=$((k+1)); O=$GRAFT_REPO_ROOT/gpurun_out/abf_$k; rm -rf $O
