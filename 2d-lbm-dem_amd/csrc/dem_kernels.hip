@@ -601,6 +601,16 @@ __global__ void k_set_last_offset(int n, const int* __restrict__ counts, int* __
   if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n] = offsets[n - 1] + counts[n - 1];
 }
 
+// A list longer than the allocation is truncated (and flagged): no kernel may index nbr[] / own[] past `cap`.
+__global__ void k_clamp_offsets(int n, int* __restrict__ offsets, long cap, int* __restrict__ overflow) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  if ((long)offsets[i] > cap) {
+    offsets[i] = (int)cap;
+    *overflow = 1;
+  }
+}
+
 inline int key_bits(int ncells) {
   int b = 1;
   while ((1L << b) < ncells) ++b;
@@ -626,15 +636,17 @@ int verlet_alloc(VerletDevice& V, int n, double cs, double ox, double oy, double
   A((void**)&V.overflow, sizeof(int));
   if (e != hipSuccess) return -1;
   V.sort_tmp_bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, V.sort_tmp_bytes, V.keys_in, V.keys_out, V.vals_in,
-                                     V.vals_out, n, 0, key_bits((int)ncell));
+  if (hipcub::DeviceRadixSort::SortPairs(nullptr, V.sort_tmp_bytes, V.keys_in, V.keys_out, V.vals_in, V.vals_out, n, 0,
+                                         key_bits((int)ncell)) != hipSuccess) return -1;
   V.scan_tmp_bytes = 0;
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, V.scan_tmp_bytes, V.counts, V.offsets, n);
+  if (hipcub::DeviceScan::ExclusiveSum(nullptr, V.scan_tmp_bytes, V.counts, V.offsets, n) != hipSuccess) return -1;
   A(&V.sort_tmp, V.sort_tmp_bytes); A(&V.scan_tmp, V.scan_tmp_bytes);
   if (e != hipSuccess) return -1;
   if (hipMemset(V.offsets, 0, sizeof(int) * (n + 1)) != hipSuccess) return -1;
   if (hipMemset(V.wallflags, 0, n) != hipSuccess) return -1;
   if (hipMemset(V.overflow, 0, sizeof(int)) != hipSuccess) return -1;
+  // the consumers run on a non-blocking stream that does not order itself after the NULL stream's memsets
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
   return 0;
 }
 
@@ -645,27 +657,32 @@ void verlet_free(VerletDevice& V) {
   V = VerletDevice{};
 }
 
-void launch_verlet_rebuild(VerletDevice& V, const Kin& K, const double* r, const DemParams& P,
-                           hipStream_t st) {
+int launch_verlet_rebuild(VerletDevice& V, const Kin& K, const double* r, const DemParams& P,
+                          hipStream_t st) {
+  hipError_t e = hipSuccess;
   const int n = P.n;
   const int nb = (n + 255) / 256;
   const size_t ncell = (size_t)V.ncx * V.ncy;
   hipLaunchKernelGGL(k_cell_keys, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, V.ox, V.oy, V.cs, V.ncx, V.ncy,
                      V.keys_in, V.vals_in);
-  (void)hipcub::DeviceRadixSort::SortPairs(V.sort_tmp, V.sort_tmp_bytes, V.keys_in, V.keys_out, V.vals_in,
-                                     V.vals_out, n, 0, key_bits((int)ncell), st);
-  (void)hipMemsetAsync(V.cell_start, 0, sizeof(int) * ncell, st);
-  (void)hipMemsetAsync(V.cell_end, 0, sizeof(int) * ncell, st);
+  e = hipcub::DeviceRadixSort::SortPairs(V.sort_tmp, V.sort_tmp_bytes, V.keys_in, V.keys_out, V.vals_in, V.vals_out, n, 0,
+                                         key_bits((int)ncell), st);
+  if (e == hipSuccess) e = hipMemsetAsync(V.cell_start, 0, sizeof(int) * ncell, st);
+  if (e == hipSuccess) e = hipMemsetAsync(V.cell_end, 0, sizeof(int) * ncell, st);
+  if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(k_cell_bounds, dim3(nb), dim3(256), 0, st, n, V.keys_out, V.cell_start, V.cell_end);
   hipLaunchKernelGGL(k_verlet_scan<0>, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, r, V.ox, V.oy, V.cs, V.ncx,
                      V.ncy, V.cell_start, V.cell_end, V.vals_out, P.distVerlet, V.counts, V.offsets, V.nbr,
                      V.own, V.cap, V.overflow);
-  (void)hipcub::DeviceScan::ExclusiveSum(V.scan_tmp, V.scan_tmp_bytes, V.counts, V.offsets, n, st);
+  e = hipcub::DeviceScan::ExclusiveSum(V.scan_tmp, V.scan_tmp_bytes, V.counts, V.offsets, n, st);
+  if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(k_set_last_offset, dim3(1), dim3(1), 0, st, n, V.counts, V.offsets);
+  hipLaunchKernelGGL(k_clamp_offsets, dim3(n / 256 + 1), dim3(256), 0, st, n, V.offsets, V.cap, V.overflow);
   hipLaunchKernelGGL(k_verlet_scan<1>, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, r, V.ox, V.oy, V.cs, V.ncx,
                      V.ncy, V.cell_start, V.cell_end, V.vals_out, P.distVerlet, V.counts, V.offsets, V.nbr,
                      V.own, V.cap, V.overflow);
   hipLaunchKernelGGL(k_wall_flags, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, r, P, V.wallflags);
+  return (int)hipGetLastError();
 }
 
 int diag_extra_alloc(DiagExtra& X, int n, long cap) {
@@ -673,15 +690,18 @@ int diag_extra_alloc(DiagExtra& X, int n, long cap) {
   double* d = nullptr;
   const size_t nd = 5 * (size_t)n + 6 * (size_t)cap + 4;
   if (hipMalloc((void**)&d, sizeof(double) * nd) != hipSuccess) return -1;
-  if (hipMemset(d, 0, sizeof(double) * nd) != hipSuccess) return -1;
+  X.fr = d;   // from here on diag_extra_free() releases whatever was allocated
+  if (hipMemset(d, 0, sizeof(double) * nd) != hipSuccess) { diag_extra_free(X); return -1; }
   X.fr = d; X.ice = d + n; X.slip = d + 2 * (size_t)n; X.rw = d + 3 * (size_t)n; X.a1gc = d + 4 * (size_t)n;
   double* e = d + 5 * (size_t)n;
   X.e_ft = e; X.e_f3 = e + cap; X.e_avt = e + 2 * cap; X.e_av3 = e + 3 * cap; X.e_dslip = e + 4 * cap; X.e_drw = e + 5 * cap;
   X.carry = e + 6 * cap;
-  if (hipMalloc((void**)&X.e_touched, (size_t)cap) != hipSuccess) return -1;
-  if (hipMemset(X.e_touched, 0, (size_t)cap) != hipSuccess) return -1;
-  if (hipMalloc((void**)&X.wlist, sizeof(int) * (4 * (size_t)n + 4)) != hipSuccess) return -1;
+  if (hipMalloc((void**)&X.e_touched, (size_t)cap) != hipSuccess) { diag_extra_free(X); return -1; }
+  if (hipMemset(X.e_touched, 0, (size_t)cap) != hipSuccess) { diag_extra_free(X); return -1; }
+  if (hipMalloc((void**)&X.wlist, sizeof(int) * (4 * (size_t)n + 4)) != hipSuccess) { diag_extra_free(X); return -1; }
   X.wcount = X.wlist + 4 * (size_t)n;
+  // the consumers run on a non-blocking stream that does not order itself after the NULL stream's memsets
+  if (hipDeviceSynchronize() != hipSuccess) { diag_extra_free(X); return -1; }
   return 0;
 }
 

@@ -80,6 +80,7 @@ struct lbmdem_handle {
   double rmax = 0.0;
   VerletDevice V{};
   bool verlet_ok = false;
+  volatile int* ovf_host = nullptr;  // pinned mirror of V.overflow, refreshed (asynchronously) after every rebuild
   long nbsteps = 0;
   int force_mode = 0;
   // derived scalars
@@ -354,6 +355,8 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
       return rc;
     }
   }
+  CREATE_TRY(hipHostMalloc((void**)&h->ovf_host, sizeof(int), hipHostMallocDefault));
+  *h->ovf_host = 0;
   // init_density (main.c:716-724) and init_obst (main.c:663-711)
   launch_fill_equilibrium(h->f[0], L, h->stream);
   launch_fill_equilibrium(h->f[1], L, h->stream);
@@ -387,6 +390,7 @@ int lbmdem_destroy(lbmdem_handle* h) {
   if (h->fs.queue) (void)hipFree(h->fs.queue);
   if (h->dpartial) (void)hipFree(h->dpartial);
   verlet_free(h->V);
+  if (h->ovf_host) (void)hipHostFree((void*)h->ovf_host);
   diag_extra_free(h->dx);
   for (hipEvent_t e : h->ev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev1) (void)hipEventDestroy(e);
@@ -561,8 +565,12 @@ int lbmdem_verlet_rebuild(lbmdem_handle* h) {
     c.Mdx = 1.e-3 * c.lx;
     c.Mhy = 1.e-3 * c.ly;
   }
-  launch_verlet_rebuild(h->V, h->kin[h->kcur], h->r, dem_params(h), h->stream);
-  HIP_TRY(hipGetLastError());
+  if (*h->ovf_host) return fail(LBMDEM_ENOMEM, "Verlet list overflow at the previous rebuild (more than %ld symmetric entries)", h->V.cap);
+  const int e = launch_verlet_rebuild(h->V, h->kin[h->kcur], h->r, dem_params(h), h->stream);
+  if (e != 0) return fail(LBMDEM_EHIP, "Verlet rebuild failed: %s", hipGetErrorString((hipError_t)e));
+  // a truncated list is flagged on the device; the flag travels to the host behind the rebuild and is looked at
+  // by the next sub-step that finds it set, by the next rebuild and by lbmdem_sync (no stall here)
+  HIP_TRY(hipMemcpyAsync((void*)h->ovf_host, h->V.overflow, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   h->verlet_ok = true;
   return LBMDEM_OK;
 }
@@ -571,6 +579,7 @@ int lbmdem_dem_substep(lbmdem_handle* h) {
   CHECK_H(h);
   CHECK_NOT_SPLIT(h);
   if (!h->verlet_ok) return fail(LBMDEM_EINVAL, "lbmdem_dem_substep before the first lbmdem_verlet_rebuild");
+  if (*h->ovf_host) return fail(LBMDEM_ENOMEM, "Verlet list overflow (more than %ld symmetric entries)", h->V.cap);
   const int film = (h->nbsteps % h->cfg.phys.stepFilm == 0) ? 1 : 0;  // main.c:1342
   // contact diagnostics are only needed by write_DEM, which renderScene calls when the step counter
   // reaches a multiple of stepStrob = 4000 (main.c:142,1773): produce them in exactly that sub-step
@@ -1097,12 +1106,16 @@ int lbmdem_write_forces(lbmdem_handle* h, const char* dir, int nfile) try {
 
 namespace {
 struct CkptHeader {
-  char magic[8];       // "LBMDEMC2"
+  char magic[8];       // "LBMDEMC3"
+  int layout;          // device layout of the populations in the file: 1 = 16-node tiles f[x][y/16][q][y%16]
+  int force_mode, diag_always, has_carry;
+  double carry[3];     // pft, pff, pf of the order-dependent contact diagnostics (main.c:130-131), when has_carry
   lbmdem_config cfg;   // incl. the wall positions VerletWall may have moved
   long nbsteps;
   int verlet_ok, nnbr; // symmetric list length
   long plane;          // sanity: nxl * sy of the writer
 };
+constexpr int CKPT_LAYOUT = 1;
 static bool wr(FILE* fp, const void* p, size_t n) { return fwrite(p, 1, n, fp) == n; }
 static bool rd(FILE* fp, void* p, size_t n) { return fread(p, 1, n, fp) == n; }
 }  // namespace
@@ -1118,7 +1131,10 @@ int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) try {
   if (h->verlet_ok) HIP_TRY(hipMemcpy(off.data(), h->V.offsets, sizeof(int) * (n + 1), hipMemcpyDeviceToHost));
   CkptHeader H;
   memset(&H, 0, sizeof H);
-  memcpy(H.magic, "LBMDEMC2", 8);
+  memcpy(H.magic, "LBMDEMC3", 8);
+  H.layout = CKPT_LAYOUT; H.force_mode = h->force_mode; H.diag_always = h->diag_always ? 1 : 0;
+  H.has_carry = h->dx_ready ? 1 : 0;
+  if (h->dx_ready) HIP_TRY(hipMemcpy(H.carry, h->dx.carry, sizeof H.carry, hipMemcpyDeviceToHost));
   H.cfg = h->cfg; H.nbsteps = h->nbsteps; H.verlet_ok = h->verlet_ok ? 1 : 0; H.nnbr = off[n]; H.plane = h->L.plane;
   FILE* fp = fopen(path, "wb");
   if (!fp) return fail(LBMDEM_EINVAL, "cannot open '%s' for writing", path);
@@ -1137,7 +1153,7 @@ int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) try {
   dump(h->V.nbr, sizeof(int) * (size_t)H.nnbr);
   dump(h->V.wallflags, n);
   dump(h->obst[h->ocur], sizeof(int) * (size_t)h->L.plane);
-  for (int q = 0; q < 9 && ok; ++q)  // plane by plane: bounded host staging
+  for (int q = 0; q < 9 && ok; ++q)  // the lattice (device layout) in nine chunks: bounded host staging
     dump(h->f[h->fcur] + (size_t)q * h->L.plane, sizeof(double) * (size_t)h->L.plane);
   ok = (fclose(fp) == 0) && ok;
   if (!ok) return fail(LBMDEM_EHIP, "writing checkpoint '%s' failed", path);
@@ -1154,7 +1170,8 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
   FILE* fp = fopen(path, "rb");
   if (!fp) return fail(LBMDEM_EINVAL, "cannot open checkpoint '%s'", path);
   CkptHeader H;
-  if (!rd(fp, &H, sizeof H) || memcmp(H.magic, "LBMDEMC2", 8) != 0) { fclose(fp); return fail(LBMDEM_EINVAL, "'%s' is not a checkpoint", path); }
+  if (!rd(fp, &H, sizeof H) || memcmp(H.magic, "LBMDEMC3", 8) != 0) { fclose(fp); return fail(LBMDEM_EINVAL, "'%s' is not a checkpoint of this library version", path); }
+  if (H.layout != CKPT_LAYOUT) { fclose(fp); return fail(LBMDEM_EINVAL, "checkpoint '%s' holds another device layout (%d)", path, H.layout); }
   const int n = H.cfg.nbgrains;
   std::vector<double> r(n), kin(9 * (size_t)n);
   if (!rd(fp, r.data(), sizeof(double) * n) || !rd(fp, kin.data(), sizeof(double) * 9 * n)) { fclose(fp); return fail(LBMDEM_EINVAL, "checkpoint truncated"); }
@@ -1183,6 +1200,16 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
   fclose(fp);
   if (!ok) { lbmdem_destroy(h); return fail(LBMDEM_EINVAL, "checkpoint '%s' is truncated or from a different decomposition", path); }
   h->cfg = cfg;  // wall positions as saved
+  h->force_mode = H.force_mode;
+  h->diag_always = H.diag_always != 0;
+  if (H.has_carry) {  // the "previous contact" carries continue across the restart
+    if (diag_extra_alloc(h->dx, n, h->V.cap) != 0 ||
+        hipMemcpy(h->dx.carry, H.carry, sizeof H.carry, hipMemcpyHostToDevice) != hipSuccess) {
+      lbmdem_destroy(h);
+      return fail(LBMDEM_ENOMEM, "diagnostic buffers: allocation failed");
+    }
+    h->dx_ready = true;
+  }
   h->nbsteps = H.nbsteps;
   h->verlet_ok = H.verlet_ok != 0;
   if (h->verlet_ok) {  // the entry -> grain map is derived from the offsets

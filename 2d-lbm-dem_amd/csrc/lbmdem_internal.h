@@ -145,8 +145,9 @@ struct VerletDevice {
 };
 int verlet_alloc(VerletDevice& V, int n, double cs, double ox, double oy, double wx, double wy);
 void verlet_free(VerletDevice& V);
-void launch_verlet_rebuild(VerletDevice& V, const Kin& K, const double* r, const DemParams& P,
-                           hipStream_t st);
+// returns 0 or the hipError_t of the failing call (hipCUB sort / scan, memset, launch)
+int launch_verlet_rebuild(VerletDevice& V, const Kin& K, const double* r, const DemParams& P,
+                          hipStream_t st);
 // Buffers of the order-dependent contact diagnostics fr, ice, slip, rw (main.c:782-789, 840-843, 851, 893,
 // 916-919, 942, 1462-1466, 1490-1494): they depend on "previous contact" carries (pft, pff, pf, ic,
 // main.c:130-131) that thread through the reference's serial contact loop. Only used by the rare sub-steps

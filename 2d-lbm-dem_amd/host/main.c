@@ -105,6 +105,7 @@ int main(int argc, char** argv) {
   double energies[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* KE, PE, SE, IFR, WF, INCE, TSLIP, TRW of the last write_DEM (main.c:1885-1889) */
   const int chunk = cfg.phys.updateVerlet;
   const int stepConsole = 400; /* main.c:140 */
+  int stop = 0;
   do {
     long todo = chunk - (nbsteps % chunk);
     if (max_steps >= 0 && nbsteps + todo > max_steps) todo = max_steps - nbsteps;
@@ -133,13 +134,15 @@ int main(int argc, char** argv) {
         DIE(lbmdem_write_dem(h, ".", nFile, energies), "write_dem");
         DIE(lbmdem_write_forces(h, ".", nFile), "write_forces");
       }
+      /* the reference tests its stop condition after EVERY renderScene() (main.c:1880-1890) */
+      if (nbsteps * cfg.dt > duration) { stop = 1; break; }
     }
     if (nbsteps % chunk == 0) {
       now = time(NULL);
       printf("steps %li steps %le KE %le PE %le SE %le WF %le INCE %le SLIP %le RW %le Time %s \n", nbsteps,
              nbsteps * cfg.dt, energies[0], energies[1], energies[2], energies[4], energies[5], energies[6], energies[7], asctime(localtime(&now)));
     }
-  } while (nbsteps * cfg.dt <= duration && (max_steps < 0 || nbsteps < max_steps));
+  } while (!stop && (max_steps < 0 || nbsteps < max_steps));
   DIE(lbmdem_sync(h), "sync");
   clock_gettime(CLOCK_MONOTONIC, &t1);
   if (ckpt_out) DIE(lbmdem_checkpoint_save(h, ckpt_out), "checkpoint_save");
@@ -149,6 +152,7 @@ int main(int argc, char** argv) {
   double secs = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
   long lbm_steps = (nbsteps + cfg.npDEM - 1) / cfg.npDEM;
   fprintf(stderr, "time: %e\n", secs);
+  fprintf(stderr, "dem_steps: %ld\n", nbsteps);
   fprintf(stderr, "MLUPS: %.1f  DEM-steps/s: %.1f\n", 1e-6 * (double)lx * ly * lbm_steps / secs, nbsteps / secs);
   now = time(NULL);
   printf("End local time and date: %s", asctime(localtime(&now)));

@@ -11,7 +11,8 @@
  * LBMDEM_E* code on failure (lbmdem_last_error() gives the text); no exceptions cross the ABI;
  * the library owns all device memory, the caller owns every host buffer; one host thread per
  * handle. Host-side lattice data uses the REFERENCE layout f[x][y][q], x slow (main.c:56,1802);
- * the device layout (SoA planes f[q][x][y], y contiguous) is internal.
+ * the device layout (tiles of 16 consecutive y with the nine directions of a tile contiguous,
+ * f[x][y / 16][q][y % 16]) is internal.
  *
  * There is no CPU fallback: every entry point fails with LBMDEM_ENODEVICE when no HIP device
  * is usable.
@@ -169,8 +170,10 @@ int lbmdem_write_forces(lbmdem_handle* h, const char* dir, int nfile);
 /* Checkpoint / restart (absent in the reference, which cannot resume a run: SURVEY.md section 5). The file
  * holds exactly the state that defines the continuation at a renderScene() boundary -- populations,
  * current obstacle map, grain kinematics, hydrodynamic forces, Verlet lists, wall positions, step
- * counter -- in the device layout of the strip that wrote it. A run restarted from it is bit-identical
- * to the uninterrupted run. load creates a new handle on `device`. */
+ * counter, the force-kernel choice, the diagnostics switch and the "previous contact" carries of the
+ * order-dependent diagnostics -- in the device layout of the strip that wrote it (a layout word in the
+ * header rejects files of another layout). A run restarted from it is bit-identical to the uninterrupted
+ * run. load creates a new handle on `device`. */
 int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path);
 int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out);
 long lbmdem_nbsteps(lbmdem_handle* h);

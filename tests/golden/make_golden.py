@@ -238,7 +238,12 @@ REAL_CASES = {
     "real_a08d83_600x500": ("a08d83.data", 600, 500, (1, 10, 20)),             # SURVEY.md section 8c known answers
     "real_7000_2048x2048": ("a08_a4b4r18_7000.data", 2048, 2048, (1, 2)),      # BASELINE.json configs[2]
     "real_50000_4096x4096": ("50000.data", 4096, 4096, (1, 2)),                # BASELINE.json configs[3]
+    "real_50000test_3072x3072": ("50000-test.data", 3072, 3072, (1, 2)),       # BASELINE.json configs[0] (47 980 grains)
+    "real_50000_8192x4096": ("50000.data", 8192, 4096, (1, 2)),                # BASELINE.json configs[4] (one domain = 8 strips)
 }
+# fixtures that do not repeat the parsed grains of another fixture of the same sample file (r, x1, x2 are the same
+# doubles: read_sample does not depend on the lattice)
+GRAINS_FROM = {"real_50000_8192x4096": "real_50000_4096x4096"}
 
 
 def _real_case(name, q):
@@ -254,6 +259,12 @@ def _real_case(name, q):
     s = R.scalars()
     out = dict(r=g0[:, po.COL["r"]].copy(), x1=g0[:, 0].copy(), x2=g0[:, 1].copy(),
                npDEM=np.int64(s["npDEM"]), dx=np.float64(s["dx"]), c=np.float64(s["c"]), dumps=np.array(dumps))
+    if name in GRAINS_FROM:
+        other = np.load(os.path.join(HERE, GRAINS_FROM[name] + ".npz"))
+        assert all(np.array_equal(out[k], other[k]) for k in ("r", "x1", "x2"))
+        for k in ("r", "x1", "x2"):
+            del out[k]
+        out["grains_from"] = np.array(GRAINS_FROM[name])
     done = 0
     for k in dumps:
         R.steps((k - done) * int(s["npDEM"]))
@@ -268,8 +279,8 @@ def _real_case(name, q):
     q.put(out)
 
 
-def make_real_fixtures():
-    for name in REAL_CASES:
+def make_real_fixtures(only=None):
+    for name in (only or REAL_CASES):
         q = mp.Queue()
         p = mp.Process(target=_real_case, args=(name, q))
         p.start()
@@ -283,6 +294,9 @@ def main():
     import pyoracle as po
     if not po.reference_available():
         raise SystemExit("the reference is not present here; golden vectors can only be made in the build container")
+    if len(sys.argv) > 1:      # python make_golden.py real_50000_8192x4096 ...: only these real-sample fixtures
+        make_real_fixtures(sys.argv[1:])
+        return
     for name, case in cases().items():
         if case["kind"] == "output":
             continue

@@ -17,7 +17,8 @@ def test_hip_matches_reference_dump(pkg, name):
 @pytest.mark.parametrize("name", sorted(gu.REAL_CASES))
 def test_hip_on_the_reference_s_own_samples(pkg, name):
     """The reference's shipped inputs at BASELINE.json's sizes -- a08d83 @ 600x500, a08_a4b4r18_7000 @ 2048^2
-    (configs[2]), 50000.data @ 4096^2 (configs[3], 49 987 grains) -- through the C ABI: populations, obstacle
+    (configs[2]), 50000.data @ 4096^2 (configs[3], 49 987 grains), 50000-test.data @ 3072^2 (configs[0], 47 980
+    grains) and 50000.data @ 8192x4096 (configs[4]'s lattice on one GPU) -- through the C ABI: populations, obstacle
     map, hydrodynamic forces and grain kinematics after whole coupled steps hash (SHA-256 of the host-layout
     buffers) to what the unmodified reference produced."""
     class Sim:

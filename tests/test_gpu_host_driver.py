@@ -64,3 +64,25 @@ def test_checkpoint_and_restart_from_the_command_line(po, tmp_path):
     assert "Restarted from half.ckpt at step 67" in b.stdout
     fd = lambda out: re.search(r"final_density: ([0-9.]+)", out.stderr).group(1)
     assert fd(full) == fd(b)
+
+
+def test_duration_stops_after_the_same_step_as_the_reference(po, tmp_path):
+    """`do renderScene() while (nbsteps * dt <= duration)` (main.c:1880-1890): the stop condition is tested after
+    every DEM step, so a run ends at the first step count with nbsteps * dt > duration -- here a count that is not
+    a multiple of the 100-step console cadence -- and final_density is the oracle's after exactly that many steps."""
+    c = gu.CASES["G4_coupled_256x200"]
+    sample = tmp_path / "packing.data"
+    po.write_sample(str(sample), c["r_mm"], c["x_mm"], c["y_mm"])
+    r, x1, x2 = po.read_sample(str(sample))
+    ora = po.Oracle(256, 200, r, x1, x2)
+    dt = ora.scalars()["dt"]
+    want_steps = 237
+    duration = (want_steps - 0.5) * dt          # 236 * dt <= duration < 237 * dt
+    out = subprocess.run([EXE, str(sample), "--lx", "256", "--ly", "200", "--duration", repr(duration)],
+                         capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert int(re.search(r"dem_steps: (\d+)", out.stderr).group(1)) == want_steps
+    assert re.search(r"steps 200 steps", out.stdout) and not re.search(r"steps 300 steps", out.stdout)
+    fd = float(re.search(r"final_density: ([0-9.]+)", out.stderr).group(1))
+    ora.steps(want_steps)
+    assert abs(fd - ora.total_density()) < 1e-5

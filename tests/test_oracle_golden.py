@@ -21,10 +21,12 @@ def test_oracle_matches_reference_dump(po, name):
 
 
 @pytest.mark.parametrize("name,dumps", [("real_a08d83_600x500", None), ("real_7000_2048x2048", None),
-                                        ("real_50000_4096x4096", (1,))])
+                                        ("real_50000_4096x4096", (1,)), ("real_50000test_3072x3072", (1,)),
+                                        ("real_50000_8192x4096", (1,))])
 def test_oracle_on_the_reference_s_own_samples(po, name, dumps):
     """The reference's shipped inputs at BASELINE.json's sizes (a08d83 @ 600x500; a08_a4b4r18_7000 @ 2048^2 =
-    configs[2]; 50000.data @ 4096^2 = configs[3]): the state after whole coupled steps must hash to what the
+    configs[2]; 50000.data @ 4096^2 = configs[3]; 50000-test.data @ 3072^2 = configs[0], the CPU-only plumbing case;
+    50000.data @ 8192x4096 = configs[4] as one domain): the state after whole coupled steps must hash to what the
     unmodified reference produced (tests/golden/real_*.npz). The serial total density too (same order)."""
     class Sim:
         def __init__(self, lx, ly, r, x1, x2): self.o = po.Oracle(lx, ly, r, x1, x2)
