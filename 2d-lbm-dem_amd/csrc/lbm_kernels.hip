@@ -1181,10 +1181,18 @@ __global__ __launch_bounds__(64) void k_forces_parity(const double* __restrict__
 // PASSES = passes over the four line families: 2 when two families fit a wave (spd <= 32), else 4.
 struct DiscTest {
   double xc, yc, R2, r2;
-  __device__ __forceinline__ bool in(int x, int y) const {  // the paint test of k_obst_paint (main.c:1024-1028)
+  int xi, xf, yi, yf;  // the paint box, clamped to the lattice interior [1, l-2] (main.c:1016-1023)
+  __device__ __forceinline__ bool in(int x, int y) const {  // the paint test of k_obst_paint (main.c:1016-1028)
     const double d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc);
-    return d2 <= R2 && d2 <= r2;
+    return d2 <= R2 && d2 <= r2 && x >= xi && x <= xf && y >= yi && y <= yf;
   }
+};
+
+// What k_forces_table does with the grains it is given
+enum : int {
+  FT_CONSUME = 0,  // grains this rank owns: complete the table, replay the sums, write fhf
+  FT_PACK = 1      // listed grains owned by a neighbour rank: complete this rank's part of the table and write
+                   // {id, slots} to the message buffer (strip decomposition; the owner merges it into its own)
 };
 
 constexpr unsigned long long M_DIAG = 0x5555555555555555ull;  // bits of q = 1, 3, 5, 7 in a bitmap word
@@ -1194,10 +1202,14 @@ constexpr unsigned long long M_YDIR = 0x8888888888888888ull;  // q = 4, 8 (ex = 
 constexpr int FT_WAVES = 4;  // waves per workgroup of k_forces_table
 
 template <int GW, int PASSES>
-__global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(LatticeView L, GrainFluidView G, ForceSlots S, int cap1,
+__global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __restrict__ f, const int* __restrict__ obst,
+                                                                LatticeView L, GrainFluidView G, ForceSlots S, int cap1,
                                                                 int cap3, int nw64, double scale12, double scale3,
                                                                 double* __restrict__ fhf,
-                                                                unsigned char* __restrict__ owner) {
+                                                                unsigned char* __restrict__ owner, int mode,
+                                                                const int* __restrict__ list,
+                                                                const int* __restrict__ list_count,
+                                                                double* __restrict__ packbuf) {
   extern __shared__ double sDyn[];
   // per grain of the workgroup: addends of fhf1 [cap1] | fhf2 [cap1] | fhf3 [cap3]
   // then per wave: the bitmap [nw64] and the three per-word prefix counts [3][nw64]; then [FT_WAVES * GW][4] counts
@@ -1210,7 +1222,10 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(LatticeView L, G
                                              (size_t)FT_WAVES * nw64 * 3);
   const int lane = threadIdx.x & 63;
   const int gslot0 = wave * GW;                       // this wave's grains within the workgroup
-  const int g0 = (blockIdx.x * FT_WAVES + wave) * GW;
+  const int g0 = (blockIdx.x * FT_WAVES + wave) * GW; // position in the list (or the grain index itself without a list)
+  const int ntodo = list ? *list_count : L.n;
+  auto grain_at = [&](int pos) { return list ? list[pos] : pos; };
+  const int own_lo = L.gx0 + L.xo0, own_hi = L.gx0 + L.xo1;  // rows whose links this rank produces: [own_lo, own_hi)
   const int spd = S.spd, HB = S.hb;
   const int B = 2 * HB + 1;
   constexpr int FPP = 4 / PASSES;   // line families per pass
@@ -1226,17 +1241,19 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(LatticeView L, G
 
   unsigned long long fw[GW][PASSES], bw[GW][PASSES];  // slots of the forward / backward link of the lane's lines
   int n1[GW], n2[GW], n3[GW];                           // addends per accumulator; n1 < 0: gather
+  int gid[GW];                                          // grain index, -1: nothing to do
   bool own[GW];
   // ---- tables of all GW grains: fetch, reset (one round of global latency for the whole wave)
 #pragma unroll
   for (int g = 0; g < GW; ++g) {
-    const int i = g0 + g;
+    gid[g] = g0 + g < ntodo ? grain_at(g0 + g) : -1;
+    const int i = gid[g];
     bool local = false;
-    if (i < L.n) {
+    if (i >= 0) {
       const double xc = G.xc[i], rbl0 = G.rbl0[i];
       local = xc + rbl0 + 2.0 >= (double)L.gx0 && xc - rbl0 - 2.0 <= (double)(L.gx0 + L.nxl);
     }
-    unsigned long long* tg = reinterpret_cast<unsigned long long*>(S.tab) + (long)(i < L.n ? i : 0) * 8 * spd;
+    unsigned long long* tg = reinterpret_cast<unsigned long long*>(S.tab) + (long)(i >= 0 ? i : 0) * 8 * spd;
 #pragma unroll
     for (int j = 0; j < PASSES; ++j) {
       const int fm = j * FPP + lane / LPF;
@@ -1258,23 +1275,20 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(LatticeView L, G
   // ---- phase A
 #pragma unroll
   for (int g = 0; g < GW; ++g) {
-    const int i = g0 + g;
+    const int i = gid[g];
     n1[g] = n2[g] = n3[g] = 0;
     own[g] = false;
-    if (i >= L.n) continue;
+    if (i < 0) continue;
     const double xc = G.xc[i], yc = G.yc[i], rbl0 = G.rbl0[i], r2 = G.r2[i];
     own[g] = grain_owned(L, xc);
     const bool was_touched = S.touched[i] != 0;
-    if (was_touched && lane == 0) S.touched[i] = 0;  // the rasteriser sets it again while it applies
+    if (was_touched && lane == 0 && mode == FT_CONSUME) S.touched[i] = 0;  // the rasteriser sets it again while it applies
     int xi, xf, yi, yf;
-    if (!own[g] || !grain_box(L, G, i, xi, xf, yi, yf)) continue;
-    // the clamp of the paint box to [1, l-2] must not cut the reduced disc: centre at least rLB (+ a margin) inside
-    const double m_lo_x = xc - 1.000001, m_hi_x = (double)(L.lx - 2) - 0.000001 - xc;
-    const double m_lo_y = yc - 1.000001, m_hi_y = (double)(L.ly - 2) - 0.000001 - yc;
-    const double m_min = fmin(fmin(m_lo_x, m_hi_x), fmin(m_lo_y, m_hi_y));
-    const bool unclamped = m_min > 0.0 && m_min * m_min >= r2;
-    if (was_touched || !unclamped) { n1[g] = -1; continue; }
-    const DiscTest D{xc, yc, rbl0 * rbl0, r2};
+    const bool todo = (mode == FT_CONSUME ? own[g] : !own[g]) && grain_box(L, G, i, xi, xf, yi, yf);
+    if (!todo) continue;
+    // overlapping discs: a lattice line may then carry several links of one direction -- not a table case
+    if (was_touched) { n1[g] = -1; continue; }
+    const DiscTest D{xc, yc, rbl0 * rbl0, r2, xi, xf, yi, yf};
     const int X0 = (int)xc, Y0 = (int)yc;
     for (int w = lane; w < nw64; w += 64) bm[w] = 0ull;
     __builtin_amdgcn_wave_barrier();
@@ -1297,18 +1311,48 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(LatticeView L, G
       const double mf = (sq - be) * inv_ee, mb = (-sq - be) * inv_ee;  // chord ends, in steps of e
       const double ff = floor(mf), cb = ceil(mb);
       // a chord end within rounding distance of a lattice node: let the gather path decide
-      const bool shaky = (mf - ff < 1e-7) || (ff + 1.0 - mf < 1e-7) || (cb - mb < 1e-7) || (mb - (cb - 1.0) < 1e-7);
-      const int kf = (int)ff, kb = (int)cb;
+      const bool shaky = (mf - ff < 1e-9) || (ff + 1.0 - mf < 1e-9) || (cb - mb < 1e-9) || (mb - (cb - 1.0) < 1e-9);
+      int kf = (int)ff, kb = (int)cb;
+      // the part of the line inside the paint box (the lattice-interior clamp cuts discs that reach a wall)
+      {
+        int lo = -(1 << 20), hi = 1 << 20;
+        if (ex != 0) { lo = max(lo, xi - px0); hi = min(hi, xf - px0); }           // ex = +1 in every family
+        else if (px0 < xi || px0 > xf) hi = lo - 1;
+        if (ey > 0) { lo = max(lo, yi - py0); hi = min(hi, yf - py0); }
+        else if (ey < 0) { lo = max(lo, py0 - yf); hi = min(hi, py0 - yi); }
+        else if (py0 < yi || py0 > yf) hi = lo - 1;
+        kf = min(kf, hi);
+        kb = max(kb, lo);
+      }
       const bool f0 = D.in(px0 + kf * ex, py0 + kf * ey), f1 = D.in(px0 + (kf + 1) * ex, py0 + (kf + 1) * ey);
       const bool b0 = D.in(px0 + kb * ex, py0 + kb * ey), b1 = D.in(px0 + (kb - 1) * ex, py0 + (kb - 1) * ey);
       const bool has = f0 && !f1 && b0 && !b1 && kb <= kf;      // the line carries a chord of in-disc nodes
       const bool none = !f0 && !f1 && !b0 && !b1;                // ... or none
       const bool meets = has && !far && lane_has_line;
-      const bool ffill = fw[g][j] != LBMDEM_SLOT_EMPTY, bfill = bw[g][j] != LBMDEM_SLOT_EMPTY;
+      bool ffill = fw[g][j] != LBMDEM_SLOT_EMPTY, bfill = bw[g][j] != LBMDEM_SLOT_EMPTY;
       if (lane_has_line && !far && ((!has && !none) || (has && shaky))) bad = true;
-      if (meets != ffill || meets != bfill) bad = true;
+      if (!meets && (ffill || bfill)) bad = true;   // a sum where the geometry has no link
+      // A link of the geometry without a sum ends in a non-fluid node (a lattice-edge wall, another grain): the
+      // fused kernel does not log those. If its far end lies in this rank's rows, gather the two populations
+      // (main.c:1313-1316); otherwise it is the neighbour rank's to complete.
+      if (meets && (!ffill || !bfill)) {
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+          if (side == 0 ? ffill : bfill) continue;
+          const int km = side == 0 ? kf : kb, sg = side == 0 ? 1 : -1;
+          const int px = px0 + km * ex, py = py0 + km * ey, nx = px + sg * ex, ny = py + sg * ey;
+          if (nx < own_lo || nx >= own_hi) continue;
+          const int ql = side == 0 ? q : q - 4, qlo = side == 0 ? q - 4 : q;
+          const long nodeP = (long)(px - L.gx0) * L.sy + py, nodeN = (long)(nx - L.gx0) * L.sy + ny;
+          if (obst[nodeP] != i || obst[nodeN] == -1) { bad = true; continue; }  // the table should have had it
+          const double sum = f[fidx(qlo, nodeP)] + f[fidx(ql, nodeN)];
+          if (side == 0) { fw[g][j] = (unsigned long long)__double_as_longlong(sum); ffill = true; }
+          else { bw[g][j] = (unsigned long long)__double_as_longlong(sum); bfill = true; }
+        }
+        if (mode == FT_CONSUME && (!ffill || !bfill)) bad = true;  // the owner must end up with every sum
+      }
       keyf[j] = keyb[j] = -1;
-      if (meets) {
+      if (meets && mode == FT_CONSUME) {
         // in-disc nodes lie within +-hb of the truncated centre (hb >= largest reduced radius + 1)
         const int bxf = px0 + kf * ex - (X0 - HB), byf = py0 + kf * ey - (Y0 - HB);
         const int bxb = px0 + kb * ex - (X0 - HB), byb = py0 + kb * ey - (Y0 - HB);
@@ -1325,6 +1369,24 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(LatticeView L, G
       }
     }
     if (__any(bad)) { n1[g] = -1; continue; }
+    if (mode == FT_PACK) {  // {id, slots} to the message; the owner merges
+      const int nslot = 8 * spd;
+      unsigned long long* e = reinterpret_cast<unsigned long long*>(packbuf) + 1 + (long)(g0 + g) * (1 + nslot);
+      if (lane == 0) reinterpret_cast<double*>(e)[0] = (double)i;
+      for (int k = lane; k < nslot; k += 64) e[1 + k] = LBMDEM_SLOT_EMPTY;
+      __builtin_amdgcn_wave_barrier();  // one wave's stores to the same address keep their order
+      __threadfence_block();
+#pragma unroll
+      for (int j = 0; j < PASSES; ++j) {
+        const int fm = j * FPP + lane / LPF;
+        const int q = fam_q(fm), rb = S.half - c;
+        if (lane_has_line) {
+          e[1 + (q - 1) * spd + rel] = fw[g][j];
+          if (rb >= 0 && rb < spd) e[1 + (q - 5) * spd + rb] = bw[g][j];
+        }
+      }
+      continue;
+    }
     __builtin_amdgcn_wave_barrier();
     // per-word exclusive prefixes of the three addend counts
     {
@@ -1394,15 +1456,21 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(LatticeView L, G
   // hand the wave's counts to the replaying wave; queue what the table could not serve
 #pragma unroll
   for (int g = 0; g < GW; ++g) {
-    const int i = g0 + g;
+    const int i = gid[g];
     if (lane == 0) {
-      int* cnt = counts + (gslot0 + g) * 4;
-      cnt[0] = n1[g]; cnt[1] = n2[g]; cnt[2] = n3[g]; cnt[3] = own[g] ? 1 : 0;
-      if (i < L.n) {
+      int* cnt = counts + (gslot0 + g) * 5;
+      cnt[0] = n1[g]; cnt[1] = n2[g]; cnt[2] = n3[g]; cnt[3] = own[g] ? 1 : 0; cnt[4] = i;
+      if (i >= 0 && mode == FT_CONSUME) {
         if (owner) owner[i] = own[g] ? 1 : 0;
         if (n1[g] < 0) S.queue[atomicAdd(S.gathered, 1)] = i;
       }
+      // a neighbour's grain whose table this rank cannot complete (overlapping discs across a strip cut)
+      if (i >= 0 && mode == FT_PACK && n1[g] < 0) atomicOr(S.error, 1);
     }
+  }
+  if (mode == FT_PACK) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) packbuf[0] = (double)ntodo;
+    return;
   }
   __syncthreads();
   if (wave != 0) return;
@@ -1412,13 +1480,14 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(LatticeView L, G
     constexpr int NG = FT_WAVES * GW;
     static_assert(3 * NG <= 64, "one lane per accumulator");
     const int g = lane / 3, a = lane - 3 * g;
-    const int gi = blockIdx.x * NG + g;
+    int gi = -1;
     int mine = 0, longest = 0;
     bool replayed = false, mine_own = false;
     if (g < NG) {
-      const int* cnt = counts + g * 4;
+      const int* cnt = counts + g * 5;
       replayed = cnt[0] >= 0;
       mine_own = cnt[3] != 0;
+      gi = cnt[4];
       if (replayed) mine = (cnt[a] + 7) & ~7;
     }
     longest = mine;
@@ -1438,7 +1507,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(LatticeView L, G
         for (int u = 0; u < 4; ++u) { h = h + v[u].x; h = h + v[u].y; }
       }
     }
-    if (g < NG && gi < L.n && replayed) fhf[a * L.n + gi] = mine_own ? h * (a == 2 ? scale3 : scale12) : 0.0;
+    if (g < NG && gi >= 0 && replayed) fhf[a * L.n + gi] = mine_own ? h * (a == 2 ? scale3 : scale12) : 0.0;
   }
 }
 
@@ -1454,6 +1523,10 @@ __global__ __launch_bounds__(64) void k_forces_gather_queue(const double* __rest
     const int i = S.queue[k];
     int xi, xf, yi, yf;
     grain_box(L, G, i, xi, xf, yi, yf);
+    if (xi - 1 < L.gx0 || xf + 1 > L.gx0 + L.nxl - 1) {  // the footprint leaves this rank's rows: cannot gather it
+      if (lane == 0) atomicOr(S.error, 2);
+      continue;
+    }
     const double h = force_gather(sh, f, obst, L, i, G.xc[i], G.yc[i], xi, xf, yi, yf, lane);
     if (lane < 3) fhf[lane * L.n + i] = h * (lane == 2 ? scale3 : scale12);
   }
@@ -1770,10 +1843,11 @@ static void launch_forces_table_t(const double* f, const int* obst, const Lattic
   // diagonal families, <= 2 hb + 1 for the axis families); fhf3 takes two addends per diagonal link
   const int cap1 = (4 * S.spd + 2 * B + 7) & ~7, cap3 = (8 * S.spd + 4 * B + 7) & ~7;
   const size_t lists_doubles = (size_t)FT_WAVES * GW * (2 * cap1 + cap3);
-  const size_t lds = lists_doubles * 8 + (size_t)FT_WAVES * nw64 * 24 + (size_t)FT_WAVES * GW * 16;
+  const size_t lds = lists_doubles * 8 + (size_t)FT_WAVES * nw64 * 24 + (size_t)FT_WAVES * GW * 20;
   const int per_block = FT_WAVES * GW;
   hipLaunchKernelGGL((k_forces_table<GW, PASSES>), dim3((L.n + per_block - 1) / per_block), dim3(64 * FT_WAVES), lds, st,
-                     L, G, S, cap1, cap3, nw64, scale12, scale3, fhf, owner);
+                     f, obst, L, G, S, cap1, cap3, nw64, scale12, scale3, fhf, owner, (int)FT_CONSUME, (const int*)nullptr,
+                     (const int*)nullptr, (double*)nullptr);
   const int grid = L.n < 256 ? L.n : 256;
   hipLaunchKernelGGL(k_forces_gather_queue, dim3(grid), dim3(64), 0, st, f, obst, L, G, S, scale12, scale3, fhf);
 }

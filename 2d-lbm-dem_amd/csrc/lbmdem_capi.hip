@@ -55,7 +55,7 @@ struct lbmdem_handle {
   const double* cs_fin = nullptr;
   const int *cs_ob_old = nullptr, *cs_ob_new = nullptr;
   int cs_lo_end = 0, cs_hi_begin = 0;  // interior = local rows [cs_lo_end, cs_hi_begin)
-  ForceSlots cs_slots{nullptr, nullptr, 0, 0, 0, nullptr, nullptr};
+  ForceSlots cs_slots{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr};
   // grains
   int n = 0;
   double* gbuf = nullptr;  // one allocation, carved below
@@ -73,7 +73,7 @@ struct lbmdem_handle {
   double* fhf = nullptr;  // [3][n]
   unsigned char* owner = nullptr;
   // link sums handed from the fused kernel to the force kernel (ForceSlots, lbmdem_internal.h)
-  ForceSlots fs{nullptr, nullptr, 0, 0, 0, nullptr, nullptr};
+  ForceSlots fs{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr};
   bool slots_clean = false;  // every slot is empty
   bool last_forces_from_table = false;
   bool slots_valid = false;  // the table was filled by the collide_stream that produced f[fcur] with the current map
@@ -308,6 +308,8 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
   CREATE_TRY(hipMalloc((void**)&h->owner, n));
   CREATE_TRY(hipMemsetAsync(h->owner, 1, n, h->stream));
   CREATE_TRY(hipMalloc((void**)&h->fs.queue, sizeof(int) * n));
+  CREATE_TRY(hipMalloc((void**)&h->fs.error, sizeof(int)));
+  CREATE_TRY(hipMemsetAsync(h->fs.error, 0, sizeof(int), h->stream));
   CREATE_TRY(hipMalloc((void**)&h->fs.gathered, sizeof(int)));
   CREATE_TRY(hipMemsetAsync(h->fs.gathered, 0, sizeof(int), h->stream));
   CREATE_TRY(hipMalloc((void**)&h->fs.touched, n));
@@ -388,6 +390,7 @@ int lbmdem_destroy(lbmdem_handle* h) {
   if (h->fs.tab) (void)hipFree(h->fs.tab);
   if (h->fs.gathered) (void)hipFree(h->fs.gathered);
   if (h->fs.queue) (void)hipFree(h->fs.queue);
+  if (h->fs.error) (void)hipFree(h->fs.error);
   if (h->dpartial) (void)hipFree(h->dpartial);
   verlet_free(h->V);
   if (h->ovf_host) (void)hipHostFree((void*)h->ovf_host);
@@ -546,6 +549,18 @@ int lbmdem_force_stats(lbmdem_handle* h, int* from_table, int* gathered) {
   if (gathered) *gathered = g;
   return LBMDEM_OK;
 }
+
+#ifdef LBMDEM_AB
+int lbmdem_debug_gather_queue(lbmdem_handle* h, int* out, int cap) {   // experiment builds only
+  CHECK_H(h);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  int g = 0;
+  HIP_TRY(hipMemcpy(&g, h->fs.gathered, sizeof(int), hipMemcpyDeviceToHost));
+  if (g > cap) g = cap;
+  if (g > 0) HIP_TRY(hipMemcpy(out, h->fs.queue, sizeof(int) * g, hipMemcpyDeviceToHost));
+  return g;
+}
+#endif
 
 int lbmdem_lbm_step(lbmdem_handle* h) {
   int rc = lbmdem_obst_construction(h);
@@ -1260,6 +1275,10 @@ int lbmdem_sync(lbmdem_handle* h) {
   int ovf = 0;
   HIP_TRY(hipMemcpy(&ovf, h->V.overflow, sizeof(int), hipMemcpyDeviceToHost));
   if (ovf) return fail(LBMDEM_ENOMEM, "Verlet list overflow (more than %ld symmetric entries)", h->V.cap);
+  int ferr = 0;
+  HIP_TRY(hipMemcpy(&ferr, h->fs.error, sizeof(int), hipMemcpyDeviceToHost));
+  if (ferr) return fail(LBMDEM_EINVAL, "hydrodynamic force of a grain cut by a strip boundary could not be formed (code %d: "
+                                       "overlapping reduced discs across the cut, or a message capacity exceeded)", ferr);
   return LBMDEM_OK;
 }
 

@@ -60,6 +60,7 @@ struct ForceSlots {
   int hb;    // >= largest reduced radius in nodes + 1: a grain's nodes lie within +-hb of its truncated centre
   int* gathered;  // device counter: grains the table could not serve ...
   int* queue;     // ... and their indices, for the gather kernel that follows
+  int* error;     // device flag: a grain cut by a strip boundary that neither the table nor a local gather can serve
 };
 #define LBMDEM_SLOT_EMPTY 0x7FF8C0DE5107E117ull  /* a quiet NaN no arithmetic produces */
 constexpr int LBMDEM_SPD_MAX = 64;               // larger grains (reduced radius > ~20 nodes): feature off

@@ -54,7 +54,7 @@ def compare(name, res, grain_cols=None):
             assert np.array_equal(val, ref), f"{name}/{key}: max abs {np.abs(val - ref).max():.3e}"
             checked += 1
             continue
-        if key in g.files:
+        if key in g:
             assert np.array_equal(val, g[key], equal_nan=True), f"{name}/{key} differs from the reference dump"
         else:
             samp = val[::4, ::4] if val.ndim == 2 else val[::4, ::4, :]

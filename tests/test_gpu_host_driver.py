@@ -78,7 +78,7 @@ def test_duration_stops_after_the_same_step_as_the_reference(po, tmp_path):
     dt = ora.scalars()["dt"]
     want_steps = 237
     duration = (want_steps - 0.5) * dt          # 236 * dt <= duration < 237 * dt
-    out = subprocess.run([EXE, str(sample), "--lx", "256", "--ly", "200", "--duration", repr(duration)],
+    out = subprocess.run([EXE, str(sample), "--lx", "256", "--ly", "200", "--duration", repr(float(duration))],
                          capture_output=True, text=True, cwd=tmp_path, timeout=300)
     assert out.returncode == 0, out.stderr[-500:]
     assert int(re.search(r"dem_steps: (\d+)", out.stderr).group(1)) == want_steps

@@ -144,7 +144,9 @@ def test_grains_touching_lattice_edges(pkg, po):
     sim.kinematics = k; ora.set_kinematics(k); sim.f = f0; ora.set_f(f0)
     for _ in range(4):
         sim.lbm_step(); ora.lbm_steps(1)
-    assert sim.force_stats() == (0, 5)     # every grain is cut by the lattice-edge clamp: all gathered
+    # every disc is cut by the lattice-interior clamp and has links into wall nodes: still served from the link
+    # table (chord ends clipped to the paint box; the few sums the fused kernel does not log are gathered one by one)
+    assert sim.force_stats() == (5, 0)
     assert np.array_equal(sim.obst, ora.get_obst())
     assert np.array_equal(sim.f, ora.get_f())
     assert np.array_equal(sim.fhf, ora.get_fhf())
