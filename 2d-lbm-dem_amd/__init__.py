@@ -112,6 +112,14 @@ def load_library():
     L.lbmdem_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.lbmdem_halo_pack.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.lbmdem_halo_unpack.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.lbmdem_dist_default_margin.argtypes = [C.c_void_p]
+    L.lbmdem_dist_enable.argtypes = [C.c_void_p, C.c_int]
+    L.lbmdem_dist_message_doubles.argtypes = [C.c_void_p, C.c_int]
+    L.lbmdem_dist_message_doubles.restype = C.c_long
+    L.lbmdem_dist_begin_period.argtypes = [C.c_void_p]
+    L.lbmdem_dist_pack.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.lbmdem_dist_unpack.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.lbmdem_dist_set_poison.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_fhf_export.argtypes = [C.c_void_p, C.c_void_p]
     L.lbmdem_fhf_import.argtypes = [C.c_void_p, C.c_void_p]
     L.lbmdem_fhf_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
@@ -427,6 +435,30 @@ class LbmDem:
 
     def halo_unpack(self, side, dev_ptr):
         _chk(self._L.lbmdem_halo_unpack(self._h, int(side), C.c_void_p(dev_ptr)))
+
+    # ---- strips with distributed grains (include/lbmdem_hip.h: lbmdem_dist_*) --------------------------------------
+    MSG_KIN, MSG_FHF, MSG_TABLES = 0, 1, 2
+
+    def dist_default_margin(self):
+        return int(self._L.lbmdem_dist_default_margin(self._h))
+
+    def dist_enable(self, margin_rows=0):
+        _chk(self._L.lbmdem_dist_enable(self._h, int(margin_rows)))
+
+    def dist_message_doubles(self, kind):
+        return int(self._L.lbmdem_dist_message_doubles(self._h, int(kind)))
+
+    def dist_begin_period(self):
+        _chk(self._L.lbmdem_dist_begin_period(self._h))
+
+    def dist_pack(self, kind, side, dev_ptr):
+        _chk(self._L.lbmdem_dist_pack(self._h, int(kind), int(side), C.c_void_p(dev_ptr)))
+
+    def dist_unpack(self, kind, side, dev_ptr):
+        _chk(self._L.lbmdem_dist_unpack(self._h, int(kind), int(side), C.c_void_p(dev_ptr)))
+
+    def dist_set_poison(self, on=True):
+        _chk(self._L.lbmdem_dist_set_poison(self._h, 1 if on else 0))
 
     def fhf_export(self, dev_ptr):
         _chk(self._L.lbmdem_fhf_export(self._h, C.c_void_p(dev_ptr)))

@@ -167,9 +167,10 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
                               const double* __restrict__ It, const double* __restrict__ fhf,
                               const int* __restrict__ offsets, const int* __restrict__ nbr,
                               const unsigned char* __restrict__ wallflags, double* __restrict__ pout,
-                              DiagOut D, DemParams P) {
+                              DiagOut D, DemParams P, const unsigned char* __restrict__ active) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
+  if (active && !active[i]) return;  // strip decomposition: a grain another rank integrates
   const GrainState me = advance(in, r, i, P);
   const double x3 = in.x3[i] + P.dt * in.v3[i] + P.dt2 * in.a3[i] / 2.;
 
@@ -260,16 +261,19 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const doub
                                                      const int* __restrict__ offsets,
                                                      const int* __restrict__ nbr, const int* __restrict__ own,
                                                      const unsigned char* __restrict__ wallflags,
-                                                     double* __restrict__ pout, DemParams P) {
+                                                     double* __restrict__ pout, DemParams P,
+                                                     const unsigned char* __restrict__ active) {
   __shared__ double sF1[DEM_ENTRIES], sF2[DEM_ENTRIES], sF3[DEM_ENTRIES], sFn[DEM_ENTRIES];
   __shared__ unsigned char sTouched[DEM_ENTRIES];
   const int tid = threadIdx.x;
   const int g0 = blockIdx.x * DEM_GRAINS;
   const int g1 = g0 + DEM_GRAINS < P.n ? g0 + DEM_GRAINS : P.n;
-  const int e0 = offsets[g0], e1 = offsets[g1];
   // phase-2 lanes: everything that does not depend on the partners is requested now
   const int i = g0 + tid;
-  const bool mine = tid < DEM_GRAINS && i < P.n;
+  // strip decomposition: only the grains this rank integrates (owned + margin); the others keep whatever they hold
+  const bool mine = tid < DEM_GRAINS && i < P.n && (!active || active[i]);
+  if (active && !__syncthreads_or(mine ? 1 : 0)) return;
+  const int e0 = offsets[g0], e1 = offsets[g1];
   GrainState me{};
   double x3 = 0., a1 = 0., a2 = 0., a3 = 0., pr = 0.0, mi = 1., Iti = 1.;
   int k0 = 0, k1 = 0;
@@ -286,6 +290,7 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const doub
     const int lim = base + DEM_ENTRIES < e1 ? base + DEM_ENTRIES : e1;
     for (int e = base + tid; e < lim; e += 256) {
       const int gi = own[e], gj = nbr[e];
+      if (active && !active[gi]) continue;   // nobody adds this entry up
       const GrainState a = advance(in, r, gi, P), b = advance(in, r, gj, P);
       const bool lower = gi < gj;
       bool touched;
@@ -730,7 +735,8 @@ void launch_fill_own(const VerletDevice& V, int n, hipStream_t st) {
 
 void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const double* m,
                         const double* It, const double* fhf, const VerletDevice& V, double* pout,
-                        const DemParams& P, int film, double* diag, const DiagExtra* X, hipStream_t st) {
+                        const DemParams& P, int film, double* diag, const DiagExtra* X, const unsigned char* active,
+                        hipStream_t st) {
   const int n = P.n;
 #ifdef LBMDEM_AB
   static const int variant = getenv("LBMDEM_DEM_VARIANT") ? atoi(getenv("LBMDEM_DEM_VARIANT")) : 1;
@@ -741,10 +747,10 @@ void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const do
     const int nbe = (n + DEM_GRAINS - 1) / DEM_GRAINS;
     if (film)
       hipLaunchKernelGGL(k_dem_entries<true>, dim3(nbe), dim3(256), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
-                         V.own, V.wallflags, pout, P);
+                         V.own, V.wallflags, pout, P, active);
     else
       hipLaunchKernelGGL(k_dem_entries<false>, dim3(nbe), dim3(256), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
-                         V.own, V.wallflags, pout, P);
+                         V.own, V.wallflags, pout, P, active);
     return;
   }
   const int nb = (P.n + 127) / 128;
@@ -757,7 +763,7 @@ void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const do
   }
 #define LBM_DEM_LAUNCH(FILM, DIAG)                                                                        \
   hipLaunchKernelGGL((k_dem_substep<FILM, DIAG>), dim3(nb), dim3(128), 0, st, in, out, r, m, It, fhf,    \
-                     V.offsets, V.nbr, V.wallflags, pout, D, P)
+                     V.offsets, V.nbr, V.wallflags, pout, D, P, active)
   if (film) { if (diag) LBM_DEM_LAUNCH(true, true); else LBM_DEM_LAUNCH(true, false); }
   else { if (diag) LBM_DEM_LAUNCH(false, true); else LBM_DEM_LAUNCH(false, false); }
 #undef LBM_DEM_LAUNCH

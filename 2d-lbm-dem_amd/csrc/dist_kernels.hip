@@ -1,0 +1,191 @@
+// dist_kernels.hip -- x-strip decomposition with the GRAINS distributed over the ranks (one process per GPU).
+//
+// The reference has one address space. Under strip decomposition every rank keeps arrays for
+// all n grains (global index = array index: the Verlet list, the ascending-partner summation order and every
+// formula stay exactly as on one GPU) but INTEGRATES only the grains it owns (centre in its rows) plus a margin on
+// either side. Between two fluid steps the npDEM sub-steps run without communication: an error at the outer edge
+// of the margin (its grains miss partners that nobody here integrates) travels at most one Verlet-list edge per
+// sub-step, and the margin is npDEM edges deep, so it never reaches an owned grain or a grain whose disc touches
+// this rank's rows. Once per fluid step the margin is refreshed by the two neighbours (kinematics, then the
+// hydrodynamic forces of the same grains); a grain that crosses a cut simply changes owner -- both sides hold its
+// exact state, the refresh message is its migration. Nothing here is a collective.
+//
+// Kernels of this file: ownership / masks / message lists from the current positions, and the packing and
+// unpacking of the three point-to-point messages (kinematics, hydrodynamic forces, link-sum tables).
+
+#include "lbmdem_internal.h"
+
+namespace {
+
+// error bits OR-ed into ForceSlots::error
+constexpr int ERR_LIST_OVERFLOW = 4;   // more grains near a cut than the message capacity
+constexpr int ERR_MERGE_CLASH = 8;     // two ranks produced the same link sum
+
+__global__ void k_dist_classify(DistDevice D, DistGeom Gm, int n, const double* __restrict__ x1,
+                                const double* __restrict__ r, const double* __restrict__ rLB,
+                                unsigned char* __restrict__ owner, int* __restrict__ error) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool act = D.active[i] != 0;   // integrated during the last period: exact wherever it matters below
+  const double xc = (x1[i] - Gm.Mgx) / Gm.dx;   // the rasteriser's lattice coordinate of the centre (main.c:1009)
+  const bool own = act && (Gm.first || xc >= Gm.lo) && (Gm.last || xc < Gm.hi);
+  owner[i] = own ? 1 : 0;
+  D.active[i] = own ? 1 : 0;           // the margin joins when the neighbours' messages are unpacked
+  // grains that may cover nodes of this rank's rows (+ halo) or have links ending there
+  const double reach = r[i] / Gm.dx + 3.0;
+  D.fluidmask[i] = (act && xc + reach >= (double)Gm.gx0 && xc - reach <= (double)(Gm.gx0 + Gm.nxl)) ? 1 : 0;
+  if (!act) return;
+  auto append = [&](int* list, int which, int cap) {
+    const int k = atomicAdd(&D.counters[which], 1);
+    if (k < cap) list[k] = i; else atomicOr(error, ERR_LIST_OVERFLOW);
+  };
+  if (own && Gm.has_lo && xc < Gm.lo + Gm.margin) append(D.send_list[0], 0, D.cap_g);
+  if (own && Gm.has_hi && xc >= Gm.hi - Gm.margin) append(D.send_list[1], 1, D.cap_g);
+  // a neighbour's grain whose ring of boundary links (reduced disc + one node) reaches into this rank's rows
+  const double ring = rLB[i] + 2.0;
+  if (!own && Gm.has_lo && xc < Gm.lo && xc + ring >= Gm.lo) append(D.strad_list[0], 2, D.cap_t);
+  if (!own && Gm.has_hi && xc >= Gm.hi && xc - ring < Gm.hi) append(D.strad_list[1], 3, D.cap_t);
+}
+
+__global__ void k_clamp_counts(DistDevice D) {
+  if (threadIdx.x < 2 && D.counters[threadIdx.x] > D.cap_g) D.counters[threadIdx.x] = D.cap_g;
+  if (threadIdx.x >= 2 && threadIdx.x < 4 && D.counters[threadIdx.x] > D.cap_t) D.counters[threadIdx.x] = D.cap_t;
+}
+
+__global__ void k_pack_kin(const int* __restrict__ list, const int* __restrict__ count, Kin K, double* __restrict__ buf) {
+  const int cnt = *count;
+  if (blockIdx.x == 0 && threadIdx.x == 0) buf[0] = (double)cnt;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) {
+    const int i = list[k];
+    double* o = buf + 1 + (long)k * 10;
+    o[0] = (double)i;
+    o[1] = K.x1[i]; o[2] = K.x2[i]; o[3] = K.x3[i]; o[4] = K.v1[i]; o[5] = K.v2[i]; o[6] = K.v3[i];
+    o[7] = K.a1[i]; o[8] = K.a2[i]; o[9] = K.a3[i];
+  }
+}
+
+__global__ void k_unpack_kin(const double* __restrict__ buf, int cap, Kin K, unsigned char* __restrict__ active,
+                             int* __restrict__ recv_ids, int* __restrict__ recv_count, int n, int* __restrict__ error) {
+  int cnt = (int)buf[0];
+  if (cnt < 0 || cnt > cap) { cnt = 0; if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(error, ERR_LIST_OVERFLOW); }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *recv_count = cnt;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) {
+    const double* o = buf + 1 + (long)k * 10;
+    const int i = (int)o[0];
+    if (i < 0 || i >= n) continue;
+    recv_ids[k] = i;
+    K.x1[i] = o[1]; K.x2[i] = o[2]; K.x3[i] = o[3]; K.v1[i] = o[4]; K.v2[i] = o[5]; K.v3[i] = o[6];
+    K.a1[i] = o[7]; K.a2[i] = o[8]; K.a3[i] = o[9];
+    active[i] = 1;
+  }
+}
+
+__global__ void k_pack_fhf(const int* __restrict__ list, const int* __restrict__ count, const double* __restrict__ fhf,
+                           int n, double* __restrict__ buf) {
+  const int cnt = *count;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) {
+    const int i = list[k];
+    buf[3 * (long)k] = fhf[i]; buf[3 * (long)k + 1] = fhf[n + i]; buf[3 * (long)k + 2] = fhf[2 * (long)n + i];
+  }
+}
+
+__global__ void k_unpack_fhf(const int* __restrict__ ids, const int* __restrict__ count, double* __restrict__ fhf, int n,
+                             const double* __restrict__ buf) {
+  const int cnt = *count;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) {
+    const int i = ids[k];
+    fhf[i] = buf[3 * (long)k]; fhf[n + i] = buf[3 * (long)k + 1]; fhf[2 * (long)n + i] = buf[3 * (long)k + 2];
+  }
+}
+
+// the neighbour's part of the link-sum tables of grains this rank owns: slot by slot into the local table
+__global__ void k_merge_tables(ForceSlots S, const double* __restrict__ buf, int cap) {
+  int cnt = (int)buf[0];
+  if (cnt < 0 || cnt > cap) { cnt = 0; if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(S.error, ERR_LIST_OVERFLOW); }
+  const int nslot = 8 * S.spd;
+  const unsigned long long* b = reinterpret_cast<const unsigned long long*>(buf);
+  unsigned long long* tab = reinterpret_cast<unsigned long long*>(S.tab);
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int e = wave; e < cnt; e += nwaves) {
+    const unsigned long long* ent = b + 1 + (long)e * (1 + nslot);
+    const int i = (int)reinterpret_cast<const double*>(ent)[0];
+    for (int k = lane; k < nslot; k += 64) {
+      const unsigned long long v = ent[1 + k];
+      if (v == LBMDEM_SLOT_EMPTY) continue;
+      unsigned long long* t = tab + (long)i * nslot + k;
+      if (*t != LBMDEM_SLOT_EMPTY) atomicOr(S.error, ERR_MERGE_CLASH);
+      *t = v;
+    }
+  }
+}
+
+// diagnostic: grains this rank does not integrate hold NaN -- a use of stale state shows up in the results
+__global__ void k_poison(const unsigned char* __restrict__ active, Kin a, Kin b, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || active[i]) return;
+  const double q = __longlong_as_double(0x7FF8000000000BADll);
+  a.x1[i] = a.x2[i] = a.x3[i] = a.v1[i] = a.v2[i] = a.v3[i] = a.a1[i] = a.a2[i] = a.a3[i] = q;
+  b.x1[i] = b.x2[i] = b.x3[i] = b.v1[i] = b.v2[i] = b.v3[i] = b.a1[i] = b.a2[i] = b.a3[i] = q;
+}
+
+}  // namespace
+
+int dist_alloc(DistDevice& D, int n, int cap_g, int cap_t) {
+  D = DistDevice{};
+  D.cap_g = cap_g; D.cap_t = cap_t;
+  hipError_t e = hipSuccess;
+  auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 16); };
+  A((void**)&D.active, n); A((void**)&D.fluidmask, n);
+  for (int s = 0; s < 2; ++s) {
+    A((void**)&D.send_list[s], sizeof(int) * cap_g);
+    A((void**)&D.strad_list[s], sizeof(int) * cap_t);
+    A((void**)&D.recv_ids[s], sizeof(int) * cap_g);
+  }
+  A((void**)&D.counters, sizeof(int) * 8);
+  if (e != hipSuccess) return -1;
+  if (hipMemset(D.active, 1, n) != hipSuccess || hipMemset(D.fluidmask, 1, n) != hipSuccess ||
+      hipMemset(D.counters, 0, sizeof(int) * 8) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+    return -1;
+  return 0;
+}
+
+void dist_free(DistDevice& D) {
+  void* ps[] = {D.active, D.fluidmask, D.send_list[0], D.send_list[1], D.strad_list[0], D.strad_list[1],
+                D.recv_ids[0], D.recv_ids[1], D.counters};
+  for (void* p : ps) if (p) (void)hipFree(p);
+  D = DistDevice{};
+}
+
+void launch_dist_classify(const DistDevice& D, const DistGeom& Gm, int n, const double* x1, const double* r,
+                          const double* rLB, unsigned char* owner, int* error, hipStream_t st) {
+  (void)hipMemsetAsync(D.counters, 0, sizeof(int) * 4, st);
+  hipLaunchKernelGGL(k_dist_classify, dim3((n + 255) / 256), dim3(256), 0, st, D, Gm, n, x1, r, rLB, owner, error);
+  hipLaunchKernelGGL(k_clamp_counts, dim3(1), dim3(64), 0, st, D);
+}
+
+void launch_dist_pack_kin(const DistDevice& D, int side, const Kin& K, double* buf, hipStream_t st) {
+  hipLaunchKernelGGL(k_pack_kin, dim3(64), dim3(256), 0, st, D.send_list[side], D.counters + side, K, buf);
+}
+
+void launch_dist_unpack_kin(const DistDevice& D, int side, const Kin& K, const double* buf, int n, int* error,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(k_unpack_kin, dim3(64), dim3(256), 0, st, buf, D.cap_g, K, D.active, D.recv_ids[side],
+                     D.counters + 4 + side, n, error);
+}
+
+void launch_dist_pack_fhf(const DistDevice& D, int side, const double* fhf, int n, double* buf, hipStream_t st) {
+  hipLaunchKernelGGL(k_pack_fhf, dim3(64), dim3(256), 0, st, D.send_list[side], D.counters + side, fhf, n, buf);
+}
+
+void launch_dist_unpack_fhf(const DistDevice& D, int side, double* fhf, int n, const double* buf, hipStream_t st) {
+  hipLaunchKernelGGL(k_unpack_fhf, dim3(64), dim3(256), 0, st, D.recv_ids[side], D.counters + 4 + side, fhf, n, buf);
+}
+
+void launch_dist_merge_tables(const ForceSlots& S, const double* buf, int cap, hipStream_t st) {
+  hipLaunchKernelGGL(k_merge_tables, dim3(64), dim3(256), 0, st, S, buf, cap);
+}
+
+void launch_dist_poison(const DistDevice& D, const Kin& a, const Kin& b, int n, hipStream_t st) {
+  hipLaunchKernelGGL(k_poison, dim3((n + 255) / 256), dim3(256), 0, st, D.active, a, b, n);
+}

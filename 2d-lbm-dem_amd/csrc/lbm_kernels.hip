@@ -219,10 +219,11 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
                              const double* __restrict__ v2, const double* __restrict__ v3,
                              double* __restrict__ oxc, double* __restrict__ oyc, double* __restrict__ or2,
                              double* __restrict__ orbl0, double* __restrict__ pk,
-                             unsigned char* __restrict__ touched) {
+                             unsigned char* __restrict__ touched, const unsigned char* __restrict__ mask) {
   const int lane = threadIdx.x & 63;
   const int i = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (i >= n) return;
+  if (mask && !mask[i]) return;  // strip decomposition: a grain that cannot reach this rank's rows
   const double gx1 = x1[i], gx2 = x2[i];
   const double xc = (gx1 - L.Mgx) / L.dx, yc = (gx2 - L.Mby) / L.dx, r2 = rLB[i] * rLB[i], rbl0 = r[i] / L.dx;
   if (lane == 0) {
@@ -1209,7 +1210,8 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
                                                                 unsigned char* __restrict__ owner, int mode,
                                                                 const int* __restrict__ list,
                                                                 const int* __restrict__ list_count,
-                                                                double* __restrict__ packbuf) {
+                                                                double* __restrict__ packbuf,
+                                                                const unsigned char* __restrict__ mask) {
   extern __shared__ double sDyn[];
   // per grain of the workgroup: addends of fhf1 [cap1] | fhf2 [cap1] | fhf3 [cap3]
   // then per wave: the bitmap [nw64] and the three per-word prefix counts [3][nw64]; then [FT_WAVES * GW][4] counts
@@ -1249,7 +1251,10 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
     gid[g] = g0 + g < ntodo ? grain_at(g0 + g) : -1;
     const int i = gid[g];
     bool local = false;
-    if (i >= 0) {
+    if (i >= 0 && mask) {
+      local = mask[i] != 0;      // strip decomposition: the grains the rasteriser saw (the others' geometry is stale)
+      if (!local) gid[g] = -1;
+    } else if (i >= 0) {
       const double xc = G.xc[i], rbl0 = G.rbl0[i];
       local = xc + rbl0 + 2.0 >= (double)L.gx0 && xc - rbl0 - 2.0 <= (double)(L.gx0 + L.nxl);
     }
@@ -1738,10 +1743,11 @@ void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st) {
 
 void launch_obst_paint(int* obst, const LatticeView& L, int n, const double* x1, const double* x2, const double* r,
                        const double* rLB, const double* v1, const double* v2, const double* v3, double* xc,
-                       double* yc, double* r2, double* rbl0, double* pk, unsigned char* touched, hipStream_t st) {
+                       double* yc, double* r2, double* rbl0, double* pk, unsigned char* touched,
+                       const unsigned char* mask, hipStream_t st) {
   const long threads = (long)n * 64;
   hipLaunchKernelGGL(k_obst_paint, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, obst, L, n, x1, x2, r,
-                     rLB, v1, v2, v3, xc, yc, r2, rbl0, pk, touched);
+                     rLB, v1, v2, v3, xc, yc, r2, rbl0, pk, touched, mask);
 }
 
 void launch_slots_clear(const ForceSlots& S, int n, hipStream_t st) {
@@ -1847,9 +1853,25 @@ static void launch_forces_table_t(const double* f, const int* obst, const Lattic
   const int per_block = FT_WAVES * GW;
   hipLaunchKernelGGL((k_forces_table<GW, PASSES>), dim3((L.n + per_block - 1) / per_block), dim3(64 * FT_WAVES), lds, st,
                      f, obst, L, G, S, cap1, cap3, nw64, scale12, scale3, fhf, owner, (int)FT_CONSUME, (const int*)nullptr,
-                     (const int*)nullptr, (double*)nullptr);
+                     (const int*)nullptr, (double*)nullptr, S.mask);
   const int grid = L.n < 256 ? L.n : 256;
   hipLaunchKernelGGL(k_forces_gather_queue, dim3(grid), dim3(64), 0, st, f, obst, L, G, S, scale12, scale3, fhf);
+}
+
+void launch_forces_table_pack(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
+                              const ForceSlots& S, const int* list, const int* list_count, int cap, double* buf,
+                              hipStream_t st) {
+  const int HB = S.hb, B = 2 * HB + 1;
+  const int nw64 = (B * B * 8 + 63) / 64;
+  const int cap1 = (4 * S.spd + 2 * B + 7) & ~7, cap3 = (8 * S.spd + 4 * B + 7) & ~7;
+  const size_t lds = (size_t)FT_WAVES * (2 * cap1 + cap3) * 8 + (size_t)FT_WAVES * nw64 * 24 + (size_t)FT_WAVES * 20;
+  const int blocks = (cap + FT_WAVES - 1) / FT_WAVES;   // the list length is only known on the device
+  if (S.spd <= 32)
+    hipLaunchKernelGGL((k_forces_table<1, 2>), dim3(blocks), dim3(64 * FT_WAVES), lds, st, f, obst, L, G, S, cap1, cap3, nw64,
+                       0.0, 0.0, (double*)nullptr, (unsigned char*)nullptr, (int)FT_PACK, list, list_count, buf, S.mask);
+  else
+    hipLaunchKernelGGL((k_forces_table<1, 4>), dim3(blocks), dim3(64 * FT_WAVES), lds, st, f, obst, L, G, S, cap1, cap3, nw64,
+                       0.0, 0.0, (double*)nullptr, (unsigned char*)nullptr, (int)FT_PACK, list, list_count, buf, S.mask);
 }
 
 void launch_forces_slots(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,

@@ -55,7 +55,7 @@ struct lbmdem_handle {
   const double* cs_fin = nullptr;
   const int *cs_ob_old = nullptr, *cs_ob_new = nullptr;
   int cs_lo_end = 0, cs_hi_begin = 0;  // interior = local rows [cs_lo_end, cs_hi_begin)
-  ForceSlots cs_slots{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr};
+  ForceSlots cs_slots{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
   // grains
   int n = 0;
   double* gbuf = nullptr;  // one allocation, carved below
@@ -73,11 +73,15 @@ struct lbmdem_handle {
   double* fhf = nullptr;  // [3][n]
   unsigned char* owner = nullptr;
   // link sums handed from the fused kernel to the force kernel (ForceSlots, lbmdem_internal.h)
-  ForceSlots fs{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr};
+  ForceSlots fs{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
   bool slots_clean = false;  // every slot is empty
   bool last_forces_from_table = false;
   bool slots_valid = false;  // the table was filled by the collide_stream that produced f[fcur] with the current map
-  double rmax = 0.0;
+  double rmax = 0.0, rmin = 0.0;
+  // strip decomposition with distributed grains (lbmdem_dist_*)
+  bool dist = false, dist_poison = false;
+  int dist_margin = 0;
+  DistDevice dd{};
   VerletDevice V{};
   bool verlet_ok = false;
   volatile int* ovf_host = nullptr;  // pinned mirror of V.overflow, refreshed (asynchronously) after every rebuild
@@ -200,7 +204,7 @@ static int paint_into(lbmdem_handle* h, int* obst) {
   const Kin& K = h->kin[h->kcur];
   launch_obst_fill(obst, h->L, h->stream);
   launch_obst_paint(obst, h->L, h->n, K.x1, K.x2, h->r, h->rLB, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0, h->pk,
-                    h->fs.touched, h->stream);
+                    h->fs.touched, h->dist ? h->dd.fluidmask : nullptr, h->stream);
   h->slots_valid = false;  // the grain geometry the table is indexed with has changed
   HIP_TRY(hipGetLastError());
   return LBMDEM_OK;
@@ -223,15 +227,19 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
   const int n = cfg->nbgrains;
   double rmax = r[0];
   for (int i = 1; i < n; ++i) if (r[i] > rmax) rmax = r[i];
+  double rmin = r[0];
+  for (int i = 1; i < n; ++i) if (r[i] < rmin) rmin = r[i];
   const bool cut_lo = cfg->x_begin > 0, cut_hi = cfg->x_end < cfg->lx;
-  const int need = 2 + (int)ceil(rmax / cfg->dx);
-  if ((cut_lo || cut_hi) && cfg->halo < need)
-    return fail(LBMDEM_EINVAL, "strip decomposition needs halo >= %d rows (2 + largest grain radius in nodes)", need);
+  // 2 rows: the f row and the two obstacle rows the fused kernel reads beyond a cut. (Replicated grains need
+  // 2 + the largest grain radius so that an owner sees its grains' whole footprints: checked in forces_fluid.)
+  if ((cut_lo || cut_hi) && cfg->halo < 2)
+    return fail(LBMDEM_EINVAL, "strip decomposition needs halo >= 2 rows");
 
   lbmdem_handle* h = new lbmdem_handle();
   h->cfg = *cfg;
   h->n = n;
   h->rmax = rmax;
+  h->rmin = rmin;
   LatticeView& L = h->L;
   L.lx = cfg->lx; L.ly = cfg->ly;
   L.gx0 = cut_lo ? cfg->x_begin - cfg->halo : 0;
@@ -393,6 +401,7 @@ int lbmdem_destroy(lbmdem_handle* h) {
   if (h->fs.error) (void)hipFree(h->fs.error);
   if (h->dpartial) (void)hipFree(h->dpartial);
   verlet_free(h->V);
+  dist_free(h->dd);
   if (h->ovf_host) (void)hipHostFree((void*)h->ovf_host);
   diag_extra_free(h->dx);
   for (hipEvent_t e : h->ev0) (void)hipEventDestroy(e);
@@ -522,6 +531,15 @@ int lbmdem_forces_fluid(lbmdem_handle* h) {
   CHECK_H(h);
   CHECK_NOT_SPLIT(h);
   const int* ob = h->obst_pending ? h->obst[1 - h->ocur] : h->obst[h->ocur];
+  {
+    const bool cut = h->cfg.x_begin > 0 || h->cfg.x_end < h->cfg.lx;
+    const int need = 2 + (int)ceil(h->rmax / h->cfg.dx);
+    if (cut && !h->dist && h->cfg.halo < need)
+      return fail(LBMDEM_EINVAL, "strips with replicated grains need halo >= %d rows (2 + largest grain radius in nodes) "
+                                 "for the hydrodynamic forces; or distribute the grains (lbmdem_dist_enable)", need);
+    if (h->dist && (h->force_mode != 0 || !h->slots_valid || h->obst_pending))
+      return fail(LBMDEM_EINVAL, "distributed grains: forces_fluid must follow collide_stream directly (parity force kernel)");
+  }
   if (h->force_mode == 0 && h->slots_valid && !h->obst_pending) {
     // the link sums were left in the slot table by the fused kernel; the kernel empties the table again
     HIP_TRY(hipMemsetAsync(h->fs.gathered, 0, sizeof(int), h->stream));
@@ -607,9 +625,14 @@ int lbmdem_dem_substep(lbmdem_handle* h) {
     if (diag_extra_alloc(h->dx, h->n, h->V.cap) != 0) return fail(LBMDEM_ENOMEM, "diagnostic buffers: hipMalloc failed");
     h->dx_ready = true;
   }
+  if (want_diag && h->dist)
+    return fail(LBMDEM_EINVAL, "the contact diagnostics of write_DEM thread through all grains in index order: not available "
+                               "with distributed grains");
   const DemParams P = dem_params(h);
   launch_dem_substep(h->kin[h->kcur], h->kin[1 - h->kcur], h->r, h->m, h->It, h->fhf, h->V, h->gp,
-                     P, film, want_diag ? h->diag : nullptr, want_diag ? &h->dx : nullptr, h->stream);
+                     P, film, want_diag ? h->diag : nullptr, want_diag ? &h->dx : nullptr,
+                     h->dist ? h->dd.active : nullptr, h->stream);
+  if (h->dist && h->dist_poison) launch_dist_poison(h->dd, h->kin[0], h->kin[1], h->n, h->stream);
   if (want_diag) launch_diag_extra(h->dx, h->kin[h->kcur], h->r, h->V, P, film, h->stream);
   h->diag_valid = want_table;
   HIP_TRY(hipGetLastError());
@@ -1326,6 +1349,100 @@ int lbmdem_halo_unpack(lbmdem_handle* h, int side, const void* dev_buf) {
   const int xl0 = side == 0 ? L.xo0 - H : L.xo1;
   if (xl0 < 0 || xl0 + H > L.nxl) return fail(LBMDEM_EINVAL, "no halo rows on side %d", side);
   launch_halo_unpack(h->f[h->fcur], L, xl0, H, (const double*)dev_buf, h->stream);
+  HIP_TRY(hipGetLastError());
+  return LBMDEM_OK;
+}
+
+// ---- strip decomposition with distributed grains ------------------------------------------------------------
+
+int lbmdem_dist_default_margin(lbmdem_handle* h) {
+  if (!h) return -1;
+  const lbmdem_config& c = h->cfg;
+  // an error travels one Verlet-list edge per sub-step: centre distance <= 2 r_max + distVerlet (+ drift)
+  const double hop = (2 * h->rmax + c.phys.distVerlet) / c.dx + 1.0;
+  return (int)ceil(c.npDEM * hop + h->rmax / c.dx) + 6;
+}
+
+int lbmdem_dist_enable(lbmdem_handle* h, int margin_rows) try {
+  CHECK_H(h);
+  const lbmdem_config& c = h->cfg;
+  if (h->dist) return fail(LBMDEM_EINVAL, "already enabled");
+  if (!h->fs.tab) return fail(LBMDEM_EINVAL, "distributed grains need the link-sum table (reductionR < 1, < 2^18 grains)");
+  const int M = margin_rows > 0 ? margin_rows : lbmdem_dist_default_margin(h);
+  const bool cut_lo = c.x_begin > 0, cut_hi = c.x_end < c.lx;
+  if ((cut_lo || cut_hi) && c.x_end - c.x_begin < M)
+    return fail(LBMDEM_EINVAL, "strip of %d rows is narrower than the margin of %d rows: a margin grain could belong to a "
+                               "rank that is not a neighbour (use fewer strips, or replicated grains)", c.x_end - c.x_begin, M);
+  if (h->nbsteps % c.npDEM != 0) return fail(LBMDEM_EINVAL, "enable at a fluid-step boundary");
+  // message capacities: twice the share of a band of (M + a grain) rows at uniform density; every disc a cut can meet
+  const double band = (double)(M + 2 * (int)ceil(h->rmax / c.dx) + 4) / c.lx;
+  long cap_g = (long)(2.0 * band * h->n) + 256;
+  if (cap_g > h->n) cap_g = h->n;
+  long cap_t = (long)(c.ly / (2 * h->rmin / c.dx)) + 32;
+  if (cap_t > h->n) cap_t = h->n;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (dist_alloc(h->dd, h->n, (int)cap_g, (int)cap_t) != 0) { dist_free(h->dd); return fail(LBMDEM_ENOMEM, "dist_alloc failed"); }
+  h->dist = true;
+  h->dist_margin = M;
+  h->fs.mask = h->dd.fluidmask;
+  return LBMDEM_OK;
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
+}
+
+int lbmdem_dist_set_poison(lbmdem_handle* h, int on) {
+  if (!h) return fail(LBMDEM_EINVAL, "null handle");
+  h->dist_poison = on != 0;
+  return LBMDEM_OK;
+}
+
+long lbmdem_dist_message_doubles(lbmdem_handle* h, int kind) {
+  if (!h || !h->dist) return -1;
+  switch (kind) {
+    case LBMDEM_MSG_KIN: return 1 + 10L * h->dd.cap_g;
+    case LBMDEM_MSG_FHF: return 3L * h->dd.cap_g;
+    case LBMDEM_MSG_TABLES: return 1 + (1 + 8L * h->fs.spd) * h->dd.cap_t;
+  }
+  return -1;
+}
+
+int lbmdem_dist_begin_period(lbmdem_handle* h) {
+  CHECK_H(h);
+  CHECK_NOT_SPLIT(h);
+  if (!h->dist) return fail(LBMDEM_EINVAL, "lbmdem_dist_enable first");
+  const lbmdem_config& c = h->cfg;
+  DistGeom Gm;
+  Gm.lo = (double)c.x_begin; Gm.hi = (double)c.x_end; Gm.margin = (double)h->dist_margin; Gm.dx = c.dx; Gm.Mgx = c.Mgx;
+  Gm.has_lo = c.x_begin > 0; Gm.has_hi = c.x_end < c.lx; Gm.first = c.x_begin == 0; Gm.last = c.x_end == c.lx;
+  Gm.gx0 = h->L.gx0; Gm.nxl = h->L.nxl;
+  launch_dist_classify(h->dd, Gm, h->n, h->kin[h->kcur].x1, h->r, h->rLB, h->owner, h->fs.error, h->stream);
+  HIP_TRY(hipGetLastError());
+  return LBMDEM_OK;
+}
+
+int lbmdem_dist_pack(lbmdem_handle* h, int kind, int side, void* dev_buf) {
+  CHECK_H(h);
+  if (!h->dist || !dev_buf || (side != 0 && side != 1)) return fail(LBMDEM_EINVAL, "bad lbmdem_dist_pack arguments");
+  if (kind == LBMDEM_MSG_KIN) launch_dist_pack_kin(h->dd, side, h->kin[h->kcur], (double*)dev_buf, h->stream);
+  else if (kind == LBMDEM_MSG_FHF) launch_dist_pack_fhf(h->dd, side, h->fhf, h->n, (double*)dev_buf, h->stream);
+  else if (kind == LBMDEM_MSG_TABLES) {
+    CHECK_NOT_SPLIT(h);
+    if (!h->slots_valid) return fail(LBMDEM_EINVAL, "table messages are packed between collide_stream and forces_fluid");
+    launch_forces_table_pack(h->f[h->fcur], h->obst[h->ocur], h->L, gview(h), h->fs, h->dd.strad_list[side],
+                             h->dd.counters + 2 + side, h->dd.cap_t, (double*)dev_buf, h->stream);
+  } else return fail(LBMDEM_EINVAL, "unknown message kind");
+  HIP_TRY(hipGetLastError());
+  return LBMDEM_OK;
+}
+
+int lbmdem_dist_unpack(lbmdem_handle* h, int kind, int side, const void* dev_buf) {
+  CHECK_H(h);
+  if (!h->dist || !dev_buf || (side != 0 && side != 1)) return fail(LBMDEM_EINVAL, "bad lbmdem_dist_unpack arguments");
+  if (kind == LBMDEM_MSG_KIN)
+    launch_dist_unpack_kin(h->dd, side, h->kin[h->kcur], (const double*)dev_buf, h->n, h->fs.error, h->stream);
+  else if (kind == LBMDEM_MSG_FHF) launch_dist_unpack_fhf(h->dd, side, h->fhf, h->n, (const double*)dev_buf, h->stream);
+  else if (kind == LBMDEM_MSG_TABLES) launch_dist_merge_tables(h->fs, (const double*)dev_buf, h->dd.cap_t, h->stream);
+  else return fail(LBMDEM_EINVAL, "unknown message kind");
   HIP_TRY(hipGetLastError());
   return LBMDEM_OK;
 }

@@ -61,6 +61,7 @@ struct ForceSlots {
   int* gathered;  // device counter: grains the table could not serve ...
   int* queue;     // ... and their indices, for the gather kernel that follows
   int* error;     // device flag: a grain cut by a strip boundary that neither the table nor a local gather can serve
+  const unsigned char* mask;  // strip decomposition with distributed grains: the grains the rasteriser handled; else null
 };
 #define LBMDEM_SLOT_EMPTY 0x7FF8C0DE5107E117ull  /* a quiet NaN no arithmetic produces */
 constexpr int LBMDEM_SPD_MAX = 64;               // larger grains (reduced radius > ~20 nodes): feature off
@@ -90,7 +91,8 @@ void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st);
 // fills xc, yc, r2, rbl0, pk (per-grain lattice geometry, main.c:1009-1013) and paints the reduced discs
 void launch_obst_paint(int* obst, const LatticeView& L, int n, const double* x1, const double* x2, const double* r,
                        const double* rLB, const double* v1, const double* v2, const double* v3, double* xc,
-                       double* yc, double* r2, double* rbl0, double* pk, unsigned char* touched, hipStream_t st);
+                       double* yc, double* r2, double* rbl0, double* pk, unsigned char* touched,
+                       const unsigned char* mask, hipStream_t st);
 void launch_collide_stream(const double* fin, double* fout, const int* obst_old, const int* obst_new,
                            const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, hipStream_t st);
 // true when launch_collide_stream(..., S) with S.tab != nullptr fills the table (the marching kernel does)
@@ -100,6 +102,35 @@ void launch_slots_clear(const ForceSlots& S, int n, hipStream_t st);
 void launch_forces_slots(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
                          const ForceSlots& S, double scale12, double scale3, double* fhf, unsigned char* owner,
                          hipStream_t st);
+// strip decomposition: this rank's part of the tables of the listed grains (owned by a neighbour rank), completed
+// and written as {count; count x {id, 8 * spd slots}} to a message buffer
+void launch_forces_table_pack(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
+                              const ForceSlots& S, const int* list, const int* list_count, int cap, double* buf,
+                              hipStream_t st);
+
+// dist_kernels.hip -- strip decomposition with the grains distributed over the ranks (strips.py)
+struct DistDevice {
+  unsigned char* active;     // [n] grains this rank integrates: owned + margin (refreshed from the neighbours)
+  unsigned char* fluidmask;  // [n] grains with exact state that may overlap this rank's rows (paint, force table)
+  int* send_list[2];         // [cap_g] owned grains within `margin` rows of the low / high cut
+  int* strad_list[2];        // [cap_t] grains owned by the low / high neighbour whose link ring reaches this rank's rows
+  int* recv_ids[2];          // [cap_g] ids of the last kinematics message from the low / high neighbour
+  int* counters;             // [6] send x2, straddler x2, received x2
+  int cap_g, cap_t;
+};
+struct DistGeom { double lo, hi, margin, dx, Mgx; int has_lo, has_hi, first, last, gx0, nxl; };
+int dist_alloc(DistDevice& D, int n, int cap_g, int cap_t);
+void dist_free(DistDevice& D);
+// ownership, masks and the send / straddler lists from the current positions of the grains that were active
+void launch_dist_classify(const DistDevice& D, const DistGeom& Gm, int n, const double* x1, const double* r,
+                          const double* rLB, unsigned char* owner, int* error, hipStream_t st);
+// messages: {count; count x {id, x1 x2 x3 v1 v2 v3 a1 a2 a3}} / {count x {fhf1 fhf2 fhf3}} in the order of that list
+void launch_dist_pack_kin(const DistDevice& D, int side, const Kin& K, double* buf, hipStream_t st);
+void launch_dist_unpack_kin(const DistDevice& D, int side, const Kin& K, const double* buf, int n, int* error, hipStream_t st);
+void launch_dist_pack_fhf(const DistDevice& D, int side, const double* fhf, int n, double* buf, hipStream_t st);
+void launch_dist_unpack_fhf(const DistDevice& D, int side, double* fhf, int n, const double* buf, hipStream_t st);
+void launch_dist_merge_tables(const ForceSlots& S, const double* buf, int cap, hipStream_t st);
+void launch_dist_poison(const DistDevice& D, const Kin& a, const Kin& b, int n, hipStream_t st);
 void launch_forces_parity(const double* f, const int* obst, const LatticeView& L,
                           const GrainFluidView& G, double scale12, double scale3, double* fhf,
                           unsigned char* owner, hipStream_t st);
@@ -172,4 +203,5 @@ void launch_diag_extra(const DiagExtra& X, const Kin& in, const double* r, const
 void launch_fill_own(const VerletDevice& V, int n, hipStream_t st);
 void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const double* m,
                         const double* It, const double* fhf, const VerletDevice& V, double* pout,
-                        const DemParams& P, int film, double* diag, const DiagExtra* X, hipStream_t st);
+                        const DemParams& P, int film, double* diag, const DiagExtra* X, const unsigned char* active,
+                        hipStream_t st);

@@ -120,9 +120,9 @@ class TorchComm:
 
     def __init__(self, dist, group=None):
         self.dist, self.group = dist, group
-        self._side = None   # stream the point-to-point transfers are issued on (device tensors only)
-        self._ready = None  # event: "the packed rows are enqueued"
-        self._p2p_cache = (None, None)   # the P2POp list is rebuilt only when the buffers change (they do not)
+        # per lane (a message class that may be in flight at the same time as another): the side stream the
+        # transfers are issued on (device tensors only), the event "the packed data is enqueued", the cached P2POps
+        self._lanes = {}
 
     def _p2p(self, ops):
         d = self.dist
@@ -132,27 +132,28 @@ class TorchComm:
             p2p.append(d.P2POp(d.irecv, recv, peer, self.group))
         return p2p
 
-    def exchange(self, ops):
-        self.exchange_end(self.exchange_begin(ops))
+    def exchange(self, ops, lane="halo"):
+        self.exchange_end(self.exchange_begin(ops, lane))
 
-    def exchange_begin(self, ops):
+    def exchange_begin(self, ops, lane="halo"):
         """Start the neighbour transfers; they depend on what has been enqueued so far (the packed edge
         rows) but not on what the caller enqueues next (the interior rows)."""
+        st = self._lanes.setdefault(lane, {"side": None, "ready": None, "cache": (None, None)})
         key = tuple((peer, send.data_ptr(), recv.data_ptr()) for peer, send, recv in ops)
-        if self._p2p_cache[0] != key:
-            self._p2p_cache = (key, self._p2p(ops))
-        p2p = self._p2p_cache[1]
+        if st["cache"][0] != key:   # the P2POp list is rebuilt only when the buffers change (they do not)
+            st["cache"] = (key, self._p2p(ops))
+        p2p = st["cache"][1]
         if not p2p:
             return []
         if ops[0][1].is_cuda:
             import torch
             dev = ops[0][1].device
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=dev)
-                self._ready = torch.cuda.Event()
-            self._ready.record(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(self._side):
-                self._side.wait_event(self._ready)
+            if st["side"] is None:
+                st["side"] = torch.cuda.Stream(device=dev)
+                st["ready"] = torch.cuda.Event()
+            st["ready"].record(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(st["side"]):
+                st["side"].wait_event(st["ready"])
                 return self.dist.batch_isend_irecv(p2p)
         return self.dist.batch_isend_irecv(p2p)
 
@@ -164,15 +165,96 @@ class TorchComm:
         self.dist.all_reduce(int64_tensor, op=self.dist.ReduceOp.SUM, group=self.group)
 
 
+KIN, FHF, TABLES = 0, 1, 2   # message kinds (include/lbmdem_hip.h LBMDEM_MSG_*)
+
+
+def default_margin(npDEM: int, rmax: float, dist_verlet: float, dx: float) -> int:
+    """Rows of grains a rank integrates beyond its cuts (lbmdem_dist_default_margin): an error travels one
+    Verlet-list edge (centre distance <= 2 r_max + distVerlet) per sub-step, npDEM sub-steps per period."""
+    hop = (2 * rmax + dist_verlet) / dx + 1.0
+    return int(math.ceil(npDEM * hop + rmax / dx)) + 6
+
+
+class DistStripRunner:
+    """One rank's share of renderScene() with the GRAINS distributed over the strips: neighbour-to-neighbour
+    messages only (no collective), halo of 2 rows. The period is written as a generator that yields the
+    communication points -- ("begin", lane, ops) starts the transfers of `ops` = [(peer, send, recv)], ("end", lane)
+    waits for them -- so that the same code is driven by TorchComm (RCCL / gloo) and, in the single-process tests,
+    by a lock-step driver that copies the buffers by hand."""
+
+    def __init__(self, backend, comm, rank: int, world: int):
+        self.b, self.comm, self.rank, self.world = backend, comm, rank, world
+        self.sides = [s for s, has in ((0, rank > 0), (1, rank < world - 1)) if has]
+
+    def _peer(self, side):
+        return self.rank - 1 if side == 0 else self.rank + 1
+
+    def _ops(self, kind):
+        return [(self._peer(s), self.b.dist_pack(kind, s), self.b.dist_recv_buffer(kind, s)) for s in self.sides]
+
+    def period(self):
+        b = self.b
+        b.dist_begin_period()                      # ownership + message lists from the current positions
+        yield ("begin", "kin", self._ops(KIN))     # margin refresh / migration: travels under the whole fluid step
+        b.obst_construction()
+        b.collision_streaming_edges()
+        yield ("begin", "halo", [(self._peer(s), b.halo_pack(s), b.halo_recv_buffer(s)) for s in self.sides])
+        b.collision_streaming_interior()           # ... while the bulk of the rows is computed
+        yield ("end", "halo")
+        for s in self.sides:
+            b.halo_unpack(s)
+        yield ("begin", "tab", self._ops(TABLES))  # link sums of the grains the neighbours own
+        yield ("end", "tab")
+        for s in self.sides:
+            b.dist_unpack(TABLES, s)
+        b.forces_fluid()
+        yield ("end", "kin")
+        for s in self.sides:
+            b.dist_unpack(KIN, s)
+        yield ("begin", "fhf", self._ops(FHF))     # forces of the margin grains, from their owners
+        yield ("end", "fhf")
+        for s in self.sides:
+            b.dist_unpack(FHF, s)
+
+    def lbm_step(self):
+        pending = {}
+        for ev in self.period():
+            if ev[0] == "begin":
+                pending[ev[1]] = self.comm.exchange_begin(ev[2], lane=ev[1])
+            else:
+                self.comm.exchange_end(pending.pop(ev[1]))
+
+    def render_scene(self, n: int = 1):
+        b = self.b
+        step = b.nbsteps
+        while n > 0:
+            if step % b.npDEM == 0:
+                self.lbm_step()
+            k = min(n, b.npDEM - step % b.npDEM)
+            b.run_dem(k)
+            step += k
+            n -= k
+
+
 class GpuStripBackend:
     """The HIP library (one LbmDem handle restricted to a strip) + the torch device tensors used as
     exchange buffers. torch is plumbing here: device memory for the buffers and the process group."""
 
-    def __init__(self, pkg, torch, lx, ly, r, x1, x2, strip, halo, device, force_mode=0):
+    def __init__(self, pkg, torch, lx, ly, r, x1, x2, strip, halo, device, force_mode=0, distributed=False,
+                 margin=0, poison=False):
         self.torch = torch
         dev = torch.device("cuda", device)
         self.sim = pkg.LbmDem(lx, ly, r, x1, x2, device=device, strip=strip, halo=halo)
         self.sim.set_force_mode(force_mode)
+        self.msg = {}
+        if distributed:
+            self.sim.dist_enable(margin)
+            if poison:
+                self.sim.dist_set_poison(True)
+            for kind in (KIN, FHF, TABLES):
+                nd = self.sim.dist_message_doubles(kind)
+                self.msg[kind] = ([torch.zeros(nd, dtype=torch.float64, device=dev) for _ in range(2)],
+                                  [torch.zeros(nd, dtype=torch.float64, device=dev) for _ in range(2)])
         # everything is enqueued on torch's current stream so that collectives issued through
         # torch.distributed are ordered with the kernels
         self.sim.set_stream(torch.cuda.current_stream(dev).cuda_stream)
@@ -206,6 +288,18 @@ class GpuStripBackend:
     def halo_unpack(self, side):
         self.sim.halo_unpack(side, self.recv[side].data_ptr())
 
+    def dist_begin_period(self): self.sim.dist_begin_period()
+
+    def dist_pack(self, kind, side):
+        self.sim.dist_pack(kind, side, self.msg[kind][0][side].data_ptr())
+        return self.msg[kind][0][side]
+
+    def dist_recv_buffer(self, kind, side):
+        return self.msg[kind][1][side]
+
+    def dist_unpack(self, kind, side):
+        self.sim.dist_unpack(kind, side, self.msg[kind][1][side].data_ptr())
+
     def fhf_export(self):
         self.sim.fhf_export(self.fhf_buf.data_ptr())
         return self.fhf_buf.view(self.torch.int64)
@@ -220,12 +314,27 @@ class _GpuRunner(StripRunner):
         return self.b.sim
 
 
-def make_gpu_runner(pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2, force_mode=0):
-    """Build this rank's strip on its GPU (bench.py --gpus N)."""
+class _GpuDistRunner(DistStripRunner):
+    @property
+    def sim(self):
+        return self.b.sim
+
+
+def make_gpu_runner(pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2, force_mode=0, distributed=None):
+    """Build this rank's strip on its GPU (bench.py --gpus N). distributed=None: distribute the grains when the
+    strips are wide enough for the margin, else replicate them (all-reduce of the forces)."""
     import torch
     cfg = pkg.derive(lx, ly, r)
-    halo = halo_rows(float(max(r)), cfg.dx)
     strip = partition(lx, world)[rank]
+    margin = default_margin(cfg.npDEM, float(max(r)), cfg.phys.distVerlet, cfg.dx)
+    widths = [b - a for a, b in partition(lx, world)]
+    if distributed is None:
+        distributed = world > 1 and min(widths) >= margin and force_mode == 0
+    if distributed:
+        backend = GpuStripBackend(pkg, torch, lx, ly, r, x1, x2, strip, 2, local_rank, force_mode, distributed=True,
+                                  margin=margin)
+        return _GpuDistRunner(backend, TorchComm(dist), rank, world)
+    halo = halo_rows(float(max(r)), cfg.dx)
     if world > 1 and strip[1] - strip[0] < halo:
         raise pkg.LbmDemError(-1, f"strips of {strip[1] - strip[0]} rows are narrower than the halo ({halo})")
     backend = GpuStripBackend(pkg, torch, lx, ly, r, x1, x2, strip, halo if world > 1 else 0, local_rank,

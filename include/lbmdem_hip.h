@@ -193,7 +193,8 @@ int lbmdem_sync(lbmdem_handle* h);
 int lbmdem_profile_enable(lbmdem_handle* h, int on);
 int lbmdem_profile_read(lbmdem_handle* h, double* mean_ms, long* launches);
 
-/* Strip decomposition along x (one process per GPU). After collide_stream the `halo` outermost
+/* Strip decomposition along x (one process per GPU); halo >= 2 rows (with REPLICATED grains, i.e. without
+ * lbmdem_dist_enable, halo >= 2 + the largest grain radius in nodes). After collide_stream the `halo` outermost
  * OWNED rows on each interior side are packed into a caller-provided DEVICE buffer
  * (9 * halo * ly doubles, plane-major), exchanged by the caller (RCCL send/recv via
  * torch.distributed) and unpacked into the neighbour's halo rows. side: 0 = low x, 1 = high x. */
@@ -209,6 +210,33 @@ long lbmdem_halo_doubles(lbmdem_handle* h);
 int lbmdem_collide_stream_part(lbmdem_handle* h, int part);
 int lbmdem_halo_pack(lbmdem_handle* h, int side, void* dev_buf);
 int lbmdem_halo_unpack(lbmdem_handle* h, int side, const void* dev_buf);
+/* ---- strips with the GRAINS distributed over the ranks (no collective) ------------------------------------------
+ * Every rank keeps arrays for all grains (global index = array index) but integrates only the grains whose centre
+ * lies in its rows plus a margin of `margin_rows` on either side, deep enough that what it does not integrate cannot
+ * influence an owned grain within the npDEM sub-steps between two fluid steps (one Verlet-list edge per sub-step).
+ * Per fluid step, with both neighbours, three point-to-point messages (fixed capacities, device buffers):
+ *   LBMDEM_MSG_KIN     kinematics of the owned grains within the neighbour's margin -- also how a grain that crossed
+ *                      the cut changes owner; may travel while the fluid step runs, unpack before the sub-steps;
+ *   LBMDEM_MSG_TABLES  this rank's part of the link-sum tables of grains the neighbour owns (packed after
+ *                      collide_stream and the f halo exchange, unpacked by the owner before forces_fluid);
+ *   LBMDEM_MSG_FHF     hydrodynamic forces of the grains of the KIN message (after forces_fluid, before the sub-steps).
+ * Sequence of one period: dist_begin_period; pack KIN (both sides); obst_construction; collide_stream (or its two
+ * parts + halo exchange); pack TABLES / exchange / unpack TABLES; forces_fluid; unpack KIN; pack FHF / exchange /
+ * unpack FHF; run_dem(npDEM). Results equal the single-GPU run bit for bit for any number of strips.
+ * Needs halo >= 2 only. Overlapping reduced discs across a cut, or more grains near a cut than the message
+ * capacities, are reported by lbmdem_sync. write_DEM's order-dependent diagnostics are not available in this mode. */
+#define LBMDEM_MSG_KIN 0
+#define LBMDEM_MSG_FHF 1
+#define LBMDEM_MSG_TABLES 2
+int lbmdem_dist_default_margin(lbmdem_handle* h);          /* rows */
+int lbmdem_dist_enable(lbmdem_handle* h, int margin_rows); /* 0 = default; the strip must be at least that wide */
+long lbmdem_dist_message_doubles(lbmdem_handle* h, int kind); /* capacity of one message, in doubles */
+int lbmdem_dist_begin_period(lbmdem_handle* h);
+int lbmdem_dist_pack(lbmdem_handle* h, int kind, int side, void* dev_buf);
+int lbmdem_dist_unpack(lbmdem_handle* h, int kind, int side, const void* dev_buf);
+/* diagnostic: after every sub-step, grains this rank does not integrate are overwritten with NaN */
+int lbmdem_dist_set_poison(lbmdem_handle* h, int on);
+
 /* Device pointer to the 3*n hydrodynamic-force table (fhf1[n], fhf2[n], fhf3[n]) and to the
  * n-entry ownership mask (1 = this rank computed the grain) for the cross-rank combine. */
 int lbmdem_fhf_device(lbmdem_handle* h, void** fhf, void** owner_mask);

@@ -126,3 +126,35 @@ def lockstep_render(runners, n):
         if b0.nbsteps % b0.updateVerlet == 0:
             for R in runners: R.b.initVerlet()
         for R in runners: R.b.dem_substep()
+
+
+def lockstep_render_dist(runners, n):
+    """Drive several DistStripRunner objects of ONE process through n renderScene() calls: all ranks advance to their
+    next communication point together; at a "begin" the posted buffers are copied sender -> receiver by hand."""
+    b0 = runners[0].b
+    step = b0.nbsteps
+    while n > 0:
+        if step % b0.npDEM == 0:
+            gens = [R.period() for R in runners]
+            while True:
+                evs = []
+                for g in gens:
+                    try:
+                        evs.append(next(g))
+                    except StopIteration:
+                        evs.append(None)
+                if all(e is None for e in evs):
+                    break
+                assert all(e is not None for e in evs) and len({(e[0], e[1]) for e in evs}) == 1, evs
+                if evs[0][0] == "begin":
+                    posts = [e[2] for e in evs]
+                    for rk, ops in enumerate(posts):
+                        for peer, send, _ in ops:
+                            dst = [rv for (p2, _, rv) in posts[peer] if p2 == rk]
+                            assert len(dst) == 1
+                            dst[0].copy_(send)
+        k = min(n, b0.npDEM - step % b0.npDEM)
+        for R in runners:
+            R.b.run_dem(k)
+        step += k
+        n -= k

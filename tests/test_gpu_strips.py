@@ -45,8 +45,14 @@ def test_strips_on_one_gpu_bit_exact(pkg, po, world):
 
 
 def test_strip_needs_enough_halo(pkg):
+    """Two rows for the fused kernel (the f row and the two obstacle rows it reads beyond a cut); with REPLICATED
+    grains the owner of a grain also gathers over its whole footprint: 2 + the largest radius in nodes."""
     with pytest.raises(pkg.LbmDemError):
-        pkg.LbmDem(128, 64, [0.8e-3], [3e-3], [3e-3], strip=(0, 64), halo=3)
+        pkg.LbmDem(128, 64, [0.8e-3], [3e-3], [3e-3], strip=(0, 64), halo=1)
+    sim = pkg.LbmDem(128, 64, [0.8e-3], [3e-3], [3e-3], strip=(0, 64), halo=3)
+    sim.obst_construction(); sim.collision_streaming()
+    with pytest.raises(pkg.LbmDemError):
+        sim.forces_fluid()
 
 
 def test_split_collide_stream_equals_the_single_launch(pkg):
@@ -103,7 +109,7 @@ for it in range(5):
     comm.exchange_end(pending)
     chk = recv.clone()                            # main stream, ordered after the transfer
     assert torch.equal(chk, send), it
-assert comm._side is not None
+assert comm._lanes["halo"]["side"] is not None
 torch.cuda.synchronize()
 dist.destroy_process_group()
 print("SELF-EXCHANGE-OK")
@@ -119,3 +125,55 @@ def test_torchcomm_overlapped_exchange_over_rccl(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", _SELF_EXCHANGE], cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "SELF-EXCHANGE-OK" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("nstrips", [2, 3])
+def test_distributed_grains_equal_single_domain(pkg, nstrips):
+    """Strips with the GRAINS distributed (halo of 2 rows, neighbour messages only: kinematics of the margin, link-sum
+    tables of the grains a cut goes through, forces of the margin) == one domain, bit for bit, while grains move
+    across the cuts. Every rank overwrites the grains it does not integrate with NaN after each sub-step, so any use
+    of state that should have come from a neighbour shows."""
+    import torch
+    from strip_backends import LoopbackComm, lockstep_render_dist
+    strips = pkg.strips_module()
+    lx, ly = 1024, 192
+    r, x, y = samples.row_packing(lx, ly, 700, seed=11)
+    r, x1, x2 = samples.to_metres(r, x, y)
+    cfg = pkg.derive(lx, ly, r)
+    margin = strips.default_margin(cfg.npDEM, float(r.max()), cfg.phys.distVerlet, cfg.dx)
+    parts = strips.partition(lx, nstrips)
+    assert min(b - a for a, b in parts) >= margin
+    rng = np.random.default_rng(5)
+    k = np.zeros((len(r), 9)); k[:, 0], k[:, 1] = x1, x2
+    k[:, 3:6] = rng.normal(0, 1, (len(r), 3)) * [0.05, 0.03, 20.0]
+    n = 30 * cfg.npDEM + 5        # crosses Verlet rebuilds at sub-steps 100, 200, 300
+    for a, _ in parts[1:]:        # the grains nearest to every cut are sent across it
+        d = x1 / cfg.dx - a
+        for i in (np.argmin(np.where(d >= 0, d, np.inf)), np.argmin(np.where(d < 0, -d, np.inf))):
+            k[i, 3] = -np.sign(d[i]) * min(0.9, (abs(d[i]) + 1.5) * cfg.dx / (n * cfg.dt))
+    runners = []
+    for rank, strip in enumerate(parts):
+        be = strips.GpuStripBackend(pkg, torch, lx, ly, r, x1, x2, strip, 2, 0, distributed=True, margin=margin,
+                                    poison=True)
+        be.sim.kinematics = k
+        runners.append(strips.DistStripRunner(be, LoopbackComm(), rank, nstrips))
+    single = pkg.LbmDem(lx, ly, r, x1, x2)
+    single.kinematics = k
+    lockstep_render_dist(runners, n)
+    single.renderScene(n)
+    for R in runners:
+        R.b.sim.sync()            # reports table / capacity errors
+    got = np.full((lx, ly, 9), np.nan)
+    for R in runners:
+        R.b.sim.download_f_into(got)
+    assert np.array_equal(got, single.f)
+    ks, fs = single.kinematics, single.fhf
+    xc = ks[:, 0] / cfg.dx
+    moved = 0
+    for R, (a, b) in zip(runners, parts):
+        own = ((a == 0) | (xc >= a)) & ((b == lx) | (xc < b))
+        assert own.sum() > 0
+        assert np.array_equal(R.b.sim.kinematics[own], ks[own])
+        xc0 = x1 / cfg.dx
+        moved += int((own & ~(((a == 0) | (xc0 >= a)) & ((b == lx) | (xc0 < b)))).sum())
+    assert moved > 0, "no grain changed owner: the test does not exercise migration"
