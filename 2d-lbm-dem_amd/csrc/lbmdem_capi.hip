@@ -1374,13 +1374,29 @@ int lbmdem_dist_enable(lbmdem_handle* h, int margin_rows) try {
     return fail(LBMDEM_EINVAL, "strip of %d rows is narrower than the margin of %d rows: a margin grain could belong to a "
                                "rank that is not a neighbour (use fewer strips, or replicated grains)", c.x_end - c.x_begin, M);
   if (h->nbsteps % c.npDEM != 0) return fail(LBMDEM_EINVAL, "enable at a fluid-step boundary");
-  // message capacities: twice the share of a band of (M + a grain) rows at uniform density; every disc a cut can meet
-  const double band = (double)(M + 2 * (int)ceil(h->rmax / c.dx) + 4) / c.lx;
-  long cap_g = (long)(2.0 * band * h->n) + 256;
+  // message capacities. Grains per side: 1.5 x the fullest band of (M + a grain) rows in the present packing (the
+  // same number on every rank: all ranks see the same positions now); tables: every disc a cut can go through.
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::vector<double> hx(h->n);
+  HIP_TRY(hipMemcpy(hx.data(), h->kin[h->kcur].x1, sizeof(double) * h->n, hipMemcpyDeviceToHost));
+  const int bandw = M + 2 * (int)ceil(h->rmax / c.dx) + 4;
+  std::vector<int> hist(c.lx + 1, 0);
+  for (int i = 0; i < h->n; ++i) {
+    long row = (long)floor((hx[i] - c.Mgx) / c.dx);
+    if (row < 0) row = 0;
+    if (row > c.lx - 1) row = c.lx - 1;
+    hist[row]++;
+  }
+  long win = 0, best = 0;
+  for (int x = 0; x < c.lx; ++x) {
+    win += hist[x];
+    if (x >= bandw) win -= hist[x - bandw];
+    if (win > best) best = win;
+  }
+  long cap_g = best + best / 2 + 256;
   if (cap_g > h->n) cap_g = h->n;
   long cap_t = (long)(c.ly / (2 * h->rmin / c.dx)) + 32;
   if (cap_t > h->n) cap_t = h->n;
-  HIP_TRY(hipStreamSynchronize(h->stream));
   if (dist_alloc(h->dd, h->n, (int)cap_g, (int)cap_t) != 0) { dist_free(h->dd); return fail(LBMDEM_ENOMEM, "dist_alloc failed"); }
   h->dist = true;
   h->dist_margin = M;

@@ -161,3 +161,45 @@ def test_real_50000_grain_sample_six_coupled_steps_vs_oracle(pkg, po):
     assert np.array_equal(sim.obst, ora.get_obst())
     got = sim.f
     assert np.array_equal(got, ora.get_f())
+
+
+def test_configs4_8192x4096_as_eight_strips_against_the_reference_digests(pkg):
+    """BASELINE.json configs[4]: 8192 x 4096, the reference's bin/50000.data, 1-D decomposition into 8 strips with
+    the grains distributed and migrated by neighbour messages -- here the 8 ranks live on ONE GPU and are stepped in
+    lock-step (a box with 8 GPUs runs the same runner under torch.distributed: tests/test_gpu_multi.py). After one and
+    two coupled steps the gathered populations, obstacle map, forces and kinematics hash to what the unmodified
+    reference produced on the whole lattice (tests/golden/real_50000_8192x4096.npz)."""
+    import torch
+    import golden_util as gu
+    from strip_backends import LoopbackComm, lockstep_render_dist
+    strips = pkg.strips_module()
+    g = gu.load("real_50000_8192x4096")
+    lx, ly, world = 8192, 4096, 8
+    r, x1, x2 = g["r"], g["x1"], g["x2"]
+    cfg = pkg.derive(lx, ly, r)
+    assert int(g["npDEM"]) == cfg.npDEM
+    margin = strips.default_margin(cfg.npDEM, float(r.max()), cfg.phys.distVerlet, cfg.dx)
+    parts = strips.partition(lx, world)
+    runners = []
+    for rank, strip in enumerate(parts):
+        be = strips.GpuStripBackend(pkg, torch, lx, ly, r, x1, x2, strip, 2, 0, distributed=True, margin=margin)
+        runners.append(strips.DistStripRunner(be, LoopbackComm(), rank, world))
+    f = np.empty((lx, ly, 9)); obst = np.empty((lx, ly), np.int32)
+    done = 0
+    for k in (1, 2):
+        lockstep_render_dist(runners, (k - done) * cfg.npDEM)
+        done = k
+        kin = np.empty((len(r), 9)); fhf = np.empty((len(r), 3))
+        for R, (a, b) in zip(runners, parts):
+            s = R.b.sim
+            s.sync()
+            s.download_f_into(f)
+            s._L.lbmdem_download_obst(s._h, obst.ctypes.data_as(__import__("ctypes").c_void_p))
+            kk = s.kinematics
+            xc = kk[:, 0] / cfg.dx     # Mgx = 0
+            own = ((a == 0) | (xc >= a)) & ((b == lx) | (xc < b))
+            kin[own] = kk[own]; fhf[own] = s.fhf[own]
+        assert gu.sha(kin) == str(g[f"sha_kin_{k}"]), (k, "kinematics")
+        assert gu.sha(fhf) == str(g[f"sha_fhf_{k}"]), (k, "hydrodynamic forces")
+        assert gu.sha(obst) == str(g[f"sha_obst_{k}"]), (k, "obstacle map")
+        assert gu.sha(f) == str(g[f"sha_f_{k}"]), (k, "populations")

@@ -136,12 +136,17 @@ def test_distributed_grains_equal_single_domain(pkg, nstrips):
     import torch
     from strip_backends import LoopbackComm, lockstep_render_dist
     strips = pkg.strips_module()
-    lx, ly = 1024, 192
-    r, x, y = samples.row_packing(lx, ly, 700, seed=11)
+    lx, ly = 1024, 256
+    r, x, y = samples.row_packing(lx, ly, 700, seed=11)          # fills the lower 19 mm of the 25.6 mm
+    parts = pkg.strips_module().partition(lx, nstrips)
+    # on every cut, one grain on each side whose disc is clipped by the lattice-interior clamp at the top wall and has
+    # links into wall nodes: their link sums are completed (gathered) by whichever rank holds the far end
+    for a, _ in parts[1:]:
+        for off in (-0.5, 0.56):
+            r = np.append(r, 0.5); x = np.append(x, 0.1 * a + off); y = np.append(y, 25.07)
     r, x1, x2 = samples.to_metres(r, x, y)
     cfg = pkg.derive(lx, ly, r)
     margin = strips.default_margin(cfg.npDEM, float(r.max()), cfg.phys.distVerlet, cfg.dx)
-    parts = strips.partition(lx, nstrips)
     assert min(b - a for a, b in parts) >= margin
     rng = np.random.default_rng(5)
     k = np.zeros((len(r), 9)); k[:, 0], k[:, 1] = x1, x2
