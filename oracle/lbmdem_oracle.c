@@ -509,6 +509,58 @@ ORA_API void ora_forces_fluid(ora_sim* s) {
   }
 }
 
+/* Test helpers for the strip-decomposition protocol (tests/strip_backends.py; no counterpart in the reference, which
+ * has one address space). The momentum-exchange sums f[P][opp q] + f[N][q] (main.c:1313-1314) of grain i's links
+ * whose far end N = P + e_q lies in rows [nlo, nhi), in the reference's scan order, as {x, y, q, sum} ... */
+ORA_API int ora_link_sums(ora_sim* s, int i, int nlo, int nhi, double* out4, int cap) {
+  const int nx_ = s->lx, ny_ = s->ly;
+  const double* f = s->f;
+  const double xc = (s->x1[i] - s->Mgx) / s->dx;
+  const double yc = (s->x2[i] - s->Mby) / s->dx;
+  const double rbl0 = s->r[i] / s->dx;
+  int xi = (int)(xc - rbl0); if (xi < 1) xi = 1;
+  int xf = (int)(xc + rbl0); if (xf > nx_ - 2) xf = nx_ - 2;
+  int yi = (int)(yc - rbl0); if (yi < 1) yi = 1;
+  int yf = (int)(yc + rbl0); if (yf > ny_ - 2) yf = ny_ - 2;
+  int cnt = 0;
+  for (int x = xi; x <= xf; ++x)
+    for (int y = yi; y <= yf; ++y) {
+      if (s->obst[NI(s, x, y)] != i) continue;
+      for (int q = 1; q < NQ; ++q) {
+        int nx = x + EX[q], ny = y + EY[q];
+        if (s->obst[NI(s, nx, ny)] == i) continue;
+        if (nx < nlo || nx >= nhi) continue;
+        const int qo = (q <= HALF) ? q + HALF : q - HALF;
+        if (cnt < cap) {
+          out4[4 * cnt] = x; out4[4 * cnt + 1] = y; out4[4 * cnt + 2] = q;
+          out4[4 * cnt + 3] = f[FI(s, x, y, qo)] + f[FI(s, nx, ny, q)];
+        }
+        ++cnt;
+      }
+    }
+  return cnt;
+}
+
+/* ... and the hydrodynamic force of grain i from the complete list of its links' sums in scan order: the additions and
+ * the scaling of main.c:1315-1331. */
+ORA_API void ora_force_from_link_sums(ora_sim* s, int i, const double* in4, int n) {
+  double h1 = 0, h2 = 0, h3 = 0;
+  for (int k = 0; k < n; ++k) {
+    const int x = (int)in4[4 * k], y = (int)in4[4 * k + 1], q = (int)in4[4 * k + 2];
+    const double sum = in4[4 * k + 3];
+    const int qo = (q <= HALF) ? q + HALF : q - HALF;
+    const double fnx = sum * EX[qo];
+    const double fny = sum * EY[qo];
+    h1 = h1 + fnx;
+    h2 = h2 + fny;
+    h3 = h3 - fnx * (y - (s->x2[i] - s->Mby) / s->dx) + fny * (x - (s->x1[i] - s->Mgx) / s->dx);
+  }
+  const double dx = s->dx, tau = s->tau, nu = s->nu, rho_moy = s->rho_moy;
+  s->fhf1[i] = h1 * (rho_moy * 9 * nu * nu / (dx * (tau - 0.5) * (tau - 0.5)));
+  s->fhf2[i] = h2 * (rho_moy * 9 * nu * nu / (dx * (tau - 0.5) * (tau - 0.5)));
+  s->fhf3[i] = h3 * (dx * rho_moy * 9 * nu * nu / (dx * (tau - 0.5) * (tau - 0.5)));
+}
+
 ORA_API void ora_lbm_steps(ora_sim* s, int n) {
   for (int k = 0; k < n; ++k) {
     ora_reinit_obst_density(s);

@@ -88,6 +88,10 @@ int ora_verlet_capacity(const ora_sim* s);
 void ora_get_verlet(const ora_sim* s, int* cumul, int* neighbours, int* counts4, int* wb, int* wt,
                     int* wl, int* wr);
 double ora_total_density(const ora_sim* s);  /* main.c:1249-1273 summation order */
+/* test-only (strip-decomposition protocol): link sums {x, y, q, f[P][opp q] + f[N][q]} of grain i whose far end N
+ * lies in rows [nlo, nhi), scan order; and the force of grain i from its complete ordered list of sums */
+int ora_link_sums(ora_sim* s, int i, int nlo, int nhi, double* out4, int cap);
+void ora_force_from_link_sums(ora_sim* s, int i, const double* in4, int n);
 
 /* Count of solid nodes whose reference `act` flag (set while grains are painted one after the other,
  * main.c:1039-1052) differs from what the HIP path derives from the FINAL obstacle map: "has a

@@ -71,6 +71,9 @@ class Oracle:
         L.ora_total_density.restype = C.c_double
         L.ora_total_density.argtypes = [C.c_void_p]
         L.ora_nbsteps.restype = C.c_long
+        L.ora_link_sums.restype = C.c_int
+        L.ora_link_sums.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.ora_force_from_link_sums.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.ora_count_act_anomalies.restype = C.c_long
         r = np.ascontiguousarray(r, dtype=np.float64)
         x1 = np.ascontiguousarray(x1, dtype=np.float64)
@@ -185,6 +188,19 @@ class Oracle:
         return np.array(out, dtype=np.int64).reshape(-1, 2)
 
     def total_density(self): return float(self.L.ora_total_density(self.h))
+
+    # test-only helpers of the strip-decomposition protocol (tests/strip_backends.py)
+    def link_sums(self, i, nlo, nhi):
+        out = np.empty((512, 4))
+        n = int(self.L.ora_link_sums(self.h, C.c_int(i), C.c_int(nlo), C.c_int(nhi), _vp(out), C.c_int(len(out))))
+        if n > len(out):
+            out = np.empty((n, 4))
+            self.L.ora_link_sums(self.h, C.c_int(i), C.c_int(nlo), C.c_int(nhi), _vp(out), C.c_int(n))
+        return out[:n].copy()
+
+    def force_from_link_sums(self, i, terms):
+        t = np.ascontiguousarray(terms, dtype=np.float64)
+        self.L.ora_force_from_link_sums(self.h, C.c_int(i), _vp(t), C.c_int(len(t)))
     def act_anomalies(self): return int(self.L.ora_count_act_anomalies(self.h))
 
 

@@ -95,6 +95,123 @@ class OracleStripBackend:
             self.o.dem_substep()
 
 
+class OracleDistBackend(OracleStripBackend):
+    """Poisoned replica for the DISTRIBUTED-grain protocol (DistStripRunner): a full-lattice CPU oracle per rank, but
+    (a) lattice rows it does not own are NaN after every fluid step and only 2 halo rows arrive from the neighbours,
+    (b) grains it does not integrate (owned + margin) are NaN after every DEM sub-step and only what the neighbours'
+    KIN / FHF messages carry is restored, (c) the force of a grain a cut goes through is formed from link sums, each
+    rank contributing the links whose far end lies in its own rows (TABLES message). Anything the protocol fails to
+    deliver turns into NaN in the gathered result. TEST INFRASTRUCTURE ONLY."""
+
+    def __init__(self, po, torch, lx, ly, r, x1, x2, strip, margin):
+        super().__init__(po, torch, lx, ly, r, x1, x2, strip, 2)
+        self.M = margin
+        self.n = len(r)
+        self.rLB = self.o.rlb()
+        self.active = np.ones(self.n, bool)
+        self.kin_send = [None, None]; self.kin_recv_ids = [None, None]; self.tab_recv = {}
+        self.first, self.last = self.xb == 0, self.xe == lx
+        cap = self.n
+        self.bufs = {0: 1 + 10 * cap, 1: 3 * cap, 2: 1 + 5 * 64 * cap}
+        self.rbuf = {k: [torch.zeros(v, dtype=torch.float64) for _ in range(2)] for k, v in self.bufs.items()}
+
+    def _xc(self):
+        return (self.o.get_grains()[:, 0] - self.Mgx) / self.dx
+
+    def dist_begin_period(self):
+        xc = self._xc()
+        act = self.active
+        own = act & (self.first | (xc >= self.xb)) & (self.last | (xc < self.xe))
+        self.own = own
+        self.kin_send = [np.flatnonzero(own & (xc < self.xb + self.M)) if not self.first else np.zeros(0, int),
+                         np.flatnonzero(own & (xc >= self.xe - self.M)) if not self.last else np.zeros(0, int)]
+        ring = self.rLB + 2.0
+        self.strad = [np.flatnonzero(act & ~own & (xc < self.xb) & (xc + ring >= self.xb)) if not self.first else np.zeros(0, int),
+                      np.flatnonzero(act & ~own & (xc >= self.xe) & (xc - ring < self.xe)) if not self.last else np.zeros(0, int)]
+        self.cut = own & (((xc - ring < self.xb) & (not self.first)) | ((xc + ring >= self.xe) & (not self.last)))
+        self.fluid_ok = act.copy()     # grains with exact state (those that matter lie near the strip)
+        self.active = own.copy()
+        self.tab_recv = {}
+
+    def obst_construction(self):
+        # grains this rank does not hold exactly are taken off the lattice (on the GPU: the rasteriser's mask)
+        g = self.o.get_grains()[:, :9]
+        keep = g.copy()
+        g[~self.fluid_ok] = 0.0
+        g[~self.fluid_ok, 0] = g[~self.fluid_ok, 1] = -1.0
+        self.o.set_kinematics(g)
+        super().obst_construction()
+        self.o.set_kinematics(keep)
+
+    def dist_pack(self, kind, side):
+        t = self.torch
+        if kind == 0:
+            ids = self.kin_send[side]
+            g = self.o.get_grains()[:, :9]
+            body = np.concatenate([ids[:, None].astype(float), g[ids]], axis=1).reshape(-1)
+            out = np.zeros(self.bufs[0]); out[0] = len(ids); out[1:1 + len(body)] = body
+        elif kind == 1:
+            ids = self.kin_send[side]
+            out = np.zeros(self.bufs[1]); out[:3 * len(ids)] = self.o.get_fhf()[ids].reshape(-1)
+        else:
+            rows = []
+            for i in self.strad[side]:
+                ts = self.o.link_sums(int(i), self.xb, self.xe)
+                rows.append(np.concatenate([np.full((len(ts), 1), float(i)), ts], axis=1))
+            body = np.concatenate(rows).reshape(-1) if rows else np.zeros(0)
+            out = np.zeros(self.bufs[2]); out[0] = len(body) // 5; out[1:1 + len(body)] = body
+        return t.from_numpy(out)
+
+    def dist_recv_buffer(self, kind, side):
+        return self.rbuf[kind][side]
+
+    def dist_unpack(self, kind, side):
+        buf = self.rbuf[kind][side].numpy()
+        if kind == 0:
+            cnt = int(buf[0]); ent = buf[1:1 + 10 * cnt].reshape(cnt, 10)
+            ids = ent[:, 0].astype(int)
+            g = self.o.get_grains()[:, :9]
+            g[ids] = ent[:, 1:]
+            self.o.set_kinematics(g)
+            self.active[ids] = True
+            self.kin_recv_ids[side] = ids
+        elif kind == 1:
+            ids = self.kin_recv_ids[side]
+            fhf = self.o.get_fhf()
+            fhf[ids] = buf[:3 * len(ids)].reshape(-1, 3)
+            self.o.set_fhf(fhf)
+        else:
+            cnt = int(buf[0]); ent = buf[1:1 + 5 * cnt].reshape(cnt, 5)
+            for i in np.unique(ent[:, 0]).astype(int):
+                self.tab_recv.setdefault(i, []).append(ent[ent[:, 0] == i][:, 1:])
+
+    def forces_fluid(self):
+        self.o.forces_fluid()                      # right for owned grains whose links all end in owned rows
+        for i in np.flatnonzero(self.cut):         # a cut goes through the ring of links: own part + the neighbour's
+            parts = [self.o.link_sums(int(i), self.xb, self.xe)] + self.tab_recv.get(int(i), [])
+            terms = np.concatenate(parts)
+            order = np.lexsort((terms[:, 2], terms[:, 1], terms[:, 0]))     # scan order: x, then y, then q
+            self.o.force_from_link_sums(int(i), terms[order])
+        fhf = self.o.get_fhf()
+        fhf[~self.own] = np.nan                    # margin grains' forces come from their owners (FHF message)
+        self.o.set_fhf(fhf)
+
+    def _poison(self):
+        g = self.o.get_grains()[:, :9]
+        g[~self.active] = np.nan
+        self.o.set_kinematics(g)
+
+    def dem_substep(self):
+        self.o.dem_substep(); self._poison()
+
+    def run_dem(self, k):
+        for _ in range(k):
+            if self.o.nbsteps % self.updateVerlet == 0:
+                self.o.verlet_rebuild()
+            self.o.dem_substep()
+            self._poison()
+
+
 class LoopbackComm:
     """Placeholder comm for runners that are stepped in lock-step inside one process."""
     def exchange(self, ops): raise RuntimeError("lock-step driver delivers the halos")

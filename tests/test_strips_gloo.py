@@ -79,6 +79,84 @@ def test_strip_driver_bit_exact_over_gloo(po, tmp_path, world):
     assert np.array_equal(got, want)
 
 
+def _dist_case():
+    lx, ly = 640, 96
+    r, x, y = samples.row_packing(lx, ly, 200, seed=17, rmin=0.45, rmax=0.6)
+    # shift the packing so that one grain's centre sits 0.03 nodes above the cut at lx / 2: a small push carries it over
+    dx_mm = 0.1 * lx / (lx - 1)
+    d = x / dx_mm - lx // 2
+    x = x - (d[d >= 0].min() - 0.03) * dx_mm
+    return lx, ly, samples.to_metres(r, x, y)
+
+
+def _dist_kin(r, x1, x2, sc, nsteps, cut):
+    rng = np.random.default_rng(9)
+    k = np.zeros((len(r), 9)); k[:, 0], k[:, 1] = x1, x2
+    k[:, 3:6] = rng.normal(0, 1, (len(r), 3)) * [0.05, 0.05, 20.0]
+    d = x1 / sc["dx"] - cut          # the grain just above the cut drifts across it
+    k[np.argmin(np.where(d >= 0, d, np.inf)), 3] = -0.25
+    return k
+
+
+def _dist_worker(rank, world, port, outdir, nsteps):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), HERE]
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    import pyoracle as po
+    from strip_backends import OracleDistBackend
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    strips = pkg.strips_module()
+    lx, ly, (r, x1, x2) = _dist_case()
+    sc = po.Oracle(lx, ly, r, x1, x2).scalars()
+    margin = strips.default_margin(sc["npDEM"], float(r.max()), 5e-4, sc["dx"])
+    strip = strips.partition(lx, world)[rank]
+    assert strip[1] - strip[0] >= margin
+    be = OracleDistBackend(po, torch, lx, ly, r, x1, x2, strip, margin)
+    be.o.set_kinematics(_dist_kin(r, x1, x2, sc, nsteps, lx // 2))
+    run = strips.DistStripRunner(be, strips.TorchComm(dist), rank, world)
+    run.render_scene(nsteps)
+    be.dist_begin_period()      # ownership at the end
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), f=be.o.get_f()[strip[0]:strip[1]], strip=np.array(strip),
+             grains=be.o.get_grains()[:, :9], fhf=be.o.get_fhf(), own=be.own)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_distributed_grain_protocol_bit_exact_over_gloo(po, tmp_path):
+    """DistStripRunner (grains owned by strips, margin integrated redundantly, neighbour messages only) on two gloo
+    ranks with poisoned oracle replicas: every owned row and every owned grain equals the single-domain run; a
+    grain changes owner on the way."""
+    import torch.multiprocessing as tmp_mp
+    world = 2
+    lx, ly, (r, x1, x2) = _dist_case()
+    single = po.Oracle(lx, ly, r, x1, x2)
+    npdem = single.scalars()["npDEM"]
+    nsteps = 12 * npdem + 3          # a Verlet rebuild at sub-step 100 inside
+    single.set_kinematics(_dist_kin(r, x1, x2, single.scalars(), nsteps, lx // 2))
+    single.steps(nsteps)
+    port = _free_port()
+    tmp_mp.spawn(_dist_worker, args=(world, port, str(tmp_path), nsteps), nprocs=world, join=True)
+    want_f, want_g = single.get_f(), single.get_grains()[:, :9]
+    got = np.full_like(want_f, np.nan)
+    owners = np.zeros(len(r), int)
+    for rank in range(world):
+        z = np.load(tmp_path / f"rank{rank}.npz")
+        xb, xe = z["strip"]
+        got[xb:xe] = z["f"]
+        own = z["own"]
+        owners += own
+        assert np.array_equal(z["grains"][own], want_g[own]), f"rank {rank}: owned grains differ"
+    assert (owners == 1).all(), "every grain has exactly one owner"
+    assert not np.isnan(got).any(), "poison reached the owned rows"
+    assert np.array_equal(got, want_f)
+    dx = single.scalars()["dx"]
+    cut = lx // 2
+    assert ((x1 / dx < cut) != (want_g[:, 0] / dx < cut)).any(), "no grain crossed the cut: migration not exercised"
+
+
 def test_partition_and_halo(pkg):
     s = pkg.strips_module()
     assert s.partition(8192, 8) == [(1024 * k, 1024 * (k + 1)) for k in range(8)]
