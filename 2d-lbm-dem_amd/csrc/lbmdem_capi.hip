@@ -1484,5 +1484,252 @@ int lbmdem_fhf_import(lbmdem_handle* h, const void* dev_buf) {
   return LBMDEM_OK;
 }
 
+// ---- RCCL transport for the distributed-grain strips (the C host driver; strips.py does the same over
+// torch.distributed) ---------------------------------------------------------------------------------------------
+// RCCL is loaded with dlopen when the first communicator is made: processes that never call lbmdem_comm_* (the
+// single-GPU driver, Python with torch's own RCCL) do not load a second copy of the library.
+
+}  // extern "C"  (reopened below)
+#pragma GCC visibility pop
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load() {
+  if (g_rccl.lib) return LBMDEM_OK;
+  void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) return fail(LBMDEM_EHIP, "cannot load RCCL: %s", dlerror());
+#define RCCL_SYM(field, name)                                                                  \
+  g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(lib, name));                  \
+  if (!g_rccl.field) { dlclose(lib); return fail(LBMDEM_EHIP, "RCCL lacks %s", name); }
+  RCCL_SYM(GetUniqueId, "ncclGetUniqueId") RCCL_SYM(CommInitRank, "ncclCommInitRank") RCCL_SYM(CommDestroy, "ncclCommDestroy")
+  RCCL_SYM(Send, "ncclSend") RCCL_SYM(Recv, "ncclRecv") RCCL_SYM(GroupStart, "ncclGroupStart") RCCL_SYM(GroupEnd, "ncclGroupEnd")
+  RCCL_SYM(AllReduce, "ncclAllReduce") RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef RCCL_SYM
+  g_rccl.lib = lib;
+  return LBMDEM_OK;
+}
+}  // namespace
+
+#define NCCL_TRY(expr)                                                                                      \
+  do {                                                                                                      \
+    ncclResult_t r_ = (expr);                                                                               \
+    if (r_ != ncclSuccess) return fail(LBMDEM_EHIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));    \
+  } while (0)
+
+// message classes that can be in flight at the same time each have their own side stream
+enum { LANE_KIN = 0, LANE_HALO, LANE_TAB, LANE_FHF, LANE_COUNT };
+
+struct lbmdem_comm {
+  ncclComm_t nccl = nullptr;
+  int rank = 0, world = 1, device = 0;
+  hipStream_t side[LANE_COUNT] = {};
+  hipEvent_t ready[LANE_COUNT] = {}, done[LANE_COUNT] = {};
+  // device buffers for one handle: [kind or halo][side][send/recv]
+  lbmdem_handle* bound = nullptr;
+  double* buf[4][2][2] = {};
+  size_t count[4] = {};   // doubles per message: KIN, FHF, TABLES, halo
+  double* scratch = nullptr;
+};
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int lbmdem_comm_unique_id(void* id128) {
+  if (!id128) return fail(LBMDEM_EINVAL, "null buffer");
+  int rc = rccl_load();
+  if (rc != LBMDEM_OK) return rc;
+  static_assert(sizeof(ncclUniqueId) == LBMDEM_COMM_ID_BYTES, "ncclUniqueId size");
+  NCCL_TRY(g_rccl.GetUniqueId(reinterpret_cast<ncclUniqueId*>(id128)));
+  return LBMDEM_OK;
+}
+
+int lbmdem_comm_destroy(lbmdem_comm* c) {
+  if (!c) return LBMDEM_OK;
+  (void)hipSetDevice(c->device);
+  for (int l = 0; l < LANE_COUNT; ++l) {
+    if (c->side[l]) { (void)hipStreamSynchronize(c->side[l]); (void)hipStreamDestroy(c->side[l]); }
+    if (c->ready[l]) (void)hipEventDestroy(c->ready[l]);
+    if (c->done[l]) (void)hipEventDestroy(c->done[l]);
+  }
+  for (auto& k : c->buf) for (auto& s : k) for (double*& p : s) if (p) (void)hipFree(p);
+  if (c->scratch) (void)hipFree(c->scratch);
+  if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
+  delete c;
+  return LBMDEM_OK;
+}
+
+int lbmdem_comm_create(const void* id128, int rank, int world, int device, lbmdem_comm** out) try {
+  if (!id128 || !out || world < 1 || rank < 0 || rank >= world) return fail(LBMDEM_EINVAL, "bad lbmdem_comm_create arguments");
+  *out = nullptr;
+  int rc = rccl_load();
+  if (rc != LBMDEM_OK) return rc;
+  HIP_TRY(hipSetDevice(device));
+  lbmdem_comm* c = new lbmdem_comm();
+  c->rank = rank; c->world = world; c->device = device;
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  ncclResult_t r = g_rccl.CommInitRank(&c->nccl, world, id, rank);
+  if (r != ncclSuccess) { delete c; return fail(LBMDEM_EHIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); }
+  for (int l = 0; l < LANE_COUNT; ++l) {
+    if (hipStreamCreateWithFlags(&c->side[l], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ready[l], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->done[l], hipEventDisableTiming) != hipSuccess) {
+      lbmdem_comm_destroy(c);
+      return fail(LBMDEM_EHIP, "stream / event creation failed");
+    }
+  }
+  if (hipMalloc((void**)&c->scratch, sizeof(double) * 1024) != hipSuccess) { lbmdem_comm_destroy(c); return fail(LBMDEM_ENOMEM, "hipMalloc"); }
+  *out = c;
+  return LBMDEM_OK;
+} catch (...) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+}
+
+// transfers of one lane with both neighbours: they depend on what the main stream has enqueued so far, not on
+// what it enqueues next; `done` is what the main stream waits for later
+static int comm_begin(lbmdem_comm* c, hipStream_t main, int lane, int kind, const bool has[2]) {
+  if (!has[0] && !has[1]) return LBMDEM_OK;
+  HIP_TRY(hipEventRecord(c->ready[lane], main));
+  HIP_TRY(hipStreamWaitEvent(c->side[lane], c->ready[lane], 0));
+  NCCL_TRY(g_rccl.GroupStart());
+  for (int s = 0; s < 2; ++s) {
+    if (!has[s]) continue;
+    const int peer = s == 0 ? c->rank - 1 : c->rank + 1;
+    NCCL_TRY(g_rccl.Send(c->buf[kind][s][0], c->count[kind], ncclDouble, peer, c->nccl, c->side[lane]));
+    NCCL_TRY(g_rccl.Recv(c->buf[kind][s][1], c->count[kind], ncclDouble, peer, c->nccl, c->side[lane]));
+  }
+  NCCL_TRY(g_rccl.GroupEnd());
+  HIP_TRY(hipEventRecord(c->done[lane], c->side[lane]));
+  return LBMDEM_OK;
+}
+static int comm_end(lbmdem_comm* c, hipStream_t main, int lane, const bool has[2]) {
+  if (!has[0] && !has[1]) return LBMDEM_OK;
+  HIP_TRY(hipStreamWaitEvent(main, c->done[lane], 0));
+  return LBMDEM_OK;
+}
+
+static int comm_bind(lbmdem_comm* c, lbmdem_handle* h) {
+  if (c->bound == h) return LBMDEM_OK;
+  if (c->bound) return fail(LBMDEM_EINVAL, "a communicator serves one handle");
+  if (!h->dist) return fail(LBMDEM_EINVAL, "lbmdem_dist_enable first");
+  c->count[LBMDEM_MSG_KIN] = (size_t)lbmdem_dist_message_doubles(h, LBMDEM_MSG_KIN);
+  c->count[LBMDEM_MSG_FHF] = (size_t)lbmdem_dist_message_doubles(h, LBMDEM_MSG_FHF);
+  c->count[LBMDEM_MSG_TABLES] = (size_t)lbmdem_dist_message_doubles(h, LBMDEM_MSG_TABLES);
+  c->count[3] = (size_t)lbmdem_halo_doubles(h);
+  for (int k = 0; k < 4; ++k)
+    for (int s = 0; s < 2; ++s)
+      for (int d = 0; d < 2; ++d) {
+        HIP_TRY(hipMalloc((void**)&c->buf[k][s][d], sizeof(double) * (c->count[k] ? c->count[k] : 1)));
+        HIP_TRY(hipMemset(c->buf[k][s][d], 0, sizeof(double) * (c->count[k] ? c->count[k] : 1)));
+      }
+  HIP_TRY(hipDeviceSynchronize());
+  c->bound = h;
+  return LBMDEM_OK;
+}
+
+#define RC_TRY(expr) do { int rc_ = (expr); if (rc_ != LBMDEM_OK) return rc_; } while (0)
+
+int lbmdem_comm_lbm_step(lbmdem_handle* h, lbmdem_comm* c) {
+  CHECK_H(h);
+  if (!c) return fail(LBMDEM_EINVAL, "null communicator");
+  RC_TRY(comm_bind(c, h));
+  const bool has[2] = {h->cfg.x_begin > 0, h->cfg.x_end < h->cfg.lx};
+  hipStream_t main = h->stream;
+  RC_TRY(lbmdem_dist_begin_period(h));                       // ownership + message lists from the current positions
+  for (int s = 0; s < 2; ++s) if (has[s]) RC_TRY(lbmdem_dist_pack(h, LBMDEM_MSG_KIN, s, c->buf[LBMDEM_MSG_KIN][s][0]));
+  RC_TRY(comm_begin(c, main, LANE_KIN, LBMDEM_MSG_KIN, has));      // margin refresh / migration, under the fluid step
+  RC_TRY(lbmdem_obst_construction(h));
+  RC_TRY(lbmdem_collide_stream_part(h, LBMDEM_CS_EDGES));
+  for (int s = 0; s < 2; ++s) if (has[s]) RC_TRY(lbmdem_halo_pack(h, s, c->buf[3][s][0]));
+  RC_TRY(comm_begin(c, main, LANE_HALO, 3, has));
+  RC_TRY(lbmdem_collide_stream_part(h, LBMDEM_CS_INTERIOR));  // ... while the bulk of the rows is computed
+  RC_TRY(comm_end(c, main, LANE_HALO, has));
+  for (int s = 0; s < 2; ++s) if (has[s]) RC_TRY(lbmdem_halo_unpack(h, s, c->buf[3][s][1]));
+  for (int s = 0; s < 2; ++s) if (has[s]) RC_TRY(lbmdem_dist_pack(h, LBMDEM_MSG_TABLES, s, c->buf[LBMDEM_MSG_TABLES][s][0]));
+  RC_TRY(comm_begin(c, main, LANE_TAB, LBMDEM_MSG_TABLES, has));  // link sums of the grains the neighbours own
+  RC_TRY(comm_end(c, main, LANE_TAB, has));
+  for (int s = 0; s < 2; ++s) if (has[s]) RC_TRY(lbmdem_dist_unpack(h, LBMDEM_MSG_TABLES, s, c->buf[LBMDEM_MSG_TABLES][s][1]));
+  RC_TRY(lbmdem_forces_fluid(h));
+  RC_TRY(comm_end(c, main, LANE_KIN, has));
+  for (int s = 0; s < 2; ++s) if (has[s]) RC_TRY(lbmdem_dist_unpack(h, LBMDEM_MSG_KIN, s, c->buf[LBMDEM_MSG_KIN][s][1]));
+  for (int s = 0; s < 2; ++s) if (has[s]) RC_TRY(lbmdem_dist_pack(h, LBMDEM_MSG_FHF, s, c->buf[LBMDEM_MSG_FHF][s][0]));
+  RC_TRY(comm_begin(c, main, LANE_FHF, LBMDEM_MSG_FHF, has));    // forces of the margin grains, from their owners
+  RC_TRY(comm_end(c, main, LANE_FHF, has));
+  for (int s = 0; s < 2; ++s) if (has[s]) RC_TRY(lbmdem_dist_unpack(h, LBMDEM_MSG_FHF, s, c->buf[LBMDEM_MSG_FHF][s][1]));
+  return LBMDEM_OK;
+}
+
+int lbmdem_comm_run(lbmdem_handle* h, lbmdem_comm* c, long n_dem_steps) {
+  CHECK_H(h);
+  for (long k = 0; k < n_dem_steps; ++k) {
+    if (h->nbsteps % h->cfg.npDEM == 0) RC_TRY(lbmdem_comm_lbm_step(h, c));                     // main.c:1710-1718
+    if (h->nbsteps % h->cfg.phys.updateVerlet == 0) RC_TRY(lbmdem_verlet_rebuild(h));            // main.c:1721-1724
+    RC_TRY(lbmdem_dem_substep(h));                                                               // main.c:1733-1764
+  }
+  return LBMDEM_OK;
+}
+
+int lbmdem_comm_allreduce_sum(lbmdem_comm* c, double* values, int n) {
+  if (!c || !values || n < 1 || n > 1024) return fail(LBMDEM_EINVAL, "bad lbmdem_comm_allreduce_sum arguments");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpy(c->scratch, values, sizeof(double) * n, hipMemcpyHostToDevice));
+  NCCL_TRY(g_rccl.AllReduce(c->scratch, c->scratch, (size_t)n, ncclDouble, ncclSum, c->nccl, c->side[0]));
+  HIP_TRY(hipStreamSynchronize(c->side[0]));
+  HIP_TRY(hipMemcpy(values, c->scratch, sizeof(double) * n, hipMemcpyDeviceToHost));
+  return LBMDEM_OK;
+}
+
+/* A send to and a receive from THIS rank, grouped on a side stream while the caller's stream is busy: the
+ * transport of lbmdem_comm_lbm_step exercised with a single rank. */
+int lbmdem_comm_selftest(lbmdem_comm* c, int doubles) {
+  if (!c || doubles < 1) return fail(LBMDEM_EINVAL, "bad lbmdem_comm_selftest arguments");
+  HIP_TRY(hipSetDevice(c->device));
+  double *a = nullptr, *b = nullptr;
+  HIP_TRY(hipMalloc((void**)&a, sizeof(double) * doubles));
+  HIP_TRY(hipMalloc((void**)&b, sizeof(double) * doubles));
+  std::vector<double> ha(doubles), hb(doubles, -1.0);
+  for (int k = 0; k < doubles; ++k) ha[k] = 0.5 * k + 1.0;
+  hipStream_t main = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&main, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMemcpyAsync(a, ha.data(), sizeof(double) * doubles, hipMemcpyHostToDevice, main);
+  if (e == hipSuccess) e = hipEventRecord(c->ready[LANE_HALO], main);
+  if (e == hipSuccess) e = hipStreamWaitEvent(c->side[LANE_HALO], c->ready[LANE_HALO], 0);
+  ncclResult_t r = ncclSuccess;
+  if (e == hipSuccess) {
+    r = g_rccl.GroupStart();
+    if (r == ncclSuccess) r = g_rccl.Send(a, (size_t)doubles, ncclDouble, c->rank, c->nccl, c->side[LANE_HALO]);
+    if (r == ncclSuccess) r = g_rccl.Recv(b, (size_t)doubles, ncclDouble, c->rank, c->nccl, c->side[LANE_HALO]);
+    ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+  }
+  if (e == hipSuccess && r == ncclSuccess) e = hipEventRecord(c->done[LANE_HALO], c->side[LANE_HALO]);
+  if (e == hipSuccess && r == ncclSuccess) e = hipStreamWaitEvent(main, c->done[LANE_HALO], 0);
+  if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(hb.data(), b, sizeof(double) * doubles, hipMemcpyDeviceToHost, main);
+  if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(main);
+  if (main) (void)hipStreamDestroy(main);
+  (void)hipFree(a); (void)hipFree(b);
+  if (r != ncclSuccess) return fail(LBMDEM_EHIP, "RCCL self send/recv failed: %s", g_rccl.GetErrorString(r));
+  HIP_TRY(e);
+  for (int k = 0; k < doubles; ++k) if (hb[k] != ha[k]) return fail(LBMDEM_EHIP, "self send/recv returned wrong data at %d", k);
+  return LBMDEM_OK;
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

@@ -14,12 +14,76 @@
 #include <string.h>
 #include <time.h>
 #include <math.h>
+#include <unistd.h>
+#include <sys/wait.h>
 
 #include "../../include/lbmdem_hip.h"
 
 #define DIE(rc, what) do { if ((rc) != LBMDEM_OK) { fprintf(stderr, "%s: %s\n", what, lbmdem_last_error()); return EXIT_FAILURE; } } while (0)
 
+/* --gpus N: one process per GPU (forked before anything touches the HIP runtime), x-strips with the grains
+ * distributed, neighbour messages over RCCL (lbmdem_comm_*). Rank 0 creates the RCCL id and hands it to the others
+ * through a file in a private temporary directory. Rank 0 prints; VTK / DEM files and checkpoints are single-GPU. */
+static int g_rank = 0, g_world = 1, g_use_comm = 0;
+static char g_iddir[256] = "";
+
+static int share_id(unsigned char* id) {
+  char path[320], tmp[340];
+  snprintf(path, sizeof path, "%s/rccl_id", g_iddir);
+  if (g_rank == 0) {
+    if (lbmdem_comm_unique_id(id) != LBMDEM_OK) return -1;
+    if (g_world == 1) return 0;
+    snprintf(tmp, sizeof tmp, "%s.tmp", path);
+    FILE* fp = fopen(tmp, "wb");
+    if (!fp || fwrite(id, 1, LBMDEM_COMM_ID_BYTES, fp) != LBMDEM_COMM_ID_BYTES) return -1;
+    fclose(fp);
+    return rename(tmp, path);
+  }
+  for (int tries = 0; tries < 6000; ++tries) { /* up to 60 s */
+    FILE* fp = fopen(path, "rb");
+    if (fp) {
+      size_t got = fread(id, 1, LBMDEM_COMM_ID_BYTES, fp);
+      fclose(fp);
+      if (got == LBMDEM_COMM_ID_BYTES) return 0;
+    }
+    usleep(10000);
+  }
+  return -1;
+}
+
+static int run(int argc, char** argv);
+
 int main(int argc, char** argv) {
+  int gpus = 1;
+  for (int a = 1; a < argc; ++a) {
+    if (!strcmp(argv[a], "--gpus") && a + 1 < argc) gpus = atoi(argv[a + 1]);
+    if (!strcmp(argv[a], "--comm")) g_use_comm = 1;   /* the RCCL path with a single rank */
+  }
+  if (gpus <= 1) return run(argc, argv);
+  g_world = gpus; g_use_comm = 1;
+  snprintf(g_iddir, sizeof g_iddir, "/tmp/lbmdem_XXXXXX");
+  if (!mkdtemp(g_iddir)) { perror("mkdtemp"); return EXIT_FAILURE; }
+  pid_t pids[64];
+  if (gpus > 64) { fprintf(stderr, "--gpus: at most 64\n"); return EXIT_FAILURE; }
+  for (int r = 0; r < gpus; ++r) {
+    pids[r] = fork();
+    if (pids[r] < 0) { perror("fork"); return EXIT_FAILURE; }
+    if (pids[r] == 0) { g_rank = r; _exit(run(argc, argv)); }
+  }
+  int bad = 0;
+  for (int r = 0; r < gpus; ++r) {
+    int st = 0;
+    waitpid(pids[r], &st, 0);
+    if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) bad = 1;
+  }
+  char path[320];
+  snprintf(path, sizeof path, "%s/rccl_id", g_iddir); unlink(path); rmdir(g_iddir);
+  return bad ? EXIT_FAILURE : 0;
+}
+
+#define SAY(...) do { if (g_rank == 0) printf(__VA_ARGS__); } while (0)
+
+static int run(int argc, char** argv) {
   int lx = 7826, ly = 2325, device = 0; /* main.c:27-32 */
   double scale = 1., duration = 1.5;   /* main.c:24-26,47 */
   long max_steps = -1;
@@ -28,7 +92,7 @@ int main(int argc, char** argv) {
   /* device-resident kernel arguments: ~1.2 us less per launch (the HIP runtime reads this when it
    * initialises, i.e. at the first lbmdem_* call below); an explicit setting of the caller wins */
   setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
-  printf("2D LBM-DEM code\n");
+  SAY("2D LBM-DEM code\n");
   for (int a = 1; a < argc; ++a) {
     if (!strcmp(argv[a], "--lx") && a + 1 < argc) lx = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--ly") && a + 1 < argc) ly = atoi(argv[++a]);
@@ -38,19 +102,21 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[a], "--device") && a + 1 < argc) device = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--checkpoint") && a + 1 < argc) ckpt_out = argv[++a];
     else if (!strcmp(argv[a], "--restart") && a + 1 < argc) ckpt_in = argv[++a];
+    else if (!strcmp(argv[a], "--gpus") && a + 1 < argc) ++a;
+    else if (!strcmp(argv[a], "--comm")) {}
     else if (argv[a][0] != '-' && !sample) sample = argv[a];
     else { sample = NULL; break; }
   }
   if (!sample) {
-    printf("usage: usage %s <filename> [--lx N --ly N --scale S --duration T --steps N --device K]\n", argv[0]);
+    SAY("usage: usage %s <filename> [--lx N --ly N --scale S --duration T --steps N --device K --gpus N]\n", argv[0]);
     exit(EXIT_FAILURE);
   }
-  printf("Opening file : %s\n", sample);
+  SAY("Opening file : %s\n", sample);
 
   int n = 0;
   double *r = NULL, *x1 = NULL, *x2 = NULL;
   DIE(lbmdem_read_sample(sample, &n, &r, &x1, &x2), "read_sample");
-  printf("Nb grains %d\n", n);
+  SAY("Nb grains %d\n", n);
   { /* check_sample, main.c:640-658 */
     double xMax = x1[0], xMin = x1[0], yMax = x2[0], yMin = x2[0], mass = 0.;
     for (int i = 0; i < n; ++i) {
@@ -59,7 +125,7 @@ int main(int argc, char** argv) {
       yMax = fmax(yMax, x2[i] + r[i]); yMin = fmin(yMin, x2[i] - r[i]);
     }
     double L0 = xMax - xMin, H0 = yMax - yMin;
-    printf("L0=%le H0=%le Mass of Grains=%le Phi=%le\n", L0, H0, mass, mass / (2650 * (L0 * H0)));
+    SAY("L0=%le H0=%le Mass of Grains=%le Phi=%le\n", L0, H0, mass, mass / (2650 * (L0 * H0)));
   }
 
   lbmdem_config cfg;
@@ -67,12 +133,19 @@ int main(int argc, char** argv) {
   DIE(lbmdem_physics_defaults(&cfg.phys), "physics_defaults");
   DIE(lbmdem_derive(&cfg, lx, ly, scale, n, r), "derive");
   cfg.x_begin = 0; cfg.x_end = lx; cfg.halo = 0; cfg.device = device;
-  printf("no space %le\n", cfg.dx);
+  if (g_use_comm) { /* this rank's strip */
+    cfg.x_begin = (int)((long)g_rank * lx / g_world);
+    cfg.x_end = (int)((long)(g_rank + 1) * lx / g_world);
+    cfg.halo = g_world > 1 ? 2 : 0;
+    cfg.device = device + g_rank;
+    if (ckpt_in || ckpt_out) { fprintf(stderr, "checkpoints are single-GPU\n"); return EXIT_FAILURE; }
+  }
+  SAY("no space %le\n", cfg.dx);
   {
     double rMin = r[0];
     for (int i = 1; i < n; ++i) rMin = fmin(rMin, r[i]);
     double dtmax = (1 / cfg.phys.iterDEM) * 3.14159265358979 * rMin * sqrt(3.14159265358979 * 2650 / cfg.phys.kg);
-    printf("dtLB=%le,  dtmax=%le,   dt=%le,   npDEM=%d,   c=%lf\n", cfg.dtLB, dtmax, cfg.dt, cfg.npDEM, cfg.c);
+    SAY("dtLB=%le,  dtmax=%le,   dt=%le,   npDEM=%d,   c=%lf\n", cfg.dtLB, dtmax, cfg.dt, cfg.npDEM, cfg.c);
   }
   lbmdem_handle* h = NULL;
   long nbsteps = 0;
@@ -84,9 +157,17 @@ int main(int argc, char** argv) {
   } else {
     DIE(lbmdem_create(&cfg, r, x1, x2, &h), "create");
   }
+  lbmdem_comm* comm = NULL;
+  if (g_use_comm) {
+    unsigned char id[LBMDEM_COMM_ID_BYTES];
+    if (share_id(id) != 0) { fprintf(stderr, "rank %d: no RCCL id: %s\n", g_rank, lbmdem_last_error()); return EXIT_FAILURE; }
+    DIE(lbmdem_dist_enable(h, 0), "dist_enable");
+    DIE(lbmdem_comm_create(id, g_rank, g_world, cfg.device, &comm), "comm_create");
+    if (g_world == 1) DIE(lbmdem_comm_selftest(comm, 4096), "comm_selftest");
+  }
   time_t now = time(NULL);
-  printf("Current local time and date: %s", asctime(localtime(&now)));
-  if (!ckpt_in) { /* stats.data header, main.c:1867-1877 */
+  SAY("Current local time and date: %s", asctime(localtime(&now)));
+  if (!ckpt_in && g_rank == 0) { /* stats.data header, main.c:1867-1877 */
     FILE* st = fopen("stats.data", "w");
     if (st) {
       fprintf(st, "#1_t 2_xfront 3_xgrainmax 4_height 5_zmean 6_energie_x 7_energie_y "
@@ -114,16 +195,23 @@ int main(int argc, char** argv) {
     for (long k = 0; k < todo; ++k) {
       int lbm_now = (nbsteps % cfg.npDEM == 0), console_now = (nbsteps % stepConsole == 0);
       if (lbm_now && console_now) {
-        DIE(lbmdem_lbm_step(h), "lbm_step");
+        if (comm) DIE(lbmdem_comm_lbm_step(h, comm), "comm_lbm_step"); else DIE(lbmdem_lbm_step(h), "lbm_step");
         double sum = 0;
         DIE(lbmdem_total_density(h, &sum), "total_density");
-        printf("Iteration Number %ld, Total density in the system %f\n", nbsteps, sum);
+        if (comm) DIE(lbmdem_comm_allreduce_sum(comm, &sum, 1), "allreduce");
+        SAY("Iteration Number %ld, Total density in the system %f\n", nbsteps, sum);
         if (nbsteps % cfg.phys.updateVerlet == 0) DIE(lbmdem_verlet_rebuild(h), "verlet_rebuild");
         DIE(lbmdem_dem_substep(h), "dem_substep");
+      } else if (comm) {
+        DIE(lbmdem_comm_run(h, comm, 1), "comm_run");
       } else {
         DIE(lbmdem_run(h, 1), "run");
       }
       ++nbsteps;
+      if (comm) { /* file output is single-GPU */
+        if (nbsteps * cfg.dt > duration) { stop = 1; break; }
+        continue;
+      }
       /* output cadence of renderScene (main.c:1767-1772): write_vtk every stepFilm DEM steps */
       if (nbsteps % cfg.phys.stepFilm == 0) {
         DIE(lbmdem_write_vtk(h, ".", nFile), "write_vtk");
@@ -139,7 +227,7 @@ int main(int argc, char** argv) {
     }
     if (nbsteps % chunk == 0) {
       now = time(NULL);
-      printf("steps %li steps %le KE %le PE %le SE %le WF %le INCE %le SLIP %le RW %le Time %s \n", nbsteps,
+      SAY("steps %li steps %le KE %le PE %le SE %le WF %le INCE %le SLIP %le RW %le Time %s \n", nbsteps,
              nbsteps * cfg.dt, energies[0], energies[1], energies[2], energies[4], energies[5], energies[6], energies[7], asctime(localtime(&now)));
     }
   } while (!stop && (max_steps < 0 || nbsteps < max_steps));
@@ -148,14 +236,25 @@ int main(int argc, char** argv) {
   if (ckpt_out) DIE(lbmdem_checkpoint_save(h, ckpt_out), "checkpoint_save");
   double sum = 0;
   DIE(lbmdem_total_density(h, &sum), "total_density");
-  fprintf(stderr, "final_density: %f\n", sum);
   double secs = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+  if (comm) { /* whole-lattice mass; the slowest rank's time */
+    DIE(lbmdem_comm_allreduce_sum(comm, &sum, 1), "allreduce");
+    double tmax[64] = {0};
+    tmax[g_rank] = secs;
+    DIE(lbmdem_comm_allreduce_sum(comm, tmax, g_world), "allreduce");
+    for (int r = 0; r < g_world; ++r) if (tmax[r] > secs) secs = tmax[r];
+  }
   long lbm_steps = (nbsteps + cfg.npDEM - 1) / cfg.npDEM;
-  fprintf(stderr, "time: %e\n", secs);
-  fprintf(stderr, "dem_steps: %ld\n", nbsteps);
-  fprintf(stderr, "MLUPS: %.1f  DEM-steps/s: %.1f\n", 1e-6 * (double)lx * ly * lbm_steps / secs, nbsteps / secs);
+  if (g_rank == 0) {
+    fprintf(stderr, "final_density: %f\n", sum);
+    fprintf(stderr, "time: %e\n", secs);
+    fprintf(stderr, "dem_steps: %ld\n", nbsteps);
+    fprintf(stderr, "MLUPS: %.1f  DEM-steps/s: %.1f  (%d GPU%s)\n", 1e-6 * (double)lx * ly * lbm_steps / secs, nbsteps / secs,
+            g_world, g_world > 1 ? "s" : "");
+  }
   now = time(NULL);
-  printf("End local time and date: %s", asctime(localtime(&now)));
+  SAY("End local time and date: %s", asctime(localtime(&now)));
+  lbmdem_comm_destroy(comm);
   lbmdem_destroy(h);
   lbmdem_free_host(r); lbmdem_free_host(x1); lbmdem_free_host(x2);
   return 0;

@@ -171,6 +171,7 @@ def main():
             sim.sync()
         barrier = lambda: None
         runner = None
+        dist_mode = False
     else:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
@@ -181,6 +182,7 @@ def main():
                                         force_mode=args.force_mode)
         sim = runner.sim
         npdem = sim.cfg.npDEM
+        dist_mode = isinstance(runner, strips.DistStripRunner)
 
         def run_steps(k):
             runner.render_scene(k * npdem)
@@ -265,9 +267,14 @@ def main():
             "config": {"workload": w["name"], "lx": lx, "ly": ly, "grains": int(len(r)), "npDEM": int(npdem),
                        "step": "1 fluid step + npDEM DEM sub-steps (+ Verlet rebuild every 100 DEM steps)",
                        "force_kernel": "parity" if args.force_mode == 0 else "fast",
-                       "decomposition": "none" if args.gpus == 1 else
-                       f"{args.gpus} x-strips; halo exchange overlapped with the interior rows, one bit-exact "
-                       f"all-reduce of the hydrodynamic forces per fluid step; DEM state replicated"},
+                       "decomposition": "none" if args.gpus == 1 else (
+                           f"{args.gpus} x-strips, halo 2 rows, grains owned by strips (margin integrated redundantly); per "
+                           f"fluid step and neighbour: f halo rows and grain kinematics (both overlapped with the fluid "
+                           f"step), link-sum tables of the grains on the cut, forces of the margin grains -- point to "
+                           f"point only" if dist_mode else
+                           f"{args.gpus} x-strips; halo exchange overlapped with the interior rows, one bit-exact "
+                           f"all-reduce of the hydrodynamic forces per fluid step; grains replicated (strips narrower "
+                           f"than the margin)")},
             "dem_steps_per_s": round(args.steps * npdem / elapsed, 1),
             "dem_only_steps_per_s": round(dem_only, 1) if dem_only else None,
             "lbm_step_only_ms": round(lbm_only_ms, 4) if lbm_only_ms else None,

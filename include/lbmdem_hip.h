@@ -237,6 +237,25 @@ int lbmdem_dist_unpack(lbmdem_handle* h, int kind, int side, const void* dev_buf
 /* diagnostic: after every sub-step, grains this rank does not integrate are overwritten with NaN */
 int lbmdem_dist_set_poison(lbmdem_handle* h, int on);
 
+/* ---- RCCL transport of that protocol for a C host (the driver 2d-lbm-dem_amd/host/lbmdem --gpus N); strips.py does
+ * the same over torch.distributed. One process per GPU; rank k talks to ranks k-1 and k+1 only: ncclSend / ncclRecv
+ * grouped per message class on side streams (the kinematics and the f halo rows travel while kernels run), no
+ * collective on the step path. RCCL is dlopen'ed by the first of these calls. */
+typedef struct lbmdem_comm lbmdem_comm;
+#define LBMDEM_COMM_ID_BYTES 128
+int lbmdem_comm_unique_id(void* id128);   /* rank 0 makes it, every rank passes the same bytes to ..._create */
+int lbmdem_comm_create(const void* id128, int rank, int world, int device, lbmdem_comm** out);
+int lbmdem_comm_destroy(lbmdem_comm* c);
+/* one fluid step of a handle in distributed-grain mode with its neighbours (the sequence documented above) */
+int lbmdem_comm_lbm_step(lbmdem_handle* h, lbmdem_comm* c);
+/* n x renderScene() (main.c:1697-1765) with that fluid step */
+int lbmdem_comm_run(lbmdem_handle* h, lbmdem_comm* c, long n_dem_steps);
+/* sum of host values over the ranks (check_density / final_density; not on the step path) */
+int lbmdem_comm_allreduce_sum(lbmdem_comm* c, double* values, int n);
+/* a grouped send + receive of `doubles` values from this rank to itself on a side stream while another stream is
+ * busy: the transport exercised on a one-GPU box */
+int lbmdem_comm_selftest(lbmdem_comm* c, int doubles);
+
 /* Device pointer to the 3*n hydrodynamic-force table (fhf1[n], fhf2[n], fhf3[n]) and to the
  * n-entry ownership mask (1 = this rank computed the grain) for the cross-rank combine. */
 int lbmdem_fhf_device(lbmdem_handle* h, void** fhf, void** owner_mask);

@@ -1,6 +1,7 @@
-"""Run under torch.distributed.run with N >= 2 ranks on N GPUs: the real multi-GPU strip path (RCCL halo exchange on
-the side stream, bit-exact force all-reduce, replicated DEM) against the CPU oracle. Used by
-tests/test_gpu_multi.py when the box has more than one GPU."""
+"""Run under torch.distributed.run with N >= 2 ranks on N GPUs: the real multi-GPU strip path over RCCL against the
+CPU oracle. MODE=distributed (default): grains owned by strips, neighbour messages only (kinematics of the margin,
+link-sum tables, forces), halo of 2 rows; MODE=replicated: every rank integrates all grains, one bit-exact
+all-reduce of the forces per fluid step. Used by tests/test_gpu_multi.py when the box has more than one GPU."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,11 +13,13 @@ rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int
 torch.cuda.set_device(local)
 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 pkg = ge.load_package(); strips = pkg.strips_module()
-lx, ly = 128 * world, 192
-r, x, y = samples.row_packing(lx, ly, 90 * world, seed=21); r, x1, x2 = samples.to_metres(r, x, y)
+distributed = os.environ.get("MODE", "distributed") == "distributed"
+lx, ly = (320 if distributed else 128) * world, 192
+r, x, y = samples.row_packing(lx, ly, (230 if distributed else 90) * world, seed=21); r, x1, x2 = samples.to_metres(r, x, y)
 rng = np.random.default_rng(4)
 k = np.zeros((len(r), 9)); k[:, 0], k[:, 1] = x1, x2; k[:, 3:6] = rng.normal(0, 1, (len(r), 3)) * [0.04, 0.03, 15.0]
-runner = strips.make_gpu_runner(pkg, dist, rank, world, local, lx, ly, r, x1, x2)
+runner = strips.make_gpu_runner(pkg, dist, rank, world, local, lx, ly, r, x1, x2, distributed=distributed)
+assert isinstance(runner, strips.DistStripRunner) == distributed
 runner.sim.kinematics = k
 n = 5 * runner.sim.cfg.npDEM + 3
 runner.render_scene(n)
@@ -33,10 +36,14 @@ else:
     ref_f = np.empty((lx, ly, 9)); ref_kin = np.empty((len(r), 9)); ref_fhf = np.empty((len(r), 3))
 for a in (ref_f, ref_kin, ref_fhf):                       # hand the oracle's result to every rank
     t = torch.from_numpy(a).cuda(); dist.broadcast(t, 0); a[...] = t.cpu().numpy()
-ok = (np.array_equal(got[x0:x1_], ref_f[x0:x1_]) and np.array_equal(runner.sim.kinematics, ref_kin)
-      and np.array_equal(runner.sim.fhf, ref_fhf))
+own = np.ones(len(r), bool)
+if distributed:      # a rank answers for the grains whose centre lies in its rows
+    xc = ref_kin[:, 0] / runner.sim.cfg.dx
+    own = ((x0 == 0) | (xc >= x0)) & ((x1_ == lx) | (xc < x1_))
+ok = (np.array_equal(got[x0:x1_], ref_f[x0:x1_]) and np.array_equal(runner.sim.kinematics[own], ref_kin[own])
+      and np.array_equal(runner.sim.fhf[own], ref_fhf[own]))
 flag = torch.tensor([1 if ok else 0], device="cuda"); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 if rank == 0:
-    print("MULTI-GPU-OK" if int(flag) == 1 else "MULTI-GPU-MISMATCH", world, flush=True)
+    print("MULTI-GPU-OK" if int(flag) == 1 else "MULTI-GPU-MISMATCH", world, "distributed" if distributed else "replicated", flush=True)
 dist.barrier(); dist.destroy_process_group()
 sys.exit(0 if int(flag) == 1 else 1)

@@ -86,3 +86,22 @@ def test_duration_stops_after_the_same_step_as_the_reference(po, tmp_path):
     fd = float(re.search(r"final_density: ([0-9.]+)", out.stderr).group(1))
     ora.steps(want_steps)
     assert abs(fd - ora.total_density()) < 1e-5
+
+
+def test_rccl_path_of_the_c_driver_with_one_rank(po, tmp_path):
+    """`lbmdem --comm`: the multi-GPU code path of the C driver (grains distributed, lbmdem_comm_* over RCCL: communicator
+    from a unique id, a grouped self send/recv on a side stream, lbmdem_comm_run, the density all-reduce) with a single
+    rank -- all a one-GPU box can run; `--gpus N` forks one such process per GPU."""
+    c = gu.CASES["G4_coupled_256x200"]
+    sample = tmp_path / "packing.data"
+    po.write_sample(str(sample), c["r_mm"], c["x_mm"], c["y_mm"])
+    nsteps = 130
+    out = subprocess.run([EXE, str(sample), "--lx", "256", "--ly", "200", "--steps", str(nsteps), "--comm"],
+                         capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert out.returncode == 0, (out.stdout[-300:], out.stderr[-600:])
+    assert int(re.search(r"dem_steps: (\d+)", out.stderr).group(1)) == nsteps
+    fd = float(re.search(r"final_density: ([0-9.]+)", out.stderr).group(1))
+    r, x1, x2 = po.read_sample(str(sample))
+    ora = po.Oracle(256, 200, r, x1, x2)
+    ora.steps(nsteps)
+    assert abs(fd - ora.total_density()) < 1e-5
