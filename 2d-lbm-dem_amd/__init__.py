@@ -120,6 +120,17 @@ def load_library():
     L.lbmdem_dist_pack.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.lbmdem_dist_unpack.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.lbmdem_dist_set_poison.argtypes = [C.c_void_p, C.c_int]
+    L.lbmdem_dist_pack2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.lbmdem_dist_unpack2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.lbmdem_halo_pack2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.lbmdem_halo_unpack2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.lbmdem_comm_unique_id.argtypes = [C.c_void_p]
+    L.lbmdem_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.lbmdem_comm_destroy.argtypes = [C.c_void_p]
+    L.lbmdem_comm_lbm_step.argtypes = [C.c_void_p, C.c_void_p]
+    L.lbmdem_comm_run.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+    L.lbmdem_comm_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.lbmdem_comm_selftest.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_fhf_export.argtypes = [C.c_void_p, C.c_void_p]
     L.lbmdem_fhf_import.argtypes = [C.c_void_p, C.c_void_p]
     L.lbmdem_fhf_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
@@ -176,6 +187,43 @@ def derive(lx, ly, r, scale=1.0, physics: Physics | None = None) -> Config:
     _chk(L.lbmdem_derive(C.byref(cfg), int(lx), int(ly), float(scale), len(r), _vp(r)))
     cfg.x_begin, cfg.x_end, cfg.halo, cfg.device = 0, int(lx), 0, 0
     return cfg
+
+
+COMM_ID_BYTES = 512
+
+
+def comm_unique_id() -> bytes:
+    """RCCL ids for one communicator group (rank 0 makes them, every rank gets the same bytes)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _chk(load_library().lbmdem_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """The library's own RCCL transport (lbmdem_comm_*): neighbour send/recv of the distributed-grain protocol, driven
+    from C -- one call per renderScene batch, no Python on the step path."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: int):
+        self._L = load_library()
+        self._c = C.c_void_p()
+        assert len(unique_id) == COMM_ID_BYTES
+        _chk(self._L.lbmdem_comm_create(C.c_char_p(unique_id), int(rank), int(world), int(device), C.byref(self._c)))
+
+    def close(self):
+        if self._c:
+            self._L.lbmdem_comm_destroy(self._c)
+            self._c = C.c_void_p()
+
+    def run(self, sim, n_dem_steps):
+        _chk(self._L.lbmdem_comm_run(sim._h, self._c, int(n_dem_steps)))
+
+    def allreduce_sum(self, values):
+        a = np.ascontiguousarray(values, dtype=np.float64)
+        _chk(self._L.lbmdem_comm_allreduce_sum(self._c, _vp(a), len(a)))
+        return a
+
+    def selftest(self, doubles=4096):
+        _chk(self._L.lbmdem_comm_selftest(self._c, int(doubles)))
 
 
 class LbmDem:
@@ -456,6 +504,19 @@ class LbmDem:
 
     def dist_unpack(self, kind, side, dev_ptr):
         _chk(self._L.lbmdem_dist_unpack(self._h, int(kind), int(side), C.c_void_p(dev_ptr)))
+
+    def dist_pack2(self, kind, ptr_lo, ptr_hi):
+        """both sides in one launch; None skips a side"""
+        _chk(self._L.lbmdem_dist_pack2(self._h, int(kind), C.c_void_p(ptr_lo), C.c_void_p(ptr_hi)))
+
+    def dist_unpack2(self, kind, ptr_lo, ptr_hi):
+        _chk(self._L.lbmdem_dist_unpack2(self._h, int(kind), C.c_void_p(ptr_lo), C.c_void_p(ptr_hi)))
+
+    def halo_pack2(self, ptr_lo, ptr_hi):
+        _chk(self._L.lbmdem_halo_pack2(self._h, C.c_void_p(ptr_lo), C.c_void_p(ptr_hi)))
+
+    def halo_unpack2(self, ptr_lo, ptr_hi):
+        _chk(self._L.lbmdem_halo_unpack2(self._h, C.c_void_p(ptr_lo), C.c_void_p(ptr_hi)))
 
     def dist_set_poison(self, on=True):
         _chk(self._L.lbmdem_dist_set_poison(self._h, 1 if on else 0))

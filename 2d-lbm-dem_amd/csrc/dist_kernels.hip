@@ -52,8 +52,17 @@ __global__ void k_clamp_counts(DistDevice D) {
   if (threadIdx.x >= 2 && threadIdx.x < 4 && D.counters[threadIdx.x] > D.cap_t) D.counters[threadIdx.x] = D.cap_t;
 }
 
-__global__ void k_pack_kin(const int* __restrict__ list, const int* __restrict__ count, Kin K, double* __restrict__ buf) {
-  const int cnt = *count;
+// The per-side kernels below take both sides in one launch: blockIdx.y = side (0 low, 1 high); a null buffer
+// skips the side.
+struct Buf2 { double* p[2]; };
+struct CBuf2 { const double* p[2]; };
+
+__global__ void k_pack_kin(DistDevice D, Kin K, Buf2 B) {
+  const int side = blockIdx.y;
+  double* __restrict__ buf = B.p[side];
+  if (!buf) return;
+  const int* __restrict__ list = D.send_list[side];
+  const int cnt = D.counters[side];
   if (blockIdx.x == 0 && threadIdx.x == 0) buf[0] = (double)cnt;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) {
     const int i = list[k];
@@ -64,8 +73,14 @@ __global__ void k_pack_kin(const int* __restrict__ list, const int* __restrict__
   }
 }
 
-__global__ void k_unpack_kin(const double* __restrict__ buf, int cap, Kin K, unsigned char* __restrict__ active,
-                             int* __restrict__ recv_ids, int* __restrict__ recv_count, int n, int* __restrict__ error) {
+__global__ void k_unpack_kin(DistDevice D, CBuf2 B, Kin K, int n, int* __restrict__ error) {
+  const int side = blockIdx.y;
+  const double* __restrict__ buf = B.p[side];
+  if (!buf) return;
+  const int cap = D.cap_g;
+  unsigned char* __restrict__ active = D.active;
+  int* __restrict__ recv_ids = D.recv_ids[side];
+  int* __restrict__ recv_count = D.counters + 4 + side;
   int cnt = (int)buf[0];
   if (cnt < 0 || cnt > cap) { cnt = 0; if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(error, ERR_LIST_OVERFLOW); }
   if (blockIdx.x == 0 && threadIdx.x == 0) *recv_count = cnt;
@@ -80,18 +95,24 @@ __global__ void k_unpack_kin(const double* __restrict__ buf, int cap, Kin K, uns
   }
 }
 
-__global__ void k_pack_fhf(const int* __restrict__ list, const int* __restrict__ count, const double* __restrict__ fhf,
-                           int n, double* __restrict__ buf) {
-  const int cnt = *count;
+__global__ void k_pack_fhf(DistDevice D, const double* __restrict__ fhf, int n, Buf2 B) {
+  const int side = blockIdx.y;
+  double* __restrict__ buf = B.p[side];
+  if (!buf) return;
+  const int* __restrict__ list = D.send_list[side];
+  const int cnt = D.counters[side];
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) {
     const int i = list[k];
     buf[3 * (long)k] = fhf[i]; buf[3 * (long)k + 1] = fhf[n + i]; buf[3 * (long)k + 2] = fhf[2 * (long)n + i];
   }
 }
 
-__global__ void k_unpack_fhf(const int* __restrict__ ids, const int* __restrict__ count, double* __restrict__ fhf, int n,
-                             const double* __restrict__ buf) {
-  const int cnt = *count;
+__global__ void k_unpack_fhf(DistDevice D, double* __restrict__ fhf, int n, CBuf2 B) {
+  const int side = blockIdx.y;
+  const double* __restrict__ buf = B.p[side];
+  if (!buf) return;
+  const int* __restrict__ ids = D.recv_ids[side];
+  const int cnt = D.counters[4 + side];
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) {
     const int i = ids[k];
     fhf[i] = buf[3 * (long)k]; fhf[n + i] = buf[3 * (long)k + 1]; fhf[2 * (long)n + i] = buf[3 * (long)k + 2];
@@ -99,7 +120,9 @@ __global__ void k_unpack_fhf(const int* __restrict__ ids, const int* __restrict_
 }
 
 // the neighbour's part of the link-sum tables of grains this rank owns: slot by slot into the local table
-__global__ void k_merge_tables(ForceSlots S, const double* __restrict__ buf, int cap) {
+__global__ void k_merge_tables(ForceSlots S, CBuf2 B, int cap) {
+  const double* __restrict__ buf = B.p[blockIdx.y];
+  if (!buf) return;
   int cnt = (int)buf[0];
   if (cnt < 0 || cnt > cap) { cnt = 0; if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(S.error, ERR_LIST_OVERFLOW); }
   const int nslot = 8 * S.spd;
@@ -164,26 +187,25 @@ void launch_dist_classify(const DistDevice& D, const DistGeom& Gm, int n, const 
   hipLaunchKernelGGL(k_clamp_counts, dim3(1), dim3(64), 0, st, D);
 }
 
-void launch_dist_pack_kin(const DistDevice& D, int side, const Kin& K, double* buf, hipStream_t st) {
-  hipLaunchKernelGGL(k_pack_kin, dim3(64), dim3(256), 0, st, D.send_list[side], D.counters + side, K, buf);
+void launch_dist_pack_kin(const DistDevice& D, const Kin& K, double* lo, double* hi, hipStream_t st) {
+  hipLaunchKernelGGL(k_pack_kin, dim3(32, 2), dim3(256), 0, st, D, K, Buf2{{lo, hi}});
 }
 
-void launch_dist_unpack_kin(const DistDevice& D, int side, const Kin& K, const double* buf, int n, int* error,
+void launch_dist_unpack_kin(const DistDevice& D, const Kin& K, const double* lo, const double* hi, int n, int* error,
                             hipStream_t st) {
-  hipLaunchKernelGGL(k_unpack_kin, dim3(64), dim3(256), 0, st, buf, D.cap_g, K, D.active, D.recv_ids[side],
-                     D.counters + 4 + side, n, error);
+  hipLaunchKernelGGL(k_unpack_kin, dim3(32, 2), dim3(256), 0, st, D, CBuf2{{lo, hi}}, K, n, error);
 }
 
-void launch_dist_pack_fhf(const DistDevice& D, int side, const double* fhf, int n, double* buf, hipStream_t st) {
-  hipLaunchKernelGGL(k_pack_fhf, dim3(64), dim3(256), 0, st, D.send_list[side], D.counters + side, fhf, n, buf);
+void launch_dist_pack_fhf(const DistDevice& D, const double* fhf, int n, double* lo, double* hi, hipStream_t st) {
+  hipLaunchKernelGGL(k_pack_fhf, dim3(32, 2), dim3(256), 0, st, D, fhf, n, Buf2{{lo, hi}});
 }
 
-void launch_dist_unpack_fhf(const DistDevice& D, int side, double* fhf, int n, const double* buf, hipStream_t st) {
-  hipLaunchKernelGGL(k_unpack_fhf, dim3(64), dim3(256), 0, st, D.recv_ids[side], D.counters + 4 + side, fhf, n, buf);
+void launch_dist_unpack_fhf(const DistDevice& D, double* fhf, int n, const double* lo, const double* hi, hipStream_t st) {
+  hipLaunchKernelGGL(k_unpack_fhf, dim3(32, 2), dim3(256), 0, st, D, fhf, n, CBuf2{{lo, hi}});
 }
 
-void launch_dist_merge_tables(const ForceSlots& S, const double* buf, int cap, hipStream_t st) {
-  hipLaunchKernelGGL(k_merge_tables, dim3(64), dim3(256), 0, st, S, buf, cap);
+void launch_dist_merge_tables(const ForceSlots& S, const double* lo, const double* hi, int cap, hipStream_t st) {
+  hipLaunchKernelGGL(k_merge_tables, dim3(32, 2), dim3(256), 0, st, S, CBuf2{{lo, hi}}, cap);
 }
 
 void launch_dist_poison(const DistDevice& D, const Kin& a, const Kin& b, int n, hipStream_t st) {

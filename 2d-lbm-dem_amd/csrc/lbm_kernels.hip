@@ -1664,9 +1664,13 @@ __global__ void k_density_partial(const double* __restrict__ f, LatticeView L, d
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-// halo rows <-> contiguous buffer [9][nrows][ly]
-__global__ void k_halo_pack(const double* __restrict__ f, LatticeView L, int xl0, int nrows,
-                            double* __restrict__ buf) {
+// halo rows <-> contiguous buffer [9][nrows][ly]; blockIdx.y = side: rows from xl0a (low) / xl0b (high), a null buffer
+// skips the side
+__global__ void k_halo_pack(const double* __restrict__ f, LatticeView L, int xl0a, int xl0b, int nrows,
+                            double* __restrict__ bufa, double* __restrict__ bufb) {
+  const int xl0 = blockIdx.y ? xl0b : xl0a;
+  double* __restrict__ buf = blockIdx.y ? bufb : bufa;
+  if (!buf) return;
   const long per = (long)nrows * L.ly, total = 9 * per;
   for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (long)gridDim.x * blockDim.x) {
     const int q = (int)(k / per);
@@ -1675,8 +1679,11 @@ __global__ void k_halo_pack(const double* __restrict__ f, LatticeView L, int xl0
     buf[k] = f[fidx(q, (long)(xl0 + xr) * L.sy + y)];
   }
 }
-__global__ void k_halo_unpack(double* __restrict__ f, LatticeView L, int xl0, int nrows,
-                              const double* __restrict__ buf) {
+__global__ void k_halo_unpack(double* __restrict__ f, LatticeView L, int xl0a, int xl0b, int nrows,
+                              const double* __restrict__ bufa, const double* __restrict__ bufb) {
+  const int xl0 = blockIdx.y ? xl0b : xl0a;
+  const double* __restrict__ buf = blockIdx.y ? bufb : bufa;
+  if (!buf) return;
   const long per = (long)nrows * L.ly, total = 9 * per;
   for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (long)gridDim.x * blockDim.x) {
     const int q = (int)(k / per);
@@ -1779,6 +1786,18 @@ static int cs_variant() {
 }
 #endif
 
+// rows per wave of the marching kernel: 32 (the measured optimum on a full lattice) unless that leaves fewer than two
+// rounds of resident waves, then as short as 8
+static int march_segment_rows(int rows, int nstrips) {
+  const int resident = 256 * 2 * 4;
+  int nseg = (2 * resident + nstrips - 1) / nstrips;
+  if (nseg < 1) nseg = 1;
+  int seg_rows = (rows + nseg - 1) / nseg;
+  if (seg_rows < 8) seg_rows = 8;
+  if (seg_rows > 32) seg_rows = 32;
+  return seg_rows;
+}
+
 template <int LX, int MINW, int WW = 62>
 static void launch_march(const double* fin, double* fout, const int* obst_old, const int* obst_new,
                          const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, int remap,
@@ -1787,13 +1806,10 @@ static void launch_march(const double* fin, double* fout, const int* obst_old, c
   const int nstrips = (L.ly + WW - 1) / WW;
   int seg_rows = LX;
   if (LX == 0) {
-    // run-time segment length: one balanced round: 256 CUs x 2 workgroups x 4 waves are resident (VGPR- and
-    // LDS-limited); give every y-strip the same number of equal x-segments
-    const int resident = 256 * 2 * 4;
-    int nseg = resident / nstrips;
-    if (nseg < 1) nseg = 1;
-    seg_rows = (rows + nseg - 1) / nseg;
-    if (seg_rows < 8) seg_rows = 8;
+    // run-time segment length for SHORT row ranges (a strip of a multi-GPU decomposition, the rows next to a cut):
+    // 256 CUs x 2 workgroups x 4 waves are resident (VGPR- and LDS-limited) and a wave takes about as long for 32
+    // rows as the whole lattice takes per round, so fewer rows than two full rounds are cut into shorter segments
+    seg_rows = march_segment_rows(rows, nstrips);
 #ifdef LBMDEM_AB
     static const int env_rows = getenv("LBMDEM_CS_ROWS") ? atoi(getenv("LBMDEM_CS_ROWS")) : 0;
     if (env_rows > 0) seg_rows = env_rows;
@@ -1828,7 +1844,12 @@ void launch_collide_stream(const double* fin, double* fout, const int* obst_old,
     default: launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;
   }
 #else
-  if (L.reduced_lt1) launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, S, /*xcd remap*/ 1, st);
+  if (L.reduced_lt1) {
+    if (march_segment_rows(L.xo1 - L.xo0, (L.ly + 61) / 62) >= 32)
+      launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, S, /*xcd remap*/ 1, st);
+    else
+      launch_march<0, 2>(fin, fout, obst_old, obst_new, L, G, S, /*xcd remap*/ 1, st);
+  }
   else launch_cs<4, 64>(fin, fout, obst_old, obst_new, L, G, 0, st);
 #endif
 }
@@ -1924,9 +1945,10 @@ void launch_density_partial(const double* f, const LatticeView& L, double* parti
                             hipStream_t st) {
   hipLaunchKernelGGL(k_density_partial, dim3(nblocks), dim3(256), 0, st, f, L, partial);
 }
-void launch_halo_pack(const double* f, const LatticeView& L, int xl0, int nrows, double* buf,
-                      hipStream_t st) {
-  hipLaunchKernelGGL(k_halo_pack, dim3(grid_for(9L * nrows * L.ly)), dim3(256), 0, st, f, L, xl0, nrows, buf);
+void launch_halo_pack(const double* f, const LatticeView& L, int xl0_lo, int xl0_hi, int nrows, double* buf_lo,
+                      double* buf_hi, hipStream_t st) {
+  hipLaunchKernelGGL(k_halo_pack, dim3(grid_for(9L * nrows * L.ly), 2), dim3(256), 0, st, f, L, xl0_lo, xl0_hi, nrows,
+                     buf_lo, buf_hi);
 }
 void launch_vtk_fields(const double* f, const int* obst, const LatticeView& L, const double* gp,
                        const double* v1, const double* v2, const double* a1, const double* a2,
@@ -1938,8 +1960,8 @@ void launch_vtk_fields(const double* f, const int* obst, const LatticeView& L, c
                      fluid_pressure, fluid_velocity);
 }
 
-void launch_halo_unpack(double* f, const LatticeView& L, int xl0, int nrows, const double* buf,
-                        hipStream_t st) {
-  hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(9L * nrows * L.ly)), dim3(256), 0, st, f, L, xl0, nrows,
-                     buf);
+void launch_halo_unpack(double* f, const LatticeView& L, int xl0_lo, int xl0_hi, int nrows, const double* buf_lo,
+                        const double* buf_hi, hipStream_t st) {
+  hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(9L * nrows * L.ly), 2), dim3(256), 0, st, f, L, xl0_lo, xl0_hi, nrows,
+                     buf_lo, buf_hi);
 }

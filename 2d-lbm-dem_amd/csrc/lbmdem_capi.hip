@@ -1329,28 +1329,39 @@ int lbmdem_profile_read(lbmdem_handle* h, double* mean_ms, long* launches) {
 
 long lbmdem_halo_doubles(lbmdem_handle* h) { return h ? 9L * h->cfg.halo * h->L.ly : -1; }
 
-int lbmdem_halo_pack(lbmdem_handle* h, int side, void* dev_buf) {
+int lbmdem_halo_pack2(lbmdem_handle* h, void* buf_lo, void* buf_hi) {
   CHECK_H(h);
   const LatticeView& L = h->L;
   const int H = h->cfg.halo;
-  if (!dev_buf || H < 1 || (side != 0 && side != 1)) return fail(LBMDEM_EINVAL, "bad halo_pack arguments");
+  if (!buf_lo && !buf_hi) return LBMDEM_OK;
+  if (H < 1) return fail(LBMDEM_EINVAL, "no halo on this handle");
   if (L.xo1 - L.xo0 < H) return fail(LBMDEM_EINVAL, "strip narrower than the halo");
-  const int xl0 = side == 0 ? L.xo0 : L.xo1 - H;
-  launch_halo_pack(h->f[h->fcur], L, xl0, H, (double*)dev_buf, h->stream);
+  launch_halo_pack(h->f[h->fcur], L, L.xo0, L.xo1 - H, H, (double*)buf_lo, (double*)buf_hi, h->stream);
   HIP_TRY(hipGetLastError());
   return LBMDEM_OK;
 }
 
-int lbmdem_halo_unpack(lbmdem_handle* h, int side, const void* dev_buf) {
+int lbmdem_halo_unpack2(lbmdem_handle* h, const void* buf_lo, const void* buf_hi) {
   CHECK_H(h);
   const LatticeView& L = h->L;
   const int H = h->cfg.halo;
-  if (!dev_buf || H < 1 || (side != 0 && side != 1)) return fail(LBMDEM_EINVAL, "bad halo_unpack arguments");
-  const int xl0 = side == 0 ? L.xo0 - H : L.xo1;
-  if (xl0 < 0 || xl0 + H > L.nxl) return fail(LBMDEM_EINVAL, "no halo rows on side %d", side);
-  launch_halo_unpack(h->f[h->fcur], L, xl0, H, (const double*)dev_buf, h->stream);
+  if (!buf_lo && !buf_hi) return LBMDEM_OK;
+  if (H < 1) return fail(LBMDEM_EINVAL, "no halo on this handle");
+  if ((buf_lo && L.xo0 - H < 0) || (buf_hi && L.xo1 + H > L.nxl)) return fail(LBMDEM_EINVAL, "no halo rows on that side");
+  if (!buf_lo && !buf_hi) return LBMDEM_OK;
+  launch_halo_unpack(h->f[h->fcur], L, L.xo0 - H, L.xo1, H, (const double*)buf_lo, (const double*)buf_hi, h->stream);
   HIP_TRY(hipGetLastError());
   return LBMDEM_OK;
+}
+
+int lbmdem_halo_pack(lbmdem_handle* h, int side, void* dev_buf) {
+  if (!dev_buf || (side != 0 && side != 1)) return fail(LBMDEM_EINVAL, "bad halo_pack arguments");
+  return lbmdem_halo_pack2(h, side == 0 ? dev_buf : nullptr, side == 1 ? dev_buf : nullptr);
+}
+
+int lbmdem_halo_unpack(lbmdem_handle* h, int side, const void* dev_buf) {
+  if (!dev_buf || (side != 0 && side != 1)) return fail(LBMDEM_EINVAL, "bad halo_unpack arguments");
+  return lbmdem_halo_unpack2(h, side == 0 ? dev_buf : nullptr, side == 1 ? dev_buf : nullptr);
 }
 
 // ---- strip decomposition with distributed grains ------------------------------------------------------------
@@ -1436,31 +1447,48 @@ int lbmdem_dist_begin_period(lbmdem_handle* h) {
   return LBMDEM_OK;
 }
 
-int lbmdem_dist_pack(lbmdem_handle* h, int kind, int side, void* dev_buf) {
+int lbmdem_dist_pack2(lbmdem_handle* h, int kind, void* buf_lo, void* buf_hi) {
   CHECK_H(h);
-  if (!h->dist || !dev_buf || (side != 0 && side != 1)) return fail(LBMDEM_EINVAL, "bad lbmdem_dist_pack arguments");
-  if (kind == LBMDEM_MSG_KIN) launch_dist_pack_kin(h->dd, side, h->kin[h->kcur], (double*)dev_buf, h->stream);
-  else if (kind == LBMDEM_MSG_FHF) launch_dist_pack_fhf(h->dd, side, h->fhf, h->n, (double*)dev_buf, h->stream);
+  if (!h->dist) return fail(LBMDEM_EINVAL, "lbmdem_dist_enable first");
+  if (!buf_lo && !buf_hi) return LBMDEM_OK;
+  if (kind == LBMDEM_MSG_KIN) launch_dist_pack_kin(h->dd, h->kin[h->kcur], (double*)buf_lo, (double*)buf_hi, h->stream);
+  else if (kind == LBMDEM_MSG_FHF) launch_dist_pack_fhf(h->dd, h->fhf, h->n, (double*)buf_lo, (double*)buf_hi, h->stream);
   else if (kind == LBMDEM_MSG_TABLES) {
     CHECK_NOT_SPLIT(h);
     if (!h->slots_valid) return fail(LBMDEM_EINVAL, "table messages are packed between collide_stream and forces_fluid");
-    launch_forces_table_pack(h->f[h->fcur], h->obst[h->ocur], h->L, gview(h), h->fs, h->dd.strad_list[side],
-                             h->dd.counters + 2 + side, h->dd.cap_t, (double*)dev_buf, h->stream);
+    void* bufs[2] = {buf_lo, buf_hi};
+    for (int side = 0; side < 2; ++side)
+      if (bufs[side])
+        launch_forces_table_pack(h->f[h->fcur], h->obst[h->ocur], h->L, gview(h), h->fs, h->dd.strad_list[side],
+                                 h->dd.counters + 2 + side, h->dd.cap_t, (double*)bufs[side], h->stream);
   } else return fail(LBMDEM_EINVAL, "unknown message kind");
   HIP_TRY(hipGetLastError());
   return LBMDEM_OK;
 }
 
-int lbmdem_dist_unpack(lbmdem_handle* h, int kind, int side, const void* dev_buf) {
+int lbmdem_dist_unpack2(lbmdem_handle* h, int kind, const void* buf_lo, const void* buf_hi) {
   CHECK_H(h);
-  if (!h->dist || !dev_buf || (side != 0 && side != 1)) return fail(LBMDEM_EINVAL, "bad lbmdem_dist_unpack arguments");
+  if (!h->dist) return fail(LBMDEM_EINVAL, "lbmdem_dist_enable first");
+  if (!buf_lo && !buf_hi) return LBMDEM_OK;
   if (kind == LBMDEM_MSG_KIN)
-    launch_dist_unpack_kin(h->dd, side, h->kin[h->kcur], (const double*)dev_buf, h->n, h->fs.error, h->stream);
-  else if (kind == LBMDEM_MSG_FHF) launch_dist_unpack_fhf(h->dd, side, h->fhf, h->n, (const double*)dev_buf, h->stream);
-  else if (kind == LBMDEM_MSG_TABLES) launch_dist_merge_tables(h->fs, (const double*)dev_buf, h->dd.cap_t, h->stream);
+    launch_dist_unpack_kin(h->dd, h->kin[h->kcur], (const double*)buf_lo, (const double*)buf_hi, h->n, h->fs.error, h->stream);
+  else if (kind == LBMDEM_MSG_FHF)
+    launch_dist_unpack_fhf(h->dd, h->fhf, h->n, (const double*)buf_lo, (const double*)buf_hi, h->stream);
+  else if (kind == LBMDEM_MSG_TABLES)
+    launch_dist_merge_tables(h->fs, (const double*)buf_lo, (const double*)buf_hi, h->dd.cap_t, h->stream);
   else return fail(LBMDEM_EINVAL, "unknown message kind");
   HIP_TRY(hipGetLastError());
   return LBMDEM_OK;
+}
+
+int lbmdem_dist_pack(lbmdem_handle* h, int kind, int side, void* dev_buf) {
+  if (!dev_buf || (side != 0 && side != 1)) return fail(LBMDEM_EINVAL, "bad lbmdem_dist_pack arguments");
+  return lbmdem_dist_pack2(h, kind, side == 0 ? dev_buf : nullptr, side == 1 ? dev_buf : nullptr);
+}
+
+int lbmdem_dist_unpack(lbmdem_handle* h, int kind, int side, const void* dev_buf) {
+  if (!dev_buf || (side != 0 && side != 1)) return fail(LBMDEM_EINVAL, "bad lbmdem_dist_unpack arguments");
+  return lbmdem_dist_unpack2(h, kind, side == 0 ? dev_buf : nullptr, side == 1 ? dev_buf : nullptr);
 }
 
 int lbmdem_fhf_device(lbmdem_handle* h, void** fhf, void** owner_mask) {
@@ -1512,7 +1540,10 @@ RcclApi g_rccl;
 
 int rccl_load() {
   if (g_rccl.lib) return LBMDEM_OK;
-  void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  // a copy that is already in the process (PyTorch-ROCm ships its own as "librccl.so") is reused: one RCCL per process
+  void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
   if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
   if (!lib) return fail(LBMDEM_EHIP, "cannot load RCCL: %s", dlerror());
 #define RCCL_SYM(field, name)                                                                  \
@@ -1537,7 +1568,9 @@ int rccl_load() {
 enum { LANE_KIN = 0, LANE_HALO, LANE_TAB, LANE_FHF, LANE_COUNT };
 
 struct lbmdem_comm {
-  ncclComm_t nccl = nullptr;
+  // one communicator per lane: messages of different lanes are in flight at the same time, and RCCL orders the
+  // operations of ONE communicator
+  ncclComm_t nccl[LANE_COUNT] = {};
   int rank = 0, world = 1, device = 0;
   hipStream_t side[LANE_COUNT] = {};
   hipEvent_t ready[LANE_COUNT] = {}, done[LANE_COUNT] = {};
@@ -1555,8 +1588,8 @@ int lbmdem_comm_unique_id(void* id128) {
   if (!id128) return fail(LBMDEM_EINVAL, "null buffer");
   int rc = rccl_load();
   if (rc != LBMDEM_OK) return rc;
-  static_assert(sizeof(ncclUniqueId) == LBMDEM_COMM_ID_BYTES, "ncclUniqueId size");
-  NCCL_TRY(g_rccl.GetUniqueId(reinterpret_cast<ncclUniqueId*>(id128)));
+  static_assert(sizeof(ncclUniqueId) * LANE_COUNT == LBMDEM_COMM_ID_BYTES, "one ncclUniqueId per lane");
+  for (int l = 0; l < LANE_COUNT; ++l) NCCL_TRY(g_rccl.GetUniqueId(reinterpret_cast<ncclUniqueId*>(id128) + l));
   return LBMDEM_OK;
 }
 
@@ -1570,7 +1603,7 @@ int lbmdem_comm_destroy(lbmdem_comm* c) {
   }
   for (auto& k : c->buf) for (auto& s : k) for (double*& p : s) if (p) (void)hipFree(p);
   if (c->scratch) (void)hipFree(c->scratch);
-  if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
+  for (int l = 0; l < LANE_COUNT; ++l) if (c->nccl[l]) (void)g_rccl.CommDestroy(c->nccl[l]);
   delete c;
   return LBMDEM_OK;
 }
@@ -1583,10 +1616,12 @@ int lbmdem_comm_create(const void* id128, int rank, int world, int device, lbmde
   HIP_TRY(hipSetDevice(device));
   lbmdem_comm* c = new lbmdem_comm();
   c->rank = rank; c->world = world; c->device = device;
-  ncclUniqueId id;
-  memcpy(&id, id128, sizeof id);
-  ncclResult_t r = g_rccl.CommInitRank(&c->nccl, world, id, rank);
-  if (r != ncclSuccess) { delete c; return fail(LBMDEM_EHIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); }
+  for (int l = 0; l < LANE_COUNT; ++l) {   // every rank creates them in the same order
+    ncclUniqueId id;
+    memcpy(&id, static_cast<const char*>(id128) + l * sizeof id, sizeof id);
+    ncclResult_t r = g_rccl.CommInitRank(&c->nccl[l], world, id, rank);
+    if (r != ncclSuccess) { lbmdem_comm_destroy(c); return fail(LBMDEM_EHIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); }
+  }
   for (int l = 0; l < LANE_COUNT; ++l) {
     if (hipStreamCreateWithFlags(&c->side[l], hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ready[l], hipEventDisableTiming) != hipSuccess ||
@@ -1612,8 +1647,8 @@ static int comm_begin(lbmdem_comm* c, hipStream_t main, int lane, int kind, cons
   for (int s = 0; s < 2; ++s) {
     if (!has[s]) continue;
     const int peer = s == 0 ? c->rank - 1 : c->rank + 1;
-    NCCL_TRY(g_rccl.Send(c->buf[kind][s][0], c->count[kind], ncclDouble, peer, c->nccl, c->side[lane]));
-    NCCL_TRY(g_rccl.Recv(c->buf[kind][s][1], c->count[kind], ncclDouble, peer, c->nccl, c->side[lane]));
+    NCCL_TRY(g_rccl.Send(c->buf[kind][s][0], c->count[kind], ncclDouble, peer, c->nccl[lane], c->side[lane]));
+    NCCL_TRY(g_rccl.Recv(c->buf[kind][s][1], c->count[kind], ncclDouble, peer, c->nccl[lane], c->side[lane]));
   }
   NCCL_TRY(g_rccl.GroupEnd());
   HIP_TRY(hipEventRecord(c->done[lane], c->side[lane]));
@@ -1653,26 +1688,26 @@ int lbmdem_comm_lbm_step(lbmdem_handle* h, lbmdem_comm* c) {
   const bool has[2] = {h->cfg.x_begin > 0, h->cfg.x_end < h->cfg.lx};
   hipStream_t main = h->stream;
   RC_TRY(lbmdem_dist_begin_period(h));                       // ownership + message lists from the current positions
-  for (int s = 0; s < 2; ++s) if (has[s]) RC_TRY(lbmdem_dist_pack(h, LBMDEM_MSG_KIN, s, c->buf[LBMDEM_MSG_KIN][s][0]));
+  RC_TRY(lbmdem_dist_pack2(h, LBMDEM_MSG_KIN, has[0] ? c->buf[LBMDEM_MSG_KIN][0][0] : nullptr, has[1] ? c->buf[LBMDEM_MSG_KIN][1][0] : nullptr));
   RC_TRY(comm_begin(c, main, LANE_KIN, LBMDEM_MSG_KIN, has));      // margin refresh / migration, under the fluid step
   RC_TRY(lbmdem_obst_construction(h));
   RC_TRY(lbmdem_collide_stream_part(h, LBMDEM_CS_EDGES));
-  for (int s = 0; s < 2; ++s) if (has[s]) RC_TRY(lbmdem_halo_pack(h, s, c->buf[3][s][0]));
+  RC_TRY(lbmdem_halo_pack2(h, has[0] ? c->buf[3][0][0] : nullptr, has[1] ? c->buf[3][1][0] : nullptr));
   RC_TRY(comm_begin(c, main, LANE_HALO, 3, has));
   RC_TRY(lbmdem_collide_stream_part(h, LBMDEM_CS_INTERIOR));  // ... while the bulk of the rows is computed
   RC_TRY(comm_end(c, main, LANE_HALO, has));
-  for (int s = 0; s < 2; ++s) if (has[s]) RC_TRY(lbmdem_halo_unpack(h, s, c->buf[3][s][1]));
-  for (int s = 0; s < 2; ++s) if (has[s]) RC_TRY(lbmdem_dist_pack(h, LBMDEM_MSG_TABLES, s, c->buf[LBMDEM_MSG_TABLES][s][0]));
+  RC_TRY(lbmdem_halo_unpack2(h, has[0] ? c->buf[3][0][1] : nullptr, has[1] ? c->buf[3][1][1] : nullptr));
+  RC_TRY(lbmdem_dist_pack2(h, LBMDEM_MSG_TABLES, has[0] ? c->buf[LBMDEM_MSG_TABLES][0][0] : nullptr, has[1] ? c->buf[LBMDEM_MSG_TABLES][1][0] : nullptr));
   RC_TRY(comm_begin(c, main, LANE_TAB, LBMDEM_MSG_TABLES, has));  // link sums of the grains the neighbours own
   RC_TRY(comm_end(c, main, LANE_TAB, has));
-  for (int s = 0; s < 2; ++s) if (has[s]) RC_TRY(lbmdem_dist_unpack(h, LBMDEM_MSG_TABLES, s, c->buf[LBMDEM_MSG_TABLES][s][1]));
+  RC_TRY(lbmdem_dist_unpack2(h, LBMDEM_MSG_TABLES, has[0] ? c->buf[LBMDEM_MSG_TABLES][0][1] : nullptr, has[1] ? c->buf[LBMDEM_MSG_TABLES][1][1] : nullptr));
   RC_TRY(lbmdem_forces_fluid(h));
   RC_TRY(comm_end(c, main, LANE_KIN, has));
-  for (int s = 0; s < 2; ++s) if (has[s]) RC_TRY(lbmdem_dist_unpack(h, LBMDEM_MSG_KIN, s, c->buf[LBMDEM_MSG_KIN][s][1]));
-  for (int s = 0; s < 2; ++s) if (has[s]) RC_TRY(lbmdem_dist_pack(h, LBMDEM_MSG_FHF, s, c->buf[LBMDEM_MSG_FHF][s][0]));
+  RC_TRY(lbmdem_dist_unpack2(h, LBMDEM_MSG_KIN, has[0] ? c->buf[LBMDEM_MSG_KIN][0][1] : nullptr, has[1] ? c->buf[LBMDEM_MSG_KIN][1][1] : nullptr));
+  RC_TRY(lbmdem_dist_pack2(h, LBMDEM_MSG_FHF, has[0] ? c->buf[LBMDEM_MSG_FHF][0][0] : nullptr, has[1] ? c->buf[LBMDEM_MSG_FHF][1][0] : nullptr));
   RC_TRY(comm_begin(c, main, LANE_FHF, LBMDEM_MSG_FHF, has));    // forces of the margin grains, from their owners
   RC_TRY(comm_end(c, main, LANE_FHF, has));
-  for (int s = 0; s < 2; ++s) if (has[s]) RC_TRY(lbmdem_dist_unpack(h, LBMDEM_MSG_FHF, s, c->buf[LBMDEM_MSG_FHF][s][1]));
+  RC_TRY(lbmdem_dist_unpack2(h, LBMDEM_MSG_FHF, has[0] ? c->buf[LBMDEM_MSG_FHF][0][1] : nullptr, has[1] ? c->buf[LBMDEM_MSG_FHF][1][1] : nullptr));
   return LBMDEM_OK;
 }
 
@@ -1690,7 +1725,7 @@ int lbmdem_comm_allreduce_sum(lbmdem_comm* c, double* values, int n) {
   if (!c || !values || n < 1 || n > 1024) return fail(LBMDEM_EINVAL, "bad lbmdem_comm_allreduce_sum arguments");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemcpy(c->scratch, values, sizeof(double) * n, hipMemcpyHostToDevice));
-  NCCL_TRY(g_rccl.AllReduce(c->scratch, c->scratch, (size_t)n, ncclDouble, ncclSum, c->nccl, c->side[0]));
+  NCCL_TRY(g_rccl.AllReduce(c->scratch, c->scratch, (size_t)n, ncclDouble, ncclSum, c->nccl[0], c->side[0]));
   HIP_TRY(hipStreamSynchronize(c->side[0]));
   HIP_TRY(hipMemcpy(values, c->scratch, sizeof(double) * n, hipMemcpyDeviceToHost));
   return LBMDEM_OK;
@@ -1714,8 +1749,8 @@ int lbmdem_comm_selftest(lbmdem_comm* c, int doubles) {
   ncclResult_t r = ncclSuccess;
   if (e == hipSuccess) {
     r = g_rccl.GroupStart();
-    if (r == ncclSuccess) r = g_rccl.Send(a, (size_t)doubles, ncclDouble, c->rank, c->nccl, c->side[LANE_HALO]);
-    if (r == ncclSuccess) r = g_rccl.Recv(b, (size_t)doubles, ncclDouble, c->rank, c->nccl, c->side[LANE_HALO]);
+    if (r == ncclSuccess) r = g_rccl.Send(a, (size_t)doubles, ncclDouble, c->rank, c->nccl[LANE_HALO], c->side[LANE_HALO]);
+    if (r == ncclSuccess) r = g_rccl.Recv(b, (size_t)doubles, ncclDouble, c->rank, c->nccl[LANE_HALO], c->side[LANE_HALO]);
     ncclResult_t r2 = g_rccl.GroupEnd();
     if (r == ncclSuccess) r = r2;
   }

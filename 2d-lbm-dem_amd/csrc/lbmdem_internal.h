@@ -125,11 +125,13 @@ void dist_free(DistDevice& D);
 void launch_dist_classify(const DistDevice& D, const DistGeom& Gm, int n, const double* x1, const double* r,
                           const double* rLB, unsigned char* owner, int* error, hipStream_t st);
 // messages: {count; count x {id, x1 x2 x3 v1 v2 v3 a1 a2 a3}} / {count x {fhf1 fhf2 fhf3}} in the order of that list
-void launch_dist_pack_kin(const DistDevice& D, int side, const Kin& K, double* buf, hipStream_t st);
-void launch_dist_unpack_kin(const DistDevice& D, int side, const Kin& K, const double* buf, int n, int* error, hipStream_t st);
-void launch_dist_pack_fhf(const DistDevice& D, int side, const double* fhf, int n, double* buf, hipStream_t st);
-void launch_dist_unpack_fhf(const DistDevice& D, int side, double* fhf, int n, const double* buf, hipStream_t st);
-void launch_dist_merge_tables(const ForceSlots& S, const double* buf, int cap, hipStream_t st);
+// (both sides in one launch: `lo` / `hi` = the low / high neighbour's buffer, null to skip)
+void launch_dist_pack_kin(const DistDevice& D, const Kin& K, double* lo, double* hi, hipStream_t st);
+void launch_dist_unpack_kin(const DistDevice& D, const Kin& K, const double* lo, const double* hi, int n, int* error,
+                            hipStream_t st);
+void launch_dist_pack_fhf(const DistDevice& D, const double* fhf, int n, double* lo, double* hi, hipStream_t st);
+void launch_dist_unpack_fhf(const DistDevice& D, double* fhf, int n, const double* lo, const double* hi, hipStream_t st);
+void launch_dist_merge_tables(const ForceSlots& S, const double* lo, const double* hi, int cap, hipStream_t st);
 void launch_dist_poison(const DistDevice& D, const Kin& a, const Kin& b, int n, hipStream_t st);
 void launch_forces_parity(const double* f, const int* obst, const LatticeView& L,
                           const GrainFluidView& G, double scale12, double scale3, double* fhf,
@@ -145,10 +147,11 @@ void launch_macro(const double* f, const LatticeView& L, int xl0, int nrows, dou
                   double* uy, hipStream_t st);
 void launch_density_partial(const double* f, const LatticeView& L, double* partial, int nblocks,
                             hipStream_t st);
-void launch_halo_pack(const double* f, const LatticeView& L, int xl0, int nrows, double* buf,
-                      hipStream_t st);
-void launch_halo_unpack(double* f, const LatticeView& L, int xl0, int nrows, const double* buf,
-                        hipStream_t st);
+// both sides in one launch; a null buffer skips the side
+void launch_halo_pack(const double* f, const LatticeView& L, int xl0_lo, int xl0_hi, int nrows, double* buf_lo,
+                      double* buf_hi, hipStream_t st);
+void launch_halo_unpack(double* f, const LatticeView& L, int xl0_lo, int xl0_hi, int nrows, const double* buf_lo,
+                        const double* buf_hi, hipStream_t st);
 // the five float32 fields of write_vtk (main.c:284-323), [ly][lx] order, owned rows only
 void launch_vtk_fields(const double* f, const int* obst, const LatticeView& L, const double* gp,
                        const double* v1, const double* v2, const double* a1, const double* a2,

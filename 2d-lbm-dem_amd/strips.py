@@ -190,7 +190,8 @@ class DistStripRunner:
         return self.rank - 1 if side == 0 else self.rank + 1
 
     def _ops(self, kind):
-        return [(self._peer(s), self.b.dist_pack(kind, s), self.b.dist_recv_buffer(kind, s)) for s in self.sides]
+        sends = self.b.dist_pack_sides(kind, self.sides)           # one launch for both sides
+        return [(self._peer(s), sends[s], self.b.dist_recv_buffer(kind, s)) for s in self.sides]
 
     def period(self):
         b = self.b
@@ -198,23 +199,20 @@ class DistStripRunner:
         yield ("begin", "kin", self._ops(KIN))     # margin refresh / migration: travels under the whole fluid step
         b.obst_construction()
         b.collision_streaming_edges()
-        yield ("begin", "halo", [(self._peer(s), b.halo_pack(s), b.halo_recv_buffer(s)) for s in self.sides])
+        rows = b.halo_pack_sides(self.sides)
+        yield ("begin", "halo", [(self._peer(s), rows[s], b.halo_recv_buffer(s)) for s in self.sides])
         b.collision_streaming_interior()           # ... while the bulk of the rows is computed
         yield ("end", "halo")
-        for s in self.sides:
-            b.halo_unpack(s)
+        b.halo_unpack_sides(self.sides)
         yield ("begin", "tab", self._ops(TABLES))  # link sums of the grains the neighbours own
         yield ("end", "tab")
-        for s in self.sides:
-            b.dist_unpack(TABLES, s)
+        b.dist_unpack_sides(TABLES, self.sides)
         b.forces_fluid()
         yield ("end", "kin")
-        for s in self.sides:
-            b.dist_unpack(KIN, s)
+        b.dist_unpack_sides(KIN, self.sides)
         yield ("begin", "fhf", self._ops(FHF))     # forces of the margin grains, from their owners
         yield ("end", "fhf")
-        for s in self.sides:
-            b.dist_unpack(FHF, s)
+        b.dist_unpack_sides(FHF, self.sides)
 
     def lbm_step(self):
         pending = {}
@@ -290,6 +288,27 @@ class GpuStripBackend:
 
     def dist_begin_period(self): self.sim.dist_begin_period()
 
+    def _ptrs(self, bufs, sides):
+        return [bufs[s].data_ptr() if s in sides else None for s in (0, 1)]
+
+    def dist_pack_sides(self, kind, sides):
+        if sides:
+            self.sim.dist_pack2(kind, *self._ptrs(self.msg[kind][0], sides))
+        return {s: self.msg[kind][0][s] for s in sides}
+
+    def dist_unpack_sides(self, kind, sides):
+        if sides:
+            self.sim.dist_unpack2(kind, *self._ptrs(self.msg[kind][1], sides))
+
+    def halo_pack_sides(self, sides):
+        if sides:
+            self.sim.halo_pack2(*self._ptrs(self.send, sides))
+        return {s: self.send[s] for s in sides}
+
+    def halo_unpack_sides(self, sides):
+        if sides:
+            self.sim.halo_unpack2(*self._ptrs(self.recv, sides))
+
     def dist_pack(self, kind, side):
         self.sim.dist_pack(kind, side, self.msg[kind][0][side].data_ptr())
         return self.msg[kind][0][side]
@@ -312,6 +331,25 @@ class _GpuRunner(StripRunner):
     @property
     def sim(self):
         return self.b.sim
+
+
+class CCommRunner:
+    """The same protocol driven entirely from C (lbmdem_comm_run: the library's RCCL transport, as the C host driver
+    uses it): one library call per batch of renderScene() calls -- no Python, no torch on the step path. `dist` is
+    only used to hand rank 0's RCCL ids to the other ranks."""
+
+    def __init__(self, pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2):
+        strip = partition(lx, world)[rank]
+        self.sim = pkg.LbmDem(lx, ly, r, x1, x2, device=local_rank, strip=strip, halo=2 if world > 1 else 0)
+        self.sim.dist_enable(0)
+        ids = [pkg.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        self.comm = pkg.Comm(ids[0], rank, world, local_rank)
+        self.rank, self.world = rank, world
+
+    def render_scene(self, n: int = 1):
+        self.comm.run(self.sim, n)
 
 
 class _GpuDistRunner(DistStripRunner):

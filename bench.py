@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--workload", choices=["metric", "configs4", "real50k"], default="metric",
                     help="metric = 4096x4096 / 50k-grain synthetic packing (BASELINE.json's metric, every N); "
                          "configs4 = 8192x4096/50k; real50k = 4096x4096 with the reference's bin/50000.data geometry")
+    ap.add_argument("--driver", choices=["c", "torch"], default="c",
+                    help="multi-GPU step driver: c = lbmdem_comm_run (RCCL inside the library, no Python on the step "
+                         "path); torch = strips.py over torch.distributed")
     ap.add_argument("--strips", action="store_true",
                     help="use the strip-decomposition driver (torch.distributed) even with one rank")
     args = ap.parse_args()
@@ -178,11 +181,18 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         strips = pkg.strips_module()
-        runner = strips.make_gpu_runner(pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2,
-                                        force_mode=args.force_mode)
+        cfg0 = pkg.derive(lx, ly, r)
+        margin = strips.default_margin(cfg0.npDEM, float(max(r)), cfg0.phys.distVerlet, cfg0.dx)
+        wide = min(b - a for a, b in strips.partition(lx, world)) >= margin
+        if args.driver == "c" and args.force_mode == 0 and (wide or world == 1):
+            # grains distributed, the library's own RCCL transport, one C call per batch of steps
+            runner = strips.CCommRunner(pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2)
+        else:
+            runner = strips.make_gpu_runner(pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2,
+                                            force_mode=args.force_mode)
         sim = runner.sim
         npdem = sim.cfg.npDEM
-        dist_mode = isinstance(runner, strips.DistStripRunner)
+        dist_mode = isinstance(runner, (strips.DistStripRunner, strips.CCommRunner))
 
         def run_steps(k):
             runner.render_scene(k * npdem)
@@ -267,6 +277,8 @@ def main():
             "config": {"workload": w["name"], "lx": lx, "ly": ly, "grains": int(len(r)), "npDEM": int(npdem),
                        "step": "1 fluid step + npDEM DEM sub-steps (+ Verlet rebuild every 100 DEM steps)",
                        "force_kernel": "parity" if args.force_mode == 0 else "fast",
+                       "driver": None if runner is None else ("C (lbmdem_comm_run, RCCL in the library)" if
+                                                                isinstance(runner, strips.CCommRunner) else "torch.distributed"),
                        "decomposition": "none" if args.gpus == 1 else (
                            f"{args.gpus} x-strips, halo 2 rows, grains owned by strips (margin integrated redundantly); per "
                            f"fluid step and neighbour: f halo rows and grain kinematics (both overlapped with the fluid "

@@ -210,6 +210,8 @@ long lbmdem_halo_doubles(lbmdem_handle* h);
 int lbmdem_collide_stream_part(lbmdem_handle* h, int part);
 int lbmdem_halo_pack(lbmdem_handle* h, int side, void* dev_buf);
 int lbmdem_halo_unpack(lbmdem_handle* h, int side, const void* dev_buf);
+int lbmdem_halo_pack2(lbmdem_handle* h, void* buf_lo, void* buf_hi);   /* both sides in one launch; null skips a side */
+int lbmdem_halo_unpack2(lbmdem_handle* h, const void* buf_lo, const void* buf_hi);
 /* ---- strips with the GRAINS distributed over the ranks (no collective) ------------------------------------------
  * Every rank keeps arrays for all grains (global index = array index) but integrates only the grains whose centre
  * lies in its rows plus a margin of `margin_rows` on either side, deep enough that what it does not integrate cannot
@@ -234,6 +236,9 @@ long lbmdem_dist_message_doubles(lbmdem_handle* h, int kind); /* capacity of one
 int lbmdem_dist_begin_period(lbmdem_handle* h);
 int lbmdem_dist_pack(lbmdem_handle* h, int kind, int side, void* dev_buf);
 int lbmdem_dist_unpack(lbmdem_handle* h, int kind, int side, const void* dev_buf);
+/* both sides in one launch (a null buffer skips the side): fewer dependent kernel launches per fluid step */
+int lbmdem_dist_pack2(lbmdem_handle* h, int kind, void* buf_lo, void* buf_hi);
+int lbmdem_dist_unpack2(lbmdem_handle* h, int kind, const void* buf_lo, const void* buf_hi);
 /* diagnostic: after every sub-step, grains this rank does not integrate are overwritten with NaN */
 int lbmdem_dist_set_poison(lbmdem_handle* h, int on);
 
@@ -242,9 +247,9 @@ int lbmdem_dist_set_poison(lbmdem_handle* h, int on);
  * grouped per message class on side streams (the kinematics and the f halo rows travel while kernels run), no
  * collective on the step path. RCCL is dlopen'ed by the first of these calls. */
 typedef struct lbmdem_comm lbmdem_comm;
-#define LBMDEM_COMM_ID_BYTES 128
-int lbmdem_comm_unique_id(void* id128);   /* rank 0 makes it, every rank passes the same bytes to ..._create */
-int lbmdem_comm_create(const void* id128, int rank, int world, int device, lbmdem_comm** out);
+#define LBMDEM_COMM_ID_BYTES 512          /* four RCCL unique ids: one communicator per message class */
+int lbmdem_comm_unique_id(void* id);      /* rank 0 makes it, every rank passes the same bytes to ..._create */
+int lbmdem_comm_create(const void* id, int rank, int world, int device, lbmdem_comm** out);
 int lbmdem_comm_destroy(lbmdem_comm* c);
 /* one fluid step of a handle in distributed-grain mode with its neighbours (the sequence documented above) */
 int lbmdem_comm_lbm_step(lbmdem_handle* h, lbmdem_comm* c);

@@ -115,6 +115,17 @@ class OracleDistBackend(OracleStripBackend):
         self.bufs = {0: 1 + 10 * cap, 1: 3 * cap, 2: 1 + 5 * 64 * cap}
         self.rbuf = {k: [torch.zeros(v, dtype=torch.float64) for _ in range(2)] for k, v in self.bufs.items()}
 
+    # the runner asks for both sides at once (one kernel launch on the GPU)
+    def dist_pack_sides(self, kind, sides): return {s: self.dist_pack(kind, s) for s in sides}
+
+    def dist_unpack_sides(self, kind, sides):
+        for s in sides: self.dist_unpack(kind, s)
+
+    def halo_pack_sides(self, sides): return {s: self.halo_pack(s) for s in sides}
+
+    def halo_unpack_sides(self, sides):
+        for s in sides: self.halo_unpack(s)
+
     def _xc(self):
         return (self.o.get_grains()[:, 0] - self.Mgx) / self.dx
 
