@@ -305,6 +305,8 @@ def main():
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, sample_mm, npdem)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)      # RCCL prints through C stdio: whatever it buffered comes out BEFORE the line
         print(json.dumps(out), flush=True)
     if world > 1 or args.strips:
         import torch.distributed as dist
