@@ -616,18 +616,17 @@ int lbmdem_dem_substep(lbmdem_handle* h) {
   const int film = (h->nbsteps % h->cfg.phys.stepFilm == 0) ? 1 : 0;  // main.c:1342
   // contact diagnostics are only needed by write_DEM, which renderScene calls when the step counter
   // reaches a multiple of stepStrob = 4000 (main.c:142,1773): produce them in exactly that sub-step
-  const bool want_table = h->diag_always || ((h->nbsteps + 1) % 4000 == 0);
+  // (with distributed grains the order-dependent diagnostics are not produced: they thread through ALL grains in
+  // index order, and write_DEM is a single-GPU output)
+  const bool want_table = !h->dist && (h->diag_always || ((h->nbsteps + 1) % 4000 == 0));
   // fr, ice, slip, rw read "previous contact" carries that thread from sub-step to sub-step (main.c:130-131):
   // the sub-step before a table sub-step runs the diagnostic pipeline too, to hand over the right carries
-  const bool want_diag = want_table || ((h->nbsteps + 2) % 4000 == 0);
+  const bool want_diag = !h->dist && (want_table || ((h->nbsteps + 2) % 4000 == 0));
   if (want_diag && !h->dx_ready) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (diag_extra_alloc(h->dx, h->n, h->V.cap) != 0) return fail(LBMDEM_ENOMEM, "diagnostic buffers: hipMalloc failed");
     h->dx_ready = true;
   }
-  if (want_diag && h->dist)
-    return fail(LBMDEM_EINVAL, "the contact diagnostics of write_DEM thread through all grains in index order: not available "
-                               "with distributed grains");
   const DemParams P = dem_params(h);
   launch_dem_substep(h->kin[h->kcur], h->kin[1 - h->kcur], h->r, h->m, h->It, h->fhf, h->V, h->gp,
                      P, film, want_diag ? h->diag : nullptr, want_diag ? &h->dx : nullptr,
