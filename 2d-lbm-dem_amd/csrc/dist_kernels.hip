@@ -133,6 +133,7 @@ __global__ void k_merge_tables(ForceSlots S, CBuf2 B, int cap) {
   for (int e = wave; e < cnt; e += nwaves) {
     const unsigned long long* ent = b + 1 + (long)e * (1 + nslot);
     const int i = (int)reinterpret_cast<const double*>(ent)[0];
+    if (i < 0) continue;   // the sender could not complete this grain (flagged on its side)
     for (int k = lane; k < nslot; k += 64) {
       const unsigned long long v = ent[1 + k];
       if (v == LBMDEM_SLOT_EMPTY) continue;

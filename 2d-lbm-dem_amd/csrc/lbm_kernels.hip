@@ -1292,7 +1292,11 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
     const bool todo = (mode == FT_CONSUME ? own[g] : !own[g]) && grain_box(L, G, i, xi, xf, yi, yf);
     if (!todo) continue;
     // overlapping discs: a lattice line may then carry several links of one direction -- not a table case
-    if (was_touched) { n1[g] = -1; continue; }
+    if (was_touched) {
+      n1[g] = -1;
+      if (mode == FT_PACK && lane == 0) packbuf[1 + (long)(g0 + g) * (1 + 8 * spd)] = -1.0;
+      continue;
+    }
     const DiscTest D{xc, yc, rbl0 * rbl0, r2, xi, xf, yi, yf};
     const int X0 = (int)xc, Y0 = (int)yc;
     for (int w = lane; w < nw64; w += 64) bm[w] = 0ull;
@@ -1373,7 +1377,12 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
         }
       }
     }
-    if (__any(bad)) { n1[g] = -1; continue; }
+    if (__any(bad)) {
+      n1[g] = -1;
+      if (mode == FT_PACK && lane == 0)   // nothing usable for this grain: the entry must not keep an older period's data
+        packbuf[1 + (long)(g0 + g) * (1 + 8 * spd)] = -1.0;
+      continue;
+    }
     if (mode == FT_PACK) {  // {id, slots} to the message; the owner merges
       const int nslot = 8 * spd;
       unsigned long long* e = reinterpret_cast<unsigned long long*>(packbuf) + 1 + (long)(g0 + g) * (1 + nslot);
