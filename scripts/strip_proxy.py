@@ -16,7 +16,8 @@ from strip_backends import LoopbackComm, lockstep_render_dist
 
 pkg = ge.load_package(); strips = pkg.strips_module()
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-lx = ly = 4096
+lx = int(sys.argv[2]) if len(sys.argv) > 2 else 4096     # 8192: BASELINE.json configs[4]
+ly = 4096
 r, x, y = samples.row_packing(lx, ly, 50000, seed=1234); r, x1, x2 = samples.to_metres(r, x, y)
 cfg = pkg.derive(lx, ly, r)
 margin = strips.default_margin(cfg.npDEM, float(r.max()), cfg.phys.distVerlet, cfg.dx)
