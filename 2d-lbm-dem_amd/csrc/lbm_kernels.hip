@@ -65,6 +65,13 @@ __device__ __forceinline__ GP load_gp(const GrainFluidView& G, int i) {
   return GP{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
 }
 
+// Lowest index of the grains covering node `node` whose highest-index cover is `top` (GrainFluidView::mincov).
+__device__ __forceinline__ int min_cover(const GrainFluidView& G, long node, int top) {
+  if (!G.mincov) return top;
+  const unsigned m = G.mincov[node];
+  return (m >> 20) == (G.epoch & 0xFFFu) ? (int)(0xFFFFFu - (m & 0xFFFFFu)) : top;
+}
+
 // rigid-body velocity of a grain at global node (x, y): main.c:974-975,1172-1173
 __device__ __forceinline__ double wall_ux(const LatticeView& L, const GP& g, int y) {
   return g.v1 - (y * L.dx + L.Mby - g.x2) * g.v3;
@@ -219,7 +226,8 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
                              const double* __restrict__ v2, const double* __restrict__ v3,
                              double* __restrict__ oxc, double* __restrict__ oyc, double* __restrict__ or2,
                              double* __restrict__ orbl0, double* __restrict__ pk,
-                             unsigned char* __restrict__ touched, const unsigned char* __restrict__ mask) {
+                             unsigned char* __restrict__ touched, const unsigned char* __restrict__ mask,
+                             unsigned* __restrict__ mincov, unsigned epoch) {
   const int lane = threadIdx.x & 63;
   const int i = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (i >= n) return;
@@ -250,8 +258,17 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
     if (d2 <= R2 && d2 <= r2) {
       // the previous owner of the node, if any: both discs are then flagged as overlapping (the force kernel
       // derives the footprint of unflagged grains from the disc test alone, without reading the map)
-      const int old = atomicMax(&obst[(long)(x - L.gx0) * L.sy + y], i);
-      if (old >= 0 && old < n && old != i) { touched[i] = 1; touched[old] = 1; }
+      const long node = (long)(x - L.gx0) * L.sy + y;
+      const int old = atomicMax(&obst[node], i);
+      if (old >= 0 && old < n && old != i) {
+        touched[i] = 1; touched[old] = 1;
+        // a node under several discs: every painter records itself and the owner it found, so the lowest index
+        // covering the node ends up in mincov whatever the order of the painters
+        if (mincov) {
+          atomicMax(&mincov[node], (epoch & 0xFFFu) << 20 | (0xFFFFFu - (unsigned)i));
+          atomicMax(&mincov[node], (epoch & 0xFFFu) << 20 | (0xFFFFFu - (unsigned)old));
+        }
+      }
     }
   }
 }
@@ -279,7 +296,8 @@ struct Tile {
   // neighbours that are fluid in the final map this also counts neighbours now covered by a
   // HIGHER-index grain that do not lie inside the owner's own disc (they were still fluid when the
   // owner was painted). Only reachable when reduced discs of different grains touch or overlap.
-  // (A neighbour additionally covered by a third, lower-index disc is not detected: DESIGN.md.)
+  // A neighbour additionally covered by a third, LOWER-index disc was not fluid then: decided with the
+  // rasteriser's record of the lowest index covering a multiply covered node (min_cover).
   __device__ __forceinline__ bool active(const LatticeView& L, const GrainFluidView& G, int tx, int ty,
                                          int gx, int gy) const {
     const int oS = O(tx, ty);
@@ -299,7 +317,7 @@ struct Tile {
       if (o > oS && o != L.n) {
         const int x = gx + EXq(q), y = gy + EYq(q);
         const double d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc);
-        if (!(d2 <= R2 && d2 <= r2)) return true;
+        if (!(d2 <= R2 && d2 <= r2) && min_cover(G, (long)(x - L.gx0) * L.sy + y, o) > oS) return true;
       }
     }
     return false;
@@ -615,7 +633,7 @@ __device__ __forceinline__ Ids3 load_ids(const int* __restrict__ ob, const Latti
 // test d2 <= R2 && d2 <= r2 reduces to d2 <= r2); the launcher routes other configurations to the
 // LDS-tile kernel.
 template <class RecFn>
-__device__ __forceinline__ bool node_active(const LatticeView& L, const Ids3& a, const Ids3& b,
+__device__ __forceinline__ bool node_active(const LatticeView& L, const GrainFluidView& G, const Ids3& a, const Ids3& b,
                                             const Ids3& c, int gx, int gy, RecFn own_rec) {
   const int o = b.c;
   // neighbour ids in direction order 1..8: (-1,1) (-1,0) (-1,-1) (0,-1) (1,-1) (1,0) (1,1) (0,1)
@@ -628,14 +646,28 @@ __device__ __forceinline__ bool node_active(const LatticeView& L, const Ids3& a,
   }
   if (fluid || !higher) return fluid;
   const GP g = own_rec();
-  bool act = false;
+  unsigned cand = 0;   // neighbours of a higher-index grain outside the owner's own disc
 #pragma unroll
   for (int q = 1; q < 9; ++q) {
     if (nb[q] > o && nb[q] != L.n) {
       const int x = gx + EXq(q), y = gy + EYq(q);
       const double d2 = (x - g.xc) * (x - g.xc) + (y - g.yc) * (y - g.yc);
-      act |= !(d2 <= g.r2);
+      if (!(d2 <= g.r2)) cand |= 1u << q;
     }
+  }
+  if (cand == 0 || G.mincov == nullptr) return cand != 0;
+  // ... and not covered by a third disc of lower index either: the rasteriser's lowest-cover record of multiply
+  // covered nodes. Global loads, but only where discs overlap (never in a packing at reductionR = 0.85); a small
+  // rolled loop so that the marching kernel's register allocation does not feel it.
+  bool act = false;
+#pragma unroll 1
+  while (cand) {
+    const int q = __ffs(cand) - 1;
+    cand &= cand - 1;
+    const int ex = (q >= 1 && q <= 3) ? -1 : ((q >= 5 && q <= 7) ? 1 : 0);
+    const int ey = (q == 1 || q >= 7) ? 1 : ((q >= 3 && q <= 5) ? -1 : 0);
+    const unsigned m = G.mincov[(long)(gx + ex - L.gx0) * L.sy + (gy + ey)];
+    act |= (m >> 20) != (G.epoch & 0xFFFu) || (int)(0xFFFFFu - (m & 0xFFFFFu)) > o;
   }
   return act;
 }
@@ -827,8 +859,8 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
   GP rec_next = grain_rec(inext.c);  // owner record of row x+3, goes into the ring next iteration
   load_raw(xs + 1, bufA);
   load_raw(xs + 2, bufB);
-  bool actm = iB.c != -1 && node_active(L, iA, iB, iC, L.gx0 + xs - 1, y, [&] { return ring.get(xs - 1, lane); });
-  bool act0 = iC.c != -1 && node_active(L, iB, iC, iD, L.gx0 + xs, y, [&] { return ring.get(xs, lane); });
+  bool actm = iB.c != -1 && node_active(L, G, iA, iB, iC, L.gx0 + xs - 1, y, [&] { return ring.get(xs - 1, lane); });
+  bool act0 = iC.c != -1 && node_active(L, G, iB, iC, iD, L.gx0 + xs, y, [&] { return ring.get(xs, lane); });
 
   // one iteration; `buf` holds row x+1 on entry and is refilled with row x+3
   auto iterate = [&](int x, double (&buf)[9]) {
@@ -846,7 +878,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
     // ---- (2) the big loads: populations of row x+3
     load_raw(x + 3, buf);
     __builtin_amdgcn_sched_barrier(0);
-    const bool actp = iD.c != -1 && node_active(L, iC, iD, iE, L.gx0 + x + 1, y, [&] { return ring.get(x + 1, lane); });
+    const bool actp = iD.c != -1 && node_active(L, G, iC, iD, iE, L.gx0 + x + 1, y, [&] { return ring.get(x + 1, lane); });
 
     RegCtx C;
     C.ring = ring;
@@ -1760,10 +1792,10 @@ void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st) {
 void launch_obst_paint(int* obst, const LatticeView& L, int n, const double* x1, const double* x2, const double* r,
                        const double* rLB, const double* v1, const double* v2, const double* v3, double* xc,
                        double* yc, double* r2, double* rbl0, double* pk, unsigned char* touched,
-                       const unsigned char* mask, hipStream_t st) {
+                       const unsigned char* mask, unsigned* mincov, unsigned epoch, hipStream_t st) {
   const long threads = (long)n * 64;
   hipLaunchKernelGGL(k_obst_paint, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, obst, L, n, x1, x2, r,
-                     rLB, v1, v2, v3, xc, yc, r2, rbl0, pk, touched, mask);
+                     rLB, v1, v2, v3, xc, yc, r2, rbl0, pk, touched, mask, mincov, epoch);
 }
 
 void launch_slots_clear(const ForceSlots& S, int n, hipStream_t st) {

@@ -72,6 +72,8 @@ struct lbmdem_handle {
   bool diag_valid = false; // the last sub-step produced diagnostics
   double* fhf = nullptr;  // [3][n]
   unsigned char* owner = nullptr;
+  unsigned* mincov = nullptr;   // GrainFluidView::mincov
+  unsigned paint_epoch = 0;
   // link sums handed from the fused kernel to the force kernel (ForceSlots, lbmdem_internal.h)
   ForceSlots fs{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
   bool slots_clean = false;  // every slot is empty
@@ -98,7 +100,7 @@ struct lbmdem_handle {
 
 static GrainFluidView gview(const lbmdem_handle* h) {
   const Kin& K = h->kin[h->kcur];
-  return GrainFluidView{K.x1, K.x2, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0, h->pk};
+  return GrainFluidView{K.x1, K.x2, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0, h->pk, h->mincov, h->paint_epoch};
 }
 
 static DemParams dem_params(const lbmdem_handle* h) {
@@ -202,9 +204,15 @@ void lbmdem_free_host(void* p) { free(p); }
 
 static int paint_into(lbmdem_handle* h, int* obst) {
   const Kin& K = h->kin[h->kcur];
+  if (h->mincov) {   // records of an older rasterisation lose against this one's; the 12-bit epoch is wound back rarely
+    if (++h->paint_epoch > 0xFFFu) {
+      HIP_TRY(hipMemsetAsync(h->mincov, 0, sizeof(unsigned) * (size_t)h->L.plane, h->stream));
+      h->paint_epoch = 1;
+    }
+  }
   launch_obst_fill(obst, h->L, h->stream);
   launch_obst_paint(obst, h->L, h->n, K.x1, K.x2, h->r, h->rLB, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0, h->pk,
-                    h->fs.touched, h->dist ? h->dd.fluidmask : nullptr, h->stream);
+                    h->fs.touched, h->dist ? h->dd.fluidmask : nullptr, h->mincov, h->paint_epoch, h->stream);
   h->slots_valid = false;  // the grain geometry the table is indexed with has changed
   HIP_TRY(hipGetLastError());
   return LBMDEM_OK;
@@ -315,6 +323,10 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
   }
   CREATE_TRY(hipMalloc((void**)&h->owner, n));
   CREATE_TRY(hipMemsetAsync(h->owner, 1, n, h->stream));
+  if (n < LBMDEM_MINCOV_IDS) {
+    CREATE_TRY(hipMalloc((void**)&h->mincov, sizeof(unsigned) * (size_t)L.plane));
+    CREATE_TRY(hipMemsetAsync(h->mincov, 0, sizeof(unsigned) * (size_t)L.plane, h->stream));
+  }
   CREATE_TRY(hipMalloc((void**)&h->fs.queue, sizeof(int) * n));
   CREATE_TRY(hipMalloc((void**)&h->fs.error, sizeof(int)));
   CREATE_TRY(hipMemsetAsync(h->fs.error, 0, sizeof(int), h->stream));
@@ -394,6 +406,7 @@ int lbmdem_destroy(lbmdem_handle* h) {
   }
   if (h->gbuf) (void)hipFree(h->gbuf);
   if (h->owner) (void)hipFree(h->owner);
+  if (h->mincov) (void)hipFree(h->mincov);
   if (h->fs.touched) (void)hipFree(h->fs.touched);
   if (h->fs.tab) (void)hipFree(h->fs.tab);
   if (h->fs.gathered) (void)hipFree(h->fs.gathered);

@@ -42,7 +42,14 @@ struct GrainFluidView {
   // the same eight values packed per grain, [n][8] = {x1, x2, v1, v2, v3, xc, yc, r2}: one 64-byte
   // record, fetched with four 16-byte loads by the fluid kernels
   const double* pk;
+  // Lowest grain index covering a node, for nodes covered by MORE than one disc (written by the rasteriser when its
+  // atomicMax finds a previous owner): (epoch & 0xFFF) << 20 | (0xFFFFF - index), valid when the epoch matches the
+  // last rasterisation. Decides `act` where discs overlap (main.c:1039-1052 sees the map as it was when the OWNER was
+  // painted: a neighbour counts as fluid iff no grain of index <= owner covers it). null: fewer than 2^20 grains only.
+  const unsigned* mincov;
+  unsigned epoch;
 };
+#define LBMDEM_MINCOV_IDS (1 << 20)
 
 // Per-grain table of link momentum-exchange sums, written by the fused fluid kernel where it evaluates the
 // interpolated bounce-back links and consumed by the hydrodynamic-force kernel (main.c:1313-1316:
@@ -92,7 +99,7 @@ void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st);
 void launch_obst_paint(int* obst, const LatticeView& L, int n, const double* x1, const double* x2, const double* r,
                        const double* rLB, const double* v1, const double* v2, const double* v3, double* xc,
                        double* yc, double* r2, double* rbl0, double* pk, unsigned char* touched,
-                       const unsigned char* mask, hipStream_t st);
+                       const unsigned char* mask, unsigned* mincov, unsigned epoch, hipStream_t st);
 void launch_collide_stream(const double* fin, double* fout, const int* obst_old, const int* obst_new,
                            const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, hipStream_t st);
 // true when launch_collide_stream(..., S) with S.tab != nullptr fills the table (the marching kernel does)

