@@ -33,12 +33,14 @@ __global__ void k_dist_classify(DistDevice D, DistGeom Gm, int n, const double* 
   D.active[i] = own ? 1 : 0;           // the margin joins when the neighbours' messages are unpacked
   // grains that may cover nodes of this rank's rows (+ halo) or have links ending there
   const double reach = r[i] / Gm.dx + 3.0;
-  D.fluidmask[i] = (act && xc + reach >= (double)Gm.gx0 && xc - reach <= (double)(Gm.gx0 + Gm.nxl)) ? 1 : 0;
+  const bool near = act && xc + reach >= (double)Gm.gx0 && xc - reach <= (double)(Gm.gx0 + Gm.nxl);
+  D.fluidmask[i] = near ? 1 : 0;
   if (!act) return;
   auto append = [&](int* list, int which, int cap) {
     const int k = atomicAdd(&D.counters[which], 1);
     if (k < cap) list[k] = i; else atomicOr(error, ERR_LIST_OVERFLOW);
   };
+  if (near) append(D.local_list, 6, D.cap_l);
   if (own && Gm.has_lo && xc < Gm.lo + Gm.margin) append(D.send_list[0], 0, D.cap_g);
   if (own && Gm.has_hi && xc >= Gm.hi - Gm.margin) append(D.send_list[1], 1, D.cap_g);
   // a neighbour's grain whose ring of boundary links (reduced disc + one node) reaches into this rank's rows
@@ -50,6 +52,7 @@ __global__ void k_dist_classify(DistDevice D, DistGeom Gm, int n, const double* 
 __global__ void k_clamp_counts(DistDevice D) {
   if (threadIdx.x < 2 && D.counters[threadIdx.x] > D.cap_g) D.counters[threadIdx.x] = D.cap_g;
   if (threadIdx.x >= 2 && threadIdx.x < 4 && D.counters[threadIdx.x] > D.cap_t) D.counters[threadIdx.x] = D.cap_t;
+  if (threadIdx.x == 6 && D.counters[6] > D.cap_l) D.counters[6] = D.cap_l;
 }
 
 // The per-side kernels below take both sides in one launch: blockIdx.y = side (0 low, 1 high); a null buffer
@@ -155,9 +158,9 @@ __global__ void k_poison(const unsigned char* __restrict__ active, Kin a, Kin b,
 
 }  // namespace
 
-int dist_alloc(DistDevice& D, int n, int cap_g, int cap_t) {
+int dist_alloc(DistDevice& D, int n, int cap_g, int cap_t, int cap_l) {
   D = DistDevice{};
-  D.cap_g = cap_g; D.cap_t = cap_t;
+  D.cap_g = cap_g; D.cap_t = cap_t; D.cap_l = cap_l;
   hipError_t e = hipSuccess;
   auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 16); };
   A((void**)&D.active, n); A((void**)&D.fluidmask, n);
@@ -166,6 +169,7 @@ int dist_alloc(DistDevice& D, int n, int cap_g, int cap_t) {
     A((void**)&D.strad_list[s], sizeof(int) * cap_t);
     A((void**)&D.recv_ids[s], sizeof(int) * cap_g);
   }
+  A((void**)&D.local_list, sizeof(int) * cap_l);
   A((void**)&D.counters, sizeof(int) * 8);
   if (e != hipSuccess) return -1;
   if (hipMemset(D.active, 1, n) != hipSuccess || hipMemset(D.fluidmask, 1, n) != hipSuccess ||
@@ -176,14 +180,14 @@ int dist_alloc(DistDevice& D, int n, int cap_g, int cap_t) {
 
 void dist_free(DistDevice& D) {
   void* ps[] = {D.active, D.fluidmask, D.send_list[0], D.send_list[1], D.strad_list[0], D.strad_list[1],
-                D.recv_ids[0], D.recv_ids[1], D.counters};
+                D.recv_ids[0], D.recv_ids[1], D.counters, D.local_list};
   for (void* p : ps) if (p) (void)hipFree(p);
   D = DistDevice{};
 }
 
 void launch_dist_classify(const DistDevice& D, const DistGeom& Gm, int n, const double* x1, const double* r,
                           const double* rLB, unsigned char* owner, int* error, hipStream_t st) {
-  (void)hipMemsetAsync(D.counters, 0, sizeof(int) * 4, st);
+  (void)hipMemsetAsync(D.counters, 0, sizeof(int) * 8, st);   // (the received counts [4], [5] are SET by the next unpack)
   hipLaunchKernelGGL(k_dist_classify, dim3((n + 255) / 256), dim3(256), 0, st, D, Gm, n, x1, r, rLB, owner, error);
   hipLaunchKernelGGL(k_clamp_counts, dim3(1), dim3(64), 0, st, D);
 }

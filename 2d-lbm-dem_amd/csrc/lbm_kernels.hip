@@ -227,11 +227,16 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
                              double* __restrict__ oxc, double* __restrict__ oyc, double* __restrict__ or2,
                              double* __restrict__ orbl0, double* __restrict__ pk,
                              unsigned char* __restrict__ touched, const unsigned char* __restrict__ mask,
-                             unsigned* __restrict__ mincov, unsigned epoch) {
+                             unsigned* __restrict__ mincov, unsigned epoch, const int* __restrict__ list,
+                             const int* __restrict__ list_count) {
   const int lane = threadIdx.x & 63;
-  const int i = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  int i = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (list) {                    // strip decomposition: only the grains that can reach this rank's rows
+    if (i >= *list_count) return;
+    i = list[i];
+  }
   if (i >= n) return;
-  if (mask && !mask[i]) return;  // strip decomposition: a grain that cannot reach this rank's rows
+  if (mask && !mask[i]) return;
   const double gx1 = x1[i], gx2 = x2[i];
   const double xc = (gx1 - L.Mgx) / L.dx, yc = (gx2 - L.Mby) / L.dx, r2 = rLB[i] * rLB[i], rbl0 = r[i] / L.dx;
   if (lane == 0) {
@@ -1792,10 +1797,11 @@ void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st) {
 void launch_obst_paint(int* obst, const LatticeView& L, int n, const double* x1, const double* x2, const double* r,
                        const double* rLB, const double* v1, const double* v2, const double* v3, double* xc,
                        double* yc, double* r2, double* rbl0, double* pk, unsigned char* touched,
-                       const unsigned char* mask, unsigned* mincov, unsigned epoch, hipStream_t st) {
-  const long threads = (long)n * 64;
+                       const unsigned char* mask, unsigned* mincov, unsigned epoch, const int* list,
+                       const int* list_count, int list_cap, hipStream_t st) {
+  const long threads = (long)(list ? list_cap : n) * 64;
   hipLaunchKernelGGL(k_obst_paint, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, obst, L, n, x1, x2, r,
-                     rLB, v1, v2, v3, xc, yc, r2, rbl0, pk, touched, mask, mincov, epoch);
+                     rLB, v1, v2, v3, xc, yc, r2, rbl0, pk, touched, mask, mincov, epoch, list, list_count);
 }
 
 void launch_slots_clear(const ForceSlots& S, int n, hipStream_t st) {
@@ -1913,9 +1919,10 @@ static void launch_forces_table_t(const double* f, const int* obst, const Lattic
   const size_t lists_doubles = (size_t)FT_WAVES * GW * (2 * cap1 + cap3);
   const size_t lds = lists_doubles * 8 + (size_t)FT_WAVES * nw64 * 24 + (size_t)FT_WAVES * GW * 20;
   const int per_block = FT_WAVES * GW;
-  hipLaunchKernelGGL((k_forces_table<GW, PASSES>), dim3((L.n + per_block - 1) / per_block), dim3(64 * FT_WAVES), lds, st,
-                     f, obst, L, G, S, cap1, cap3, nw64, scale12, scale3, fhf, owner, (int)FT_CONSUME, (const int*)nullptr,
-                     (const int*)nullptr, (double*)nullptr, S.mask);
+  const int ntodo = S.local_list ? S.local_cap : L.n;   // strips: the compacted list of local grains bounds the launch
+  hipLaunchKernelGGL((k_forces_table<GW, PASSES>), dim3((ntodo + per_block - 1) / per_block), dim3(64 * FT_WAVES), lds, st,
+                     f, obst, L, G, S, cap1, cap3, nw64, scale12, scale3, fhf, owner, (int)FT_CONSUME, S.local_list,
+                     S.local_count, (double*)nullptr, S.mask);
   const int grid = L.n < 256 ? L.n : 256;
   hipLaunchKernelGGL(k_forces_gather_queue, dim3(grid), dim3(64), 0, st, f, obst, L, G, S, scale12, scale3, fhf);
 }

@@ -55,7 +55,7 @@ struct lbmdem_handle {
   const double* cs_fin = nullptr;
   const int *cs_ob_old = nullptr, *cs_ob_new = nullptr;
   int cs_lo_end = 0, cs_hi_begin = 0;  // interior = local rows [cs_lo_end, cs_hi_begin)
-  ForceSlots cs_slots{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+  ForceSlots cs_slots{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   // grains
   int n = 0;
   double* gbuf = nullptr;  // one allocation, carved below
@@ -75,13 +75,14 @@ struct lbmdem_handle {
   unsigned* mincov = nullptr;   // GrainFluidView::mincov
   unsigned paint_epoch = 0;
   // link sums handed from the fused kernel to the force kernel (ForceSlots, lbmdem_internal.h)
-  ForceSlots fs{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+  ForceSlots fs{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   bool slots_clean = false;  // every slot is empty
   bool last_forces_from_table = false;
   bool slots_valid = false;  // the table was filled by the collide_stream that produced f[fcur] with the current map
   double rmax = 0.0, rmin = 0.0;
   // strip decomposition with distributed grains (lbmdem_dist_*)
   bool dist = false, dist_poison = false;
+  bool dist_period_open = false;   // lbmdem_dist_begin_period has classified the grains for the coming fluid step
   int dist_margin = 0;
   DistDevice dd{};
   VerletDevice V{};
@@ -212,7 +213,9 @@ static int paint_into(lbmdem_handle* h, int* obst) {
   }
   launch_obst_fill(obst, h->L, h->stream);
   launch_obst_paint(obst, h->L, h->n, K.x1, K.x2, h->r, h->rLB, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0, h->pk,
-                    h->fs.touched, h->dist ? h->dd.fluidmask : nullptr, h->mincov, h->paint_epoch, h->stream);
+                    h->fs.touched, h->dist ? h->dd.fluidmask : nullptr, h->mincov, h->paint_epoch,
+                    h->dist ? h->dd.local_list : nullptr, h->dist ? h->dd.counters + 6 : nullptr, h->dist ? h->dd.cap_l : 0,
+                    h->stream);
   h->slots_valid = false;  // the grain geometry the table is indexed with has changed
   HIP_TRY(hipGetLastError());
   return LBMDEM_OK;
@@ -428,6 +431,8 @@ int lbmdem_destroy(lbmdem_handle* h) {
 
 int lbmdem_obst_construction(lbmdem_handle* h) {
   CHECK_H(h);
+  if (h->dist && !h->dist_period_open)
+    return fail(LBMDEM_EINVAL, "distributed grains: lbmdem_dist_begin_period comes before the fluid step");
   if (h->cs_interior_pending) return fail(LBMDEM_EINVAL, "lbmdem_collide_stream_part(LBMDEM_CS_INTERIOR) has not been called after LBMDEM_CS_EDGES");
   int rc = paint_into(h, h->obst[1 - h->ocur]);
   if (rc == LBMDEM_OK) h->obst_pending = true;
@@ -558,6 +563,7 @@ int lbmdem_forces_fluid(lbmdem_handle* h) {
     HIP_TRY(hipMemsetAsync(h->fs.gathered, 0, sizeof(int), h->stream));
     launch_forces_slots(h->f[h->fcur], ob, h->L, gview(h), h->fs, h->fscale12, h->fscale3, h->fhf, h->owner, h->stream);
     h->last_forces_from_table = true;
+    h->dist_period_open = false;
     h->slots_valid = false;
     h->slots_clean = true;
   } else if (h->force_mode == 0) {
@@ -1420,10 +1426,21 @@ int lbmdem_dist_enable(lbmdem_handle* h, int margin_rows) try {
   if (cap_g > h->n) cap_g = h->n;
   long cap_t = (long)(c.ly / (2 * h->rmin / c.dx)) + 32;
   if (cap_t > h->n) cap_t = h->n;
-  if (dist_alloc(h->dd, h->n, (int)cap_g, (int)cap_t) != 0) { dist_free(h->dd); return fail(LBMDEM_ENOMEM, "dist_alloc failed"); }
+  // grains that can reach this rank's rows (+ halo): launch bound of the rasteriser and the force-table kernel
+  long cap_l = 0;
+  {
+    const int reach = (int)ceil(h->rmax / c.dx) + 8;
+    for (int x = (c.x_begin - reach > 0 ? c.x_begin - reach : 0); x < c.lx && x < c.x_end + reach; ++x) cap_l += hist[x];
+    cap_l = cap_l + cap_l / 2 + 256;
+    if (cap_l > h->n) cap_l = h->n;
+  }
+  if (dist_alloc(h->dd, h->n, (int)cap_g, (int)cap_t, (int)cap_l) != 0) { dist_free(h->dd); return fail(LBMDEM_ENOMEM, "dist_alloc failed"); }
   h->dist = true;
   h->dist_margin = M;
   h->fs.mask = h->dd.fluidmask;
+  h->fs.local_list = h->dd.local_list;
+  h->fs.local_count = h->dd.counters + 6;
+  h->fs.local_cap = h->dd.cap_l;
   return LBMDEM_OK;
 } catch (...) {
   return fail(LBMDEM_EINVAL, "unexpected C++ exception");
@@ -1456,6 +1473,7 @@ int lbmdem_dist_begin_period(lbmdem_handle* h) {
   Gm.gx0 = h->L.gx0; Gm.nxl = h->L.nxl;
   launch_dist_classify(h->dd, Gm, h->n, h->kin[h->kcur].x1, h->r, h->rLB, h->owner, h->fs.error, h->stream);
   HIP_TRY(hipGetLastError());
+  h->dist_period_open = true;
   return LBMDEM_OK;
 }
 

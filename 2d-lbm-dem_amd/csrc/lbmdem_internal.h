@@ -69,6 +69,9 @@ struct ForceSlots {
   int* queue;     // ... and their indices, for the gather kernel that follows
   int* error;     // device flag: a grain cut by a strip boundary that neither the table nor a local gather can serve
   const unsigned char* mask;  // strip decomposition with distributed grains: the grains the rasteriser handled; else null
+  const int* local_list;      // ... the same set as a list (+ its device-side length and its capacity), else null
+  const int* local_count;
+  int local_cap;
 };
 #define LBMDEM_SLOT_EMPTY 0x7FF8C0DE5107E117ull  /* a quiet NaN no arithmetic produces */
 constexpr int LBMDEM_SPD_MAX = 64;               // larger grains (reduced radius > ~20 nodes): feature off
@@ -99,7 +102,8 @@ void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st);
 void launch_obst_paint(int* obst, const LatticeView& L, int n, const double* x1, const double* x2, const double* r,
                        const double* rLB, const double* v1, const double* v2, const double* v3, double* xc,
                        double* yc, double* r2, double* rbl0, double* pk, unsigned char* touched,
-                       const unsigned char* mask, unsigned* mincov, unsigned epoch, hipStream_t st);
+                       const unsigned char* mask, unsigned* mincov, unsigned epoch, const int* list,
+                       const int* list_count, int list_cap, hipStream_t st);
 void launch_collide_stream(const double* fin, double* fout, const int* obst_old, const int* obst_new,
                            const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, hipStream_t st);
 // true when launch_collide_stream(..., S) with S.tab != nullptr fills the table (the marching kernel does)
@@ -122,11 +126,12 @@ struct DistDevice {
   int* send_list[2];         // [cap_g] owned grains within `margin` rows of the low / high cut
   int* strad_list[2];        // [cap_t] grains owned by the low / high neighbour whose link ring reaches this rank's rows
   int* recv_ids[2];          // [cap_g] ids of the last kinematics message from the low / high neighbour
-  int* counters;             // [6] send x2, straddler x2, received x2
-  int cap_g, cap_t;
+  int* local_list;           // [cap_l] the grains of fluidmask, compacted (launch bound of the per-grain kernels)
+  int* counters;             // [8] send x2, straddler x2, received x2, local
+  int cap_g, cap_t, cap_l;
 };
 struct DistGeom { double lo, hi, margin, dx, Mgx; int has_lo, has_hi, first, last, gx0, nxl; };
-int dist_alloc(DistDevice& D, int n, int cap_g, int cap_t);
+int dist_alloc(DistDevice& D, int n, int cap_g, int cap_t, int cap_l);
 void dist_free(DistDevice& D);
 // ownership, masks and the send / straddler lists from the current positions of the grains that were active
 void launch_dist_classify(const DistDevice& D, const DistGeom& Gm, int n, const double* x1, const double* r,
