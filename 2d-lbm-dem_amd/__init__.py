@@ -107,6 +107,7 @@ def load_library():
     L.lbmdem_checkpoint_save.argtypes = [C.c_void_p, C.c_char_p]
     L.lbmdem_checkpoint_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     L.lbmdem_set_force_mode.argtypes = [C.c_void_p, C.c_int]
+    L.lbmdem_set_lid.argtypes = [C.c_void_p, C.c_double]
     L.lbmdem_force_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lbmdem_profile_enable.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -447,6 +448,10 @@ class LbmDem:
         return out
 
     # ---- plumbing -------------------------------------------------------------------------------
+    def set_lid(self, uw_h):
+        """EXTENSION: the top plate's lid terms the reference has commented out (main.c:1129-1130); lattice units."""
+        _chk(self._L.lbmdem_set_lid(self._h, float(uw_h)))
+
     def set_force_mode(self, mode):
         _chk(self._L.lbmdem_set_force_mode(self._h, int(mode)))
 

@@ -384,6 +384,14 @@ __device__ __forceinline__ bool pull_classify(const Ctx& C, const LatticeView& L
     const bool s_yedge = (syg == 0 || syg == L.ly - 1) && sxg >= 1 && sxg <= L.lx - 2;
     const bool copied = gy >= 1 && gy <= L.ly - 2 && ((gx >= 1 && gx <= L.lx - 2) || s_yedge);
     out = copied ? C.own(qo) : C.in(qo);
+    // EXTENSION (off unless lbmdem_set_lid): the top plate's lid terms the reference has commented out,
+    // f[x][ly-1][3] = ... - uw_h/6, f[x][ly-1][5] = ... + uw_h/6 (main.c:1129-1130)
+    if ((q == 3 || q == 5) && L.lid6 != 0.0 && copied && syg == L.ly - 1 && sxg >= 1 && sxg <= L.lx - 2)
+      out = q == 3 ? out - L.lid6 : out + L.lid6;
+    // ... which the side-wall copies that run afterwards (main.c:1134,1138) hand on to the two wall nodes next to the
+    // top corners: f[0][ly-2][7] = f[1][ly-1][3], f[lx-1][ly-2][1] = f[lx-2][ly-1][5]
+    if (q == 7 && L.lid6 != 0.0 && sxg == 0 && syg == L.ly - 2) out = out - L.lid6;
+    if (q == 1 && L.lid6 != 0.0 && sxg == L.lx - 1 && syg == L.ly - 2) out = out + L.lid6;
     return false;
   }
   const int oS = C.o_nb(qo);

@@ -271,6 +271,7 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
     L.rc = 1.0 / cfg->c;
     L.rcc = 1.0 / cc;
     L.cc = cc;
+    L.lid6 = 0.0;
     L.wc_diag = (1. / 36) / cfg->c;
     L.wc_axis = (1. / 9) / cfg->c;
     auto all_ones = [](double v) {
@@ -679,6 +680,12 @@ int lbmdem_run_dem(lbmdem_handle* h, long n_dem_steps) {
     if (rc == LBMDEM_OK) rc = lbmdem_dem_substep(h);                                // main.c:1733-1764
     if (rc != LBMDEM_OK) return rc;
   }
+  return LBMDEM_OK;
+}
+
+int lbmdem_set_lid(lbmdem_handle* h, double uw_h) {
+  if (!h) return fail(LBMDEM_EINVAL, "null handle");
+  h->L.lid6 = uw_h / 6;   // the reference's commented-out expression: -uw_h/6, +uw_h/6
   return LBMDEM_OK;
 }
 
@@ -1162,7 +1169,8 @@ int lbmdem_write_forces(lbmdem_handle* h, const char* dir, int nfile) try {
 
 namespace {
 struct CkptHeader {
-  char magic[8];       // "LBMDEMC3"
+  char magic[8];       // "LBMDEMC4"
+  double lid6;         // lbmdem_set_lid
   int layout;          // device layout of the populations in the file: 1 = 16-node tiles f[x][y/16][q][y%16]
   int force_mode, diag_always, has_carry;
   double carry[3];     // pft, pff, pf of the order-dependent contact diagnostics (main.c:130-131), when has_carry
@@ -1187,7 +1195,8 @@ int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) try {
   if (h->verlet_ok) HIP_TRY(hipMemcpy(off.data(), h->V.offsets, sizeof(int) * (n + 1), hipMemcpyDeviceToHost));
   CkptHeader H;
   memset(&H, 0, sizeof H);
-  memcpy(H.magic, "LBMDEMC3", 8);
+  memcpy(H.magic, "LBMDEMC4", 8);
+  H.lid6 = h->L.lid6;
   H.layout = CKPT_LAYOUT; H.force_mode = h->force_mode; H.diag_always = h->diag_always ? 1 : 0;
   H.has_carry = h->dx_ready ? 1 : 0;
   if (h->dx_ready) HIP_TRY(hipMemcpy(H.carry, h->dx.carry, sizeof H.carry, hipMemcpyDeviceToHost));
@@ -1226,7 +1235,7 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
   FILE* fp = fopen(path, "rb");
   if (!fp) return fail(LBMDEM_EINVAL, "cannot open checkpoint '%s'", path);
   CkptHeader H;
-  if (!rd(fp, &H, sizeof H) || memcmp(H.magic, "LBMDEMC3", 8) != 0) { fclose(fp); return fail(LBMDEM_EINVAL, "'%s' is not a checkpoint of this library version", path); }
+  if (!rd(fp, &H, sizeof H) || memcmp(H.magic, "LBMDEMC4", 8) != 0) { fclose(fp); return fail(LBMDEM_EINVAL, "'%s' is not a checkpoint of this library version", path); }
   if (H.layout != CKPT_LAYOUT) { fclose(fp); return fail(LBMDEM_EINVAL, "checkpoint '%s' holds another device layout (%d)", path, H.layout); }
   const int n = H.cfg.nbgrains;
   std::vector<double> r(n), kin(9 * (size_t)n);
@@ -1257,6 +1266,7 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
   if (!ok) { lbmdem_destroy(h); return fail(LBMDEM_EINVAL, "checkpoint '%s' is truncated or from a different decomposition", path); }
   h->cfg = cfg;  // wall positions as saved
   h->force_mode = H.force_mode;
+  h->L.lid6 = H.lid6;
   h->diag_always = H.diag_always != 0;
   if (H.has_carry) {  // the "previous contact" carries continue across the restart
     if (diag_extra_alloc(h->dx, n, h->V.cap) != 0 ||

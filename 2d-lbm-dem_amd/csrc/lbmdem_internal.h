@@ -29,6 +29,7 @@ struct LatticeView {
   // recip_ok = 0 when a divisor's significand is all ones (the one case the construction does not cover)
   double rc, rcc;
   int recip_ok;
+  double lid6;               // EXTENSION: uw_h / 6 of the lid terms commented out at main.c:1129-1130; 0 = off
   double cc;                 // c * c
   double wc_diag, wc_axis;   // w_q / c for the diagonal and the axis directions (main.c:1174,1184)
 };

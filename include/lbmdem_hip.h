@@ -116,6 +116,12 @@ int lbmdem_run(lbmdem_handle* h, long n_dem_steps);
  * fluid step themselves (strip decomposition: halo exchange and force combine sit between its phases). */
 int lbmdem_run_dem(lbmdem_handle* h, long n_dem_steps);
 
+/* EXTENSION, not in the reference as it runs: a lid. The reference's top-plate copies carry commented-out moving-wall
+ * terms (main.c:1129-1130: f[x][ly-1][3] = f[x-1][ly-2][7]; //-uw_h/6;  f[x][ly-1][5] = f[x+1][ly-2][1]; //+uw_h/6;
+ * `uw_h` is not even declared). lbmdem_set_lid enables exactly those two terms with uw_h in lattice units (0 = off, the
+ * default) -- BASELINE.json configs[1], a lid-driven cavity. Checked against the CPU oracle carrying the same terms. */
+int lbmdem_set_lid(lbmdem_handle* h, double uw_h);
+
 /* hydrodynamic-force kernel choice: 0 = parity (one thread per grain, reference summation order,
  * bit-exact); 1 = fast (wave per grain, shuffle reduction; differs in the last bits). Default 0. */
 int lbmdem_set_force_mode(lbmdem_handle* h, int mode);

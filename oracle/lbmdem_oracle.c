@@ -35,6 +35,8 @@ struct ora_sim {
   double scale;
   /* fluid constants (main.c:74-94) */
   double rho_moy, tau, s2, s3, s5, s7, s8, s9, nu, reductionR;
+  double lid_u; /* EXTENSION, not reference-pinned: the top plate's velocity `uw_h` of the terms the reference has
+                   commented out at main.c:1129-1130 (`//-uw_h/6`, `//+uw_h/6`); 0 = the reference as it runs */
   /* DEM constants (main.c:97-118) */
   double G, angleG, xG, yG, km, kg, kt, ktm, nug, num, nugt, mu, mum, mumb, murf;
   double distVerlet, dtt, iterDEM, freq, amp, t;
@@ -199,6 +201,9 @@ ORA_API void ora_set_physics(ora_sim* s, const double* p, int updateVerlet, int 
 
 /* test-only: another reduced-radius factor (the reference's is the global reductionR = 0.85, main.c:94);
  * recomputes rLB (main.c:1858-1860) and repaints the initial obstacle map (main.c:1861) */
+/* EXTENSION: lid velocity of the top plate in lattice units (see lid_u above) */
+ORA_API void ora_set_lid(ora_sim* s, double uw_h) { s->lid_u = uw_h; }
+
 ORA_API void ora_set_reduction(ora_sim* s, double reductionR) {
   s->reductionR = reductionR;
   for (int i = 0; i < s->n; ++i) s->rLB[i] = s->reductionR * s->r[i] / s->dx;
@@ -387,6 +392,10 @@ ORA_API void ora_edges(ora_sim* s) {
     f[FI(s, x, ly - 1, 4)] = f[FI(s, x, ly - 2, 8)];
     f[FI(s, x, ly - 1, 3)] = f[FI(s, x - 1, ly - 2, 7)];
     f[FI(s, x, ly - 1, 5)] = f[FI(s, x + 1, ly - 2, 1)];
+    if (s->lid_u != 0.0) { /* the commented-out lid terms of main.c:1129-1130 */
+      f[FI(s, x, ly - 1, 3)] = f[FI(s, x - 1, ly - 2, 7)] - s->lid_u / 6;
+      f[FI(s, x, ly - 1, 5)] = f[FI(s, x + 1, ly - 2, 1)] + s->lid_u / 6;
+    }
   }
   for (int y = 1; y < ly - 1; y++) {
     f[FI(s, 0, y, 6)] = f[FI(s, 1, y, 2)];

@@ -88,6 +88,8 @@ int ora_verlet_capacity(const ora_sim* s);
 void ora_get_verlet(const ora_sim* s, int* cumul, int* neighbours, int* counts4, int* wb, int* wt,
                     int* wl, int* wr);
 double ora_total_density(const ora_sim* s);  /* main.c:1249-1273 summation order */
+/* EXTENSION (not reference-pinned): enable the lid terms the reference has commented out at main.c:1129-1130 */
+void ora_set_lid(ora_sim* s, double uw_h);
 /* test-only (strip-decomposition protocol): link sums {x, y, q, f[P][opp q] + f[N][q]} of grain i whose far end N
  * lies in rows [nlo, nhi), scan order; and the force of grain i from its complete ordered list of sums */
 int ora_link_sums(ora_sim* s, int i, int nlo, int nhi, double* out4, int cap);

@@ -118,6 +118,7 @@ class Oracle:
     def dem_substep(self): self._call("ora_dem_substep")
     def set_threads(self, n): self._call("ora_set_threads", C.c_int(n))
     def set_reduction(self, v): self._call("ora_set_reduction", C.c_double(v))
+    def set_lid(self, uw_h): self._call("ora_set_lid", C.c_double(uw_h))
 
     def set_physics(self, p29, updateVerlet, stepFilm):
         p = np.ascontiguousarray(p29, dtype=np.float64); assert p.shape == (29,)

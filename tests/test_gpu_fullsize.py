@@ -203,3 +203,28 @@ def test_configs4_8192x4096_as_eight_strips_against_the_reference_digests(pkg):
         assert gu.sha(fhf) == str(g[f"sha_fhf_{k}"]), (k, "hydrodynamic forces")
         assert gu.sha(obst) == str(g[f"sha_obst_{k}"]), (k, "obstacle map")
         assert gu.sha(f) == str(g[f"sha_f_{k}"]), (k, "populations")
+
+
+def test_c2_1024_lid_driven_cavity(pkg, po):
+    """BASELINE.json configs[1]: 1024 x 1024 lid-driven cavity, fluid only. The reference has no lid as it runs (its
+    top-plate terms are commented out, main.c:1129-1130) and cannot run with 0 grains (main.c:220); the case is
+    therefore: one small grain in a corner, lattice at rest, and the EXTENSION lbmdem_set_lid enabling exactly the two
+    commented-out terms with uw_h = 0.05 (lattice units) -- against the CPU oracle carrying the same two terms
+    (not reference-pinned). 40 fluid steps: every population equal, and the lid drags the fluid below it."""
+    lx = ly = 1024
+    r, x1, x2 = np.array([0.5e-3]), np.array([1.2e-3]), np.array([1.1e-3])
+    sim = pkg.LbmDem(lx, ly, r, x1, x2)
+    ora = po.Oracle(lx, ly, r, x1, x2)
+    sim.set_lid(0.05); ora.set_lid(0.05)
+    for _ in range(40):
+        sim.lbm_step(); ora.lbm_steps(1)
+    fc = ora.get_f()
+    assert np.array_equal(sim.f, fc)
+    rho, jx, jy = sim.macro()
+    assert jx[lx // 2, ly - 2] > 1e-3 and abs(jx[lx // 2, ly // 2]) < 1e-6     # a shear layer under the lid only
+    # the switch is off by default and off means the reference's bits
+    sim0 = pkg.LbmDem(64, 64, r, x1, x2); ora0 = po.Oracle(64, 64, r, x1, x2)
+    sim0.set_lid(0.0)
+    for _ in range(5):
+        sim0.lbm_step(); ora0.lbm_steps(1)
+    assert np.array_equal(sim0.f, ora0.get_f())
