@@ -1,6 +1,7 @@
 """Run under torch.distributed.run with N >= 2 ranks on N GPUs: the real multi-GPU strip path over RCCL against the
 CPU oracle. MODE=distributed (default): grains owned by strips, neighbour messages only (kinematics of the margin,
-link-sum tables, forces), halo of 2 rows; MODE=replicated: every rank integrates all grains, one bit-exact
+link-sum tables, forces), halo of 2 rows; MODE=ccomm: the same protocol driven from C (lbmdem_comm_run, the
+library's RCCL transport); MODE=replicated: every rank integrates all grains, one bit-exact
 all-reduce of the forces per fluid step. Used by tests/test_gpu_multi.py when the box has more than one GPU."""
 import os, sys
 import numpy as np
@@ -13,13 +14,17 @@ rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int
 torch.cuda.set_device(local)
 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 pkg = ge.load_package(); strips = pkg.strips_module()
-distributed = os.environ.get("MODE", "distributed") == "distributed"
+mode = os.environ.get("MODE", "distributed")     # distributed | replicated | ccomm (distributed, driven from C)
+distributed = mode in ("distributed", "ccomm")
 lx, ly = (320 if distributed else 128) * world, 192
 r, x, y = samples.row_packing(lx, ly, (230 if distributed else 90) * world, seed=21); r, x1, x2 = samples.to_metres(r, x, y)
 rng = np.random.default_rng(4)
 k = np.zeros((len(r), 9)); k[:, 0], k[:, 1] = x1, x2; k[:, 3:6] = rng.normal(0, 1, (len(r), 3)) * [0.04, 0.03, 15.0]
-runner = strips.make_gpu_runner(pkg, dist, rank, world, local, lx, ly, r, x1, x2, distributed=distributed)
-assert isinstance(runner, strips.DistStripRunner) == distributed
+if mode == "ccomm":     # lbmdem_comm_run: the library's own RCCL transport, as the C host driver uses it
+    runner = strips.CCommRunner(pkg, dist, rank, world, local, lx, ly, r, x1, x2)
+else:
+    runner = strips.make_gpu_runner(pkg, dist, rank, world, local, lx, ly, r, x1, x2, distributed=distributed)
+    assert isinstance(runner, strips.DistStripRunner) == distributed
 runner.sim.kinematics = k
 n = 5 * runner.sim.cfg.npDEM + 3
 runner.render_scene(n)
@@ -44,6 +49,6 @@ ok = (np.array_equal(got[x0:x1_], ref_f[x0:x1_]) and np.array_equal(runner.sim.k
       and np.array_equal(runner.sim.fhf[own], ref_fhf[own]))
 flag = torch.tensor([1 if ok else 0], device="cuda"); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 if rank == 0:
-    print("MULTI-GPU-OK" if int(flag) == 1 else "MULTI-GPU-MISMATCH", world, "distributed" if distributed else "replicated", flush=True)
+    print("MULTI-GPU-OK" if int(flag) == 1 else "MULTI-GPU-MISMATCH", world, mode, flush=True)
 dist.barrier(); dist.destroy_process_group()
 sys.exit(0 if int(flag) == 1 else 1)

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", ["distributed", "replicated"])
+@pytest.mark.parametrize("mode", ["distributed", "ccomm", "replicated"])
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_strips_over_rccl_on_real_gpus(world, mode):
     import torch
