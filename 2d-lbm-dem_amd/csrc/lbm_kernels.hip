@@ -1603,6 +1603,7 @@ __global__ __launch_bounds__(64) void k_forces_gather_queue(const double* __rest
   __shared__ ForceLds sh;
   const int lane = threadIdx.x;
   const int count = *S.gathered;
+  if (blockIdx.x == 0 && lane == 0) *S.gathered_next = 0;   // the next step's counter (nobody reads or adds to it now)
   if (lane == 0) sh.sT[FORCE_TERMS_CAP * 4] = 0.0;
   for (int k = blockIdx.x; k < count; k += gridDim.x) {  // wave-uniform
     const int i = S.queue[k];

@@ -55,7 +55,7 @@ struct lbmdem_handle {
   const double* cs_fin = nullptr;
   const int *cs_ob_old = nullptr, *cs_ob_new = nullptr;
   int cs_lo_end = 0, cs_hi_begin = 0;  // interior = local rows [cs_lo_end, cs_hi_begin)
-  ForceSlots cs_slots{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  ForceSlots cs_slots{};
   // grains
   int n = 0;
   double* gbuf = nullptr;  // one allocation, carved below
@@ -75,7 +75,8 @@ struct lbmdem_handle {
   unsigned* mincov = nullptr;   // GrainFluidView::mincov
   unsigned paint_epoch = 0;
   // link sums handed from the fused kernel to the force kernel (ForceSlots, lbmdem_internal.h)
-  ForceSlots fs{nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  ForceSlots fs{};
+  int* gathered2 = nullptr;   // both counters (fs.gathered / fs.gathered_next alternate between them)
   bool slots_clean = false;  // every slot is empty
   bool last_forces_from_table = false;
   bool slots_valid = false;  // the table was filled by the collide_stream that produced f[fcur] with the current map
@@ -334,8 +335,9 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
   CREATE_TRY(hipMalloc((void**)&h->fs.queue, sizeof(int) * n));
   CREATE_TRY(hipMalloc((void**)&h->fs.error, sizeof(int)));
   CREATE_TRY(hipMemsetAsync(h->fs.error, 0, sizeof(int), h->stream));
-  CREATE_TRY(hipMalloc((void**)&h->fs.gathered, sizeof(int)));
-  CREATE_TRY(hipMemsetAsync(h->fs.gathered, 0, sizeof(int), h->stream));
+  CREATE_TRY(hipMalloc((void**)&h->gathered2, 2 * sizeof(int)));
+  CREATE_TRY(hipMemsetAsync(h->gathered2, 0, 2 * sizeof(int), h->stream));
+  h->fs.gathered = h->gathered2; h->fs.gathered_next = h->gathered2 + 1;
   CREATE_TRY(hipMalloc((void**)&h->fs.touched, n));
   CREATE_TRY(hipMemsetAsync(h->fs.touched, 0, n, h->stream));
   {
@@ -413,7 +415,7 @@ int lbmdem_destroy(lbmdem_handle* h) {
   if (h->mincov) (void)hipFree(h->mincov);
   if (h->fs.touched) (void)hipFree(h->fs.touched);
   if (h->fs.tab) (void)hipFree(h->fs.tab);
-  if (h->fs.gathered) (void)hipFree(h->fs.gathered);
+  if (h->gathered2) (void)hipFree(h->gathered2);
   if (h->fs.queue) (void)hipFree(h->fs.queue);
   if (h->fs.error) (void)hipFree(h->fs.error);
   if (h->dpartial) (void)hipFree(h->dpartial);
@@ -561,7 +563,7 @@ int lbmdem_forces_fluid(lbmdem_handle* h) {
   }
   if (h->force_mode == 0 && h->slots_valid && !h->obst_pending) {
     // the link sums were left in the slot table by the fused kernel; the kernel empties the table again
-    HIP_TRY(hipMemsetAsync(h->fs.gathered, 0, sizeof(int), h->stream));
+    { int* t = h->fs.gathered; h->fs.gathered = h->fs.gathered_next; h->fs.gathered_next = t; }  // zeroed by the last queue kernel
     launch_forces_slots(h->f[h->fcur], ob, h->L, gview(h), h->fs, h->fscale12, h->fscale3, h->fhf, h->owner, h->stream);
     h->last_forces_from_table = true;
     h->dist_period_open = false;

@@ -66,7 +66,9 @@ struct ForceSlots {
   int spd;   // slots per direction (2 * half + 1 rounded up)
   int half;
   int hb;    // >= largest reduced radius in nodes + 1: a grain's nodes lie within +-hb of its truncated centre
-  int* gathered;  // device counter: grains the table could not serve ...
+  int* gathered;  // device counter: grains the table could not serve ... (one of two: the queue kernel zeroes the
+                  // OTHER one for the next fluid step, so no memset sits between the kernels)
+  int* gathered_next;
   int* queue;     // ... and their indices, for the gather kernel that follows
   int* error;     // device flag: a grain cut by a strip boundary that neither the table nor a local gather can serve
   const unsigned char* mask;  // strip decomposition with distributed grains: the grains the rasteriser handled; else null
