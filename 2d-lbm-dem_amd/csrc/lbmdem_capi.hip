@@ -1191,6 +1191,8 @@ int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) try {
   CHECK_NOT_SPLIT(h);
   if (!path) return fail(LBMDEM_EINVAL, "null path");
   if (h->obst_pending) return fail(LBMDEM_EINVAL, "checkpoint between obst_construction and collide_stream");
+  if (h->dist) return fail(LBMDEM_EINVAL, "checkpoints are written by single-GPU handles (with distributed grains a rank holds "
+                                          "only the grains it integrates)");
   HIP_TRY(hipStreamSynchronize(h->stream));
   const int n = h->n;
   std::vector<int> off(n + 1, 0);
