@@ -1263,8 +1263,10 @@ struct DiscTest {
 // What k_forces_table does with the grains it is given
 enum : int {
   FT_CONSUME = 0,  // grains this rank owns: complete the table, replay the sums, write fhf
-  FT_PACK = 1      // listed grains owned by a neighbour rank: complete this rank's part of the table and write
+  FT_PACK = 1,     // listed grains owned by a neighbour rank: complete this rank's part of the table and write
                    // {id, slots} to the message buffer (strip decomposition; the owner merges it into its own)
+  FT_FAST = 2      // as FT_CONSUME, but the addends are summed by a cross-lane reduction instead of being replayed in
+                   // the reference's order (force mode 1: same terms, last-bit differences)
 };
 
 constexpr unsigned long long M_DIAG = 0x5555555555555555ull;  // bits of q = 1, 3, 5, 7 in a bitmap word
@@ -1299,6 +1301,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
   const int ntodo = list ? *list_count : L.n;
   auto grain_at = [&](int pos) { return list ? list[pos] : pos; };
   const int own_lo = L.gx0 + L.xo0, own_hi = L.gx0 + L.xo1;  // rows whose links this rank produces: [own_lo, own_hi)
+  const bool consume = mode != FT_PACK;
   const int spd = S.spd, HB = S.hb;
   const int B = 2 * HB + 1;
   constexpr int FPP = 4 / PASSES;   // line families per pass
@@ -1358,9 +1361,9 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
     const double xc = G.xc[i], yc = G.yc[i], rbl0 = G.rbl0[i], r2 = G.r2[i];
     own[g] = grain_owned(L, xc);
     const bool was_touched = S.touched[i] != 0;
-    if (was_touched && lane == 0 && mode == FT_CONSUME) S.touched[i] = 0;  // the rasteriser sets it again while it applies
+    if (was_touched && lane == 0 && consume) S.touched[i] = 0;  // the rasteriser sets it again while it applies
     int xi, xf, yi, yf;
-    const bool todo = (mode == FT_CONSUME ? own[g] : !own[g]) && grain_box(L, G, i, xi, xf, yi, yf);
+    const bool todo = (consume ? own[g] : !own[g]) && grain_box(L, G, i, xi, xf, yi, yf);
     if (!todo) continue;
     // overlapping discs: a lattice line may then carry several links of one direction -- not a table case
     if (was_touched) {
@@ -1373,6 +1376,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
     for (int w = lane; w < nw64; w += 64) bm[w] = 0ull;
     __builtin_amdgcn_wave_barrier();
     bool bad = false;
+    double h1 = 0.0, h2 = 0.0, h3 = 0.0;  // FT_FAST: this lane's part of the three sums
     int keyf[PASSES], keyb[PASSES];  // -1: no link; else ((bx * B + by) * 8 + q - 1) | bx << 20 | by << 26
 #pragma unroll
     for (int j = 0; j < PASSES; ++j) {
@@ -1429,9 +1433,19 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
           if (side == 0) { fw[g][j] = (unsigned long long)__double_as_longlong(sum); ffill = true; }
           else { bw[g][j] = (unsigned long long)__double_as_longlong(sum); bfill = true; }
         }
-        if (mode == FT_CONSUME && (!ffill || !bfill)) bad = true;  // the owner must end up with every sum
+        if (consume && (!ffill || !bfill)) bad = true;  // the owner must end up with every sum
       }
       keyf[j] = keyb[j] = -1;
+      if (meets && mode == FT_FAST) {
+        // forward link: direction q out of node kf, momentum along the opposite direction (main.c:1315-1318)
+        const double sf = __longlong_as_double((long long)fw[g][j]), sb = __longlong_as_double((long long)bw[g][j]);
+        const double wxf = px0 + kf * ex - xc, wyf = py0 + kf * ey - yc;
+        const double wxb = px0 + kb * ex - xc, wyb = py0 + kb * ey - yc;
+        const double fxf = sf * -ex, fyf = sf * -ey, fxb = sb * ex, fyb = sb * ey;
+        h1 = h1 + fxf + fxb;
+        h2 = h2 + fyf + fyb;
+        h3 = h3 - fxf * wyf + fyf * wxf - fxb * wyb + fyb * wxb;
+      }
       if (meets && mode == FT_CONSUME) {
         // in-disc nodes lie within +-hb of the truncated centre (hb >= largest reduced radius + 1)
         const int bxf = px0 + kf * ex - (X0 - HB), byf = py0 + kf * ey - (Y0 - HB);
@@ -1452,6 +1466,21 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
       n1[g] = -1;
       if (mode == FT_PACK && lane == 0)   // nothing usable for this grain: the entry must not keep an older period's data
         packbuf[1 + (long)(g0 + g) * (1 + 8 * spd)] = -1.0;
+      continue;
+    }
+    if (mode == FT_FAST) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        h1 += __shfl_xor(h1, off, 64);
+        h2 += __shfl_xor(h2, off, 64);
+        h3 += __shfl_xor(h3, off, 64);
+      }
+      if (lane == 0) {
+        fhf[i] = h1 * scale12;
+        fhf[L.n + i] = h2 * scale12;
+        fhf[2 * L.n + i] = h3 * scale3;
+      }
+      n1[g] = -2;  // written; nothing to replay, nothing to queue
       continue;
     }
     if (mode == FT_PACK) {  // {id, slots} to the message; the owner merges
@@ -1545,9 +1574,9 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
     if (lane == 0) {
       int* cnt = counts + (gslot0 + g) * 5;
       cnt[0] = n1[g]; cnt[1] = n2[g]; cnt[2] = n3[g]; cnt[3] = own[g] ? 1 : 0; cnt[4] = i;
-      if (i >= 0 && mode == FT_CONSUME) {
+      if (i >= 0 && consume) {
         if (owner) owner[i] = own[g] ? 1 : 0;
-        if (n1[g] < 0) S.queue[atomicAdd(S.gathered, 1)] = i;
+        if (n1[g] == -1) S.queue[atomicAdd(S.gathered, 1)] = i;
       }
       // a neighbour's grain whose table this rank cannot complete (overlapping discs across a strip cut)
       if (i >= 0 && mode == FT_PACK && n1[g] < 0) atomicOr(S.error, 1);
@@ -1945,7 +1974,7 @@ void launch_forces_parity(const double* f, const int* obst, const LatticeView& L
 template <int GW, int PASSES>
 static void launch_forces_table_t(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
                                   const ForceSlots& S, double scale12, double scale3, double* fhf, unsigned char* owner,
-                                  hipStream_t st) {
+                                  int fast, hipStream_t st) {
   const int HB = S.hb, B = 2 * HB + 1;
   const int nw64 = (B * B * 8 + 63) / 64;
   // addends per accumulator: one link per direction and lattice line meeting the disc (<= spd lines for the
@@ -1956,7 +1985,7 @@ static void launch_forces_table_t(const double* f, const int* obst, const Lattic
   const int per_block = FT_WAVES * GW;
   const int ntodo = S.local_list ? S.local_cap : L.n;   // strips: the compacted list of local grains bounds the launch
   hipLaunchKernelGGL((k_forces_table<GW, PASSES>), dim3((ntodo + per_block - 1) / per_block), dim3(64 * FT_WAVES), lds, st,
-                     f, obst, L, G, S, cap1, cap3, nw64, scale12, scale3, fhf, owner, (int)FT_CONSUME, S.local_list,
+                     f, obst, L, G, S, cap1, cap3, nw64, scale12, scale3, fhf, owner, fast ? (int)FT_FAST : (int)FT_CONSUME, S.local_list,
                      S.local_count, (double*)nullptr, S.mask);
   const int grid = L.n < 256 ? L.n : 256;
   hipLaunchKernelGGL(k_forces_gather_queue, dim3(grid), dim3(64), 0, st, f, obst, L, G, S, scale12, scale3, fhf);
@@ -1980,7 +2009,7 @@ void launch_forces_table_pack(const double* f, const int* obst, const LatticeVie
 
 void launch_forces_slots(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
                          const ForceSlots& S, double scale12, double scale3, double* fhf, unsigned char* owner,
-                         hipStream_t st) {
+                         int fast, hipStream_t st) {
 #ifdef LBMDEM_AB
   static const int gw = getenv("LBMDEM_FORCE_GW") ? atoi(getenv("LBMDEM_FORCE_GW")) : 1;
 #else
@@ -1989,14 +2018,14 @@ void launch_forces_slots(const double* f, const int* obst, const LatticeView& L,
   if (S.spd <= 32) {
     switch (gw) {
 #ifdef LBMDEM_AB
-      case 2: launch_forces_table_t<2, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, st); break;
-      case 3: launch_forces_table_t<3, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, st); break;
-      case 5: launch_forces_table_t<5, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, st); break;
+      case 2: launch_forces_table_t<2, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, st); break;
+      case 3: launch_forces_table_t<3, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, st); break;
+      case 5: launch_forces_table_t<5, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, st); break;
 #endif
-      default: launch_forces_table_t<1, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, st); break;
+      default: launch_forces_table_t<1, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, st); break;
     }
   } else {
-    launch_forces_table_t<1, 4>(f, obst, L, G, S, scale12, scale3, fhf, owner, st);
+    launch_forces_table_t<1, 4>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, st);
   }
 }
 

@@ -442,11 +442,10 @@ int lbmdem_obst_construction(lbmdem_handle* h) {
   return rc;
 }
 
-// The slot table the next fused-kernel launch fills (tab == nullptr: none, e.g. the fast force kernel does not
-// read it). A table that still holds sums nobody consumed is emptied first.
+// The slot table the next fused-kernel launch fills (tab == nullptr: none). A table that still holds sums nobody
+// consumed is emptied first.
 static ForceSlots slots_for_launch(lbmdem_handle* h) {
   ForceSlots S = h->fs;
-  if (h->force_mode != 0) S.tab = nullptr;
   if (S.tab) {
     if (!h->slots_clean) launch_slots_clear(h->fs, h->n, h->stream);
     h->slots_clean = false;
@@ -482,7 +481,7 @@ int lbmdem_collide_stream(lbmdem_handle* h) try {
   if (rc != LBMDEM_OK) return rc;
   launch_collide_stream(h->f[h->fcur], h->f[1 - h->fcur], ob_old, ob_new, h->L, gview(h), slots_for_launch(h), h->stream);
   if (e1) HIP_TRY(hipEventRecord(e1, h->stream));
-  h->slots_valid = h->fs.tab != nullptr && h->force_mode == 0;
+  h->slots_valid = h->fs.tab != nullptr;
   HIP_TRY(hipGetLastError());
   h->fcur = 1 - h->fcur;
   if (h->obst_pending) { h->ocur = 1 - h->ocur; h->obst_pending = false; }
@@ -561,10 +560,11 @@ int lbmdem_forces_fluid(lbmdem_handle* h) {
     if (h->dist && (h->force_mode != 0 || !h->slots_valid || h->obst_pending))
       return fail(LBMDEM_EINVAL, "distributed grains: forces_fluid must follow collide_stream directly (parity force kernel)");
   }
-  if (h->force_mode == 0 && h->slots_valid && !h->obst_pending) {
+  if (h->slots_valid && !h->obst_pending) {
     // the link sums were left in the slot table by the fused kernel; the kernel empties the table again
     { int* t = h->fs.gathered; h->fs.gathered = h->fs.gathered_next; h->fs.gathered_next = t; }  // zeroed by the last queue kernel
-    launch_forces_slots(h->f[h->fcur], ob, h->L, gview(h), h->fs, h->fscale12, h->fscale3, h->fhf, h->owner, h->stream);
+    launch_forces_slots(h->f[h->fcur], ob, h->L, gview(h), h->fs, h->fscale12, h->fscale3, h->fhf, h->owner,
+                        h->force_mode != 0, h->stream);
     h->last_forces_from_table = true;
     h->dist_period_open = false;
     h->slots_valid = false;

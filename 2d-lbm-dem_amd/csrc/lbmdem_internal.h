@@ -115,7 +115,7 @@ void launch_slots_clear(const ForceSlots& S, int n, hipStream_t st);
 // parity forces from the slot table (resets it to empty); grains whose table is incomplete gather from f
 void launch_forces_slots(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
                          const ForceSlots& S, double scale12, double scale3, double* fhf, unsigned char* owner,
-                         hipStream_t st);
+                         int fast, hipStream_t st);
 // strip decomposition: this rank's part of the tables of the listed grains (owned by a neighbour rank), completed
 // and written as {count; count x {id, 8 * spd slots}} to a message buffer
 void launch_forces_table_pack(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,

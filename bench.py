@@ -248,7 +248,7 @@ def main():
         sim.set_force_mode(0)
         fast = {"ms_per_step": round(1e3 * (t1 - t0) / nf, 4), "mlups": round(1e-6 * lx * ly * nf / (t1 - t0), 1),
                 "steps": nf, "max_rel_drift_vs_parity": drift,
-                "note": "force_mode=1: wave-per-grain shuffle-tree sums (last-bit differences); not the headline"}
+                "note": "force_mode=1: the table's link sums reduced across lanes instead of replayed in reference order (last-bit differences); not the headline"}
 
     mass = sim.final_density()
     if world > 1 or args.strips:   # every rank holds the mass of its own rows

@@ -122,8 +122,9 @@ int lbmdem_run_dem(lbmdem_handle* h, long n_dem_steps);
  * default) -- BASELINE.json configs[1], a lid-driven cavity. Checked against the CPU oracle carrying the same terms. */
 int lbmdem_set_lid(lbmdem_handle* h, double uw_h);
 
-/* hydrodynamic-force kernel choice: 0 = parity (one thread per grain, reference summation order,
- * bit-exact); 1 = fast (wave per grain, shuffle reduction; differs in the last bits). Default 0. */
+/* hydrodynamic-force summation: 0 = parity (the reference's order of additions, bit-exact); 1 = fast (the same
+ * addends reduced across the lanes of a wavefront: differs in the last bits; same speed as parity since round 2,
+ * kept for callers that do not need the reference's bits). Default 0. */
 int lbmdem_set_force_mode(lbmdem_handle* h, int mode);
 
 /* ---- state in / out (host layout) ------------------------------------------------------------ */

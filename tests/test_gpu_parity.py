@@ -213,7 +213,8 @@ def test_medium_packing_20_fluid_steps_bit_exact(pkg, po):
 
 
 def test_fast_force_kernel_close_to_parity_kernel(pkg, po):
-    """The wave-per-grain shuffle kernel sums the same terms in a different tree; the drift against
+    """Force mode 1 (wave-per-grain shuffle kernel, or the table kernel's cross-lane reduction when the fused kernel
+    left the link sums) sums the same terms in a different tree; the drift against
     the reference-order kernel is reported relative to the sum of |terms| (cancellation makes the
     net force itself tiny)."""
     lx, ly = 256, 200
@@ -234,6 +235,14 @@ def test_fast_force_kernel_close_to_parity_kernel(pkg, po):
     scale12 = cfg.phys.rho_moy * 9 * cfg.phys.nu ** 2 / (cfg.dx * (cfg.phys.tau - 0.5) ** 2)
     term = 2.0 / 9 * scale12 * 150
     assert np.abs(exact[:, :2]).max() > 1e-6 * term          # forces are not trivially zero
+    assert np.all(np.abs(fast[:, :2] - exact[:, :2]) <= 1e-13 * term)
+    assert np.all(np.abs(fast[:, 2] - exact[:, 2]) <= 1e-13 * term * 10 * cfg.dx)
+    # a whole step in fast mode: the sums come from the link-sum table, reduced across lanes
+    sim.lbm_step(); ora.lbm_steps(1)
+    assert sim.force_stats()[0] > 0.9 * len(r)
+    fast, exact = sim.fhf, ora.get_fhf()
+    assert np.array_equal(sim.f, ora.get_f())
+    assert not np.array_equal(fast, exact)                    # a different summation tree
     assert np.all(np.abs(fast[:, :2] - exact[:, :2]) <= 1e-13 * term)
     assert np.all(np.abs(fast[:, 2] - exact[:, 2]) <= 1e-13 * term * 10 * cfg.dx)
 
@@ -309,7 +318,7 @@ def test_force_slot_table_and_gather_path_give_the_same_bits(pkg, po):
     sim.f = f1; ora.set_f(f1)
     sim.forces_fluid(); ora.forces_fluid()
     assert np.array_equal(sim.fhf, ora.get_fhf())
-    # fast kernel for one step (does not consume the table), then parity again
+    # fast mode for one step, then parity again
     sim.set_force_mode(1); sim.lbm_step(); ora.lbm_steps(1)
     sim.set_force_mode(0)
     sim.forces_fluid()
