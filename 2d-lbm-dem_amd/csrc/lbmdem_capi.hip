@@ -1807,6 +1807,45 @@ int lbmdem_comm_selftest(lbmdem_comm* c, int doubles) {
   if (r != ncclSuccess) return fail(LBMDEM_EHIP, "RCCL self send/recv failed: %s", g_rccl.GetErrorString(r));
   HIP_TRY(e);
   for (int k = 0; k < doubles; ++k) if (hb[k] != ha[k]) return fail(LBMDEM_EHIP, "self send/recv returned wrong data at %d", k);
+  if (c->world == 1) return LBMDEM_OK;
+  // several ranks: the step's own pattern -- on every lane one grouped exchange with both neighbours, all lanes in
+  // flight at once -- with a payload that names sender and lane
+  const int left = c->rank - 1, right = c->rank + 1 < c->world ? c->rank + 1 : -1;
+  double* d = nullptr;   // [lane][send L, send R, recv L, recv R][doubles]
+  HIP_TRY(hipMalloc((void**)&d, sizeof(double) * doubles * 4 * LANE_COUNT));
+  std::vector<double> host((size_t)doubles * 4 * LANE_COUNT, -1.0);
+  auto value = [&](int rank, int lane, int to_right, int k) { return 1000.0 * rank + 100.0 * lane + 10.0 * to_right + 1e-3 * k; };
+  for (int l = 0; l < LANE_COUNT; ++l)
+    for (int sd = 0; sd < 2; ++sd)
+      for (int k = 0; k < doubles; ++k) host[((size_t)l * 4 + sd) * doubles + k] = value(c->rank, l, sd, k);
+  e = hipMemcpy(d, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice);
+  r = ncclSuccess;
+  for (int l = 0; l < LANE_COUNT && e == hipSuccess && r == ncclSuccess; ++l) {
+    double* base = d + (size_t)l * 4 * doubles;
+    r = g_rccl.GroupStart();
+    if (left >= 0 && r == ncclSuccess) r = g_rccl.Send(base, (size_t)doubles, ncclDouble, left, c->nccl[l], c->side[l]);
+    if (left >= 0 && r == ncclSuccess) r = g_rccl.Recv(base + 2 * (size_t)doubles, (size_t)doubles, ncclDouble, left, c->nccl[l], c->side[l]);
+    if (right >= 0 && r == ncclSuccess) r = g_rccl.Send(base + (size_t)doubles, (size_t)doubles, ncclDouble, right, c->nccl[l], c->side[l]);
+    if (right >= 0 && r == ncclSuccess) r = g_rccl.Recv(base + 3 * (size_t)doubles, (size_t)doubles, ncclDouble, right, c->nccl[l], c->side[l]);
+    ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+  }
+  for (int l = 0; l < LANE_COUNT; ++l) {
+    const hipError_t e2 = hipStreamSynchronize(c->side[l]);
+    if (e == hipSuccess) e = e2;
+  }
+  if (e == hipSuccess && r == ncclSuccess) e = hipMemcpy(host.data(), d, sizeof(double) * host.size(), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (r != ncclSuccess) return fail(LBMDEM_EHIP, "RCCL neighbour exchange failed: %s", g_rccl.GetErrorString(r));
+  HIP_TRY(e);
+  for (int l = 0; l < LANE_COUNT; ++l)
+    for (int k = 0; k < doubles; ++k) {
+      // the left neighbour's message "to the right" lands in recv L, the right neighbour's "to the left" in recv R
+      if (left >= 0 && host[((size_t)l * 4 + 2) * doubles + k] != value(left, l, 1, k))
+        return fail(LBMDEM_EHIP, "lane %d: wrong data from rank %d at %d", l, left, k);
+      if (right >= 0 && host[((size_t)l * 4 + 3) * doubles + k] != value(right, l, 0, k))
+        return fail(LBMDEM_EHIP, "lane %d: wrong data from rank %d at %d", l, right, k);
+    }
   return LBMDEM_OK;
 }
 

@@ -163,7 +163,7 @@ static int run(int argc, char** argv) {
     if (share_id(id) != 0) { fprintf(stderr, "rank %d: no RCCL id: %s\n", g_rank, lbmdem_last_error()); return EXIT_FAILURE; }
     DIE(lbmdem_dist_enable(h, 0), "dist_enable");
     DIE(lbmdem_comm_create(id, g_rank, g_world, cfg.device, &comm), "comm_create");
-    if (g_world == 1) DIE(lbmdem_comm_selftest(comm, 4096), "comm_selftest");
+    DIE(lbmdem_comm_selftest(comm, 4096), "comm_selftest");   /* one rank: to itself; several: with both neighbours */
   }
   time_t now = time(NULL);
   SAY("Current local time and date: %s", asctime(localtime(&now)));

@@ -184,10 +184,23 @@ def main():
         cfg0 = pkg.derive(lx, ly, r)
         margin = strips.default_margin(cfg0.npDEM, float(max(r)), cfg0.phys.distVerlet, cfg0.dx)
         wide = min(b - a for a, b in strips.partition(lx, world)) >= margin
+        runner = None
         if args.driver == "c" and args.force_mode == 0 and (wide or world == 1):
             # grains distributed, the library's own RCCL transport, one C call per batch of steps
-            runner = strips.CCommRunner(pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2)
-        else:
+            ok = 1
+            try:
+                runner = strips.CCommRunner(pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2)
+                runner.comm.selftest()
+            except Exception as e:      # every rank must take the same path: agree on it below
+                print(f"[rank {rank}] C driver unavailable: {e}", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 0:
+                if rank == 0:
+                    print("falling back to the torch.distributed strip driver on all ranks", file=sys.stderr)
+                runner = None
+        if runner is None:
             runner = strips.make_gpu_runner(pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2,
                                             force_mode=args.force_mode)
         sim = runner.sim

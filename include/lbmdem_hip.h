@@ -265,7 +265,8 @@ int lbmdem_comm_run(lbmdem_handle* h, lbmdem_comm* c, long n_dem_steps);
 /* sum of host values over the ranks (check_density / final_density; not on the step path) */
 int lbmdem_comm_allreduce_sum(lbmdem_comm* c, double* values, int n);
 /* a grouped send + receive of `doubles` values from this rank to itself on a side stream while another stream is
- * busy: the transport exercised on a one-GPU box */
+ * busy (the transport exercised on a one-GPU box); with several ranks also the step's own pattern: on every lane one
+ * grouped exchange with both neighbours, all lanes in flight at once, payload checked. Collective over the ranks. */
 int lbmdem_comm_selftest(lbmdem_comm* c, int doubles);
 
 /* Device pointer to the 3*n hydrodynamic-force table (fhf1[n], fhf2[n], fhf3[n]) and to the
