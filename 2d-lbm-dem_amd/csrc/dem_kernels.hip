@@ -91,10 +91,14 @@ __device__ __forceinline__ Force3 contact(const GrainState& A, const GrainState&
 
 // The four wall laws applied to one grain, in the reference's order bottom, top, left, right
 // (main.c:1455-1508); wf = the grain's wall candidate flags (VerletWall, main.c:1563-1593).
+// what the wall laws leave for the "previous contact" carries (CarryTrack): which walls the grain touched and the ft
+// (bottom: also f3) the reference assigns to pft / pff / pf there (main.c:842-843, 919, 942, 1466, 1494)
+struct WallHits { unsigned mask = 0; double ftB = 0., f3B = 0., ftL = 0., ftR = 0.; };
+
 template <bool DIAG>
 __device__ __forceinline__ void walls(const GrainState& me, unsigned wf, const DemParams& P, double& a1,
                                       double& a2, double& a3, double& pr, double& ds, double& df1, int& dz,
-                                      double& dM11, double& dM12, double& dM21, double& dM22) {
+                                      double& dM11, double& dM12, double& dM21, double& dM22, WallHits& wh) {
   if (wf & 1u) {
     const double dn = me.x2 - me.r - P.Mby;
     if (dn < 0) {  // force_WallB, main.c:809-828
@@ -105,6 +109,7 @@ __device__ __forceinline__ void walls(const GrainState& me, unsigned wf, const D
       const double ftest = P.mumb * fn;
       if (fabs(ft) > ftest) ft = (ft < 0.0) ? ftest : -ftest;
       a1 = a1 + ft; a2 = a2 + fn; a3 = a3 + (-(ft * me.r * P.murf));
+      wh.mask |= 1u; wh.ftB = ft; wh.f3B = -(ft * me.r * P.murf);
       pr += fn;
       if (DIAG) { ds += ft; df1 += ft; dz += 1; dM12 += ft * P.dt; dM22 += fn * P.dt; }  // main.c:830-838
     }
@@ -137,6 +142,7 @@ __device__ __forceinline__ void walls(const GrainState& me, unsigned wf, const D
       double ft = P.mum * fn;
       if (vt > 0) ft = -ft;
       a1 = a1 + fn; a2 = a2 + ft; a3 = a3 + ft * me.r * P.murf;
+      wh.mask |= 4u; wh.ftL = ft;
       if (DIAG) { dM11 += fn * fabs(P.dt); dM21 += ft * fabs(P.dt); }  // main.c:907-915
       pr += fn;
       if (DIAG) { ds += ft; df1 += fn; dz += 1; }
@@ -150,6 +156,7 @@ __device__ __forceinline__ void walls(const GrainState& me, unsigned wf, const D
       const double vt = me.v2;
       double ft = P.mum * fn;
       if (vt > 0) ft = -ft;
+      wh.mask |= 8u; wh.ftR = ft;
       if (fn > 0.) fn = 0.;
       a1 = a1 + fn; a2 = a2 + (-ft); a3 = a3 + ft * me.r * P.murf;
       pr += fn;
@@ -215,7 +222,8 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
   }
   if (DIAG) D.X.a1gc[i] = a1;
   // walls: bottom, top, left, right (main.c:1455-1508)
-  walls<DIAG>(me, wallflags[i], P, a1, a2, a3, pr, ds, df1, dz, dM11, dM12, dM21, dM22);
+  WallHits wh;
+  walls<DIAG>(me, wallflags[i], P, a1, a2, a3, pr, ds, df1, dz, dM11, dM12, dM21, dM22, wh);
   // main.c:1511-1515 (mw = 0: SURVEY.md hard part 5)
   const double mi = m[i], mw = 0.0;
   a1 = a1 / mi + ((mi - mw) / mi) * P.xG;
@@ -250,7 +258,7 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
 // A workgroup owns DEM_GRAINS consecutive grains and therefore a contiguous slice of the list.
 // x - y == x + (-y) in IEEE arithmetic, so `a1 + (i < j ? f1 : -f1)` is bit for bit the reference's
 // `a1 + f1` / `a1 - f1`.
-constexpr int DEM_GRAINS = 64;    // grains per workgroup
+constexpr int DEM_GRAINS = DEM_TILE;  // grains per workgroup
 constexpr int DEM_ENTRIES = 512;  // list entries staged per round (8 per grain; denser lists take more rounds)
 
 template <bool FILM>
@@ -262,10 +270,16 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const doub
                                                      const int* __restrict__ nbr, const int* __restrict__ own,
                                                      const unsigned char* __restrict__ wallflags,
                                                      double* __restrict__ pout, DemParams P,
-                                                     const unsigned char* __restrict__ active) {
+                                                     const unsigned char* __restrict__ active, CarryTrack T,
+                                                     long long stamp) {
   __shared__ double sF1[DEM_ENTRIES], sF2[DEM_ENTRIES], sF3[DEM_ENTRIES], sFn[DEM_ENTRIES];
   __shared__ unsigned char sTouched[DEM_ENTRIES];
+  __shared__ int sLast;   // highest list entry of this tile that is a touching contact in the reference's frame
   const int tid = threadIdx.x;
+  if (T.stamp) {   // before anything is in flight: the barrier costs nothing here
+    if (tid == 0) sLast = -1;
+    __syncthreads();
+  }
   const int g0 = blockIdx.x * DEM_GRAINS;
   const int g1 = g0 + DEM_GRAINS < P.n ? g0 + DEM_GRAINS : P.n;
   // phase-2 lanes: everything that does not depend on the partners is requested now
@@ -286,6 +300,8 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const doub
     wf = wallflags[i];
     mi = m[i]; Iti = It[i];
   }
+  int last_e = -1;            // this thread's youngest touching contact (own < partner: the reference evaluates it there)
+  double last_ft = 0., last_f3 = 0.;
   for (int base = e0; base < e1; base += DEM_ENTRIES) {
     const int lim = base + DEM_ENTRIES < e1 ? base + DEM_ENTRIES : e1;
     for (int e = base + tid; e < lim; e += 256) {
@@ -295,6 +311,7 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const doub
       const bool lower = gi < gj;
       bool touched;
       const Force3 F = contact<FILM>(lower ? a : b, lower ? b : a, P, touched);  // main.c:1443-1448
+      if (touched && lower) { last_e = e; last_ft = F.ft; last_f3 = F.f3; if (T.stamp) atomicMax(&sLast, e); }
       const int s = e - base;
       sF1[s] = lower ? F.f1 : -F.f1;
       sF2[s] = lower ? F.f2 : -F.f2;
@@ -313,10 +330,31 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const doub
     }
     __syncthreads();
   }
-  if (!mine) return;
+  if (T.stamp) {  // the tile's last grain contact, for the carries (every round of the loop above ends with a barrier)
+    if (last_e >= 0 && last_e == sLast) {
+      const long rec = (long)blockIdx.x * 4 + CARRY_GRAIN;
+      T.stamp[rec] = stamp; T.val[2 * rec] = last_ft; T.val[2 * rec + 1] = last_f3;
+    }
+  }
+  if (tid >= 64) return;   // the first wavefront holds the tile's grains
   double ds = 0., df1 = 0., dM11 = 0., dM12 = 0., dM21 = 0., dM22 = 0.;
   int dz = 0;
-  walls<false>(me, wf, P, a1, a2, a3, pr, ds, df1, dz, dM11, dM12, dM21, dM22);
+  WallHits wh;
+  if (mine) walls<false>(me, wf, P, a1, a2, a3, pr, ds, df1, dz, dM11, dM12, dM21, dM22, wh);
+  if (T.stamp) {  // per wall, the highest grain of the tile that touched it (the wall lists are in grain order)
+#pragma unroll
+    for (int kind = CARRY_BOTTOM; kind <= CARRY_RIGHT; ++kind) {
+      const unsigned bit = kind == CARRY_BOTTOM ? 1u : (kind == CARRY_LEFT ? 4u : 8u);
+      const unsigned long long hit = __ballot((wh.mask & bit) != 0);
+      if (hit != 0 && tid == 63 - __builtin_clzll(hit)) {
+        const long rec = (long)blockIdx.x * 4 + kind;
+        T.stamp[rec] = stamp;
+        T.val[2 * rec] = kind == CARRY_BOTTOM ? wh.ftB : (kind == CARRY_LEFT ? wh.ftL : wh.ftR);
+        T.val[2 * rec + 1] = wh.f3B;
+      }
+    }
+  }
+  if (!mine) return;
   const double mw = 0.0;
   a1 = a1 / mi + ((mi - mw) / mi) * P.xG;
   a2 = (a2 / mi) + ((mi - mw) / mi) * P.yG;
@@ -348,8 +386,9 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const doub
 //                 with the carries, `ic`, and the reference's own indexing of g[] by the list POSITION in
 //                 the two `fr` updates of acceleration_grains (main.c:1462-1465, 1490-1493) -- a few hundred
 //                 wall candidates, once per 4000 sub-steps.
-// carry[] = {pft, pff, pf} persists on the device; the sub-step before a table sub-step runs the same pipeline so
-// that the table starts from the right carries (exact whenever that sub-step has a contact of each kind).
+// carry[] = {pft, pff, pf} persists on the device; between diagnostic sub-steps the ordinary sub-step kernel keeps
+// per-tile records of its last contacts (CarryTrack, lbmdem_internal.h) from which k_carry_resolve rebuilds the
+// carries exactly before the next diagnostic sub-step.
 
 __global__ __launch_bounds__(1024) void k_diag_scan(DiagExtra X, const int* __restrict__ offsets, int n, double kt) {
   __shared__ double sFt[1024], sF3[1024];
@@ -498,6 +537,36 @@ __global__ void k_diag_walls(DiagExtra X, Kin in, const double* __restrict__ r, 
   X.carry[0] = pft; X.carry[1] = pff; X.carry[2] = pf;
 }
 
+// The carries as the reference holds them now: per carry the youngest record among the kinds that assign it, in
+// program order (sub-step, then grain contacts < bottom < left < right wall, then grain index = tile).
+__global__ __launch_bounds__(256) void k_carry_resolve(CarryTrack T, long long min_stamp) {
+  __shared__ unsigned long long best[3];
+  if (threadIdx.x < 3) best[threadIdx.x] = 0ull;
+  __syncthreads();
+  unsigned long long b_ft = 0ull, b_ff = 0ull, b_f = 0ull;
+  for (int t = threadIdx.x; t < T.tiles; t += 256) {
+#pragma unroll
+    for (int kind = 0; kind < 4; ++kind) {
+      const long long st = T.stamp[(long)t * 4 + kind];
+      if (st < min_stamp) continue;
+      // 0 = nothing; tiles < 2^24, kinds 2 bits, the rest for the sub-step
+      const unsigned long long key = ((unsigned long long)(st + 1) << 26) | ((unsigned long long)kind << 24) | (unsigned)t;
+      if (key > b_ft) b_ft = key;                                                    // pft: all four
+      if ((kind == CARRY_GRAIN || kind == CARRY_BOTTOM) && key > b_ff) b_ff = key;   // pff
+      if ((kind == CARRY_BOTTOM || kind == CARRY_LEFT) && key > b_f) b_f = key;      // pf
+    }
+  }
+  if (b_ft) atomicMax(&best[0], b_ft);
+  if (b_ff) atomicMax(&best[1], b_ff);
+  if (b_f) atomicMax(&best[2], b_f);
+  __syncthreads();
+  if (threadIdx.x < 3 && best[threadIdx.x] != 0ull) {
+    const unsigned long long key = best[threadIdx.x];
+    const long rec = (long)(key & 0xFFFFFFu) * 4 + (long)((key >> 24) & 3u);
+    T.carry[threadIdx.x] = T.val[2 * rec + (threadIdx.x == 1 ? 1 : 0)];   // pft, pf: ft; pff: f3
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Verlet list
 // ---------------------------------------------------------------------------------------------
@@ -624,6 +693,33 @@ inline int key_bits(int ncells) {
 
 }  // namespace
 
+int carry_track_alloc(CarryTrack& T, int n) {
+  T = CarryTrack{};
+  T.tiles = (n + DEM_TILE - 1) / DEM_TILE;
+  if (T.tiles >= (1 << 24)) return -1;
+  const size_t recs = (size_t)T.tiles * 4;
+  if (hipMalloc((void**)&T.stamp, sizeof(long long) * recs) != hipSuccess) return -1;
+  if (hipMalloc((void**)&T.val, sizeof(double) * (2 * recs + 3)) != hipSuccess) { carry_track_free(T); return -1; }
+  T.carry = T.val + 2 * recs;
+  if (hipMemset(T.stamp, 0xFF, sizeof(long long) * recs) != hipSuccess ||
+      hipMemset(T.val, 0, sizeof(double) * (2 * recs + 3)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    carry_track_free(T);
+    return -1;
+  }
+  return 0;
+}
+
+void carry_track_free(CarryTrack& T) {
+  if (T.stamp) (void)hipFree(T.stamp);
+  if (T.val) (void)hipFree(T.val);
+  T = CarryTrack{};
+}
+
+void launch_carry_resolve(const CarryTrack& T, long long min_stamp, hipStream_t st) {
+  hipLaunchKernelGGL(k_carry_resolve, dim3(1), dim3(256), 0, st, T, min_stamp);
+}
+
+
 int verlet_alloc(VerletDevice& V, int n, double cs, double ox, double oy, double wx, double wy) {
   V = VerletDevice{};
   V.cs = cs; V.ox = ox; V.oy = oy;
@@ -690,17 +786,17 @@ int launch_verlet_rebuild(VerletDevice& V, const Kin& K, const double* r, const 
   return (int)hipGetLastError();
 }
 
-int diag_extra_alloc(DiagExtra& X, int n, long cap) {
+int diag_extra_alloc(DiagExtra& X, int n, long cap, double* carry) {
   X = DiagExtra{};
   double* d = nullptr;
-  const size_t nd = 5 * (size_t)n + 6 * (size_t)cap + 4;
+  const size_t nd = 5 * (size_t)n + 6 * (size_t)cap;
   if (hipMalloc((void**)&d, sizeof(double) * nd) != hipSuccess) return -1;
   X.fr = d;   // from here on diag_extra_free() releases whatever was allocated
   if (hipMemset(d, 0, sizeof(double) * nd) != hipSuccess) { diag_extra_free(X); return -1; }
   X.fr = d; X.ice = d + n; X.slip = d + 2 * (size_t)n; X.rw = d + 3 * (size_t)n; X.a1gc = d + 4 * (size_t)n;
   double* e = d + 5 * (size_t)n;
   X.e_ft = e; X.e_f3 = e + cap; X.e_avt = e + 2 * cap; X.e_av3 = e + 3 * cap; X.e_dslip = e + 4 * cap; X.e_drw = e + 5 * cap;
-  X.carry = e + 6 * cap;
+  X.carry = carry;   // lives with the handle's CarryTrack
   if (hipMalloc((void**)&X.e_touched, (size_t)cap) != hipSuccess) { diag_extra_free(X); return -1; }
   if (hipMemset(X.e_touched, 0, (size_t)cap) != hipSuccess) { diag_extra_free(X); return -1; }
   if (hipMalloc((void**)&X.wlist, sizeof(int) * (4 * (size_t)n + 4)) != hipSuccess) { diag_extra_free(X); return -1; }
@@ -736,8 +832,9 @@ void launch_fill_own(const VerletDevice& V, int n, hipStream_t st) {
 void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const double* m,
                         const double* It, const double* fhf, const VerletDevice& V, double* pout,
                         const DemParams& P, int film, double* diag, const DiagExtra* X, const unsigned char* active,
-                        hipStream_t st) {
+                        const CarryTrack* track, long long stamp, hipStream_t st) {
   const int n = P.n;
+  const CarryTrack T = track ? *track : CarryTrack{};
 #ifdef LBMDEM_AB
   static const int variant = getenv("LBMDEM_DEM_VARIANT") ? atoi(getenv("LBMDEM_DEM_VARIANT")) : 1;
 #else
@@ -747,10 +844,10 @@ void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const do
     const int nbe = (n + DEM_GRAINS - 1) / DEM_GRAINS;
     if (film)
       hipLaunchKernelGGL(k_dem_entries<true>, dim3(nbe), dim3(256), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
-                         V.own, V.wallflags, pout, P, active);
+                         V.own, V.wallflags, pout, P, active, T, stamp);
     else
       hipLaunchKernelGGL(k_dem_entries<false>, dim3(nbe), dim3(256), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
-                         V.own, V.wallflags, pout, P, active);
+                         V.own, V.wallflags, pout, P, active, T, stamp);
     return;
   }
   const int nb = (P.n + 127) / 128;

@@ -69,6 +69,9 @@ struct lbmdem_handle {
   bool diag_always = false;
   DiagExtra dx{};          // buffers of the order-dependent diagnostics fr, ice, slip, rw (allocated on first use)
   bool dx_ready = false;
+  CarryTrack ct{};            // "previous contact" carries: records left by every ordinary sub-step (single-domain handles)
+  long long substep_seq = 0;  // sequence number of the next sub-step (the records' stamps)
+  long long carry_from = 0;   // ct.carry is as of the sub-step before this one; only younger records override it
   bool diag_valid = false; // the last sub-step produced diagnostics
   double* fhf = nullptr;  // [3][n]
   unsigned char* owner = nullptr;
@@ -328,6 +331,10 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
   }
   CREATE_TRY(hipMalloc((void**)&h->owner, n));
   CREATE_TRY(hipMemsetAsync(h->owner, 1, n, h->stream));
+  if (carry_track_alloc(h->ct, n) != 0) {
+    lbmdem_destroy(h);
+    return fail(LBMDEM_ENOMEM, "carry records: hipMalloc failed");
+  }
   if (n < LBMDEM_MINCOV_IDS) {
     CREATE_TRY(hipMalloc((void**)&h->mincov, sizeof(unsigned) * (size_t)L.plane));
     CREATE_TRY(hipMemsetAsync(h->mincov, 0, sizeof(unsigned) * (size_t)L.plane, h->stream));
@@ -423,6 +430,7 @@ int lbmdem_destroy(lbmdem_handle* h) {
   dist_free(h->dd);
   if (h->ovf_host) (void)hipHostFree((void*)h->ovf_host);
   diag_extra_free(h->dx);
+  carry_track_free(h->ct);
   for (hipEvent_t e : h->ev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev1) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -641,20 +649,30 @@ int lbmdem_dem_substep(lbmdem_handle* h) {
   // (with distributed grains the order-dependent diagnostics are not produced: they thread through ALL grains in
   // index order, and write_DEM is a single-GPU output)
   const bool want_table = !h->dist && (h->diag_always || ((h->nbsteps + 1) % 4000 == 0));
-  // fr, ice, slip, rw read "previous contact" carries that thread from sub-step to sub-step (main.c:130-131):
-  // the sub-step before a table sub-step runs the diagnostic pipeline too, to hand over the right carries
-  const bool want_diag = !h->dist && (want_table || ((h->nbsteps + 2) % 4000 == 0));
+  // fr, ice, slip, rw read "previous contact" carries that thread from sub-step to sub-step (main.c:130-131): every
+  // ordinary sub-step leaves per-tile records of its last contacts (CarryTrack), resolved just before a table sub-step
+  const bool want_diag = want_table;
   if (want_diag && !h->dx_ready) {
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (diag_extra_alloc(h->dx, h->n, h->V.cap) != 0) return fail(LBMDEM_ENOMEM, "diagnostic buffers: hipMalloc failed");
+    if (diag_extra_alloc(h->dx, h->n, h->V.cap, h->ct.carry) != 0) return fail(LBMDEM_ENOMEM, "diagnostic buffers: hipMalloc failed");
     h->dx_ready = true;
   }
+  if (want_diag && h->carry_from < h->substep_seq) launch_carry_resolve(h->ct, h->carry_from, h->stream);
+  const CarryTrack* track = (h->dist || want_diag) ? nullptr : &h->ct;
+#ifdef LBMDEM_NO_CARRY_TRACK   /* experiment: shows what the records are for (tests/test_gpu_dem_output.py fails) */
+  track = nullptr;
+#endif
   const DemParams P = dem_params(h);
   launch_dem_substep(h->kin[h->kcur], h->kin[1 - h->kcur], h->r, h->m, h->It, h->fhf, h->V, h->gp,
                      P, film, want_diag ? h->diag : nullptr, want_diag ? &h->dx : nullptr,
-                     h->dist ? h->dd.active : nullptr, h->stream);
+                     h->dist ? h->dd.active : nullptr, track, h->substep_seq,
+                     h->stream);
   if (h->dist && h->dist_poison) launch_dist_poison(h->dd, h->kin[0], h->kin[1], h->n, h->stream);
-  if (want_diag) launch_diag_extra(h->dx, h->kin[h->kcur], h->r, h->V, P, film, h->stream);
+  if (want_diag) {
+    launch_diag_extra(h->dx, h->kin[h->kcur], h->r, h->V, P, film, h->stream);   // leaves the carries as of this sub-step
+    h->carry_from = h->substep_seq + 1;
+  }
+  h->substep_seq++;
   h->diag_valid = want_table;
   HIP_TRY(hipGetLastError());
   h->kcur = 1 - h->kcur;
@@ -1202,8 +1220,12 @@ int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) try {
   memcpy(H.magic, "LBMDEMC4", 8);
   H.lid6 = h->L.lid6;
   H.layout = CKPT_LAYOUT; H.force_mode = h->force_mode; H.diag_always = h->diag_always ? 1 : 0;
-  H.has_carry = h->dx_ready ? 1 : 0;
-  if (h->dx_ready) HIP_TRY(hipMemcpy(H.carry, h->dx.carry, sizeof H.carry, hipMemcpyDeviceToHost));
+  H.has_carry = 1;
+  if (h->carry_from < h->substep_seq) {
+    launch_carry_resolve(h->ct, h->carry_from, h->stream);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  HIP_TRY(hipMemcpy(H.carry, h->ct.carry, sizeof H.carry, hipMemcpyDeviceToHost));
   H.cfg = h->cfg; H.nbsteps = h->nbsteps; H.verlet_ok = h->verlet_ok ? 1 : 0; H.nnbr = off[n]; H.plane = h->L.plane;
   FILE* fp = fopen(path, "wb");
   if (!fp) return fail(LBMDEM_EINVAL, "cannot open '%s' for writing", path);
@@ -1272,13 +1294,11 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
   h->force_mode = H.force_mode;
   h->L.lid6 = H.lid6;
   h->diag_always = H.diag_always != 0;
-  if (H.has_carry) {  // the "previous contact" carries continue across the restart
-    if (diag_extra_alloc(h->dx, n, h->V.cap) != 0 ||
-        hipMemcpy(h->dx.carry, H.carry, sizeof H.carry, hipMemcpyHostToDevice) != hipSuccess) {
+  if (H.has_carry) {  // the "previous contact" carries continue across the restart (no records yet: ct.carry stands)
+    if (hipMemcpy(h->ct.carry, H.carry, sizeof H.carry, hipMemcpyHostToDevice) != hipSuccess) {
       lbmdem_destroy(h);
-      return fail(LBMDEM_ENOMEM, "diagnostic buffers: allocation failed");
+      return fail(LBMDEM_EHIP, "checkpoint: carries not restored");
     }
-    h->dx_ready = true;
   }
   h->nbsteps = H.nbsteps;
   h->verlet_ok = H.verlet_ok != 0;

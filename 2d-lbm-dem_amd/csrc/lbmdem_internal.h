@@ -212,7 +212,26 @@ struct DiagExtra {
   int* wcount;                           // [4]
   double* carry;                         // pft, pff, pf: persist from sub-step to sub-step
 };
-int diag_extra_alloc(DiagExtra& X, int n, long cap);
+int diag_extra_alloc(DiagExtra& X, int n, long cap, double* carry);
+
+// Where the carries come from when the sub-step before was not a diagnostic one: every ordinary sub-step leaves, per
+// tile of DEM_TILE consecutive grains and per kind of contact that assigns a carry (main.c:784-786/1410-1411 grain
+// contacts, 842-843 bottom wall, 919 left wall, 942 right wall), the values of the LAST such contact of the tile in
+// the reference's order, stamped with the sub-step's sequence number. Before a diagnostic sub-step one small kernel
+// picks, per carry, the youngest record (sub-step, then kind in program order, then tile) -- the contact the
+// reference evaluated last, however long ago.
+constexpr int DEM_TILE = 64;
+enum : int { CARRY_GRAIN = 0, CARRY_BOTTOM = 1, CARRY_LEFT = 2, CARRY_RIGHT = 3 };
+struct CarryTrack {
+  long long* stamp;  // [tiles][4] sequence number of the sub-step that wrote the record, -1: none
+  double* val;       // [tiles][4][2] ft, f3
+  double* carry;     // [3] pft, pff, pf
+  int tiles;
+};
+int carry_track_alloc(CarryTrack& T, int n);
+void carry_track_free(CarryTrack& T);
+// carry[] <- the youngest records with stamp >= min_stamp (carry[] itself is younger than anything below that)
+void launch_carry_resolve(const CarryTrack& T, long long min_stamp, hipStream_t st);
 void diag_extra_free(DiagExtra& X);
 // after the DIAG sub-step kernel: carries scanned over the contacts in the reference's order, per-grain sums,
 // then the four wall loops replayed serially
@@ -222,4 +241,4 @@ void launch_fill_own(const VerletDevice& V, int n, hipStream_t st);
 void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const double* m,
                         const double* It, const double* fhf, const VerletDevice& V, double* pout,
                         const DemParams& P, int film, double* diag, const DiagExtra* X, const unsigned char* active,
-                        hipStream_t st);
+                        const CarryTrack* track, long long stamp, hipStream_t st);

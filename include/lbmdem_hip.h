@@ -160,8 +160,9 @@ int lbmdem_write_vtk(lbmdem_handle* h, const char* dir, int nfile);
  * order (main.c:182-197): x1 x2 x3 v1 v2 v3 a1 a2 a3 r m mw It p s f1 f2 ifm fm fr ifr M11 M12 M21 M22 ice
  * slip rw z zz. fr, ice, slip, rw read "previous contact" carries that thread through the reference's serial
  * contact loop and from sub-step to sub-step (pft, pff, pf, ic: main.c:130-131); the library replays them in
- * the reference's order, starting one sub-step before a table sub-step (exact when that sub-step has a contact
- * of each kind, which a packed bed always has; always exact after lbmdem_set_diagnostics(h, 1) from step 0). */
+ * the reference's order in the table sub-steps; the carries such a sub-step starts from are those of the last
+ * contact of each kind however many sub-steps ago (every ordinary sub-step records its last contacts per tile of
+ * grains; single-domain handles). */
 int lbmdem_set_diagnostics(lbmdem_handle* h, int always);
 int lbmdem_download_grain_table(lbmdem_handle* h, double* table30);
 /* write_DEM (main.c:340-438): <dir>/DEM%06d.dat and one line appended to <dir>/stats.data; energies8 (may be

@@ -102,3 +102,40 @@ def test_order_dependent_diagnostics_with_walls_and_film(pkg, po):
         for nme in seen:
             seen[nme] = max(seen[nme], int((to[:, po.COL[nme]] != 0).sum()))
     assert all(v > 0 for v in seen.values()), seen
+
+
+@pytest.mark.parametrize("start", [0, 3, 26, 150, 199, 200, 341, 342, 400])
+def test_carries_are_exact_from_any_sub_step(pkg, po, start):
+    """The "previous contact" carries (pft, pff, pf: main.c:130-131) as the reference holds them after `start` ordinary
+    sub-steps, without the diagnostic pipeline having run before: every sub-step leaves per-tile records of its last
+    grain / bottom / left / right contact, resolved when the first table sub-step comes. In this case the contacts are
+    intermittent: nothing touches in sub-steps 198 and 340, so the table of sub-step 199 / 341 reads carries that
+    are dozens of sub-steps old (which the round-1 scheme -- hand-over from the sub-step before -- got wrong)."""
+    import ctypes
+    c = gu.ALL_CASES["G5_dem_64x48"]
+    r, x1, x2 = gu.inputs_m("G5_dem_64x48")
+    sim = pkg.LbmDem(c["lx"], c["ly"], r, x1, x2)
+    ora = po.Oracle(c["lx"], c["ly"], r, x1, x2)
+    k = gu.mg.dem_initial_kinematics(c)
+    sim.kinematics = k; ora.set_kinematics(k)
+    cols = [po.COL[n] for n in "fr ice slip rw p s z".split()]
+    if start:
+        sim.renderScene(start); ora.steps(start)
+        if start in (199, 341):
+            assert ora.get_grains()[:, po.COL["z"]].sum() == 0      # nothing touched in the sub-step before
+    sim.set_diagnostics(True)
+    for n in (1, 1, 3):
+        sim.renderScene(n); ora.steps(n)
+        tg, to = sim.grain_table(), ora.get_grains()
+        for cc in cols:
+            assert np.array_equal(tg[:, cc], to[:, cc]), (sim.nbsteps, cc)
+    if start in (199, 341):
+        assert (to[:, po.COL["slip"]] != 0).any() or (to[:, po.COL["fr"]] != 0).any()
+    # back to ordinary sub-steps, then a table again: records younger than the last table win, older ones do not
+    sim.set_diagnostics(False)
+    sim.renderScene(17); ora.steps(17)
+    sim.set_diagnostics(True)
+    sim.renderScene(1); ora.steps(1)
+    tg, to = sim.grain_table(), ora.get_grains()
+    for cc in cols:
+        assert np.array_equal(tg[:, cc], to[:, cc]), (sim.nbsteps, cc)
