@@ -21,38 +21,50 @@ namespace {
 constexpr int ERR_LIST_OVERFLOW = 4;   // more grains near a cut than the message capacity
 constexpr int ERR_MERGE_CLASH = 8;     // two ranks produced the same link sum
 
-__global__ void k_dist_classify(DistDevice D, DistGeom Gm, int n, const double* __restrict__ x1,
-                                const double* __restrict__ r, const double* __restrict__ rLB,
-                                unsigned char* __restrict__ owner, int* __restrict__ error) {
+__global__ __launch_bounds__(1024) void k_dist_classify(DistDevice D, DistGeom Gm, int n, const double* __restrict__ x1,
+                                                       const double* __restrict__ r, const double* __restrict__ rLB,
+                                                       unsigned char* __restrict__ owner, int* __restrict__ error) {
+  __shared__ int sCnt[5], sBase[5];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const bool act = D.active[i] != 0;   // integrated during the last period: exact wherever it matters below
-  const double xc = (x1[i] - Gm.Mgx) / Gm.dx;   // the rasteriser's lattice coordinate of the centre (main.c:1009)
+  // the other set of counters (the period before used it; every reader is earlier in the stream) is zeroed for the next period
+  if (blockIdx.x == 0 && threadIdx.x < 8) D.counters_alt[threadIdx.x] = 0;
+  const bool in = i < n;
+  const bool act = in && D.active[i] != 0;   // integrated during the last period: exact wherever it matters below
+  const double xc = in ? (x1[i] - Gm.Mgx) / Gm.dx : 0.0;   // the rasteriser's lattice coordinate of the centre (main.c:1009)
   const bool own = act && (Gm.first || xc >= Gm.lo) && (Gm.last || xc < Gm.hi);
-  owner[i] = own ? 1 : 0;
-  D.active[i] = own ? 1 : 0;           // the margin joins when the neighbours' messages are unpacked
   // grains that may cover nodes of this rank's rows (+ halo) or have links ending there
-  const double reach = r[i] / Gm.dx + 3.0;
+  const double reach = in ? r[i] / Gm.dx + 3.0 : 0.0;
   const bool near = act && xc + reach >= (double)Gm.gx0 && xc - reach <= (double)(Gm.gx0 + Gm.nxl);
-  D.fluidmask[i] = near ? 1 : 0;
-  if (!act) return;
-  auto append = [&](int* list, int which, int cap) {
-    const int k = atomicAdd(&D.counters[which], 1);
+  if (in) {
+    owner[i] = own ? 1 : 0;
+    D.active[i] = own ? 1 : 0;           // the margin joins when the neighbours' messages are unpacked
+    D.fluidmask[i] = near ? 1 : 0;
+  }
+  // one global atomic per workgroup and list (same-address atomics from hundreds of wavefronts serialise at ~30 ns
+  // each on this GPU); the order within a list is immaterial
+  const double ring = in ? rLB[i] + 2.0 : 0.0;   // reduced disc + one node: the grain's ring of boundary links
+  const bool want[5] = {own && Gm.has_lo && xc < Gm.lo + Gm.margin,                      // kinematics to the low neighbour
+                        own && Gm.has_hi && xc >= Gm.hi - Gm.margin,                     // ... the high neighbour
+                        act && !own && Gm.has_lo && xc < Gm.lo && xc + ring >= Gm.lo,    // its link sums reach this rank's rows
+                        act && !own && Gm.has_hi && xc >= Gm.hi && xc - ring < Gm.hi,
+                        near};
+  int pos[5];
+  if (threadIdx.x < 5) sCnt[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 5; ++w) pos[w] = want[w] ? atomicAdd(&sCnt[w], 1) : 0;
+  __syncthreads();
+  if (threadIdx.x < 5 && sCnt[threadIdx.x] > 0)
+    sBase[threadIdx.x] = atomicAdd(&D.counters[threadIdx.x == 4 ? 6 : threadIdx.x], sCnt[threadIdx.x]);
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 5; ++w) {
+    if (!want[w]) continue;
+    int* list = w == 4 ? D.local_list : (w < 2 ? D.send_list[w] : D.strad_list[w - 2]);
+    const int cap = w == 4 ? D.cap_l : (w < 2 ? D.cap_g : D.cap_t);
+    const int k = sBase[w] + pos[w];
     if (k < cap) list[k] = i; else atomicOr(error, ERR_LIST_OVERFLOW);
-  };
-  if (near) append(D.local_list, 6, D.cap_l);
-  if (own && Gm.has_lo && xc < Gm.lo + Gm.margin) append(D.send_list[0], 0, D.cap_g);
-  if (own && Gm.has_hi && xc >= Gm.hi - Gm.margin) append(D.send_list[1], 1, D.cap_g);
-  // a neighbour's grain whose ring of boundary links (reduced disc + one node) reaches into this rank's rows
-  const double ring = rLB[i] + 2.0;
-  if (!own && Gm.has_lo && xc < Gm.lo && xc + ring >= Gm.lo) append(D.strad_list[0], 2, D.cap_t);
-  if (!own && Gm.has_hi && xc >= Gm.hi && xc - ring < Gm.hi) append(D.strad_list[1], 3, D.cap_t);
-}
-
-__global__ void k_clamp_counts(DistDevice D) {
-  if (threadIdx.x < 2 && D.counters[threadIdx.x] > D.cap_g) D.counters[threadIdx.x] = D.cap_g;
-  if (threadIdx.x >= 2 && threadIdx.x < 4 && D.counters[threadIdx.x] > D.cap_t) D.counters[threadIdx.x] = D.cap_t;
-  if (threadIdx.x == 6 && D.counters[6] > D.cap_l) D.counters[6] = D.cap_l;
+  }
 }
 
 // The per-side kernels below take both sides in one launch: blockIdx.y = side (0 low, 1 high); a null buffer
@@ -65,7 +77,7 @@ __global__ void k_pack_kin(DistDevice D, Kin K, Buf2 B) {
   double* __restrict__ buf = B.p[side];
   if (!buf) return;
   const int* __restrict__ list = D.send_list[side];
-  const int cnt = D.counters[side];
+  const int cnt = D.counters[side] < D.cap_g ? D.counters[side] : D.cap_g;   // an overflow is flagged by k_dist_classify
   if (blockIdx.x == 0 && threadIdx.x == 0) buf[0] = (double)cnt;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) {
     const int i = list[k];
@@ -103,7 +115,7 @@ __global__ void k_pack_fhf(DistDevice D, const double* __restrict__ fhf, int n, 
   double* __restrict__ buf = B.p[side];
   if (!buf) return;
   const int* __restrict__ list = D.send_list[side];
-  const int cnt = D.counters[side];
+  const int cnt = D.counters[side] < D.cap_g ? D.counters[side] : D.cap_g;   // an overflow is flagged by k_dist_classify
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) {
     const int i = list[k];
     buf[3 * (long)k] = fhf[i]; buf[3 * (long)k + 1] = fhf[n + i]; buf[3 * (long)k + 2] = fhf[2 * (long)n + i];
@@ -170,26 +182,27 @@ int dist_alloc(DistDevice& D, int n, int cap_g, int cap_t, int cap_l) {
     A((void**)&D.recv_ids[s], sizeof(int) * cap_g);
   }
   A((void**)&D.local_list, sizeof(int) * cap_l);
-  A((void**)&D.counters, sizeof(int) * 8);
+  A((void**)&D.counters, sizeof(int) * 16);   // two sets of 8, used by alternate periods
   if (e != hipSuccess) return -1;
+  D.counters_alt = D.counters + 8;
   if (hipMemset(D.active, 1, n) != hipSuccess || hipMemset(D.fluidmask, 1, n) != hipSuccess ||
-      hipMemset(D.counters, 0, sizeof(int) * 8) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+      hipMemset(D.counters, 0, sizeof(int) * 16) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
     return -1;
   return 0;
 }
 
 void dist_free(DistDevice& D) {
   void* ps[] = {D.active, D.fluidmask, D.send_list[0], D.send_list[1], D.strad_list[0], D.strad_list[1],
-                D.recv_ids[0], D.recv_ids[1], D.counters, D.local_list};
+                D.recv_ids[0], D.recv_ids[1], D.counters < D.counters_alt ? D.counters : D.counters_alt, D.local_list};
   for (void* p : ps) if (p) (void)hipFree(p);
   D = DistDevice{};
 }
 
 void launch_dist_classify(const DistDevice& D, const DistGeom& Gm, int n, const double* x1, const double* r,
                           const double* rLB, unsigned char* owner, int* error, hipStream_t st) {
-  (void)hipMemsetAsync(D.counters, 0, sizeof(int) * 8, st);   // (the received counts [4], [5] are SET by the next unpack)
-  hipLaunchKernelGGL(k_dist_classify, dim3((n + 255) / 256), dim3(256), 0, st, D, Gm, n, x1, r, rLB, owner, error);
-  hipLaunchKernelGGL(k_clamp_counts, dim3(1), dim3(64), 0, st, D);
+  // D.counters is all zero here: the classification of the period before cleared it (the received counts [4], [5] are
+  // SET by the next unpack). The counts may exceed the capacities (flagged): every reader clamps.
+  hipLaunchKernelGGL(k_dist_classify, dim3((n + 1023) / 1024), dim3(1024), 0, st, D, Gm, n, x1, r, rLB, owner, error);
 }
 
 void launch_dist_pack_kin(const DistDevice& D, const Kin& K, double* lo, double* hi, hipStream_t st) {

@@ -234,11 +234,11 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
                              double* __restrict__ orbl0, double* __restrict__ pk,
                              unsigned char* __restrict__ touched, const unsigned char* __restrict__ mask,
                              unsigned* __restrict__ mincov, unsigned epoch, const int* __restrict__ list,
-                             const int* __restrict__ list_count) {
+                             const int* __restrict__ list_count, int list_cap) {
   const int lane = threadIdx.x & 63;
   int i = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (list) {                    // strip decomposition: only the grains that can reach this rank's rows
-    if (i >= *list_count) return;
+    if (i >= *list_count || i >= list_cap) return;   // (an overflowing list is flagged by its producer)
     i = list[i];
   }
   if (i >= n) return;
@@ -1275,6 +1275,9 @@ constexpr unsigned long long M_YDIR = 0x8888888888888888ull;  // q = 4, 8 (ex = 
 
 constexpr int FT_WAVES = 4;  // waves per workgroup of k_forces_table
 
+// FT_PACK takes both neighbours in one launch: blockIdx.y = side (0 low, 1 high); a null buffer skips the side
+struct PackSides { const int* list[2]; const int* count[2]; double* buf[2]; };
+
 template <int GW, int PASSES>
 __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __restrict__ f, const int* __restrict__ obst,
                                                                 LatticeView L, GrainFluidView G, ForceSlots S, int cap1,
@@ -1283,9 +1286,16 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
                                                                 unsigned char* __restrict__ owner, int mode,
                                                                 const int* __restrict__ list,
                                                                 const int* __restrict__ list_count,
-                                                                double* __restrict__ packbuf,
-                                                                const unsigned char* __restrict__ mask) {
+                                                                PackSides sides,
+                                                                const unsigned char* __restrict__ mask, int list_cap) {
   extern __shared__ double sDyn[];
+  double* __restrict__ packbuf = nullptr;
+  if (mode == FT_PACK) {
+    packbuf = sides.buf[blockIdx.y];
+    if (!packbuf) return;
+    list = sides.list[blockIdx.y];
+    list_count = sides.count[blockIdx.y];
+  }
   // per grain of the workgroup: addends of fhf1 [cap1] | fhf2 [cap1] | fhf3 [cap3]
   // then per wave: the bitmap [nw64] and the three per-word prefix counts [3][nw64]; then [FT_WAVES * GW][4] counts
   const int per_grain = 2 * cap1 + cap3;
@@ -1298,7 +1308,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
   const int lane = threadIdx.x & 63;
   const int gslot0 = wave * GW;                       // this wave's grains within the workgroup
   const int g0 = (blockIdx.x * FT_WAVES + wave) * GW; // position in the list (or the grain index itself without a list)
-  const int ntodo = list ? *list_count : L.n;
+  const int ntodo = list ? (*list_count < list_cap ? *list_count : list_cap) : L.n;   // (an overflowing list is flagged by its producer)
   auto grain_at = [&](int pos) { return list ? list[pos] : pos; };
   const int own_lo = L.gx0 + L.xo0, own_hi = L.gx0 + L.xo1;  // rows whose links this rank produces: [own_lo, own_hi)
   const bool consume = mode != FT_PACK;
@@ -1865,7 +1875,7 @@ void launch_obst_paint(int* obst, const LatticeView& L, int n, const double* x1,
                        const int* list_count, int list_cap, hipStream_t st) {
   const long threads = (long)(list ? list_cap : n) * 64;
   hipLaunchKernelGGL(k_obst_paint, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, obst, L, n, x1, x2, r,
-                     rLB, v1, v2, v3, xc, yc, r2, rbl0, pk, touched, mask, mincov, epoch, list, list_count);
+                     rLB, v1, v2, v3, xc, yc, r2, rbl0, pk, touched, mask, mincov, epoch, list, list_count, list_cap);
 }
 
 void launch_slots_clear(const ForceSlots& S, int n, hipStream_t st) {
@@ -1986,25 +1996,28 @@ static void launch_forces_table_t(const double* f, const int* obst, const Lattic
   const int ntodo = S.local_list ? S.local_cap : L.n;   // strips: the compacted list of local grains bounds the launch
   hipLaunchKernelGGL((k_forces_table<GW, PASSES>), dim3((ntodo + per_block - 1) / per_block), dim3(64 * FT_WAVES), lds, st,
                      f, obst, L, G, S, cap1, cap3, nw64, scale12, scale3, fhf, owner, fast ? (int)FT_FAST : (int)FT_CONSUME, S.local_list,
-                     S.local_count, (double*)nullptr, S.mask);
+                     S.local_count, PackSides{}, S.mask, S.local_cap);
   const int grid = L.n < 256 ? L.n : 256;
   hipLaunchKernelGGL(k_forces_gather_queue, dim3(grid), dim3(64), 0, st, f, obst, L, G, S, scale12, scale3, fhf);
 }
 
 void launch_forces_table_pack(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
-                              const ForceSlots& S, const int* list, const int* list_count, int cap, double* buf,
-                              hipStream_t st) {
+                              const ForceSlots& S, const int* const list[2], const int* const list_count[2], int cap,
+                              double* const buf[2], hipStream_t st) {
   const int HB = S.hb, B = 2 * HB + 1;
   const int nw64 = (B * B * 8 + 63) / 64;
   const int cap1 = (4 * S.spd + 2 * B + 7) & ~7, cap3 = (8 * S.spd + 4 * B + 7) & ~7;
   const size_t lds = (size_t)FT_WAVES * (2 * cap1 + cap3) * 8 + (size_t)FT_WAVES * nw64 * 24 + (size_t)FT_WAVES * 20;
-  const int blocks = (cap + FT_WAVES - 1) / FT_WAVES;   // the list length is only known on the device
+  const int blocks = (cap + FT_WAVES - 1) / FT_WAVES;   // the list lengths are only known on the device
+  const PackSides P{{list[0], list[1]}, {list_count[0], list_count[1]}, {buf[0], buf[1]}};
   if (S.spd <= 32)
-    hipLaunchKernelGGL((k_forces_table<1, 2>), dim3(blocks), dim3(64 * FT_WAVES), lds, st, f, obst, L, G, S, cap1, cap3, nw64,
-                       0.0, 0.0, (double*)nullptr, (unsigned char*)nullptr, (int)FT_PACK, list, list_count, buf, S.mask);
+    hipLaunchKernelGGL((k_forces_table<1, 2>), dim3(blocks, 2), dim3(64 * FT_WAVES), lds, st, f, obst, L, G, S, cap1, cap3,
+                       nw64, 0.0, 0.0, (double*)nullptr, (unsigned char*)nullptr, (int)FT_PACK, (const int*)nullptr,
+                       (const int*)nullptr, P, S.mask, cap);
   else
-    hipLaunchKernelGGL((k_forces_table<1, 4>), dim3(blocks), dim3(64 * FT_WAVES), lds, st, f, obst, L, G, S, cap1, cap3, nw64,
-                       0.0, 0.0, (double*)nullptr, (unsigned char*)nullptr, (int)FT_PACK, list, list_count, buf, S.mask);
+    hipLaunchKernelGGL((k_forces_table<1, 4>), dim3(blocks, 2), dim3(64 * FT_WAVES), lds, st, f, obst, L, G, S, cap1, cap3,
+                       nw64, 0.0, 0.0, (double*)nullptr, (unsigned char*)nullptr, (int)FT_PACK, (const int*)nullptr,
+                       (const int*)nullptr, P, S.mask, cap);
 }
 
 void launch_forces_slots(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,

@@ -1505,6 +1505,8 @@ int lbmdem_dist_begin_period(lbmdem_handle* h) {
   Gm.lo = (double)c.x_begin; Gm.hi = (double)c.x_end; Gm.margin = (double)h->dist_margin; Gm.dx = c.dx; Gm.Mgx = c.Mgx;
   Gm.has_lo = c.x_begin > 0; Gm.has_hi = c.x_end < c.lx; Gm.first = c.x_begin == 0; Gm.last = c.x_end == c.lx;
   Gm.gx0 = h->L.gx0; Gm.nxl = h->L.nxl;
+  { int* t = h->dd.counters; h->dd.counters = h->dd.counters_alt; h->dd.counters_alt = t; }   // the set cleared last period
+  h->fs.local_count = h->dd.counters + 6;
   launch_dist_classify(h->dd, Gm, h->n, h->kin[h->kcur].x1, h->r, h->rLB, h->owner, h->fs.error, h->stream);
   HIP_TRY(hipGetLastError());
   h->dist_period_open = true;
@@ -1520,11 +1522,12 @@ int lbmdem_dist_pack2(lbmdem_handle* h, int kind, void* buf_lo, void* buf_hi) {
   else if (kind == LBMDEM_MSG_TABLES) {
     CHECK_NOT_SPLIT(h);
     if (!h->slots_valid) return fail(LBMDEM_EINVAL, "table messages are packed between collide_stream and forces_fluid");
-    void* bufs[2] = {buf_lo, buf_hi};
-    for (int side = 0; side < 2; ++side)
-      if (bufs[side])
-        launch_forces_table_pack(h->f[h->fcur], h->obst[h->ocur], h->L, gview(h), h->fs, h->dd.strad_list[side],
-                                 h->dd.counters + 2 + side, h->dd.cap_t, (double*)bufs[side], h->stream);
+    // both neighbours in one launch (a null buffer skips the side)
+    double* const bufs[2] = {(double*)buf_lo, (double*)buf_hi};
+    const int* const lists[2] = {h->dd.strad_list[0], h->dd.strad_list[1]};
+    const int* const counts[2] = {h->dd.counters + 2, h->dd.counters + 3};
+    launch_forces_table_pack(h->f[h->fcur], h->obst[h->ocur], h->L, gview(h), h->fs, lists, counts, h->dd.cap_t, bufs,
+                             h->stream);
   } else return fail(LBMDEM_EINVAL, "unknown message kind");
   HIP_TRY(hipGetLastError());
   return LBMDEM_OK;

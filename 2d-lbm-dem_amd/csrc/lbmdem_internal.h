@@ -119,8 +119,8 @@ void launch_forces_slots(const double* f, const int* obst, const LatticeView& L,
 // strip decomposition: this rank's part of the tables of the listed grains (owned by a neighbour rank), completed
 // and written as {count; count x {id, 8 * spd slots}} to a message buffer
 void launch_forces_table_pack(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
-                              const ForceSlots& S, const int* list, const int* list_count, int cap, double* buf,
-                              hipStream_t st);
+                              const ForceSlots& S, const int* const list[2], const int* const list_count[2], int cap,
+                              double* const buf[2], hipStream_t st);
 
 // dist_kernels.hip -- strip decomposition with the grains distributed over the ranks (strips.py)
 struct DistDevice {
@@ -130,7 +130,8 @@ struct DistDevice {
   int* strad_list[2];        // [cap_t] grains owned by the low / high neighbour whose link ring reaches this rank's rows
   int* recv_ids[2];          // [cap_g] ids of the last kinematics message from the low / high neighbour
   int* local_list;           // [cap_l] the grains of fluidmask, compacted (launch bound of the per-grain kernels)
-  int* counters;             // [8] send x2, straddler x2, received x2, local
+  int* counters;             // [8] send x2, straddler x2, received x2, local, ticket -- this period's set
+  int* counters_alt;         // the other set: zeroed during this period, used by the next (the host swaps the two)
   int cap_g, cap_t, cap_l;
 };
 struct DistGeom { double lo, hi, margin, dx, Mgx; int has_lo, has_hi, first, last, gx0, nxl; };

@@ -58,6 +58,7 @@ for rank in sorted({0, world // 2}):
     out[f"rank{rank}_host_enqueue_ms_per_step"] = round(1e3 * t_enq / 100, 4)
     a, g = R.b.sim.force_stats()
     out[f"rank{rank}_alone_ms_per_step"] = round(ms, 4)
+    out[f"rank{rank}_forces_from_table_and_gathered"] = [int(a), int(g)]
     out[f"rank{rank}_messages_doubles"] = {k: R.b.sim.dist_message_doubles(v) for k, v in (("kin", 0), ("fhf", 1), ("tables", 2))}
 # transport latency floor: RCCL send+recv to self, grouped, on a side stream (one-rank group)
 import torch.distributed as dist

@@ -13,5 +13,6 @@ for r in rows[a:b]:
     tot[n][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); tot[n][1] += 1
 out = {"busy_us_per_period": round(sum(v[0] for v in tot.values()) / 100 / 1e3, 1),
        "launches_per_period": round(sum(v[1] for v in tot.values()) / 100, 1),
-       "kernels_us_per_period": {n: round(d / 100 / 1e3, 1) for n, (d, c) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:14]}}
+       "kernels_us_per_period": {n: round(d / 100 / 1e3, 1) for n, (d, c) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:16]},
+       "kernels_launches_per_period": {n: round(c / 100, 2) for n, (d, c) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:16]}}
 print(json.dumps(out))
