@@ -803,7 +803,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
                                                   const int* __restrict__ ob_old,
                                                   const int* __restrict__ ob_new, LatticeView L,
                                                   GrainFluidView G, ForceSlots S, int nstrips, int nwork,
-                                                  int xcd_remap, int seg_rows) {
+                                                  int xcd_remap, int seg_rows, int seg_stride) {
   const int lane = threadIdx.x & 63;
   int blk = blockIdx.x;
   if (xcd_remap) {  // XCD k (blocks b % 8 == k) walks the k-th contiguous eighth of the work list
@@ -822,7 +822,9 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
   // rows per wave: the template value, or (LX == 0) a run-time value chosen so that one round of resident
   // waves covers the lattice
   const int rows_per_wave = LX > 0 ? LX : seg_rows;
-  const int xs = L.xo0 + seg * rows_per_wave;
+  // segment k starts seg_stride rows after segment k-1: = rows_per_wave for a contiguous row range; larger when one
+  // launch covers the two edge-row ranges of a strip
+  const int xs = L.xo0 + seg * seg_stride;
   const int xe = xs + rows_per_wave < L.xo1 ? xs + rows_per_wave : L.xo1;
 
   // Software pipeline. In iteration x (producing row x) the wave issues, in this order,
@@ -1941,7 +1943,22 @@ static void launch_march(const double* fin, double* fout, const int* obst_old, c
   int grid = (nwork + 3) / 4;
   if (remap) grid = ((grid + 7) / 8) * 8;
   hipLaunchKernelGGL((k_cs_march<LX, MINW, WW>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, L, G,
-                     S, nstrips, nwork, remap, seg_rows);
+                     S, nstrips, nwork, remap, seg_rows, seg_rows);
+}
+
+// Two row ranges of equal width w <= 32 (the rows next to the two cuts of a strip) in ONE launch: two segments of w rows,
+// the second `stride` rows after the first.
+static void launch_march_two_ranges(const double* fin, double* fout, const int* obst_old, const int* obst_new,
+                                    const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, int lo0, int w,
+                                    int hi0, hipStream_t st) {
+  constexpr int WW = 62;
+  LatticeView Ls = L;
+  Ls.xo0 = lo0; Ls.xo1 = hi0 + w;
+  const int nstrips = (L.ly + WW - 1) / WW;
+  const int nwork = nstrips * 2;
+  const int grid = (nwork + 3) / 4;
+  hipLaunchKernelGGL((k_cs_march<0, 2, WW>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, Ls, G, S, nstrips,
+                     nwork, 0, w, hi0 - lo0);
 }
 
 // The marching kernel assumes reductionR < 1 (always true in the reference); other configurations run the
@@ -1973,6 +1990,22 @@ void launch_collide_stream(const double* fin, double* fout, const int* obst_old,
   }
   else launch_cs<4, 64>(fin, fout, obst_old, obst_new, L, G, 0, st);
 #endif
+}
+
+void launch_collide_stream_edges(const double* fin, double* fout, const int* obst_old, const int* obst_new,
+                                 const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, int lo0, int lo1,
+                                 int hi0, int hi1, hipStream_t st) {
+  bool one_launch = lo1 > lo0 && hi1 > hi0 && lo1 - lo0 == hi1 - hi0 && lo1 - lo0 <= 32 && lo1 <= hi0 && L.reduced_lt1;
+#ifdef LBMDEM_AB
+  if (getenv("LBMDEM_CS_VARIANT")) one_launch = false;   // an experiment with another fused kernel
+#endif
+  if (one_launch) {
+    launch_march_two_ranges(fin, fout, obst_old, obst_new, L, G, S, lo0, lo1 - lo0, hi0, st);
+    return;
+  }
+  LatticeView Ls = L;
+  if (lo1 > lo0) { Ls.xo0 = lo0; Ls.xo1 = lo1; launch_collide_stream(fin, fout, obst_old, obst_new, Ls, G, S, st); }
+  if (hi1 > hi0) { Ls.xo0 = hi0; Ls.xo1 = hi1; launch_collide_stream(fin, fout, obst_old, obst_new, Ls, G, S, st); }
 }
 
 void launch_forces_parity(const double* f, const int* obst, const LatticeView& L,

@@ -518,16 +518,9 @@ int lbmdem_collide_stream_part(lbmdem_handle* h, int part) try {
     hipEvent_t e1 = nullptr;  // the interval of this step's fused kernels ends in INTERIOR
     int rc = prof_begin(h, &e1);
     if (rc != LBMDEM_OK) return rc;
-    LatticeView Ls = L;
     h->cs_slots = slots_for_launch(h);
-    if (lo_end > L.xo0) {
-      Ls.xo0 = L.xo0; Ls.xo1 = lo_end;
-      launch_collide_stream(h->cs_fin, h->f[1 - h->fcur], h->cs_ob_old, h->cs_ob_new, Ls, gview(h), h->cs_slots, h->stream);
-    }
-    if (L.xo1 > hi_begin) {
-      Ls.xo0 = hi_begin; Ls.xo1 = L.xo1;
-      launch_collide_stream(h->cs_fin, h->f[1 - h->fcur], h->cs_ob_old, h->cs_ob_new, Ls, gview(h), h->cs_slots, h->stream);
-    }
+    launch_collide_stream_edges(h->cs_fin, h->f[1 - h->fcur], h->cs_ob_old, h->cs_ob_new, L, gview(h), h->cs_slots, L.xo0,
+                                lo_end, hi_begin, L.xo1, h->stream);
     HIP_TRY(hipGetLastError());
     h->fcur = 1 - h->fcur;
     if (h->obst_pending) { h->ocur = 1 - h->ocur; h->obst_pending = false; }

@@ -109,6 +109,11 @@ void launch_obst_paint(int* obst, const LatticeView& L, int n, const double* x1,
                        const int* list_count, int list_cap, hipStream_t st);
 void launch_collide_stream(const double* fin, double* fout, const int* obst_old, const int* obst_new,
                            const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, hipStream_t st);
+// the two edge-row ranges [lo0, lo1) and [hi0, hi1) of a strip (either may be empty): one launch when they are equally
+// wide (two segments), else one launch_collide_stream each
+void launch_collide_stream_edges(const double* fin, double* fout, const int* obst_old, const int* obst_new,
+                                 const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, int lo0, int lo1,
+                                 int hi0, int hi1, hipStream_t st);
 // true when launch_collide_stream(..., S) with S.tab != nullptr fills the table (the marching kernel does)
 bool collide_stream_fills_slots(const LatticeView& L);
 void launch_slots_clear(const ForceSlots& S, int n, hipStream_t st);
