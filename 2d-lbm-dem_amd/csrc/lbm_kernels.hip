@@ -874,6 +874,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
   auto grain_rec = [&](int id) { return load_gp(G, (id < 0 || id >= L.n) ? 0 : id); };
 
   double Fm[9], F0[9], Fp[9], bufA[9], bufB[9];
+
   Ids3 iA = load_ids(ob_new, L, xs - 2, y);  // row x-2 (only needed for act of row x-1)
   Ids3 iB = load_ids(ob_new, L, xs - 1, y);  // row x-1
   Ids3 iC = load_ids(ob_new, L, xs, y);      // row x
@@ -953,7 +954,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
       const bool deep = deep_y && gx >= 2 && gx <= L.lx - 3;
       // (a) everything but the interpolated bounce-back links: computed and stored
       unsigned ibb = 0, nnm = 0, hzm = 0;
-      if (writer) {
+      if (writer && x < xe) {
         if (deep) classify_store_row<false>(C, L, gx, y, fout, node, ibb, nnm, hzm);
         else classify_store_row<true>(C, L, gx, y, fout, node, ibb, nnm, hzm);
       }
@@ -1024,9 +1025,15 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
     actm = act0; act0 = actp;
   };
 
+  // Both halves run unconditionally (a row >= xe stores nothing): with `if (x + 1 < xe)` around the second one the
+  // compiler cannot count its loads as younger than the first half's when it places s_waitcnt at the loop head, and
+  // waits for more of the pipeline than the data it needs (vmcnt(4) instead of vmcnt(9); 1.5-2 % of the kernel).
   for (int x = xs; x < xe; x += 2) {
     iterate(x, bufA);
-    if (x + 1 < xe) iterate(x + 1, bufB);
+#ifdef MARCH_COND2   /* experiment builds: the former form */
+    if (x + 1 < xe)
+#endif
+    iterate(x + 1, bufB);
   }
 }
 
@@ -1910,12 +1917,18 @@ static int cs_variant() {
 #endif
 
 // rows per wave of the marching kernel: 32 (the measured optimum on a full lattice) unless that leaves fewer than two
-// rounds of resident waves, then as short as 8
+// rounds of resident waves; then the largest even count (the kernel works through its rows in pairs) that still gives
+// two full rounds, as short as 8. Measured on 508 rows x 66 windows (the interior of a 512-row strip), fused kernel
+// in us for 4 / 6 / 8 / 10 / 12 / 14 / 16 / 18 / 20 rows: 146 / 144 / 138 / 150 / 157 / 169 / 145 / 144 / 156 -- a
+// little more than a whole number of rounds is good, a little less than the next one is bad.
 static int march_segment_rows(int rows, int nstrips) {
   const int resident = 256 * 2 * 4;
   int nseg = (2 * resident + nstrips - 1) / nstrips;
   if (nseg < 1) nseg = 1;
-  int seg_rows = (rows + nseg - 1) / nseg;
+  int seg_rows = rows / nseg;
+#ifndef MARCH_COND2
+  seg_rows &= ~1;
+#endif
   if (seg_rows < 8) seg_rows = 8;
   if (seg_rows > 32) seg_rows = 32;
   return seg_rows;
@@ -1968,20 +1981,22 @@ bool collide_stream_fills_slots(const LatticeView& L) { return L.reduced_lt1 != 
 void launch_collide_stream(const double* fin, double* fout, const int* obst_old, const int* obst_new,
                            const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, hipStream_t st) {
 #ifdef LBMDEM_AB
-  int v = cs_variant();
-  const int remap = (v >> 3) & 1;
-  if (!L.reduced_lt1 && (v & ~8) >= 16) v = 1;
-  switch (v & ~8) {
-    case 0: launch_cs<8, 64>(fin, fout, obst_old, obst_new, L, G, remap, st); return;
-    case 1: launch_cs<4, 64>(fin, fout, obst_old, obst_new, L, G, remap, st); return;
-    case 2: launch_cs<4, 128>(fin, fout, obst_old, obst_new, L, G, remap, st); return;
-    case 16: launch_march<16, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;
-    case 19: launch_march<64, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;
-    case 20: launch_march<0, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;  // one balanced round
-    case 21: launch_march<32, 2, 56>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;  // 64-byte aligned stores
-    default: launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;
+  if (getenv("LBMDEM_CS_VARIANT")) {   // experiments with other kernel shapes; without the variable: the product's choice
+    int v = cs_variant();
+    const int remap = (v >> 3) & 1;
+    if (!L.reduced_lt1 && (v & ~8) >= 16) v = 1;
+    switch (v & ~8) {
+      case 0: launch_cs<8, 64>(fin, fout, obst_old, obst_new, L, G, remap, st); return;
+      case 1: launch_cs<4, 64>(fin, fout, obst_old, obst_new, L, G, remap, st); return;
+      case 2: launch_cs<4, 128>(fin, fout, obst_old, obst_new, L, G, remap, st); return;
+      case 16: launch_march<16, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;
+      case 19: launch_march<64, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;
+      case 20: launch_march<0, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;  // one balanced round
+      case 21: launch_march<32, 2, 56>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;  // 64-byte aligned stores
+      default: launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;
+    }
   }
-#else
+#endif
   if (L.reduced_lt1) {
     if (march_segment_rows(L.xo1 - L.xo0, (L.ly + 61) / 62) >= 32)
       launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, S, /*xcd remap*/ 1, st);
@@ -1989,7 +2004,6 @@ void launch_collide_stream(const double* fin, double* fout, const int* obst_old,
       launch_march<0, 2>(fin, fout, obst_old, obst_new, L, G, S, /*xcd remap*/ 1, st);
   }
   else launch_cs<4, 64>(fin, fout, obst_old, obst_new, L, G, 0, st);
-#endif
 }
 
 void launch_collide_stream_edges(const double* fin, double* fout, const int* obst_old, const int* obst_new,
