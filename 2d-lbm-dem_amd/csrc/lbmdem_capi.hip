@@ -1865,5 +1865,61 @@ int lbmdem_comm_selftest(lbmdem_comm* c, int doubles) {
   return LBMDEM_OK;
 }
 
+/* Measurement helper: what one exchange on the step's critical path costs on this stack. `iters` times
+ * { small kernel on a main stream; ready event -> side stream; grouped send + receive of `doubles` values to this rank
+ * itself; done event -> main stream; small kernel on the main stream }, timed with events on the main stream, and the
+ * same loop without the exchange. us[0] = mean with, us[1] = mean without the exchange. */
+int lbmdem_comm_exchange_probe(lbmdem_comm* c, int doubles, int iters, double* us) {
+  if (!c || doubles < 1 || iters < 1 || !us) return fail(LBMDEM_EINVAL, "bad lbmdem_comm_exchange_probe arguments");
+  HIP_TRY(hipSetDevice(c->device));
+  double *a = nullptr, *b = nullptr;
+  hipStream_t main = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipMalloc((void**)&a, sizeof(double) * doubles);
+  if (e == hipSuccess) e = hipMalloc((void**)&b, sizeof(double) * doubles);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&main, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  ncclResult_t r = ncclSuccess;
+  const int lane = LANE_TAB;
+  for (int with = 1; with >= 0 && e == hipSuccess && r == ncclSuccess; --with) {
+    for (int pass = 0; pass < 2 && e == hipSuccess && r == ncclSuccess; ++pass) {   // pass 0 warms up
+      const int n = pass == 0 ? 10 : iters;
+      if (pass == 1) e = hipEventRecord(e0, main);
+      for (int k = 0; k < n && e == hipSuccess && r == ncclSuccess; ++k) {
+        e = hipMemsetAsync(a, 0, 8, main);                       // the producer of the message
+        if (with) {
+          if (e == hipSuccess) e = hipEventRecord(c->ready[lane], main);
+          if (e == hipSuccess) e = hipStreamWaitEvent(c->side[lane], c->ready[lane], 0);
+          if (e == hipSuccess) {
+            r = g_rccl.GroupStart();
+            if (r == ncclSuccess) r = g_rccl.Send(a, (size_t)doubles, ncclDouble, c->rank, c->nccl[lane], c->side[lane]);
+            if (r == ncclSuccess) r = g_rccl.Recv(b, (size_t)doubles, ncclDouble, c->rank, c->nccl[lane], c->side[lane]);
+            const ncclResult_t r2 = g_rccl.GroupEnd();
+            if (r == ncclSuccess) r = r2;
+          }
+          if (e == hipSuccess && r == ncclSuccess) e = hipEventRecord(c->done[lane], c->side[lane]);
+          if (e == hipSuccess && r == ncclSuccess) e = hipStreamWaitEvent(main, c->done[lane], 0);
+        }
+        if (e == hipSuccess && r == ncclSuccess) e = hipMemsetAsync(b, 0, 8, main);   // its consumer
+      }
+      if (pass == 1 && e == hipSuccess && r == ncclSuccess) {
+        e = hipEventRecord(e1, main);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        us[with ? 0 : 1] = 1e3 * ms / iters;
+      } else if (e == hipSuccess) e = hipStreamSynchronize(main);
+    }
+  }
+  if (main) { (void)hipStreamSynchronize(main); (void)hipStreamDestroy(main); }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(a); (void)hipFree(b);
+  if (r != ncclSuccess) return fail(LBMDEM_EHIP, "RCCL self send/recv failed: %s", g_rccl.GetErrorString(r));
+  HIP_TRY(e);
+  return LBMDEM_OK;
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

@@ -60,26 +60,19 @@ for rank in sorted({0, world // 2}):
     out[f"rank{rank}_alone_ms_per_step"] = round(ms, 4)
     out[f"rank{rank}_forces_from_table_and_gathered"] = [int(a), int(g)]
     out[f"rank{rank}_messages_doubles"] = {k: R.b.sim.dist_message_doubles(v) for k, v in (("kin", 0), ("fhf", 1), ("tables", 2))}
-# transport latency floor: RCCL send+recv to self, grouped, on a side stream (one-rank group)
-import torch.distributed as dist
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
-comm = strips.TorchComm(dist)
+# what one exchange on the critical path costs: the library's own RCCL transport (as lbmdem_comm_lbm_step uses it), one-rank
+# communicator, producer kernel -> event -> side stream -> grouped send + receive to self -> event -> consumer kernel
+comm = pkg.Comm(pkg.comm_unique_id(), 0, 1, 0)
 lat = {}
 for name, nd in (("tables", runners[world // 2].b.sim.dist_message_doubles(2)), ("fhf", runners[world // 2].b.sim.dist_message_doubles(1))):
-    a = torch.zeros(nd, dtype=torch.float64, device="cuda"); b = torch.zeros_like(a)
-    ops = [(0, a, b)]
-    for _ in range(20): comm.exchange(ops, lane=name)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(200): comm.exchange(ops, lane=name)
-    torch.cuda.synchronize()
-    lat[name] = round(1e6 * (time.perf_counter() - t0) / 200, 1)
-dist.destroy_process_group()
+    w, wo = comm.exchange_probe(nd, 300)
+    lat[name] = round(w - wo, 1)
+    lat[name + "_loop_with_without_us"] = [round(w, 1), round(wo, 1)]
 out["rccl_self_exchange_us"] = lat
 mid = out[f"rank{world // 2}_alone_ms_per_step"]
 out["projected_ms_per_step"] = round(mid + 1e-3 * (lat["tables"] + lat["fhf"]), 4)
 out["projected_speedup"] = round(out["one_gpu_ms_per_step"] / out["projected_ms_per_step"], 2)
 out["note"] = ("projection = an interior rank alone + the two exchanges on its critical path (tables, forces) at the measured "
-               "self-exchange time; the kinematics and f-halo messages overlap the fluid kernels")
+               "self-exchange time (C transport, one-rank communicator: event hand-overs + RCCL kernel, no wire); the kinematics and "
+               "f-halo messages overlap the fluid kernels")
 print(json.dumps(out))
