@@ -228,10 +228,11 @@ class Comm:
         _chk(self._L.lbmdem_comm_selftest(self._c, int(doubles)))
 
     def exchange_probe(self, doubles, iters=200):
-        """(us with, us without) one critical-path exchange of `doubles` values to this rank itself."""
-        out = (C.c_double * 2)()
+        """(us with the exchange on a side stream, us without it, us with it in line on the main stream): one
+        critical-path exchange of `doubles` values to this rank itself."""
+        out = (C.c_double * 3)()
         _chk(self._L.lbmdem_comm_exchange_probe(self._c, int(doubles), int(iters), out))
-        return float(out[0]), float(out[1])
+        return float(out[0]), float(out[1]), float(out[2])
 
 
 class LbmDem:

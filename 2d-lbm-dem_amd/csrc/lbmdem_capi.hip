@@ -1714,6 +1714,21 @@ static int comm_begin(lbmdem_comm* c, hipStream_t main, int lane, int kind, cons
   HIP_TRY(hipEventRecord(c->done[lane], c->side[lane]));
   return LBMDEM_OK;
 }
+// A transfer nothing can overlap with (link-sum tables, forces: the next kernel needs them) simply takes its place in the
+// main stream: measured with lbmdem_comm_exchange_probe, the two event hand-overs of the side-stream form cost ~25 us
+// more than the transfer itself (~10 us).
+static int comm_inline(lbmdem_comm* c, hipStream_t main, int lane, int kind, const bool has[2]) {
+  if (!has[0] && !has[1]) return LBMDEM_OK;
+  NCCL_TRY(g_rccl.GroupStart());
+  for (int s = 0; s < 2; ++s) {
+    if (!has[s]) continue;
+    const int peer = s == 0 ? c->rank - 1 : c->rank + 1;
+    NCCL_TRY(g_rccl.Send(c->buf[kind][s][0], c->count[kind], ncclDouble, peer, c->nccl[lane], main));
+    NCCL_TRY(g_rccl.Recv(c->buf[kind][s][1], c->count[kind], ncclDouble, peer, c->nccl[lane], main));
+  }
+  NCCL_TRY(g_rccl.GroupEnd());
+  return LBMDEM_OK;
+}
 static int comm_end(lbmdem_comm* c, hipStream_t main, int lane, const bool has[2]) {
   if (!has[0] && !has[1]) return LBMDEM_OK;
   HIP_TRY(hipStreamWaitEvent(main, c->done[lane], 0));
@@ -1758,15 +1773,13 @@ int lbmdem_comm_lbm_step(lbmdem_handle* h, lbmdem_comm* c) {
   RC_TRY(comm_end(c, main, LANE_HALO, has));
   RC_TRY(lbmdem_halo_unpack2(h, has[0] ? c->buf[3][0][1] : nullptr, has[1] ? c->buf[3][1][1] : nullptr));
   RC_TRY(lbmdem_dist_pack2(h, LBMDEM_MSG_TABLES, has[0] ? c->buf[LBMDEM_MSG_TABLES][0][0] : nullptr, has[1] ? c->buf[LBMDEM_MSG_TABLES][1][0] : nullptr));
-  RC_TRY(comm_begin(c, main, LANE_TAB, LBMDEM_MSG_TABLES, has));  // link sums of the grains the neighbours own
-  RC_TRY(comm_end(c, main, LANE_TAB, has));
+  RC_TRY(comm_inline(c, main, LANE_TAB, LBMDEM_MSG_TABLES, has));  // link sums of the grains the neighbours own
   RC_TRY(lbmdem_dist_unpack2(h, LBMDEM_MSG_TABLES, has[0] ? c->buf[LBMDEM_MSG_TABLES][0][1] : nullptr, has[1] ? c->buf[LBMDEM_MSG_TABLES][1][1] : nullptr));
   RC_TRY(lbmdem_forces_fluid(h));
   RC_TRY(comm_end(c, main, LANE_KIN, has));
   RC_TRY(lbmdem_dist_unpack2(h, LBMDEM_MSG_KIN, has[0] ? c->buf[LBMDEM_MSG_KIN][0][1] : nullptr, has[1] ? c->buf[LBMDEM_MSG_KIN][1][1] : nullptr));
   RC_TRY(lbmdem_dist_pack2(h, LBMDEM_MSG_FHF, has[0] ? c->buf[LBMDEM_MSG_FHF][0][0] : nullptr, has[1] ? c->buf[LBMDEM_MSG_FHF][1][0] : nullptr));
-  RC_TRY(comm_begin(c, main, LANE_FHF, LBMDEM_MSG_FHF, has));    // forces of the margin grains, from their owners
-  RC_TRY(comm_end(c, main, LANE_FHF, has));
+  RC_TRY(comm_inline(c, main, LANE_FHF, LBMDEM_MSG_FHF, has));    // forces of the margin grains, from their owners
   RC_TRY(lbmdem_dist_unpack2(h, LBMDEM_MSG_FHF, has[0] ? c->buf[LBMDEM_MSG_FHF][0][1] : nullptr, has[1] ? c->buf[LBMDEM_MSG_FHF][1][1] : nullptr));
   return LBMDEM_OK;
 }
@@ -1868,7 +1881,8 @@ int lbmdem_comm_selftest(lbmdem_comm* c, int doubles) {
 /* Measurement helper: what one exchange on the step's critical path costs on this stack. `iters` times
  * { small kernel on a main stream; ready event -> side stream; grouped send + receive of `doubles` values to this rank
  * itself; done event -> main stream; small kernel on the main stream }, timed with events on the main stream, and the
- * same loop without the exchange. us[0] = mean with, us[1] = mean without the exchange. */
+ * same loop without the exchange, and with the send + receive enqueued on the main stream itself (no events).
+ * us[0] = mean with the exchange on the side stream, us[1] = without, us[2] = with it in line. */
 int lbmdem_comm_exchange_probe(lbmdem_comm* c, int doubles, int iters, double* us) {
   if (!c || doubles < 1 || iters < 1 || !us) return fail(LBMDEM_EINVAL, "bad lbmdem_comm_exchange_probe arguments");
   HIP_TRY(hipSetDevice(c->device));
@@ -1882,13 +1896,21 @@ int lbmdem_comm_exchange_probe(lbmdem_comm* c, int doubles, int iters, double* u
   if (e == hipSuccess) e = hipEventCreate(&e1);
   ncclResult_t r = ncclSuccess;
   const int lane = LANE_TAB;
-  for (int with = 1; with >= 0 && e == hipSuccess && r == ncclSuccess; --with) {
+  for (int with = 2; with >= 0 && e == hipSuccess && r == ncclSuccess; --with) {
     for (int pass = 0; pass < 2 && e == hipSuccess && r == ncclSuccess; ++pass) {   // pass 0 warms up
       const int n = pass == 0 ? 10 : iters;
       if (pass == 1) e = hipEventRecord(e0, main);
       for (int k = 0; k < n && e == hipSuccess && r == ncclSuccess; ++k) {
         e = hipMemsetAsync(a, 0, 8, main);                       // the producer of the message
-        if (with) {
+        if (with == 2) {   // in line: the transfer simply takes its place in the main stream
+          if (e == hipSuccess) {
+            r = g_rccl.GroupStart();
+            if (r == ncclSuccess) r = g_rccl.Send(a, (size_t)doubles, ncclDouble, c->rank, c->nccl[lane], main);
+            if (r == ncclSuccess) r = g_rccl.Recv(b, (size_t)doubles, ncclDouble, c->rank, c->nccl[lane], main);
+            const ncclResult_t r2 = g_rccl.GroupEnd();
+            if (r == ncclSuccess) r = r2;
+          }
+        } else if (with == 1) {
           if (e == hipSuccess) e = hipEventRecord(c->ready[lane], main);
           if (e == hipSuccess) e = hipStreamWaitEvent(c->side[lane], c->ready[lane], 0);
           if (e == hipSuccess) {
@@ -1908,7 +1930,7 @@ int lbmdem_comm_exchange_probe(lbmdem_comm* c, int doubles, int iters, double* u
         if (e == hipSuccess) e = hipEventSynchronize(e1);
         float ms = 0.f;
         if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-        us[with ? 0 : 1] = 1e3 * ms / iters;
+        us[with == 1 ? 0 : (with == 0 ? 1 : 2)] = 1e3 * ms / iters;
       } else if (e == hipSuccess) e = hipStreamSynchronize(main);
     }
   }

@@ -65,9 +65,9 @@ for rank in sorted({0, world // 2}):
 comm = pkg.Comm(pkg.comm_unique_id(), 0, 1, 0)
 lat = {}
 for name, nd in (("tables", runners[world // 2].b.sim.dist_message_doubles(2)), ("fhf", runners[world // 2].b.sim.dist_message_doubles(1))):
-    w, wo = comm.exchange_probe(nd, 300)
-    lat[name] = round(w - wo, 1)
-    lat[name + "_loop_with_without_us"] = [round(w, 1), round(wo, 1)]
+    w, wo, inline = comm.exchange_probe(nd, 300)
+    lat[name] = round(min(w, inline) - wo, 1)
+    lat[name + "_loop_side_stream_without_inline_us"] = [round(w, 1), round(wo, 1), round(inline, 1)]
 out["rccl_self_exchange_us"] = lat
 mid = out[f"rank{world // 2}_alone_ms_per_step"]
 out["projected_ms_per_step"] = round(mid + 1e-3 * (lat["tables"] + lat["fhf"]), 4)
