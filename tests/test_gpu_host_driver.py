@@ -105,3 +105,25 @@ def test_rccl_path_of_the_c_driver_with_one_rank(po, tmp_path):
     ora = po.Oracle(256, 200, r, x1, x2)
     ora.steps(nsteps)
     assert abs(fd - ora.total_density()) < 1e-5
+
+
+def test_transport_selftest_and_exchange_probe_with_one_rank():
+    """The library's RCCL transport from Python (one-rank communicator, in a fresh process: RCCL initialises once per
+    process): the self-test, and the probe that prices one critical-path exchange -- through a side stream with event
+    hand-overs, and in line on the main stream, which is how lbmdem_comm_lbm_step sends the link-sum tables and the
+    forces."""
+    import subprocess, sys
+    code = r'''
+import os, sys
+sys.path.insert(0, os.getcwd())
+import __graft_entry__ as ge
+pkg = ge.load_package()
+c = pkg.Comm(pkg.comm_unique_id(), 0, 1, 0)
+c.selftest()
+side, without, inline = c.exchange_probe(20000, 100)
+assert 0 < without < inline < side, (side, without, inline)
+print("PROBE-OK %.1f %.1f %.1f" % (side, without, inline))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "PROBE-OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
