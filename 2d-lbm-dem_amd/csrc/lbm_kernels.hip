@@ -1260,14 +1260,6 @@ __global__ __launch_bounds__(64) void k_forces_parity(const double* __restrict__
 // Phase B: lanes 3g, 3g+1, 3g+2 replay the additions of grain g's three accumulators (the serial part is
 // shared by the GW grains of the wave). The wave also resets the tables to empty for the next step.
 // PASSES = passes over the four line families: 2 when two families fit a wave (spd <= 32), else 4.
-struct DiscTest {
-  double xc, yc, R2, r2;
-  int xi, xf, yi, yf;  // the paint box, clamped to the lattice interior [1, l-2] (main.c:1016-1023)
-  __device__ __forceinline__ bool in(int x, int y) const {  // the paint test of k_obst_paint (main.c:1016-1028)
-    const double d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc);
-    return d2 <= R2 && d2 <= r2 && x >= xi && x <= xf && y >= yi && y <= yf;
-  }
-};
 
 // What k_forces_table does with the grains it is given
 enum : int {
@@ -1377,7 +1369,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
     n1[g] = n2[g] = n3[g] = 0;
     own[g] = false;
     if (i < 0) continue;
-    const double xc = G.xc[i], yc = G.yc[i], rbl0 = G.rbl0[i], r2 = G.r2[i];
+    const double xc = G.xc[i], yc = G.yc[i], r2 = G.r2[i];
     own[g] = grain_owned(L, xc);
     const bool was_touched = S.touched[i] != 0;
     if (was_touched && lane == 0 && consume) S.touched[i] = 0;  // the rasteriser sets it again while it applies
@@ -1390,7 +1382,6 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
       if (mode == FT_PACK && lane == 0) packbuf[1 + (long)(g0 + g) * (1 + 8 * spd)] = -1.0;
       continue;
     }
-    const DiscTest D{xc, yc, rbl0 * rbl0, r2, xi, xf, yi, yf};
     const int X0 = (int)xc, Y0 = (int)yc;
     for (int w = lane; w < nw64; w += 64) bm[w] = 0ull;
     __builtin_amdgcn_wave_barrier();
@@ -1409,6 +1400,12 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
       const double be = ax * ex + ay * ey;
       double disc = be * be - ee * (ax * ax + ay * ay - r2);
       const bool far = disc < -4.0;
+      // The rasteriser's test (x - xc)^2 + (y - yc)^2 <= r2 and this chord can only disagree about a node whose d2 is
+      // within rounding (~1e-13) of r2, i.e. a node within 1e-13 / (2 sqrt(disc)) of a chord end: with disc >= 1e-6
+      // that is < 1e-9 of an end (`shaky` below), and lines with |disc| < 1e-6 (all but tangent) are left to the gather
+      // path altogether. So no node has to be tested against the disc here.
+      const bool tangent = disc > -1e-6 && disc < 1e-6;
+      const bool cuts = disc >= 1e-6;
       if (disc < 0.0) disc = 0.0;
       const double sq = sqrt(disc);
       const double mf = (sq - be) * inv_ee, mb = (-sq - be) * inv_ee;  // chord ends, in steps of e
@@ -1427,13 +1424,10 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
         kf = min(kf, hi);
         kb = max(kb, lo);
       }
-      const bool f0 = D.in(px0 + kf * ex, py0 + kf * ey), f1 = D.in(px0 + (kf + 1) * ex, py0 + (kf + 1) * ey);
-      const bool b0 = D.in(px0 + kb * ex, py0 + kb * ey), b1 = D.in(px0 + (kb - 1) * ex, py0 + (kb - 1) * ey);
-      const bool has = f0 && !f1 && b0 && !b1 && kb <= kf;      // the line carries a chord of in-disc nodes
-      const bool none = !f0 && !f1 && !b0 && !b1;                // ... or none
+      const bool has = cuts && kb <= kf;      // the line carries a chord of in-disc nodes (inside the paint box)
       const bool meets = has && !far && lane_has_line;
       bool ffill = fw[g][j] != LBMDEM_SLOT_EMPTY, bfill = bw[g][j] != LBMDEM_SLOT_EMPTY;
-      if (lane_has_line && !far && ((!has && !none) || (has && shaky))) bad = true;
+      if (lane_has_line && !far && (tangent || (cuts && shaky))) bad = true;
       if (!meets && (ffill || bfill)) bad = true;   // a sum where the geometry has no link
       // A link of the geometry without a sum ends in a non-fluid node (a lattice-edge wall, another grain): the
       // fused kernel does not log those. If its far end lies in this rank's rows, gather the two populations
