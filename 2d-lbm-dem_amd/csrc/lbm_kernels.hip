@@ -1250,8 +1250,9 @@ __global__ __launch_bounds__(64) void k_forces_parity(const double* __restrict__
 // the lattice-edge clamp, the grain's nodes are exactly those passing the paint test, so every lattice line
 // parallel to a direction e that meets the disc carries exactly two boundary links: from its last in-disc node
 // forwards (direction q(e)) and from its first in-disc node backwards (the opposite direction). One lane takes
-// one line: the chord ends come from the line/circle intersection (one square root), then the exact paint test
-// around them decides. A slot must hold a sum iff that link exists -- an empty slot where the geometry has a
+// one line: the chord ends come from the line/circle intersection (one square root); chords whose ends could be a
+// rounding error away from a lattice node (or that are nearly tangent) send the grain to the gather queue, for all
+// others the chord IS the painted run of nodes (error bound in the code). A slot must hold a sum iff that link exists -- an empty slot where the geometry has a
 // link means the link ends in a non-fluid node (another grain, a lattice-edge wall) or belongs to another
 // rank's rows: the grain is then GATHERED from obst and f like in k_forces_parity. The links are ranked in the
 // reference's scan order (x outer, y, q; main.c:1305-1309) through an LDS bitmap over (node, q), and the
