@@ -1412,7 +1412,8 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
       const double mf = (sq - be) * inv_ee, mb = (-sq - be) * inv_ee;  // chord ends, in steps of e
       const double ff = floor(mf), cb = ceil(mb);
       // a chord end within rounding distance of a lattice node: let the gather path decide
-      const bool shaky = (mf - ff < 1e-9) || (ff + 1.0 - mf < 1e-9) || (cb - mb < 1e-9) || (mb - (cb - 1.0) < 1e-9);
+      // (mf - ff and cb - mb lie in [0, 1): near 0 or near 1 <=> far from 1/2)
+      const bool shaky = fabs((mf - ff) - 0.5) > 0.5 - 1e-9 || fabs((cb - mb) - 0.5) > 0.5 - 1e-9;
       int kf = (int)ff, kb = (int)cb;
       // the part of the line inside the paint box (the lattice-interior clamp cuts discs that reach a wall)
       {
@@ -1549,17 +1550,14 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
     double* const l1 = sDyn + (size_t)(gslot0 + g) * per_grain;
     double* const l2 = l1 + cap1;
     double* const l3 = l2 + cap1;
-    auto emit = [&](int keyp, unsigned long long slot) {
+    // (exo, eyo): the direction opposite to the link's, along which its momentum is exchanged
+    auto emit = [&](int keyp, unsigned long long slot, int exo, int eyo) {
       const int key = keyp & 0xFFFFF;
-      const int q = (key & 7) + 1;
       const int x = X0 - HB + ((keyp >> 20) & 63), y = Y0 - HB + ((keyp >> 26) & 63);
       const int w = key >> 6;
       const unsigned long long below = bm[w] & ((1ull << (key & 63)) - 1ull);
       const int bd = __popcll(below & M_DIAG), bx = __popcll(below & M_XDIR), by = __popcll(below & M_YDIR);
       const int r1 = pw[w] + bd + bx, r2_ = pw[nw64 + w] + bd + by, r3 = pw[2 * nw64 + w] + 2 * bd + bx + by;
-      const int qo = q <= 4 ? q + 4 : q - 4;
-      const int exo = (qo >= 1 && qo <= 3) ? -1 : ((qo >= 5 && qo <= 7) ? 1 : 0);
-      const int eyo = (qo == 1 || qo >= 7) ? 1 : ((qo >= 3 && qo <= 5) ? -1 : 0);
       const double sum = __longlong_as_double((long long)slot);
       const double fnx = sum * exo, fny = sum * eyo;  // main.c:1315-1316
       const double wx = x - xc, wy = y - yc;
@@ -1570,8 +1568,10 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
 #pragma unroll
     for (int j = 0; j < PASSES; ++j) {
       if (keyf[j] >= 0) {
-        emit(keyf[j], fw[g][j]);
-        emit(keyb[j], bw[g][j]);
+        const int fm = j * FPP + lane / LPF;
+        const int ex = fam_ex(fm), ey = fam_ey(fm);
+        emit(keyf[j], fw[g][j], -ex, -ey);   // forward link, direction e: opposite -e
+        emit(keyb[j], bw[g][j], ex, ey);     // backward link, direction -e
       }
     }
     // pad every list to a multiple of 8 addends with zeros
