@@ -94,6 +94,7 @@ def load_library():
     for name in ("upload_f", "download_f", "download_obst", "total_density", "upload_kinematics",
                  "download_kinematics", "download_fhf", "set_stream"):
         getattr(L, "lbmdem_" + name).argtypes = [C.c_void_p, C.c_void_p]
+    L.lbmdem_total_density_serial.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
     L.lbmdem_download_macro.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.lbmdem_download_verlet.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.lbmdem_download_grain_pressure.argtypes = [C.c_void_p, C.c_void_p]
@@ -338,13 +339,21 @@ class LbmDem:
         """the integrator + acceleration_grains block of renderScene (main.c:1733-1764)."""
         _chk(self._L.lbmdem_dem_substep(self._h))
 
-    def final_density(self):
-        """check_density / final_density (main.c:1249-1273)."""
-        s = C.c_double(0)
-        _chk(self._L.lbmdem_total_density(self._h, C.byref(s)))
+    def final_density(self, sum_in=0.0):
+        """check_density / final_density (main.c:1249-1273) with the reference's bits: the serial chain over f[x][y][q],
+        continued from `sum_in` over the owned rows. `self.density_rows_replayed` = rows added element by element."""
+        s, n = C.c_double(0), C.c_int(0)
+        _chk(self._L.lbmdem_total_density_serial(self._h, C.c_double(sum_in), C.byref(s), C.byref(n)))
+        self.density_rows_replayed = n.value
         return s.value
 
     check_density = final_density
+
+    def total_density_tree(self):
+        """the same sum in tree order (one pass, last bits differ from the reference's)"""
+        s = C.c_double(0)
+        _chk(self._L.lbmdem_total_density(self._h, C.byref(s)))
+        return s.value
 
     # ---- state ----------------------------------------------------------------------------------
     @property

@@ -2193,6 +2193,68 @@ __global__ void k_density_partial(const double* __restrict__ f, LatticeView L, d
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+// ---- the reference's SERIAL total density (main.c:1249-1273: sum = sum + f[x][y][q], x outer, y, q inner) -----------
+// A serial floating-point sum is a chain, but while the running sum s stays inside one binade [2^k, 2^(k+1)) every
+// addition of a positive a rounds to the same quantum u = 2^(k-52): s is a multiple of u, so RN(s + a) = s + RN_u(a),
+// where RN_u(a) -- a rounded to a multiple of u -- does not depend on s unless a / u falls exactly half-way between two
+// integers (then the tie goes to the even multiple: depends on s). Hence for one lattice row whose additions all
+// happen in binade k and which holds no tie, no non-positive and no over-large value, the chain adds exactly
+// (sum of the integers n = RN(a / u)) * u -- and integer sums associate. One workgroup per row forms that integer
+// sum and the flags; the host walks the rows with the exact running sum and replays a row element by element (in
+// the reference's order) whenever the shortcut does not apply: the rows where the sum crosses a power of two (~13 of
+// 4096 at 4096^2), tie rows (~1), and whatever the first pass could not classify.
+__global__ void k_density_rowsum(const double* __restrict__ f, LatticeView L, double* __restrict__ rowsum) {
+  __shared__ double red[256];
+  const long row = L.xo0 + blockIdx.x;
+  double s = 0.0;
+  for (int y = threadIdx.x; y < L.ly; y += blockDim.x) {
+    const long node = row * L.sy + y;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) s += f[fidx(q, node)];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) rowsum[blockIdx.x] = red[0];
+}
+
+// quanta[row] = sum over the row of RN(a / 2^(kexp[row] - 52)); flags[row] != 0: the shortcut does not apply
+__global__ void k_density_rowquanta(const double* __restrict__ f, LatticeView L, const int* __restrict__ kexp,
+                                    unsigned long long* __restrict__ quanta, int* __restrict__ flags) {
+  __shared__ unsigned long long red[256];
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  const long row = L.xo0 + blockIdx.x;
+  const int k = kexp[blockIdx.x];
+  const double top = ldexp(1.0, k + 1);   // a >= 2^(k+1) would leave the binade on its own
+  unsigned long long n = 0;
+  int mybad = 0;
+  for (int y = threadIdx.x; y < L.ly; y += blockDim.x) {
+    const long node = row * L.sy + y;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const double a = f[fidx(q, node)];
+      if (!(a > 0.0) || !(a < top)) { mybad = 1; continue; }   // also NaN
+      const double t = ldexp(a, 52 - k);   // a / u, exact (a power-of-two scaling; a tiny a may underflow to 0: n = 0, right)
+      const double fl = floor(t);
+      if (t - fl == 0.5) mybad = 1;        // a tie: the rounding depends on the running sum
+      n += (unsigned long long)rint(t);
+    }
+  }
+  if (mybad) bad = 1;
+  red[threadIdx.x] = n;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { quanta[blockIdx.x] = red[0]; flags[blockIdx.x] = bad; }
+}
+
 // halo rows <-> contiguous buffer [9][nrows][ly]; blockIdx.y = side: rows from xl0a (low) / xl0b (high), a null buffer
 // skips the side
 __global__ void k_halo_pack(const double* __restrict__ f, LatticeView L, int xl0a, int xl0b, int nrows,
@@ -2553,6 +2615,13 @@ void launch_macro(const double* f, const LatticeView& L, int xl0, int nrows, dou
 void launch_density_partial(const double* f, const LatticeView& L, double* partial, int nblocks,
                             hipStream_t st) {
   hipLaunchKernelGGL(k_density_partial, dim3(nblocks), dim3(256), 0, st, f, L, partial);
+}
+void launch_density_rowsum(const double* f, const LatticeView& L, double* rowsum, hipStream_t st) {
+  hipLaunchKernelGGL(k_density_rowsum, dim3(L.xo1 - L.xo0), dim3(256), 0, st, f, L, rowsum);
+}
+void launch_density_rowquanta(const double* f, const LatticeView& L, const int* kexp, unsigned long long* quanta,
+                              int* flags, hipStream_t st) {
+  hipLaunchKernelGGL(k_density_rowquanta, dim3(L.xo1 - L.xo0), dim3(256), 0, st, f, L, kexp, quanta, flags);
 }
 void launch_halo_pack(const double* f, const LatticeView& L, int xl0_lo, int xl0_hi, int nrows, double* buf_lo,
                       double* buf_hi, hipStream_t st) {

@@ -792,6 +792,87 @@ int lbmdem_total_density(lbmdem_handle* h, double* sum) {
   return LBMDEM_OK;
 }
 
+// check_density / final_density exactly as the reference adds them (main.c:1249-1273): one serial chain over
+// f[x][y][q], continued from `sum_in` over this handle's owned rows (a strip passes its result on to the next strip).
+// The printed line `final_density: %f` is what the reference's own benchmark parses (benchmark.xml:99-102).
+int lbmdem_total_density_serial(lbmdem_handle* h, double sum_in, double* sum_out, int* rows_replayed) try {
+  CHECK_H(h);
+  CHECK_NOT_SPLIT(h);
+  if (!sum_out) return fail(LBMDEM_EINVAL, "null buffer");
+  const LatticeView& L = h->L;
+  const int rows = L.xo1 - L.xo0;
+  const double* f = h->f[h->fcur];
+  double* d_rowsum = nullptr; int* d_k = nullptr; unsigned long long* d_q = nullptr; int* d_flag = nullptr; double* d_row = nullptr;
+  std::vector<double> rowsum(rows), rowbuf((size_t)L.ly * 9);
+  std::vector<int> kexp(rows), flag(rows);
+  std::vector<unsigned long long> quanta(rows);
+  hipError_t e = hipMalloc((void**)&d_rowsum, sizeof(double) * rows);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_k, sizeof(int) * rows);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_q, sizeof(unsigned long long) * rows);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_flag, sizeof(int) * rows);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_row, sizeof(double) * L.ly * 9);
+  auto cleanup = [&] { (void)hipFree(d_rowsum); (void)hipFree(d_k); (void)hipFree(d_q); (void)hipFree(d_flag); (void)hipFree(d_row); };
+  if (e != hipSuccess) { cleanup(); HIP_TRY(e); }
+  // pass 1: approximate row sums -> the binade the running sum is (most probably) in when it reaches each row
+  launch_density_rowsum(f, L, d_rowsum, h->stream);
+  e = hipMemcpyAsync(rowsum.data(), d_rowsum, sizeof(double) * rows, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) { cleanup(); HIP_TRY(e); }
+  {
+    double approx = sum_in;
+    for (int r = 0; r < rows; ++r) {
+      int ex = 0;
+      if (approx > 0.0 && isfinite(approx)) (void)frexp(approx, &ex);   // approx = m * 2^ex, m in [0.5, 1)
+      kexp[r] = ex - 1;
+      approx += rowsum[r];
+    }
+  }
+  // pass 2: integer quanta per row for that binade
+  e = hipMemcpyAsync(d_k, kexp.data(), sizeof(int) * rows, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) {
+    launch_density_rowquanta(f, L, d_k, d_q, d_flag, h->stream);
+    e = hipMemcpyAsync(quanta.data(), d_q, sizeof(unsigned long long) * rows, hipMemcpyDeviceToHost, h->stream);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(flag.data(), d_flag, sizeof(int) * rows, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) { cleanup(); HIP_TRY(e); }
+  // the chain, with the exact running sum
+  volatile double s = sum_in;   // volatile: every addition rounded to double, whatever the host compiler's flags
+  int replayed = 0;
+  for (int r = 0; r < rows; ++r) {
+    bool fast = false;
+    const double sv = s;
+    if (!flag[r] && sv > 0.0 && isfinite(sv) && quanta[r] < (1ull << 53)) {
+      int ex = 0;
+      (void)frexp(sv, &ex);
+      if (ex - 1 == kexp[r]) {
+        const double u = ldexp(1.0, kexp[r] - 52);
+        const double add = (double)quanta[r] * u;          // exact: quanta < 2^53, u a power of two
+        const double top = ldexp(1.0, kexp[r] + 1);
+        const double t = sv + add;                          // exact while the result stays below 2^(k+1) (multiples of u)
+        if (t < top) { s = t; fast = true; }
+      }
+    }
+    if (fast) continue;
+    // replay this row element by element in the reference's order (y, then q)
+    launch_soa_to_aos(f, d_row, L, L.xo0 + r, 1, h->stream);
+    e = hipMemcpyAsync(rowbuf.data(), d_row, sizeof(double) * L.ly * 9, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { cleanup(); HIP_TRY(e); }
+    const size_t cnt = (size_t)L.ly * 9;
+    for (size_t i = 0; i < cnt; ++i) s = s + rowbuf[i];
+    ++replayed;
+  }
+  cleanup();
+  *sum_out = s;
+  if (rows_replayed) *rows_replayed = replayed;
+  return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
+}
+
 int lbmdem_upload_kinematics(lbmdem_handle* h, const double* k9) try {
   CHECK_H(h);
   if (!k9) return fail(LBMDEM_EINVAL, "null buffer");

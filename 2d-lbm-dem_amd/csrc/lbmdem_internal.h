@@ -168,6 +168,11 @@ void launch_macro(const double* f, const LatticeView& L, int xl0, int nrows, dou
                   double* uy, hipStream_t st);
 void launch_density_partial(const double* f, const LatticeView& L, double* partial, int nblocks,
                             hipStream_t st);
+// the reference's serial total density (see k_density_rowquanta): per owned row an approximate sum, then the integer
+// number of quanta 2^(kexp[row] - 52) the row adds + a flag when the shortcut does not apply to the row
+void launch_density_rowsum(const double* f, const LatticeView& L, double* rowsum, hipStream_t st);
+void launch_density_rowquanta(const double* f, const LatticeView& L, const int* kexp, unsigned long long* quanta,
+                              int* flags, hipStream_t st);
 // both sides in one launch; a null buffer skips the side
 void launch_halo_pack(const double* f, const LatticeView& L, int xl0_lo, int xl0_hi, int nrows, double* buf_lo,
                       double* buf_hi, hipStream_t st);

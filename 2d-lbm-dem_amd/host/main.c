@@ -83,6 +83,26 @@ int main(int argc, char** argv) {
 
 #define SAY(...) do { if (g_rank == 0) printf(__VA_ARGS__); } while (0)
 
+/* check_density / final_density with the reference's own bits (main.c:1249-1273): ONE serial chain over the whole
+ * lattice. With several strips the chain runs through the ranks in x order: rank r continues from rank r-1's sum
+ * (handed on through the all-reduce: everybody else contributes 0). Every rank returns the lattice's sum. */
+static double serial_density(lbmdem_handle* h, lbmdem_comm* comm) {
+  double s = 0.;
+  for (int r = 0; r < g_world; ++r) {
+    double v = 0.;
+    if (r == g_rank && lbmdem_total_density_serial(h, s, &v, NULL) != LBMDEM_OK) {
+      fprintf(stderr, "total_density_serial: %s\n", lbmdem_last_error());
+      exit(EXIT_FAILURE);
+    }
+    if (comm && lbmdem_comm_allreduce_sum(comm, &v, 1) != LBMDEM_OK) {
+      fprintf(stderr, "allreduce: %s\n", lbmdem_last_error());
+      exit(EXIT_FAILURE);
+    }
+    s = v;
+  }
+  return s;
+}
+
 static int run(int argc, char** argv) {
   int lx = 7826, ly = 2325, device = 0; /* main.c:27-32 */
   double scale = 1., duration = 1.5;   /* main.c:24-26,47 */
@@ -196,9 +216,7 @@ static int run(int argc, char** argv) {
       int lbm_now = (nbsteps % cfg.npDEM == 0), console_now = (nbsteps % stepConsole == 0);
       if (lbm_now && console_now) {
         if (comm) DIE(lbmdem_comm_lbm_step(h, comm), "comm_lbm_step"); else DIE(lbmdem_lbm_step(h), "lbm_step");
-        double sum = 0;
-        DIE(lbmdem_total_density(h, &sum), "total_density");
-        if (comm) DIE(lbmdem_comm_allreduce_sum(comm, &sum, 1), "allreduce");
+        double sum = serial_density(h, comm);
         SAY("Iteration Number %ld, Total density in the system %f\n", nbsteps, sum);
         if (nbsteps % cfg.phys.updateVerlet == 0) DIE(lbmdem_verlet_rebuild(h), "verlet_rebuild");
         DIE(lbmdem_dem_substep(h), "dem_substep");
@@ -234,11 +252,9 @@ static int run(int argc, char** argv) {
   DIE(lbmdem_sync(h), "sync");
   clock_gettime(CLOCK_MONOTONIC, &t1);
   if (ckpt_out) DIE(lbmdem_checkpoint_save(h, ckpt_out), "checkpoint_save");
-  double sum = 0;
-  DIE(lbmdem_total_density(h, &sum), "total_density");
+  double sum = serial_density(h, comm);
   double secs = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
-  if (comm) { /* whole-lattice mass; the slowest rank's time */
-    DIE(lbmdem_comm_allreduce_sum(comm, &sum, 1), "allreduce");
+  if (comm) { /* the slowest rank's time */
     double tmax[64] = {0};
     tmax[g_rank] = secs;
     DIE(lbmdem_comm_allreduce_sum(comm, tmax, g_world), "allreduce");

@@ -24,6 +24,17 @@
 extern "C" {
 #endif
 
+/* The reference fixes its lattice with the object-like MACROS lx, ly and scale (main.c:24-32; its benchmark passes
+ * them as -Dlx= -Dly= -Dscale=, benchmark.xml:85). They would rewrite the member and parameter names below, so they
+ * are parked while this header is read and restored at its end: the header can be included anywhere in the reference's
+ * main.c (found by compiling the binding of INTEGRATION.md: oracle/make_integration_check.py). */
+#pragma push_macro("lx")
+#pragma push_macro("ly")
+#pragma push_macro("scale")
+#undef lx
+#undef ly
+#undef scale
+
 #define LBMDEM_OK 0
 #define LBMDEM_EINVAL (-1)    /* bad argument / bad state */
 #define LBMDEM_ENODEVICE (-2) /* no usable HIP device */
@@ -133,7 +144,12 @@ int lbmdem_upload_f(lbmdem_handle* h, const double* f_aos);   /* [lx][ly][9]; ro
 int lbmdem_download_f(lbmdem_handle* h, double* f_aos);       /* [lx][ly][9]; only the OWNED rows are written */
 int lbmdem_download_obst(lbmdem_handle* h, int* obst);        /* [lx][ly]; owned rows */
 int lbmdem_download_macro(lbmdem_handle* h, double* rho, double* ux, double* uy); /* [lx][ly] each; owned rows; sums of f, f*ex, f*ey as write_vtk forms them (main.c:315-319) */
-int lbmdem_total_density(lbmdem_handle* h, double* sum);      /* check_density/final_density, main.c:1249-1273, owned rows */
+int lbmdem_total_density(lbmdem_handle* h, double* sum);      /* sum of f over the owned rows, tree order (fast; last bits differ from the reference's serial sum) */
+/* check_density / final_density (main.c:1249-1273) with the reference's own bits: the serial chain sum = sum + f[x][y][q]
+ * (x outer, y, q inner) continued from `sum_in` over the owned rows -- 0 for one domain; a strip passes its result to the
+ * next strip. Computed on the device as integer quanta per lattice row wherever the running sum stays in one binade
+ * (exact), rows where it does not are replayed element by element; `rows_replayed` (may be null) counts those. */
+int lbmdem_total_density_serial(lbmdem_handle* h, double sum_in, double* sum_out, int* rows_replayed);
 /* kinematics table, 9 doubles per grain: x1 x2 x3 v1 v2 v3 a1 a2 a3 */
 int lbmdem_upload_kinematics(lbmdem_handle* h, const double* k9);
 int lbmdem_download_kinematics(lbmdem_handle* h, double* k9);
@@ -287,6 +303,10 @@ int lbmdem_fhf_import(lbmdem_handle* h, const void* dev_buf);
 
 const char* lbmdem_last_error(void);
 const char* lbmdem_version(void);
+
+#pragma pop_macro("scale")
+#pragma pop_macro("ly")
+#pragma pop_macro("lx")
 
 #ifdef __cplusplus
 }

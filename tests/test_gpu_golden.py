@@ -24,7 +24,8 @@ def test_hip_on_the_reference_s_own_samples(pkg, name):
     class Sim:
         def __init__(self, lx, ly, r, x1, x2): self.s = pkg.LbmDem(lx, ly, r, x1, x2)
         def steps(self, n): self.s.renderScene(n)
-    gu.check_real_case(name, Sim, lambda s: (s.s.f, s.s.obst, s.s.fhf, s.s.kinematics, None))
+    # ... and the total density the reference itself printed for that state (check_density, main.c:1249-1261)
+    gu.check_real_case(name, Sim, lambda s: (s.s.f, s.s.obst, s.s.fhf, s.s.kinematics, s.s.final_density()))
 
 
 def test_vtk_files_byte_identical_to_the_reference(pkg, tmp_path):

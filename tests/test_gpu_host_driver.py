@@ -32,11 +32,11 @@ def test_run_matches_oracle_and_writes_a_frame(po, tmp_path):
     assert "Nb grains %d" % len(c["r_mm"]) in out.stdout
     assert re.search(r"dtLB=.*npDEM=\d+", out.stdout)
     assert "Iteration Number 0, Total density in the system" in out.stdout
-    fd = float(re.search(r"final_density: ([0-9.]+)", out.stderr).group(1))
+    fd_text = re.search(r"final_density: ([0-9.]+)", out.stderr).group(1)
     r, x1, x2 = po.read_sample(str(sample))
     ora = po.Oracle(256, 200, r, x1, x2)
     ora.steps(nsteps)
-    assert abs(fd - ora.total_density()) < 1e-5
+    assert fd_text == "%f" % ora.total_density()     # the string the reference's benchmark parses (benchmark.xml:99-102)
     frames = sorted(p.name for p in tmp_path.glob("*.vtk"))
     assert frames == ["fluid_pressure_000000.vtk", "fluid_velocity_000000.vtk", "grain_acceleration_000000.vtk",
                       "grain_pressure_000000.vtk", "grain_velocity_000000.vtk"]
@@ -83,9 +83,9 @@ def test_duration_stops_after_the_same_step_as_the_reference(po, tmp_path):
     assert out.returncode == 0, out.stderr[-500:]
     assert int(re.search(r"dem_steps: (\d+)", out.stderr).group(1)) == want_steps
     assert re.search(r"steps 200 steps", out.stdout) and not re.search(r"steps 300 steps", out.stdout)
-    fd = float(re.search(r"final_density: ([0-9.]+)", out.stderr).group(1))
+    fd_text = re.search(r"final_density: ([0-9.]+)", out.stderr).group(1)
     ora.steps(want_steps)
-    assert abs(fd - ora.total_density()) < 1e-5
+    assert fd_text == "%f" % ora.total_density()     # the string the reference's benchmark parses (benchmark.xml:99-102)
 
 
 def test_rccl_path_of_the_c_driver_with_one_rank(po, tmp_path):
@@ -100,11 +100,11 @@ def test_rccl_path_of_the_c_driver_with_one_rank(po, tmp_path):
                          capture_output=True, text=True, cwd=tmp_path, timeout=300)
     assert out.returncode == 0, (out.stdout[-300:], out.stderr[-600:])
     assert int(re.search(r"dem_steps: (\d+)", out.stderr).group(1)) == nsteps
-    fd = float(re.search(r"final_density: ([0-9.]+)", out.stderr).group(1))
+    fd_text = re.search(r"final_density: ([0-9.]+)", out.stderr).group(1)
     r, x1, x2 = po.read_sample(str(sample))
     ora = po.Oracle(256, 200, r, x1, x2)
     ora.steps(nsteps)
-    assert abs(fd - ora.total_density()) < 1e-5
+    assert fd_text == "%f" % ora.total_density()     # the string the reference's benchmark parses (benchmark.xml:99-102)
 
 
 def test_transport_selftest_and_exchange_probe_with_one_rank():

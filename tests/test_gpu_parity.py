@@ -4,7 +4,7 @@ The oracle (oracle/lbmdem_oracle.c) is pinned bit-for-bit to the unmodified refe
 tests/test_oracle_vs_reference.py and tests/golden/. Everything on the device path is element-wise
 in the reference's expression order and compiled with -ffp-contract=off, so the bar here is exact
 equality (np.array_equal) for f, obst, hydrodynamic forces and grain kinematics -- not a tolerance.
-The only tolerance is on the total-mass reduction (different summation tree).
+Exact everywhere, including the total density (the reference's serial chain of additions).
 """
 import numpy as np
 import pytest
@@ -206,7 +206,8 @@ def test_medium_packing_20_fluid_steps_bit_exact(pkg, po):
     sim.renderScene(n); ora.steps(n)
     assert_same_state(sim, ora, "medium packing")
     rho_g = sim.final_density(); rho_c = ora.total_density()
-    assert abs(rho_g - rho_c) <= 1e-10 * abs(rho_c)   # different summation trees
+    assert rho_g == rho_c                              # the reference's serial chain, bit for bit
+    assert abs(sim.total_density_tree() - rho_c) <= 1e-10 * abs(rho_c)   # the one-pass tree sum
     rho, ux, uy = sim.macro()
     fc = ora.get_f()
     assert np.allclose(rho, fc.sum(-1), rtol=1e-14, atol=0)
@@ -510,3 +511,44 @@ def test_long_verlet_lists_take_several_staging_rounds(pkg, po):
     sim.renderScene(n); ora.steps(n)
     assert_same_state(sim, ora, "long lists")
     assert np.array_equal(sim.grain_pressure, ora.get_grains()[:, po.COL["p"]])
+
+
+def test_serial_total_density_bit_exact_on_awkward_lattices(pkg, po):
+    """check_density / final_density (main.c:1249-1273) add 9*lx*ly values in ONE serial chain; the HIP path reproduces
+    the chain's bits from per-row integer quanta and replays only the rows where that shortcut does not hold. Awkward
+    inputs: the sum crossing many powers of two, exact rounding ties, zeros, negative and huge values, a row pitch that
+    is not the row length (ly not a multiple of 16)."""
+    lx, ly = 96, 77
+    r, x1, x2 = np.array([0.6e-3]), np.array([4.0e-3]), np.array([3.5e-3])
+    sim, ora = make_pair(pkg, po, lx, ly, r, x1, x2)
+    rng = np.random.default_rng(11)
+    def check(f, what, min_replayed=0, max_replayed=None):
+        sim.f = f; ora.set_f(f)
+        got, want = sim.final_density(), ora.total_density()
+        assert got == want, (what, got, want, sim.density_rows_replayed)
+        assert sim.density_rows_replayed >= min_replayed, (what, sim.density_rows_replayed)
+        if max_replayed is not None:
+            assert sim.density_rows_replayed <= max_replayed, (what, sim.density_rows_replayed)
+    f0 = sim.f
+    # 1. the initial state and a perturbed one: almost every row takes the integer shortcut
+    check(f0, "weights", max_replayed=20)
+    check(f0 * (1 + 1e-3 * rng.standard_normal(f0.shape)), "perturbed", max_replayed=20)
+    # 2. magnitudes spread over 30 binades: many crossings
+    check(f0 * np.exp2(rng.integers(-20, 10, f0.shape).astype(float)), "spread")
+    # 3. exact ties: with the running sum in [2^16, 2^17) the quantum is 2^-36; values k * 2^-36 + 2^-37 tie
+    f = np.full_like(f0, 2.0 ** -36 * 3)
+    f[0, :, :] = 100.0                       # gets the sum up to 2^16 quickly
+    f[5:, ::7, 3] = 2.0 ** -36 * 5 + 2.0 ** -37
+    check(f, "ties", min_replayed=10)
+    # 4. zeros, negative values, one huge value, one NaN-free tiny value
+    f = f0 * (1 + 1e-2 * rng.standard_normal(f0.shape))
+    f[10, 3, 2] = 0.0; f[20, 40, 5] = -0.25; f[30, 7, 0] = 1e12; f[31, 8, 1] = 1e-300
+    check(f, "signs", min_replayed=3)
+    # 5. a continued chain (what a strip does with its predecessor's sum)
+    sim.f = f0; ora.set_f(f0)
+    assert sim.final_density(123456.789) != sim.final_density(0.0)
+    # 6. and the state after some steps
+    sim.f = f0 * (1 + 1e-3 * rng.standard_normal(f0.shape)); ora.set_f(sim.f)
+    for _ in range(3):
+        sim.lbm_step(); ora.lbm_steps(1)
+    assert sim.final_density() == ora.total_density()

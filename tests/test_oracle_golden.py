@@ -22,12 +22,19 @@ def test_oracle_matches_reference_dump(po, name):
 
 @pytest.mark.parametrize("name,dumps", [("real_a08d83_600x500", None), ("real_7000_2048x2048", None),
                                         ("real_50000_4096x4096", (1,)), ("real_50000test_3072x3072", (1,)),
-                                        ("real_50000_8192x4096", (1,))])
+                                        ("real_50000_8192x4096", (1,)),
+                                        # the JUBE cases of the reference's benchmark.xml and the remaining samples
+                                        ("real_a08d83_2000x1000", None), ("real_a6d83_2000x1000", None),
+                                        ("real_spl04_1600x2400", (1, 2)), ("real_slope_12500x2500", (1,))])
 def test_oracle_on_the_reference_s_own_samples(po, name, dumps):
     """The reference's shipped inputs at BASELINE.json's sizes (a08d83 @ 600x500; a08_a4b4r18_7000 @ 2048^2 =
     configs[2]; 50000.data @ 4096^2 = configs[3]; 50000-test.data @ 3072^2 = configs[0], the CPU-only plumbing case;
     50000.data @ 8192x4096 = configs[4] as one domain): the state after whole coupled steps must hash to what the
-    unmodified reference produced (tests/golden/real_*.npz). The serial total density too (same order)."""
+    unmodified reference produced (tests/golden/real_*.npz). The serial total density too (same order).
+    Round 3: the reference's own benchmark cases (benchmark.xml:7-27) -- a08d83 and a6d83 @ 2000x1000 (a6d83's packing
+    is 1493 nodes tall: a third of its grains lie OUTSIDE the lattice, clipped by the bounding-box clamps main.c:1016-1023,
+    1300-1303) and slope @ 12500x2500 (radii up to 1.5 mm) -- and spl04.data. The CPU suite checks the first dumps (the
+    oracle needs ~6 s per fluid step at 12500x2500); the GPU suite checks every dump of every case (10-20 fluid steps)."""
     class Sim:
         def __init__(self, lx, ly, r, x1, x2): self.o = po.Oracle(lx, ly, r, x1, x2)
         def steps(self, n): self.o.steps(n)
