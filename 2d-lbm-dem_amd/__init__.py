@@ -94,6 +94,10 @@ def load_library():
     for name in ("upload_f", "download_f", "download_obst", "total_density", "upload_kinematics",
                  "download_kinematics", "download_fhf", "set_stream"):
         getattr(L, "lbmdem_" + name).argtypes = [C.c_void_p, C.c_void_p]
+    L.lbmdem_dist_export_owned.argtypes = [C.c_void_p] * 5
+    L.lbmdem_dist_table_substep.argtypes = [C.c_void_p] * 4
+    L.lbmdem_vtk_place_owned.argtypes = [C.c_void_p, C.c_void_p]
+    L.lbmdem_write_vtk_fields.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.lbmdem_total_density_serial.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
     L.lbmdem_download_macro.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.lbmdem_download_verlet.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -148,6 +152,12 @@ def strips_module():
     """The x-strip decomposition driver (one process per GPU), imported lazily."""
     from . import strips
     return strips
+
+
+def write_vtk_fields(directory, nFile, lx, ly, fields11):
+    """the five VTK files of write_vtk (main.c:237-338) from merged lattice-sized fields (LbmDem.vtk_place_owned)"""
+    f = np.ascontiguousarray(fields11, dtype=np.float32)
+    _chk(load_library().lbmdem_write_vtk_fields(os.fsencode(directory), int(nFile), int(lx), int(ly), _vp(f)))
 
 
 def exported_symbols():
@@ -539,6 +549,27 @@ class LbmDem:
 
     def halo_unpack2(self, ptr_lo, ptr_hi):
         _chk(self._L.lbmdem_halo_unpack2(self._h, C.c_void_p(ptr_lo), C.c_void_p(ptr_hi)))
+
+    # ---- drop-in outputs of a strip decomposition (include/lbmdem_hip.h) ----------------------------------
+    def dist_export_owned(self):
+        """-> (state12 [n][12], owned [n] uint8, carry_keys [3][2] int64, carry_vals [3]): what this rank contributes
+        to the sub-step that feeds write_DEM (strips.merge_exports combines the ranks' exports)."""
+        st = np.zeros((self.n, 12)); owned = np.zeros(self.n, np.uint8)
+        keys = np.zeros((3, 2), np.int64); vals = np.zeros(3)
+        _chk(self._L.lbmdem_dist_export_owned(self._h, _vp(st), _vp(owned), _vp(keys), _vp(vals)))
+        return st, owned, keys, vals
+
+    def dist_table_substep(self, state12_full, carry_vals, carry_has):
+        """the root's sub-step on the full replica; afterwards grain_table / write_DEM / write_forces work here"""
+        st = np.ascontiguousarray(state12_full, dtype=np.float64)
+        cv = np.ascontiguousarray(carry_vals, dtype=np.float64); ch = np.ascontiguousarray(carry_has, dtype=np.int32)
+        assert st.shape == (self.n, 12)
+        _chk(self._L.lbmdem_dist_table_substep(self._h, _vp(st), _vp(cv), _vp(ch)))
+
+    def vtk_place_owned(self, fields11):
+        """this strip's columns of the five write_vtk fields into a zero-initialised float32 array of 11 * lx * ly"""
+        assert fields11.dtype == np.float32 and fields11.size == 11 * self.lx * self.ly and fields11.flags.c_contiguous
+        _chk(self._L.lbmdem_vtk_place_owned(self._h, _vp(fields11)))
 
     def dist_set_poison(self, on=True):
         _chk(self._L.lbmdem_dist_set_poison(self._h, 1 if on else 0))

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const doub
                                                      const unsigned char* __restrict__ wallflags,
                                                      double* __restrict__ pout, DemParams P,
                                                      const unsigned char* __restrict__ active, CarryTrack T,
-                                                     long long stamp) {
+                                                     long long stamp, const unsigned char* __restrict__ owner) {
   __shared__ double sF1[DEM_ENTRIES], sF2[DEM_ENTRIES], sF3[DEM_ENTRIES], sFn[DEM_ENTRIES];
   __shared__ unsigned char sTouched[DEM_ENTRIES];
   __shared__ int sLast;   // highest list entry of this tile that is a touching contact in the reference's frame
@@ -302,6 +302,9 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const doub
   }
   int last_e = -1;            // this thread's youngest touching contact (own < partner: the reference evaluates it there)
   double last_ft = 0., last_f3 = 0.;
+  long long last_who = 0;     // ... and the pair, (own << 32) | partner: the reference's contact order, whatever the list
+  // strips with distributed grains: a rank only vouches for (and records) the contacts of the grains it OWNS -- every
+  // contact is evaluated in the frame of its lower grain, so exactly one rank records it
   for (int base = e0; base < e1; base += DEM_ENTRIES) {
     const int lim = base + DEM_ENTRIES < e1 ? base + DEM_ENTRIES : e1;
     for (int e = base + tid; e < lim; e += 256) {
@@ -311,7 +314,10 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const doub
       const bool lower = gi < gj;
       bool touched;
       const Force3 F = contact<FILM>(lower ? a : b, lower ? b : a, P, touched);  // main.c:1443-1448
-      if (touched && lower) { last_e = e; last_ft = F.ft; last_f3 = F.f3; if (T.stamp) atomicMax(&sLast, e); }
+      if (touched && lower && (!owner || owner[gi])) {
+        last_e = e; last_ft = F.ft; last_f3 = F.f3; last_who = ((long long)gi << 32) | (unsigned)gj;
+        if (T.stamp) atomicMax(&sLast, e);
+      }
       const int s = e - base;
       sF1[s] = lower ? F.f1 : -F.f1;
       sF2[s] = lower ? F.f2 : -F.f2;
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const doub
   if (T.stamp) {  // the tile's last grain contact, for the carries (every round of the loop above ends with a barrier)
     if (last_e >= 0 && last_e == sLast) {
       const long rec = (long)blockIdx.x * 4 + CARRY_GRAIN;
-      T.stamp[rec] = stamp; T.val[2 * rec] = last_ft; T.val[2 * rec + 1] = last_f3;
+      T.stamp[rec] = stamp; T.val[2 * rec] = last_ft; T.val[2 * rec + 1] = last_f3; T.who[rec] = last_who;
     }
   }
   if (tid >= 64) return;   // the first wavefront holds the tile's grains
@@ -345,10 +351,11 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const doub
 #pragma unroll
     for (int kind = CARRY_BOTTOM; kind <= CARRY_RIGHT; ++kind) {
       const unsigned bit = kind == CARRY_BOTTOM ? 1u : (kind == CARRY_LEFT ? 4u : 8u);
-      const unsigned long long hit = __ballot((wh.mask & bit) != 0);
+      const unsigned long long hit = __ballot((wh.mask & bit) != 0 && (!owner || (mine && owner[i])));
       if (hit != 0 && tid == 63 - __builtin_clzll(hit)) {
         const long rec = (long)blockIdx.x * 4 + kind;
         T.stamp[rec] = stamp;
+        T.who[rec] = (long long)i << 32;
         T.val[2 * rec] = kind == CARRY_BOTTOM ? wh.ftB : (kind == CARRY_LEFT ? wh.ftL : wh.ftR);
         T.val[2 * rec + 1] = wh.f3B;
       }
@@ -560,10 +567,17 @@ __global__ __launch_bounds__(256) void k_carry_resolve(CarryTrack T, long long m
   if (b_ff) atomicMax(&best[1], b_ff);
   if (b_f) atomicMax(&best[2], b_f);
   __syncthreads();
-  if (threadIdx.x < 3 && best[threadIdx.x] != 0ull) {
-    const unsigned long long key = best[threadIdx.x];
-    const long rec = (long)(key & 0xFFFFFFu) * 4 + (long)((key >> 24) & 3u);
-    T.carry[threadIdx.x] = T.val[2 * rec + (threadIdx.x == 1 ? 1 : 0)];   // pft, pf: ft; pff: f3
+  if (threadIdx.x < 3) {
+    // what won, in rank-independent terms, for the cross-rank resolve of a strip decomposition:
+    // best_key[c] = {(stamp + 1) * 4 + kind, (grain << 32) | partner}; {0, 0} = this handle has no record
+    T.best_key[2 * threadIdx.x] = 0; T.best_key[2 * threadIdx.x + 1] = 0;
+    if (best[threadIdx.x] != 0ull) {
+      const unsigned long long key = best[threadIdx.x];
+      const long rec = (long)(key & 0xFFFFFFu) * 4 + (long)((key >> 24) & 3u);
+      T.carry[threadIdx.x] = T.val[2 * rec + (threadIdx.x == 1 ? 1 : 0)];   // pft, pf: ft; pff: f3
+      T.best_key[2 * threadIdx.x] = (long long)((key >> 26) * 4 + ((key >> 24) & 3u));
+      T.best_key[2 * threadIdx.x + 1] = T.who[rec];
+    }
   }
 }
 
@@ -700,6 +714,9 @@ int carry_track_alloc(CarryTrack& T, int n) {
   const size_t recs = (size_t)T.tiles * 4;
   if (hipMalloc((void**)&T.stamp, sizeof(long long) * recs) != hipSuccess) return -1;
   if (hipMalloc((void**)&T.val, sizeof(double) * (2 * recs + 3)) != hipSuccess) { carry_track_free(T); return -1; }
+  if (hipMalloc((void**)&T.who, sizeof(long long) * (recs + 6)) != hipSuccess) { carry_track_free(T); return -1; }
+  if (hipMemset(T.who, 0, sizeof(long long) * (recs + 6)) != hipSuccess) { carry_track_free(T); return -1; }
+  T.best_key = T.who + recs;
   T.carry = T.val + 2 * recs;
   if (hipMemset(T.stamp, 0xFF, sizeof(long long) * recs) != hipSuccess ||
       hipMemset(T.val, 0, sizeof(double) * (2 * recs + 3)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
@@ -711,6 +728,7 @@ int carry_track_alloc(CarryTrack& T, int n) {
 
 void carry_track_free(CarryTrack& T) {
   if (T.stamp) (void)hipFree(T.stamp);
+  if (T.who) (void)hipFree(T.who);
   if (T.val) (void)hipFree(T.val);
   T = CarryTrack{};
 }
@@ -832,7 +850,7 @@ void launch_fill_own(const VerletDevice& V, int n, hipStream_t st) {
 void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const double* m,
                         const double* It, const double* fhf, const VerletDevice& V, double* pout,
                         const DemParams& P, int film, double* diag, const DiagExtra* X, const unsigned char* active,
-                        const CarryTrack* track, long long stamp, hipStream_t st) {
+                        const CarryTrack* track, long long stamp, const unsigned char* owner, hipStream_t st) {
   const int n = P.n;
   const CarryTrack T = track ? *track : CarryTrack{};
 #ifdef LBMDEM_AB
@@ -844,10 +862,10 @@ void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const do
     const int nbe = (n + DEM_GRAINS - 1) / DEM_GRAINS;
     if (film)
       hipLaunchKernelGGL(k_dem_entries<true>, dim3(nbe), dim3(256), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
-                         V.own, V.wallflags, pout, P, active, T, stamp);
+                         V.own, V.wallflags, pout, P, active, T, stamp, owner);
     else
       hipLaunchKernelGGL(k_dem_entries<false>, dim3(nbe), dim3(256), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
-                         V.own, V.wallflags, pout, P, active, T, stamp);
+                         V.own, V.wallflags, pout, P, active, T, stamp, owner);
     return;
   }
   const int nb = (P.n + 127) / 128;

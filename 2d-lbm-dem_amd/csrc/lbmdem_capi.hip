@@ -651,20 +651,26 @@ int lbmdem_dem_substep(lbmdem_handle* h) {
     h->dx_ready = true;
   }
   if (want_diag && h->carry_from < h->substep_seq) launch_carry_resolve(h->ct, h->carry_from, h->stream);
-  const CarryTrack* track = (h->dist || want_diag) ? nullptr : &h->ct;
+  // strips with distributed grains: every rank records the last contacts of the grains it OWNS; the table sub-step itself
+  // is run by one rank on a full replica (lbmdem_dist_table_substep)
+  const CarryTrack* track = want_diag ? nullptr : &h->ct;
+  const bool table_cadence = (h->nbsteps + 1) % 4000 == 0;
 #ifdef LBMDEM_NO_CARRY_TRACK   /* experiment: shows what the records are for (tests/test_gpu_dem_output.py fails) */
   track = nullptr;
 #endif
   const DemParams P = dem_params(h);
   launch_dem_substep(h->kin[h->kcur], h->kin[1 - h->kcur], h->r, h->m, h->It, h->fhf, h->V, h->gp,
                      P, film, want_diag ? h->diag : nullptr, want_diag ? &h->dx : nullptr,
-                     h->dist ? h->dd.active : nullptr, track, h->substep_seq,
+                     h->dist ? h->dd.active : nullptr, track, h->substep_seq, h->dist ? h->owner : nullptr,
                      h->stream);
   if (h->dist && h->dist_poison) launch_dist_poison(h->dd, h->kin[0], h->kin[1], h->n, h->stream);
   if (want_diag) {
     launch_diag_extra(h->dx, h->kin[h->kcur], h->r, h->V, P, film, h->stream);   // leaves the carries as of this sub-step
     h->carry_from = h->substep_seq + 1;
   }
+  // (distributed grains: the rank holding the full replica ran this sub-step as a table sub-step and now holds the
+  // carries; the records the other ranks have left up to here are superseded on every rank alike)
+  if (h->dist && table_cadence) h->carry_from = h->substep_seq + 1;
   h->substep_seq++;
   h->diag_valid = want_table;
   HIP_TRY(hipGetLastError());
@@ -1492,12 +1498,17 @@ int lbmdem_halo_unpack(lbmdem_handle* h, int side, const void* dev_buf) {
 
 // ---- strip decomposition with distributed grains ------------------------------------------------------------
 
+// host arithmetic only (a driver checks its decomposition before it forks one process per GPU)
+int lbmdem_dist_margin_for(const lbmdem_config* cfg, double rmax) {
+  if (!cfg || !(rmax > 0) || !(cfg->dx > 0)) return -1;
+  // an error travels one Verlet-list edge per sub-step: centre distance <= 2 r_max + distVerlet (+ drift)
+  const double hop = (2 * rmax + cfg->phys.distVerlet) / cfg->dx + 1.0;
+  return (int)ceil(cfg->npDEM * hop + rmax / cfg->dx) + 6;
+}
+
 int lbmdem_dist_default_margin(lbmdem_handle* h) {
   if (!h) return -1;
-  const lbmdem_config& c = h->cfg;
-  // an error travels one Verlet-list edge per sub-step: centre distance <= 2 r_max + distVerlet (+ drift)
-  const double hop = (2 * h->rmax + c.phys.distVerlet) / c.dx + 1.0;
-  return (int)ceil(c.npDEM * hop + h->rmax / c.dx) + 6;
+  return lbmdem_dist_margin_for(&h->cfg, h->rmax);
 }
 
 int lbmdem_dist_enable(lbmdem_handle* h, int margin_rows) try {
@@ -1630,6 +1641,138 @@ int lbmdem_dist_pack(lbmdem_handle* h, int kind, int side, void* dev_buf) {
 int lbmdem_dist_unpack(lbmdem_handle* h, int kind, int side, const void* dev_buf) {
   if (!dev_buf || (side != 0 && side != 1)) return fail(LBMDEM_EINVAL, "bad lbmdem_dist_unpack arguments");
   return lbmdem_dist_unpack2(h, kind, side == 0 ? dev_buf : nullptr, side == 1 ? dev_buf : nullptr);
+}
+
+// ---- drop-in outputs of a strip decomposition -----------------------------------------------------------------------
+// write_DEM's table (main.c:340-438) holds, for every grain, diagnostics of the last sub-step; four of them (fr, ice,
+// slip, rw) thread "previous contact" carries through ALL contacts in grain-index order (main.c:130-131), which no
+// strip can do alone. So the sub-step that feeds write_DEM (every 4000th) is run by ONE rank -- the root -- on a full
+// replica: every rank exports the exact state of the grains it owns (+ the youngest carry records of their contacts),
+// the caller merges the exports (disjoint: every grain has exactly one owner), the root imports the merged state,
+// rebuilds its Verlet list from it and runs the sub-step for all n grains with the single-domain diagnostic pipeline.
+// Its own grains come out as the distributed sub-step would have left them (same arithmetic), so it simply carries on.
+
+// state12: [n][12] = 9 kinematic columns + fhf1..3 of the grains this rank owns, zeros elsewhere; owned: [n] 0/1;
+// carry_keys: [3][2], carry_vals: [3] -- the youngest record of each carry among the owned grains' contacts
+// ({0, 0} = none since the last table sub-step). Pure host outputs; nothing on the device changes.
+int lbmdem_dist_export_owned(lbmdem_handle* h, double* state12, unsigned char* owned, long long* carry_keys,
+                             double* carry_vals) try {
+  CHECK_H(h);
+  if (!h->dist) return fail(LBMDEM_EINVAL, "lbmdem_dist_enable first");
+  if (!state12 || !owned || !carry_keys || !carry_vals) return fail(LBMDEM_EINVAL, "null buffer");
+  const int n = h->n;
+  HIP_TRY(hipMemsetAsync(h->ct.best_key, 0, sizeof(long long) * 6, h->stream));
+  if (h->carry_from < h->substep_seq) launch_carry_resolve(h->ct, h->carry_from, h->stream);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::vector<double> kin(9 * (size_t)n), hf(3 * (size_t)n);
+  HIP_TRY(hipMemcpy(kin.data(), h->kin[h->kcur].x1, sizeof(double) * 9 * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(hf.data(), h->fhf, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(owned, h->owner, n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(carry_keys, h->ct.best_key, sizeof(long long) * 6, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(carry_vals, h->ct.carry, sizeof(double) * 3, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; ++i) {
+    double* o = state12 + (size_t)i * 12;
+    if (owned[i]) {
+      for (int k = 0; k < 9; ++k) o[k] = kin[(size_t)k * n + i];
+      for (int k = 0; k < 3; ++k) o[9 + k] = hf[(size_t)k * n + i];
+    } else {
+      for (int k = 0; k < 12; ++k) o[k] = 0.0;
+    }
+  }
+  return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
+}
+
+// The root's table sub-step: state12_full = the merged exports of all ranks ([n][12]); carry_vals[c] replaces carry c
+// where carry_has[c] != 0 (the youngest record over all ranks; otherwise the root's own carry, as of the last table
+// sub-step, stands). Replaces lbmdem_dem_substep for this one sub-step on this rank.
+int lbmdem_dist_table_substep(lbmdem_handle* h, const double* state12_full, const double* carry_vals,
+                              const int* carry_has) try {
+  CHECK_H(h);
+  CHECK_NOT_SPLIT(h);
+  if (!h->dist) return fail(LBMDEM_EINVAL, "lbmdem_dist_enable first");
+  if (!state12_full || !carry_vals || !carry_has) return fail(LBMDEM_EINVAL, "null buffer");
+  const int n = h->n;
+  std::vector<double> soa(12 * (size_t)n);
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 12; ++k) soa[(size_t)k * n + i] = state12_full[(size_t)i * 12 + k];
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(h->kin[h->kcur].x1, soa.data(), sizeof(double) * 9 * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->fhf, soa.data() + 9 * (size_t)n, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+  for (int c = 0; c < 3; ++c)
+    if (carry_has[c]) HIP_TRY(hipMemcpy(h->ct.carry + c, carry_vals + c, sizeof(double), hipMemcpyHostToDevice));
+  // a list over ALL grains from their exact positions (this rank's own list was built with whatever the grains it does
+  // not integrate held). Every pair in contact is in any valid list, pairs that do not touch contribute nothing, and
+  // partners are sorted by index: the sub-step's sums are those of the reference's list.
+  int rc = lbmdem_verlet_rebuild(h);
+  if (rc != LBMDEM_OK) return rc;
+  if (!h->dx_ready) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (diag_extra_alloc(h->dx, h->n, h->V.cap, h->ct.carry) != 0) return fail(LBMDEM_ENOMEM, "diagnostic buffers: hipMalloc failed");
+    h->dx_ready = true;
+  }
+  const int film = (h->nbsteps % h->cfg.phys.stepFilm == 0) ? 1 : 0;
+  const DemParams P = dem_params(h);
+  launch_dem_substep(h->kin[h->kcur], h->kin[1 - h->kcur], h->r, h->m, h->It, h->fhf, h->V, h->gp, P, film, h->diag,
+                     &h->dx, nullptr, nullptr, h->substep_seq, nullptr, h->stream);
+  launch_diag_extra(h->dx, h->kin[h->kcur], h->r, h->V, P, film, h->stream);
+  h->carry_from = h->substep_seq + 1;
+  h->substep_seq++;
+  h->diag_valid = true;
+  HIP_TRY(hipGetLastError());
+  h->kcur = 1 - h->kcur;
+  h->nbsteps++;
+  return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
+}
+
+// write_vtk of a strip decomposition (main.c:237-338): every rank drops its owned columns into zero-initialised
+// lattice-sized arrays (fields11 = grain_pressure[cnt], grain_velocity[3 cnt], grain_acceleration[3 cnt],
+// fluid_pressure[cnt], fluid_velocity[3 cnt], cnt = lx * ly, each [ly][lx]); the caller merges the ranks' arrays
+// (disjoint columns) and one rank writes the five files with lbmdem_write_vtk_fields.
+int lbmdem_vtk_place_owned(lbmdem_handle* h, float* fields11) try {
+  CHECK_H(h);
+  if (!fields11) return fail(LBMDEM_EINVAL, "null buffer");
+  const LatticeView& L = h->L;
+  const int nx = L.xo1 - L.xo0, x0 = L.gx0 + L.xo0;
+  const size_t part = (size_t)nx * L.ly, cnt = (size_t)L.lx * L.ly;
+  std::vector<float> loc(11 * part);
+  float* lp[5] = {loc.data(), loc.data() + part, loc.data() + 4 * part, loc.data() + 7 * part, loc.data() + 8 * part};
+  int rc = lbmdem_download_vtk_fields(h, lp[0], lp[1], lp[2], lp[3], lp[4]);
+  if (rc != LBMDEM_OK) return rc;
+  float* fp[5] = {fields11, fields11 + cnt, fields11 + 4 * cnt, fields11 + 7 * cnt, fields11 + 8 * cnt};
+  const int dims[5] = {1, 3, 3, 1, 3};
+  for (int k = 0; k < 5; ++k)
+    for (int y = 0; y < L.ly; ++y)
+      memcpy(fp[k] + ((size_t)y * L.lx + x0) * dims[k], lp[k] + (size_t)y * nx * dims[k], sizeof(float) * nx * dims[k]);
+  return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
+}
+
+static int write_vtk_file(const char* path, int nx, int ny, const char* name, int dim, const float* data);
+
+int lbmdem_write_vtk_fields(const char* dir, int nfile, int lx, int ly, const float* fields11) {
+  if (!fields11 || lx < 2 || ly < 2) return fail(LBMDEM_EINVAL, "bad lbmdem_write_vtk_fields arguments");
+  const size_t cnt = (size_t)lx * ly;
+  const char* names[5] = {"grain_pressure", "grain_velocity", "grain_acceleration", "fluid_pressure", "fluid_velocity"};
+  const int dims[5] = {1, 3, 3, 1, 3};
+  const float* data[5] = {fields11, fields11 + cnt, fields11 + 4 * cnt, fields11 + 7 * cnt, fields11 + 8 * cnt};
+  for (int k = 0; k < 5; ++k) {
+    char path[4096];
+    snprintf(path, sizeof path, "%s/%s_%.6i.vtk", (dir && *dir) ? dir : ".", names[k], nfile);  // main.c:241-249
+    const int rc = write_vtk_file(path, lx, ly, names[k], dims[k], data[k]);
+    if (rc != LBMDEM_OK) return rc;
+  }
+  return LBMDEM_OK;
 }
 
 int lbmdem_fhf_device(lbmdem_handle* h, void** fhf, void** owner_mask) {
@@ -1865,14 +2008,80 @@ int lbmdem_comm_lbm_step(lbmdem_handle* h, lbmdem_comm* c) {
   return LBMDEM_OK;
 }
 
+// Bitwise merge of host buffers whose non-zero bits are DISJOINT across the ranks (every grain has one owner, every
+// lattice column one rank): an integer SUM all-reduce then is a bitwise OR (no bit position receives two ones, so no
+// carries). Not on the step path (output cadence). In place; every rank gets the merged buffer.
+int lbmdem_comm_allreduce_bits(lbmdem_comm* c, void* host_buf, size_t nbytes) {
+  if (!c || !host_buf || nbytes == 0) return fail(LBMDEM_EINVAL, "bad lbmdem_comm_allreduce_bits arguments");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t words = (nbytes + 7) / 8;
+  unsigned long long* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, words * 8));
+  hipError_t e = hipMemset(d, 0, words * 8);
+  if (e == hipSuccess) e = hipMemcpy(d, host_buf, nbytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(d); HIP_TRY(e); }
+  const ncclResult_t r = g_rccl.AllReduce(d, d, words, ncclUint64, ncclSum, c->nccl[0], c->side[0]);
+  if (r != ncclSuccess) { (void)hipFree(d); return fail(LBMDEM_EHIP, "ncclAllReduce failed: %s", g_rccl.GetErrorString(r)); }
+  e = hipStreamSynchronize(c->side[0]);
+  if (e == hipSuccess) e = hipMemcpy(host_buf, d, nbytes, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIP_TRY(e);
+  return LBMDEM_OK;
+}
+
+// The sub-step that feeds write_DEM (the one that brings the step counter to a multiple of 4000, main.c:1773) over
+// the ranks: exports merged with lbmdem_comm_allreduce_bits, the youngest carry record picked over all ranks, rank 0
+// runs lbmdem_dist_table_substep on the full replica, the others their ordinary sub-step.
+static int comm_table_substep(lbmdem_handle* h, lbmdem_comm* c) try {
+  const int n = h->n, W = c->world;
+  std::vector<double> st(12 * (size_t)n), vals(3 * (size_t)W, 0.0);
+  std::vector<unsigned char> owned(n);
+  std::vector<long long> keys(6 * (size_t)W, 0);
+  RC_TRY(lbmdem_dist_export_owned(h, st.data(), owned.data(), keys.data() + 6 * (size_t)c->rank, vals.data() + 3 * (size_t)c->rank));
+  RC_TRY(lbmdem_comm_allreduce_bits(c, st.data(), sizeof(double) * st.size()));
+  RC_TRY(lbmdem_comm_allreduce_bits(c, owned.data(), owned.size()));
+  RC_TRY(lbmdem_comm_allreduce_bits(c, keys.data(), sizeof(long long) * keys.size()));
+  RC_TRY(lbmdem_comm_allreduce_bits(c, vals.data(), sizeof(double) * vals.size()));
+  for (int i = 0; i < n; ++i)
+    if (owned[i] != 1) return fail(LBMDEM_EINVAL, "grain %d has %d owners at sub-step %ld", i, (int)owned[i], h->nbsteps);
+  if (c->rank != 0) return lbmdem_dem_substep(h);
+  double best_val[3] = {0, 0, 0};
+  int has[3] = {0, 0, 0};
+  for (int k = 0; k < 3; ++k) {
+    long long b0 = 0, b1 = 0;
+    for (int r = 0; r < W; ++r) {
+      const long long k0 = keys[6 * (size_t)r + 2 * k], k1 = keys[6 * (size_t)r + 2 * k + 1];
+      if (k0 > b0 || (k0 == b0 && k0 != 0 && k1 > b1)) { b0 = k0; b1 = k1; best_val[k] = vals[3 * (size_t)r + k]; has[k] = 1; }
+    }
+  }
+  return lbmdem_dist_table_substep(h, st.data(), best_val, has);
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+}
+
 int lbmdem_comm_run(lbmdem_handle* h, lbmdem_comm* c, long n_dem_steps) {
   CHECK_H(h);
   for (long k = 0; k < n_dem_steps; ++k) {
     if (h->nbsteps % h->cfg.npDEM == 0) RC_TRY(lbmdem_comm_lbm_step(h, c));                     // main.c:1710-1718
     if (h->nbsteps % h->cfg.phys.updateVerlet == 0) RC_TRY(lbmdem_verlet_rebuild(h));            // main.c:1721-1724
-    RC_TRY(lbmdem_dem_substep(h));                                                               // main.c:1733-1764
+    if ((h->nbsteps + 1) % 4000 == 0) RC_TRY(comm_table_substep(h, c));                          // feeds write_DEM, main.c:1773
+    else RC_TRY(lbmdem_dem_substep(h));                                                          // main.c:1733-1764
   }
   return LBMDEM_OK;
+}
+
+// write_vtk (main.c:237-338) of the whole lattice: the strips' columns merged, rank 0 writes the five files.
+int lbmdem_comm_write_vtk(lbmdem_handle* h, lbmdem_comm* c, const char* dir, int nfile) try {
+  CHECK_H(h);
+  if (!c) return fail(LBMDEM_EINVAL, "null communicator");
+  const size_t cnt = (size_t)h->cfg.lx * h->cfg.ly;
+  std::vector<float> fields(11 * cnt, 0.f);
+  RC_TRY(lbmdem_vtk_place_owned(h, fields.data()));
+  if (c->world > 1) RC_TRY(lbmdem_comm_allreduce_bits(c, fields.data(), sizeof(float) * fields.size()));
+  if (c->rank != 0) return LBMDEM_OK;
+  return lbmdem_write_vtk_fields(dir, nfile, h->cfg.lx, h->cfg.ly, fields.data());
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
 }
 
 int lbmdem_comm_allreduce_sum(lbmdem_comm* c, double* values, int n) {

@@ -238,6 +238,8 @@ struct CarryTrack {
   double* val;       // [tiles][4][2] ft, f3
   double* carry;     // [3] pft, pff, pf
   int tiles;
+  long long* who;       // [tiles][4] the contact of the record: (grain << 32) | partner (walls: partner 0)
+  long long* best_key;  // [3][2] left by launch_carry_resolve: {(stamp + 1) * 4 + kind, who} of the record each carry came from
 };
 int carry_track_alloc(CarryTrack& T, int n);
 void carry_track_free(CarryTrack& T);
@@ -252,4 +254,4 @@ void launch_fill_own(const VerletDevice& V, int n, hipStream_t st);
 void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const double* m,
                         const double* It, const double* fhf, const VerletDevice& V, double* pout,
                         const DemParams& P, int film, double* diag, const DiagExtra* X, const unsigned char* active,
-                        const CarryTrack* track, long long stamp, hipStream_t st);
+                        const CarryTrack* track, long long stamp, const unsigned char* owner, hipStream_t st);

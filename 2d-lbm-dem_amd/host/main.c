@@ -16,6 +16,7 @@
 #include <math.h>
 #include <unistd.h>
 #include <sys/wait.h>
+#include <signal.h>
 
 #include "../../include/lbmdem_hip.h"
 
@@ -23,7 +24,7 @@
 
 /* --gpus N: one process per GPU (forked before anything touches the HIP runtime), x-strips with the grains
  * distributed, neighbour messages over RCCL (lbmdem_comm_*). Rank 0 creates the RCCL id and hands it to the others
- * through a file in a private temporary directory. Rank 0 prints; VTK / DEM files and checkpoints are single-GPU. */
+ * through a file in a private temporary directory. Rank 0 prints and writes the VTK frames and DEM tables (merged over the ranks); checkpoints are single-GPU. */
 static int g_rank = 0, g_world = 1, g_use_comm = 0;
 static char g_iddir[256] = "";
 
@@ -53,6 +54,43 @@ static int share_id(unsigned char* id) {
 
 static int run(int argc, char** argv);
 
+static int check_decomposition(int argc, char** argv, int gpus) {
+  int lx = 7826, ly = 2325;
+  double scale = 1.;
+  const char* sample = NULL;
+  for (int a = 1; a < argc; ++a) {
+    if (!strcmp(argv[a], "--lx") && a + 1 < argc) lx = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "--ly") && a + 1 < argc) ly = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "--scale") && a + 1 < argc) scale = atof(argv[++a]);
+    else if (argv[a][0] == '-' && argv[a][1] == '-' && strcmp(argv[a], "--comm") && a + 1 < argc) ++a;
+    else if (argv[a][0] != '-' && !sample) sample = argv[a];
+  }
+  if (!sample) return 0;   /* run() prints the usage line */
+  int n = 0;
+  double *r = NULL, *x1 = NULL, *x2 = NULL;
+  if (lbmdem_read_sample(sample, &n, &r, &x1, &x2) != LBMDEM_OK) { fprintf(stderr, "read_sample: %s\n", lbmdem_last_error()); return EXIT_FAILURE; }
+  lbmdem_config cfg;
+  memset(&cfg, 0, sizeof cfg);
+  lbmdem_physics_defaults(&cfg.phys);
+  if (lbmdem_derive(&cfg, lx, ly, scale, n, r) != LBMDEM_OK) { fprintf(stderr, "derive: %s\n", lbmdem_last_error()); return EXIT_FAILURE; }
+  double rmax = r[0];
+  for (int i = 1; i < n; ++i) rmax = fmax(rmax, r[i]);
+  lbmdem_free_host(r); lbmdem_free_host(x1); lbmdem_free_host(x2);
+  const int margin = lbmdem_dist_margin_for(&cfg, rmax);
+  int narrowest = lx;
+  for (int k = 0; k < gpus; ++k) {
+    int w = (int)((long)(k + 1) * lx / gpus) - (int)((long)k * lx / gpus);
+    if (w < narrowest) narrowest = w;
+  }
+  if (narrowest < margin) {
+    fprintf(stderr, "--gpus %d: strips of %d rows are narrower than the margin of %d rows this packing needs "
+                    "(npDEM = %d sub-steps per fluid step); use at most %d GPUs for a lattice %d rows long\n",
+            gpus, narrowest, margin, cfg.npDEM, lx / margin, lx);
+    return EXIT_FAILURE;
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
   int gpus = 1;
   for (int a = 1; a < argc; ++a) {
@@ -61,6 +99,11 @@ int main(int argc, char** argv) {
   }
   if (gpus <= 1) return run(argc, argv);
   g_world = gpus; g_use_comm = 1;
+  { /* every strip must be at least one margin wide (lbmdem_dist_enable would refuse on the ranks whose strip is one
+     * row narrower, and the others would wait for them): checked here, on the host, before anything is forked */
+    int rc = check_decomposition(argc, argv, gpus);
+    if (rc != 0) return rc;
+  }
   snprintf(g_iddir, sizeof g_iddir, "/tmp/lbmdem_XXXXXX");
   if (!mkdtemp(g_iddir)) { perror("mkdtemp"); return EXIT_FAILURE; }
   pid_t pids[64];
@@ -70,11 +113,18 @@ int main(int argc, char** argv) {
     if (pids[r] < 0) { perror("fork"); return EXIT_FAILURE; }
     if (pids[r] == 0) { g_rank = r; _exit(run(argc, argv)); }
   }
-  int bad = 0;
-  for (int r = 0; r < gpus; ++r) {
+  /* the first rank that fails takes the others with it: its peers would otherwise block for ever inside an RCCL call */
+  int bad = 0, left = gpus;
+  while (left > 0) {
     int st = 0;
-    waitpid(pids[r], &st, 0);
-    if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) bad = 1;
+    pid_t p = waitpid(-1, &st, 0);
+    if (p < 0) break;
+    --left;
+    for (int r = 0; r < gpus; ++r) if (pids[r] == p) pids[r] = 0;
+    if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+      if (!bad) for (int r = 0; r < gpus; ++r) if (pids[r] > 0) kill(pids[r], SIGKILL);
+      bad = 1;
+    }
   }
   char path[320];
   snprintf(path, sizeof path, "%s/rccl_id", g_iddir); unlink(path); rmdir(g_iddir);
@@ -226,17 +276,16 @@ static int run(int argc, char** argv) {
         DIE(lbmdem_run(h, 1), "run");
       }
       ++nbsteps;
-      if (comm) { /* file output is single-GPU */
-        if (nbsteps * cfg.dt > duration) { stop = 1; break; }
-        continue;
-      }
-      /* output cadence of renderScene (main.c:1767-1772): write_vtk every stepFilm DEM steps */
+      /* output cadence of renderScene (main.c:1767-1772): write_vtk every stepFilm DEM steps. With several strips
+       * the columns are merged over the ranks and rank 0 writes the same five files */
       if (nbsteps % cfg.phys.stepFilm == 0) {
-        DIE(lbmdem_write_vtk(h, ".", nFile), "write_vtk");
+        if (comm) DIE(lbmdem_comm_write_vtk(h, comm, ".", nFile), "comm_write_vtk");
+        else DIE(lbmdem_write_vtk(h, ".", nFile), "write_vtk");
         nFile++;
       }
-      /* write_DEM and write_forces every stepStrob = 4000 DEM steps (main.c:142,1773-1776) */
-      if (nbsteps % 4000 == 0) {
+      /* write_DEM and write_forces every stepStrob = 4000 DEM steps (main.c:142,1773-1776). With several strips the
+       * sub-step before was run by rank 0 on a full replica (lbmdem_comm_run): it holds the whole table */
+      if (nbsteps % 4000 == 0 && g_rank == 0) {
         DIE(lbmdem_write_dem(h, ".", nFile, energies), "write_dem");
         DIE(lbmdem_write_forces(h, ".", nFile), "write_forces");
       }

@@ -164,6 +164,18 @@ class TorchComm:
     def all_reduce_bits(self, int64_tensor):
         self.dist.all_reduce(int64_tensor, op=self.dist.ReduceOp.SUM, group=self.group)
 
+    def all_reduce_host_bits(self, array):
+        """bitwise merge, in place, of numpy arrays whose non-zero bits are disjoint across the ranks (integer sum)"""
+        import numpy as np
+        import torch
+        raw = array.reshape(-1).view(np.uint8)
+        pad = (-raw.size) % 8
+        t = torch.from_numpy(np.concatenate([raw, np.zeros(pad, np.uint8)]).view(np.int64).copy())
+        if self.dist.get_backend(self.group) == "nccl":
+            t = t.cuda()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        raw[:] = t.cpu().numpy().view(np.uint8)[:raw.size]
+
 
 KIN, FHF, TABLES = 0, 1, 2   # message kinds (include/lbmdem_hip.h LBMDEM_MSG_*)
 
@@ -173,6 +185,32 @@ def default_margin(npDEM: int, rmax: float, dist_verlet: float, dx: float) -> in
     Verlet-list edge (centre distance <= 2 r_max + distVerlet) per sub-step, npDEM sub-steps per period."""
     hop = (2 * rmax + dist_verlet) / dx + 1.0
     return int(math.ceil(npDEM * hop + rmax / dx)) + 6
+
+
+def merge_exports(exports):
+    """Combine the ranks' LbmDem.dist_export_owned() results for the sub-step that feeds write_DEM: the states are
+    disjoint (every grain has exactly one owner: bitwise OR), per carry the record with the greatest key pair
+    (sub-step, kind, grain, partner = the contact the reference evaluated last) wins.
+    -> (state12 [n][12], carry_vals [3], carry_has [3])"""
+    import numpy as np
+    state = np.zeros_like(exports[0][0]).view(np.uint64)
+    owners = np.zeros(exports[0][1].shape, np.int32)
+    for st, owned, _, _ in exports:
+        state |= np.ascontiguousarray(st).view(np.uint64)
+        owners += owned
+    if not (owners == 1).all():
+        raise RuntimeError(f"grains without exactly one owner: {np.flatnonzero(owners != 1)[:8]}")
+    vals, has = np.zeros(3), np.zeros(3, np.int32)
+    for c in range(3):
+        best = (0, 0)
+        for _, _, keys, v in exports:
+            k = (int(keys[c, 0]), int(keys[c, 1]))
+            if k[0] != 0 and k > best:
+                best, vals[c], has[c] = k, v[c], 1
+    return state.view(np.float64), vals, has
+
+
+STEP_STROB = 4000     # write_DEM / write_forces cadence (main.c:142, 1773)
 
 
 class DistStripRunner:
@@ -222,6 +260,32 @@ class DistStripRunner:
             else:
                 self.comm.exchange_end(pending.pop(ev[1]))
 
+    def table_substep(self):
+        """The sub-step that brings the step counter to a multiple of 4000 (it feeds write_DEM): rank 0 runs it on a
+        full replica assembled from every rank's owned grains; the exchange is a bitwise all-reduce of host arrays."""
+        import numpy as np
+        sim = self.b.sim
+        if self.b.nbsteps % self.b.updateVerlet == 0:
+            sim.initVerlet()
+        st, owned, keys, vals = sim.dist_export_owned()
+        allk = np.zeros((self.world, 3, 2), np.int64); allv = np.zeros((self.world, 3))
+        allk[self.rank], allv[self.rank] = keys, vals
+        for a in (st, owned, allk, allv):
+            self.comm.all_reduce_host_bits(a)
+        if not (owned == 1).all():
+            raise RuntimeError(f"grains without exactly one owner: {np.flatnonzero(owned != 1)[:8]}")
+        if self.rank != 0:
+            sim.dem_substep()
+            return
+        vals_best, has = np.zeros(3), np.zeros(3, np.int32)
+        for c in range(3):           # per carry, the youngest record over all ranks
+            best = (0, 0)
+            for r in range(self.world):
+                k = (int(allk[r, c, 0]), int(allk[r, c, 1]))
+                if k[0] != 0 and k > best:
+                    best, vals_best[c], has[c] = k, allv[r, c], 1
+        sim.dist_table_substep(st, vals_best, has)
+
     def render_scene(self, n: int = 1):
         b = self.b
         step = b.nbsteps
@@ -229,7 +293,13 @@ class DistStripRunner:
             if step % b.npDEM == 0:
                 self.lbm_step()
             k = min(n, b.npDEM - step % b.npDEM)
-            b.run_dem(k)
+            to_table = STEP_STROB - 1 - step % STEP_STROB      # ordinary sub-steps before the next table sub-step
+            if to_table == 0:
+                self.table_substep()
+                k = 1
+            else:
+                k = min(k, to_table)
+                b.run_dem(k)
             step += k
             n -= k
 

@@ -20,6 +20,8 @@
 #ifndef LBMDEM_HIP_H
 #define LBMDEM_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -255,6 +257,7 @@ int lbmdem_halo_unpack2(lbmdem_handle* h, const void* buf_lo, const void* buf_hi
 #define LBMDEM_MSG_FHF 1
 #define LBMDEM_MSG_TABLES 2
 int lbmdem_dist_default_margin(lbmdem_handle* h);          /* rows */
+int lbmdem_dist_margin_for(const lbmdem_config* cfg, double rmax_m);   /* the same from a derived config and the largest radius (host only) */
 int lbmdem_dist_enable(lbmdem_handle* h, int margin_rows); /* 0 = default; the strip must be at least that wide */
 long lbmdem_dist_message_doubles(lbmdem_handle* h, int kind); /* capacity of one message, in doubles */
 int lbmdem_dist_begin_period(lbmdem_handle* h);
@@ -279,6 +282,30 @@ int lbmdem_comm_destroy(lbmdem_comm* c);
 int lbmdem_comm_lbm_step(lbmdem_handle* h, lbmdem_comm* c);
 /* n x renderScene() (main.c:1697-1765) with that fluid step */
 int lbmdem_comm_run(lbmdem_handle* h, lbmdem_comm* c, long n_dem_steps);
+/* Drop-in outputs of a strip decomposition (not on the step path; output cadence).
+ * The sub-step that feeds write_DEM -- the one that brings the step counter to a multiple of 4000, main.c:1773 -- is
+ * run by ONE rank on a full replica, because four columns of the table (fr, ice, slip, rw) thread "previous contact"
+ * carries through all contacts in grain-index order (main.c:130-131):
+ *   lbmdem_dist_export_owned   state12 [n][12] (9 kinematic columns + fhf1..3) of the grains this rank owns, zeros
+ *                              elsewhere; owned [n]; per carry the youngest record among the owned grains' contacts:
+ *                              carry_keys [3][2] ({0,0} = none since the last table sub-step), carry_vals [3]
+ *   (the caller merges the exports: disjoint, every grain has one owner; per carry the greatest key pair wins)
+ *   lbmdem_dist_table_substep  the root imports the merged state, rebuilds its Verlet list from it and runs the
+ *                              sub-step for all n grains with the single-domain diagnostic pipeline; afterwards
+ *                              lbmdem_download_grain_table / lbmdem_write_dem / lbmdem_write_forces work on it.
+ * lbmdem_comm_run does all of this over RCCL (rank 0 = root). write_vtk: lbmdem_vtk_place_owned drops the owned
+ * columns into zeroed lattice-sized arrays (fields11: grain_pressure[cnt], grain_velocity[3 cnt],
+ * grain_acceleration[3 cnt], fluid_pressure[cnt], fluid_velocity[3 cnt], each [ly][lx]), the merged arrays go to
+ * lbmdem_write_vtk_fields; lbmdem_comm_write_vtk = both over RCCL, rank 0 writes. */
+int lbmdem_dist_export_owned(lbmdem_handle* h, double* state12, unsigned char* owned, long long* carry_keys,
+                             double* carry_vals);
+int lbmdem_dist_table_substep(lbmdem_handle* h, const double* state12_full, const double* carry_vals,
+                              const int* carry_has);
+int lbmdem_vtk_place_owned(lbmdem_handle* h, float* fields11);
+int lbmdem_write_vtk_fields(const char* dir, int nfile, int lx, int ly, const float* fields11);
+int lbmdem_comm_write_vtk(lbmdem_handle* h, lbmdem_comm* c, const char* dir, int nfile);
+/* bitwise merge (integer sum) of host buffers whose non-zero bits are disjoint across the ranks; in place */
+int lbmdem_comm_allreduce_bits(lbmdem_comm* c, void* host_buf, size_t nbytes);
 /* sum of host values over the ranks (check_density / final_density; not on the step path) */
 int lbmdem_comm_allreduce_sum(lbmdem_comm* c, double* values, int n);
 /* a grouped send + receive of `doubles` values from this rank to itself on a side stream while another stream is

@@ -282,7 +282,22 @@ def lockstep_render_dist(runners, n):
                             assert len(dst) == 1
                             dst[0].copy_(send)
         k = min(n, b0.npDEM - step % b0.npDEM)
-        for R in runners:
-            R.b.run_dem(k)
+        to_table = 4000 - 1 - step % 4000
+        if to_table == 0 and hasattr(runners[0].b, "sim"):
+            # the sub-step that feeds write_DEM: rank 0 on a full replica merged from every rank's owned grains
+            import importlib
+            strips = importlib.import_module(type(runners[0]).__module__)
+            for R in runners:
+                if step % b0.updateVerlet == 0:
+                    R.b.sim.initVerlet()
+            state, vals, has = strips.merge_exports([R.b.sim.dist_export_owned() for R in runners])
+            runners[0].b.sim.dist_table_substep(state, vals, has)
+            for R in runners[1:]:
+                R.b.sim.dem_substep()
+            k = 1
+        else:
+            k = min(k, to_table) if to_table > 0 else k
+            for R in runners:
+                R.b.run_dem(k)
         step += k
         n -= k

@@ -127,3 +127,28 @@ print("PROBE-OK %.1f %.1f %.1f" % (side, without, inline))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "PROBE-OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
+def test_comm_driver_writes_the_same_files_as_the_single_gpu_driver(po, tmp_path):
+    """`lbmdem --comm` (the code path of `--gpus N`: grains distributed, lbmdem_comm_run, outputs merged over the ranks:
+    lbmdem_comm_write_vtk, the table sub-step on rank 0's full replica) leaves the same frames and tables on disk as the
+    single-GPU driver: five VTK files at DEM step 8000, DEM000000.dat/.ps at 4000, DEM000001.dat/.ps at 8000, stats.data."""
+    c = gu.CASES["G4_coupled_256x200"]
+    outs = {}
+    for mode in ("single", "comm"):
+        d = tmp_path / mode
+        d.mkdir()
+        sample = d / "packing.data"
+        po.write_sample(str(sample), c["r_mm"], c["x_mm"], c["y_mm"])
+        cmd = [EXE, str(sample), "--lx", "256", "--ly", "200", "--steps", "8001"] + (["--comm"] if mode == "comm" else [])
+        out = subprocess.run(cmd, capture_output=True, text=True, cwd=d, timeout=600)
+        assert out.returncode == 0, (out.stdout[-300:], out.stderr[-600:])
+        outs[mode] = out
+    a, b = tmp_path / "single", tmp_path / "comm"
+    names = sorted(p.name for p in a.iterdir())
+    assert names == sorted(p.name for p in b.iterdir())
+    assert sum(n.endswith(".vtk") for n in names) == 5 and "DEM000001.dat" in names and "DEM000000.ps" in names
+    for n in names:
+        assert (a / n).read_bytes() == (b / n).read_bytes(), n
+    fd = lambda o: re.search(r"final_density: ([0-9.]+)", o.stderr).group(1)
+    assert fd(outs["single"]) == fd(outs["comm"])

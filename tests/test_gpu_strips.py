@@ -184,3 +184,66 @@ def test_distributed_grains_equal_single_domain(pkg, nstrips):
         xc0 = x1 / cfg.dx
         moved += int((own & ~(((a == 0) | (xc0 >= a)) & ((b == lx) | (xc0 < b)))).sum())
     assert moved > 0, "no grain changed owner: the test does not exercise migration"
+
+
+@pytest.mark.parametrize("nstrips", [2, 3])
+def test_strip_outputs_are_the_single_domain_files(pkg, tmp_path, nstrips):
+    """Drop-in outputs under a strip decomposition (main.c:1767-1776, 237-478): after 4000 renderScene() calls the five
+    VTK files (columns merged over the strips), DEM000000.dat, its stats.data line and DEM000000.ps -- written from the
+    table sub-step rank 0 ran on a replica merged from every rank's owned grains, with the "previous contact" carries
+    resolved over all ranks -- are byte for byte the files of the single-domain run, whose writers are pinned to the
+    reference's files (tests/test_gpu_dem_output.py, tests/test_gpu_golden.py)."""
+    import torch
+    from strip_backends import LoopbackComm, lockstep_render_dist
+    strips = pkg.strips_module()
+    lx, ly = 1024, 256
+    r, x, y = samples.row_packing(lx, ly, 700, seed=11)
+    # one grain pressed into the left DEM wall above the packing (a wall carry)
+    r = np.append(r, [0.6]); x = np.append(x, [0.6 - 0.002]); y = np.append(y, [22.0])
+    r, x1, x2 = samples.to_metres(r, x, y)
+    cfg = pkg.derive(lx, ly, r)
+    parts = strips.partition(lx, nstrips)
+    margin = strips.default_margin(cfg.npDEM, float(r.max()), cfg.phys.distVerlet, cfg.dx)
+    assert min(b - a for a, b in parts) >= margin
+    rng = np.random.default_rng(8)
+    k = np.zeros((len(r), 9)); k[:, 0], k[:, 1] = x1, x2
+    k[:, 3:6] = rng.normal(0, 1, (len(r), 3)) * [0.25, 0.2, 40.0]     # ~1 mm in 4000 sub-steps: plenty of collisions
+    k[-1:, 3:6] = 0.0
+    n = 4000
+    single = pkg.LbmDem(lx, ly, r, x1, x2)
+    single.kinematics = k
+    single.renderScene(n)
+    da, db = tmp_path / "single", tmp_path / "strips"
+    da.mkdir(); db.mkdir()
+    single.write_DEM(str(da), 0); single.write_forces(str(da), 0); single.write_vtk(str(da), 0)
+    ts = single.grain_table()
+    col = {c: i for i, c in enumerate("x1 x2 x3 v1 v2 v3 a1 a2 a3 r m mw It p s f1 f2 ifm fm fr ifr M11 M12 M21 M22 ice slip rw z zz".split())}
+    assert (ts[:, col["z"]] > 0).sum() > 15 and (ts[:, col["slip"]] != 0).sum() >= 3, ((ts[:, col["z"]] > 0).sum(), (ts[:, col["slip"]] != 0).sum())
+    runners = []
+    for rank, strip in enumerate(parts):
+        be = strips.GpuStripBackend(pkg, torch, lx, ly, r, x1, x2, strip, 2, 0, distributed=True, margin=margin, poison=True)
+        be.sim.kinematics = k
+        runners.append(strips.DistStripRunner(be, LoopbackComm(), rank, nstrips))
+    lockstep_render_dist(runners, n)
+    for R in runners:
+        R.b.sim.sync()
+    root = runners[0].b.sim
+    assert np.array_equal(root.grain_table(), ts)              # all 30 columns, fr / ice / slip / rw included
+    root.write_DEM(str(db), 0); root.write_forces(str(db), 0)
+    fields = np.zeros(11 * lx * ly, np.float32)
+    for R in runners:
+        part = np.zeros_like(fields)
+        R.b.sim.vtk_place_owned(part)
+        fields.view(np.uint32)[:] |= part.view(np.uint32)          # disjoint columns
+    pkg.write_vtk_fields(str(db), 0, lx, ly, fields)
+    names = sorted(p.name for p in da.iterdir())
+    assert len(names) == 8 and names == sorted(p.name for p in db.iterdir())
+    for nme in names:
+        assert (da / nme).read_bytes() == (db / nme).read_bytes(), nme
+    # ... and the run goes on identically after the table sub-step (rank 0 swapped its Verlet list for one sub-step)
+    lockstep_render_dist(runners, 2 * cfg.npDEM + 3); single.renderScene(2 * cfg.npDEM + 3)
+    ks = single.kinematics
+    xc = ks[:, 0] / cfg.dx
+    for R, (a, b) in zip(runners, parts):
+        own = ((a == 0) | (xc >= a)) & ((b == lx) | (xc < b))
+        assert np.array_equal(R.b.sim.kinematics[own], ks[own])
