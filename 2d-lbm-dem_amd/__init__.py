@@ -94,6 +94,7 @@ def load_library():
     for name in ("upload_f", "download_f", "download_obst", "total_density", "upload_kinematics",
                  "download_kinematics", "download_fhf", "set_stream"):
         getattr(L, "lbmdem_" + name).argtypes = [C.c_void_p, C.c_void_p]
+    L.lbmdem_path_info.argtypes = [C.c_void_p, C.c_void_p]
     L.lbmdem_dist_export_owned.argtypes = [C.c_void_p] * 5
     L.lbmdem_dist_table_substep.argtypes = [C.c_void_p] * 4
     L.lbmdem_vtk_place_owned.argtypes = [C.c_void_p, C.c_void_p]
@@ -551,6 +552,12 @@ class LbmDem:
         _chk(self._L.lbmdem_halo_unpack2(self._h, C.c_void_p(ptr_lo), C.c_void_p(ptr_hi)))
 
     # ---- drop-in outputs of a strip decomposition (include/lbmdem_hip.h) ----------------------------------
+    def path_info(self):
+        """which size-dependent fast paths are active: dict(table, slots_per_direction, mincov, marching)"""
+        v = (C.c_int * 4)()
+        _chk(self._L.lbmdem_path_info(self._h, v))
+        return dict(table=bool(v[0]), slots_per_direction=int(v[1]), mincov=bool(v[2]), marching=bool(v[3]))
+
     def dist_export_owned(self):
         """-> (state12 [n][12], owned [n] uint8, carry_keys [3][2] int64, carry_vals [3]): what this rank contributes
         to the sub-step that feeds write_DEM (strips.merge_exports combines the ranks' exports)."""

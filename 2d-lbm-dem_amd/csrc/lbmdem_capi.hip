@@ -92,6 +92,7 @@ struct lbmdem_handle {
   VerletDevice V{};
   bool verlet_ok = false;
   volatile int* ovf_host = nullptr;  // pinned mirror of V.overflow, refreshed (asynchronously) after every rebuild
+  volatile int* ferr_host = nullptr; // pinned mirror of fs.error (strip decomposition), refreshed after every period's forces
   long nbsteps = 0;
   int force_mode = 0;
   // derived scalars
@@ -392,6 +393,8 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
   }
   CREATE_TRY(hipHostMalloc((void**)&h->ovf_host, sizeof(int), hipHostMallocDefault));
   *h->ovf_host = 0;
+  CREATE_TRY(hipHostMalloc((void**)&h->ferr_host, sizeof(int), hipHostMallocDefault));
+  *h->ferr_host = 0;
   // init_density (main.c:716-724) and init_obst (main.c:663-711)
   launch_fill_equilibrium(h->f[0], L, h->stream);
   launch_fill_equilibrium(h->f[1], L, h->stream);
@@ -429,6 +432,7 @@ int lbmdem_destroy(lbmdem_handle* h) {
   verlet_free(h->V);
   dist_free(h->dd);
   if (h->ovf_host) (void)hipHostFree((void*)h->ovf_host);
+  if (h->ferr_host) (void)hipHostFree((void*)h->ferr_host);
   diag_extra_free(h->dx);
   carry_track_free(h->ct);
   for (hipEvent_t e : h->ev0) (void)hipEventDestroy(e);
@@ -588,6 +592,19 @@ int lbmdem_force_stats(lbmdem_handle* h, int* from_table, int* gathered) {
   }
   if (from_table) *from_table = h->last_forces_from_table ? h->n - g : 0;
   if (gathered) *gathered = g;
+  return LBMDEM_OK;
+}
+
+// Which of the size-dependent fast paths this handle runs with (they switch off by size, silently otherwise):
+// info[0] = link-sum table in use (needs < 2^18 grains, reduced radius < ~20 nodes, reductionR < 1), info[1] = its slots
+// per direction, info[2] = the lowest-cover record that makes `act` exact where three or more discs overlap (needs
+// < 2^20 grains; without it the two-disc rule applies), info[3] = the marching fused kernel (reductionR < 1).
+int lbmdem_path_info(lbmdem_handle* h, int* info4) {
+  if (!h || !info4) return fail(LBMDEM_EINVAL, "null argument");
+  info4[0] = h->fs.tab != nullptr ? 1 : 0;
+  info4[1] = h->fs.tab != nullptr ? h->fs.spd : 0;
+  info4[2] = h->mincov != nullptr ? 1 : 0;
+  info4[3] = h->L.reduced_lt1 ? 1 : 0;
   return LBMDEM_OK;
 }
 
@@ -1543,7 +1560,22 @@ int lbmdem_dist_enable(lbmdem_handle* h, int margin_rows) try {
   }
   long cap_g = best + best / 2 + 256;
   if (cap_g > h->n) cap_g = h->n;
-  long cap_t = (long)(c.ly / (2 * h->rmin / c.dx)) + 32;
+  // grains a cut can go through (link ring included): the fullest band of one largest diameter + 4 rows anywhere in the
+  // present packing, x 1.5 -- from the same histogram as cap_g, hence also right when several columns of small grains
+  // fit into the band (the former ly / (2 rmin) counted one column)
+  long cap_t;
+  {
+    const int tw = 2 * (int)ceil(h->rmax / c.dx) + 4;
+    long w2 = 0, b2 = 0;
+    for (int x = 0; x < c.lx; ++x) {
+      w2 += hist[x];
+      if (x >= tw) w2 -= hist[x - tw];
+      if (w2 > b2) b2 = w2;
+    }
+    cap_t = b2 + b2 / 2 + 32;
+    const long one_column = (long)(c.ly / (2 * h->rmin / c.dx)) + 32;
+    if (cap_t < one_column) cap_t = one_column;
+  }
   if (cap_t > h->n) cap_t = h->n;
   // grains that can reach this rank's rows (+ halo): launch bound of the rasteriser and the force-table kernel
   long cap_l = 0;
@@ -1585,6 +1617,14 @@ int lbmdem_dist_begin_period(lbmdem_handle* h) {
   CHECK_H(h);
   CHECK_NOT_SPLIT(h);
   if (!h->dist) return fail(LBMDEM_EINVAL, "lbmdem_dist_enable first");
+  // errors of earlier periods (a truncated message list, overlapping discs across a cut, a clash while merging tables)
+  // are flagged on the device; the flag follows every period to pinned host memory and stops the run HERE, at the next
+  // period, instead of letting it continue on truncated messages until somebody calls lbmdem_sync
+  if (*h->ferr_host)
+    return fail(LBMDEM_EINVAL, "strip decomposition: device error flag %d in an earlier fluid step (4: more grains near a cut "
+                               "than the message capacity, 8: two ranks produced the same link sum, others: the force of a "
+                               "grain on a cut could not be formed)", (int)*h->ferr_host);
+  HIP_TRY(hipMemcpyAsync((void*)h->ferr_host, h->fs.error, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   const lbmdem_config& c = h->cfg;
   DistGeom Gm;
   Gm.lo = (double)c.x_begin; Gm.hi = (double)c.x_end; Gm.margin = (double)h->dist_margin; Gm.dx = c.dx; Gm.Mgx = c.Mgx;

@@ -408,15 +408,21 @@ class CCommRunner:
     uses it): one library call per batch of renderScene() calls -- no Python, no torch on the step path. `dist` is
     only used to hand rank 0's RCCL ids to the other ranks."""
 
-    def __init__(self, pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2):
+    def __init__(self, pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2, connect=True):
         strip = partition(lx, world)[rank]
+        self.pkg, self.rank, self.world, self.local_rank = pkg, rank, world, local_rank
         self.sim = pkg.LbmDem(lx, ly, r, x1, x2, device=local_rank, strip=strip, halo=2 if world > 1 else 0)
         self.sim.dist_enable(0)
-        ids = [pkg.comm_unique_id() if rank == 0 else None]
-        if world > 1:
+        self.comm = None
+        if connect:
+            self.connect(dist)
+
+    def connect(self, dist):
+        """the collective part (RCCL communicators): only after every rank is known to have come this far"""
+        ids = [self.pkg.comm_unique_id() if self.rank == 0 else None]
+        if self.world > 1:
             dist.broadcast_object_list(ids, src=0)
-        self.comm = pkg.Comm(ids[0], rank, world, local_rank)
-        self.rank, self.world = rank, world
+        self.comm = self.pkg.Comm(ids[0], self.rank, self.world, self.local_rank)
 
     def render_scene(self, n: int = 1):
         self.comm.run(self.sim, n)

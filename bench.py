@@ -138,9 +138,11 @@ def main():
     ap.add_argument("--workload", choices=["metric", "configs4", "real50k"], default="metric",
                     help="metric = 4096x4096 / 50k-grain synthetic packing (BASELINE.json's metric, every N); "
                          "configs4 = 8192x4096/50k; real50k = 4096x4096 with the reference's bin/50000.data geometry")
-    ap.add_argument("--driver", choices=["c", "torch"], default="c",
-                    help="multi-GPU step driver: c = lbmdem_comm_run (RCCL inside the library, no Python on the step "
-                         "path); torch = strips.py over torch.distributed")
+    ap.add_argument("--driver", choices=["c", "torch"], default="torch",
+                    help="multi-GPU step driver: torch = strips.py over torch.distributed (the transport that has run on "
+                         "several ranks: gloo tests, RCCL self-exchange); c = lbmdem_comm_run (RCCL inside the library, "
+                         "no Python on the step path -- has only ever run with ONE rank, no multi-GPU box was available: "
+                         "opt-in until tests/test_gpu_multi.py has passed on real GPUs)")
     ap.add_argument("--strips", action="store_true",
                     help="use the strip-decomposition driver (torch.distributed) even with one rank")
     args = ap.parse_args()
@@ -187,11 +189,12 @@ def main():
         runner = None
         if args.driver == "c" and args.force_mode == 0 and (wide or world == 1):
             # grains distributed, the library's own RCCL transport, one C call per batch of steps
+            # every rank must take the same path. The vote comes BEFORE the RCCL communicator is made: a rank that
+            # fails in its local set-up would otherwise leave the others blocked inside ncclCommInitRank
             ok = 1
             try:
-                runner = strips.CCommRunner(pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2)
-                runner.comm.selftest()
-            except Exception as e:      # every rank must take the same path: agree on it below
+                runner = strips.CCommRunner(pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2, connect=False)
+            except Exception as e:
                 print(f"[rank {rank}] C driver unavailable: {e}", file=sys.stderr)
                 ok = 0
             flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
@@ -200,6 +203,9 @@ def main():
                 if rank == 0:
                     print("falling back to the torch.distributed strip driver on all ranks", file=sys.stderr)
                 runner = None
+            else:
+                runner.connect(dist)
+                runner.comm.selftest()
         if runner is None:
             runner = strips.make_gpu_runner(pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2,
                                             force_mode=args.force_mode)

@@ -112,6 +112,10 @@ int lbmdem_forces_fluid(lbmdem_handle* h);      /* main.c:1285-1333 */
  * same bits either way. Returns how many grains of the LAST forces_fluid call took each route (from_table = 0
  * when the table did not describe the current lattice and every grain was gathered). Synchronises. */
 int lbmdem_force_stats(lbmdem_handle* h, int* from_table, int* gathered);
+/* Which size-dependent fast paths are active on this handle: info4[0] link-sum table (needs < 2^18 grains, reduced radius
+ * < ~20 nodes, reductionR < 1), info4[1] its slots per direction, info4[2] the lowest-cover record that keeps `act` exact
+ * where three or more reduced discs overlap (< 2^20 grains; else the two-disc rule), info4[3] the marching fused kernel. */
+int lbmdem_path_info(lbmdem_handle* h, int* info4);
 
 /* initVerlet + VerletWall, main.c:1519-1594 (same pair set; uniform grid + radix sort instead of
  * the O(N^2) scan). Also moves the right/top DEM walls as VerletWall does (main.c:1555-1561). */

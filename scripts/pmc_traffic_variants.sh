@@ -1,5 +1,9 @@
 # HBM traffic (FETCH_SIZE 2048 B/unit, WRITE_SIZE 1024 B/unit on gfx950, see profiles/r01_d_pmc_traffic.json) of the fused
 # kernel for several LBMDEM_CS_VARIANT values.   usage: VARS="25 29 30" bash scripts/pmc_traffic_variants.sh
+# The LBMDEM_CS_* / LBMDEM_MARCH knobs only exist in the experiment build (make -C 2d-lbm-dem_amd/csrc AB=1): the product
+# library ignores them, so without this line every "variant" below would silently be the same kernel.
+export LBMDEM_HIP_LIBRARY=${LBMDEM_HIP_LIBRARY:-$GRAFT_REPO_ROOT/2d-lbm-dem_amd/liblbmdem_hip_ab.so}
+[ -f "$LBMDEM_HIP_LIBRARY" ] || { echo "experiment build $LBMDEM_HIP_LIBRARY not found: make -C 2d-lbm-dem_amd/csrc AB=1"; exit 1; }
 cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/trafficv; mkdir -p $O
 for v in $VARS; do for c in FETCH_SIZE WRITE_SIZE; do

@@ -1,3 +1,7 @@
+# The LBMDEM_CS_* / LBMDEM_MARCH knobs only exist in the experiment build (make -C 2d-lbm-dem_amd/csrc AB=1): the product
+# library ignores them, so without this line every "variant" below would silently be the same kernel.
+export LBMDEM_HIP_LIBRARY=${LBMDEM_HIP_LIBRARY:-$GRAFT_REPO_ROOT/2d-lbm-dem_amd/liblbmdem_hip_ab.so}
+[ -f "$LBMDEM_HIP_LIBRARY" ] || { echo "experiment build $LBMDEM_HIP_LIBRARY not found: make -C 2d-lbm-dem_amd/csrc AB=1"; exit 1; }
 cd $GRAFT_REPO_ROOT
 VARS=${VARS:-"9 16 24 17 25 18 26 19 27"}
 for v in ${TESTVARS:-25}; do echo "pytest variant $v: $(LBMDEM_CS_VARIANT=$v python -m pytest tests -m gpu -x -q 2>&1 | tail -2 | tr '\n' ' ')"; done

@@ -552,3 +552,25 @@ def test_serial_total_density_bit_exact_on_awkward_lattices(pkg, po):
     for _ in range(3):
         sim.lbm_step(); ora.lbm_steps(1)
     assert sim.final_density() == ora.total_density()
+
+
+@pytest.mark.parametrize("knobs", ["LBMDEM_CS_VARIANT=24", "LBMDEM_CS_VARIANT=27", "LBMDEM_CS_VARIANT=28", "LBMDEM_CS_VARIANT=29",
+                                   "LBMDEM_MARCH=22", "LBMDEM_MARCH=21"])
+def test_experiment_build_kernel_variants_are_bit_exact(knobs):
+    """The experiment build (make AB=1; liblbmdem_hip_ab.so, git-ignored, shipped with the tree when it was built) holds
+    the other shapes of the fused kernel behind environment knobs the product library does not have: marching with 16 /
+    64 rows per wave, run-time segment rows (what strips and edge rows use), 56 producing lanes, and k_cs_march3 (per-link
+    record DMA, no record ring) with one and two row buffers. Each must reproduce the reference's golden vectors too --
+    so that the A/B timings in DESIGN.md compare kernels that compute the same thing."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "2d-lbm-dem_amd", "liblbmdem_hip_ab.so")
+    if not os.path.exists(lib):
+        pytest.skip("experiment build not present")
+    env = dict(os.environ, LBMDEM_HIP_LIBRARY=lib)
+    k, v = knobs.split("=")
+    env[k] = v
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_golden.py"), "-q", "-x", "-k",
+                          "G1_fluid_128 or G2 or G3 or G4 or a08d83_600"], env=env, capture_output=True, text=True, cwd=root,
+                         timeout=900)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-1500:]
