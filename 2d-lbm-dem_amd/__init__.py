@@ -95,6 +95,8 @@ def load_library():
                  "download_kinematics", "download_fhf", "set_stream"):
         getattr(L, "lbmdem_" + name).argtypes = [C.c_void_p, C.c_void_p]
     L.lbmdem_path_info.argtypes = [C.c_void_p, C.c_void_p]
+    L.lbmdem_dist_export_carries.argtypes = [C.c_void_p] * 4
+    L.lbmdem_dist_set_carries.argtypes = [C.c_void_p, C.c_void_p]
     L.lbmdem_dist_export_owned.argtypes = [C.c_void_p] * 5
     L.lbmdem_dist_table_substep.argtypes = [C.c_void_p] * 4
     L.lbmdem_vtk_place_owned.argtypes = [C.c_void_p, C.c_void_p]
@@ -552,6 +554,15 @@ class LbmDem:
         _chk(self._L.lbmdem_halo_unpack2(self._h, C.c_void_p(ptr_lo), C.c_void_p(ptr_hi)))
 
     # ---- drop-in outputs of a strip decomposition (include/lbmdem_hip.h) ----------------------------------
+    def dist_export_carries(self):
+        keys = np.zeros((3, 2), np.int64); vals = np.zeros(3); standing = np.zeros(3)
+        _chk(self._L.lbmdem_dist_export_carries(self._h, _vp(keys), _vp(vals), _vp(standing)))
+        return keys, vals, standing
+
+    def dist_set_carries(self, carry3):
+        c = np.ascontiguousarray(carry3, dtype=np.float64)
+        _chk(self._L.lbmdem_dist_set_carries(self._h, _vp(c)))
+
     def path_info(self):
         """which size-dependent fast paths are active: dict(table, slots_per_direction, mincov, marching)"""
         v = (C.c_int * 4)()

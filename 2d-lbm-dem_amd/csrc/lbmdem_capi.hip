@@ -1296,6 +1296,13 @@ struct CkptHeader {
   int verlet_ok, nnbr; // symmetric list length
   long plane;          // sanity: nxl * sy of the writer
 };
+}  // namespace
+static int dist_enable_caps(lbmdem_handle* h, int M, long cap_g, long cap_t, long cap_l);
+namespace {
+struct CkptDist {       // follows the lattice when the writer had its grains distributed over strips
+  char magic[8];        // "LBMDIST1"
+  int margin, cap_g, cap_t, cap_l, poison, pad;
+};
 constexpr int CKPT_LAYOUT = 1;
 static bool wr(FILE* fp, const void* p, size_t n) { return fwrite(p, 1, n, fp) == n; }
 static bool rd(FILE* fp, void* p, size_t n) { return fread(p, 1, n, fp) == n; }
@@ -1306,8 +1313,8 @@ int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) try {
   CHECK_NOT_SPLIT(h);
   if (!path) return fail(LBMDEM_EINVAL, "null path");
   if (h->obst_pending) return fail(LBMDEM_EINVAL, "checkpoint between obst_construction and collide_stream");
-  if (h->dist) return fail(LBMDEM_EINVAL, "checkpoints are written by single-GPU handles (with distributed grains a rank holds "
-                                          "only the grains it integrates)");
+  // (a handle with distributed grains writes ITS strip, the grains as it holds them, its ownership masks and message
+  // capacities: one file per rank; the carries must have been agreed over the ranks first, lbmdem_comm_sync_carries)
   HIP_TRY(hipStreamSynchronize(h->stream));
   const int n = h->n;
   std::vector<int> off(n + 1, 0);
@@ -1318,7 +1325,7 @@ int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) try {
   H.lid6 = h->L.lid6;
   H.layout = CKPT_LAYOUT; H.force_mode = h->force_mode; H.diag_always = h->diag_always ? 1 : 0;
   H.has_carry = 1;
-  if (h->carry_from < h->substep_seq) {
+  if (!h->dist && h->carry_from < h->substep_seq) {
     launch_carry_resolve(h->ct, h->carry_from, h->stream);
     HIP_TRY(hipStreamSynchronize(h->stream));
   }
@@ -1343,6 +1350,15 @@ int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) try {
   dump(h->obst[h->ocur], sizeof(int) * (size_t)h->L.plane);
   for (int q = 0; q < 9 && ok; ++q)  // the lattice (device layout) in nine chunks: bounded host staging
     dump(h->f[h->fcur] + (size_t)q * h->L.plane, sizeof(double) * (size_t)h->L.plane);
+  if (h->dist && ok) {   // optional trailing section
+    CkptDist D;
+    memset(&D, 0, sizeof D);
+    memcpy(D.magic, "LBMDIST1", 8);
+    D.margin = h->dist_margin; D.cap_g = h->dd.cap_g; D.cap_t = h->dd.cap_t; D.cap_l = h->dd.cap_l;
+    D.poison = h->dist_poison ? 1 : 0;
+    ok = wr(fp, &D, sizeof D);
+    dump(h->dd.active, n); dump(h->dd.fluidmask, n); dump(h->owner, n);
+  }
   ok = (fclose(fp) == 0) && ok;
   if (!ok) return fail(LBMDEM_EHIP, "writing checkpoint '%s' failed", path);
   return LBMDEM_OK;
@@ -1385,6 +1401,13 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
   h->ocur = 0; h->obst_pending = false;
   for (int q = 0; q < 9 && ok; ++q) fill(h->f[0] + (size_t)q * h->L.plane, sizeof(double) * (size_t)h->L.plane);
   h->fcur = 0;
+  if (ok) {   // a strip with distributed grains: masks and message capacities as the writer had them
+    CkptDist D;
+    if (rd(fp, &D, sizeof D)) {
+      ok = memcmp(D.magic, "LBMDIST1", 8) == 0 && dist_enable_caps(h, D.margin, D.cap_g, D.cap_t, D.cap_l) == LBMDEM_OK;
+      if (ok) { fill(h->dd.active, n); fill(h->dd.fluidmask, n); fill(h->owner, n); h->dist_poison = D.poison != 0; }
+    }
+  }
   fclose(fp);
   if (!ok) { lbmdem_destroy(h); return fail(LBMDEM_EINVAL, "checkpoint '%s' is truncated or from a different decomposition", path); }
   h->cfg = cfg;  // wall positions as saved
@@ -1528,6 +1551,19 @@ int lbmdem_dist_default_margin(lbmdem_handle* h) {
   return lbmdem_dist_margin_for(&h->cfg, h->rmax);
 }
 
+// allocation + switches of the distributed-grain mode with given message capacities (lbmdem_dist_enable derives them
+// from the packing; a restart takes them from the checkpoint: neighbours must agree on the message sizes)
+static int dist_enable_caps(lbmdem_handle* h, int M, long cap_g, long cap_t, long cap_l) {
+  if (dist_alloc(h->dd, h->n, (int)cap_g, (int)cap_t, (int)cap_l) != 0) { dist_free(h->dd); return fail(LBMDEM_ENOMEM, "dist_alloc failed"); }
+  h->dist = true;
+  h->dist_margin = M;
+  h->fs.mask = h->dd.fluidmask;
+  h->fs.local_list = h->dd.local_list;
+  h->fs.local_count = h->dd.counters + 6;
+  h->fs.local_cap = h->dd.cap_l;
+  return LBMDEM_OK;
+}
+
 int lbmdem_dist_enable(lbmdem_handle* h, int margin_rows) try {
   CHECK_H(h);
   const lbmdem_config& c = h->cfg;
@@ -1585,16 +1621,37 @@ int lbmdem_dist_enable(lbmdem_handle* h, int margin_rows) try {
     cap_l = cap_l + cap_l / 2 + 256;
     if (cap_l > h->n) cap_l = h->n;
   }
-  if (dist_alloc(h->dd, h->n, (int)cap_g, (int)cap_t, (int)cap_l) != 0) { dist_free(h->dd); return fail(LBMDEM_ENOMEM, "dist_alloc failed"); }
-  h->dist = true;
-  h->dist_margin = M;
-  h->fs.mask = h->dd.fluidmask;
-  h->fs.local_list = h->dd.local_list;
-  h->fs.local_count = h->dd.counters + 6;
-  h->fs.local_cap = h->dd.cap_l;
-  return LBMDEM_OK;
+  return dist_enable_caps(h, M, cap_g, cap_t, cap_l);
 } catch (...) {
   return fail(LBMDEM_EINVAL, "unexpected C++ exception");
+}
+
+// The "previous contact" carries as agreed over all ranks (strip decomposition: before a checkpoint, see
+// lbmdem_comm_sync_carries): they stand until a younger contact is recorded.
+int lbmdem_dist_set_carries(lbmdem_handle* h, const double* carry3) {
+  CHECK_H(h);
+  if (!carry3) return fail(LBMDEM_EINVAL, "null buffer");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(h->ct.carry, carry3, sizeof(double) * 3, hipMemcpyHostToDevice));
+  h->carry_from = h->substep_seq;
+  return LBMDEM_OK;
+}
+
+// this rank's youngest record per carry (keys {0,0} = none) and its carry[] as it stands (only meaningful on the rank
+// that ran the last table sub-step)
+int lbmdem_dist_export_carries(lbmdem_handle* h, long long* carry_keys, double* carry_vals, double* carry_standing) {
+  CHECK_H(h);
+  if (!carry_keys || !carry_vals || !carry_standing) return fail(LBMDEM_EINVAL, "null buffer");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(carry_standing, h->ct.carry, sizeof(double) * 3, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemsetAsync(h->ct.best_key, 0, sizeof(long long) * 6, h->stream));
+  if (h->carry_from < h->substep_seq) launch_carry_resolve(h->ct, h->carry_from, h->stream);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(carry_keys, h->ct.best_key, sizeof(long long) * 6, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(carry_vals, h->ct.carry, sizeof(double) * 3, hipMemcpyDeviceToHost));
+  // the resolve may have overwritten carry[] with a local record: put the standing values back (the caller decides)
+  HIP_TRY(hipMemcpy(h->ct.carry, carry_standing, sizeof(double) * 3, hipMemcpyHostToDevice));
+  return LBMDEM_OK;
 }
 
 int lbmdem_dist_set_poison(lbmdem_handle* h, int on) {
@@ -2095,6 +2152,35 @@ static int comm_table_substep(lbmdem_handle* h, lbmdem_comm* c) try {
     }
   }
   return lbmdem_dist_table_substep(h, st.data(), best_val, has);
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+}
+
+// Before a checkpoint: every rank learns the carries as the reference holds them now -- per carry the youngest record
+// over all ranks, else what rank 0 has kept since the last table sub-step -- and they stand from here on.
+int lbmdem_comm_sync_carries(lbmdem_handle* h, lbmdem_comm* c) try {
+  CHECK_H(h);
+  if (!c) return fail(LBMDEM_EINVAL, "null communicator");
+  const int W = c->world;
+  std::vector<long long> keys(6 * (size_t)W, 0);
+  std::vector<double> vals(3 * (size_t)W, 0.0), standing(3 * (size_t)W, 0.0);
+  RC_TRY(lbmdem_dist_export_carries(h, keys.data() + 6 * (size_t)c->rank, vals.data() + 3 * (size_t)c->rank,
+                                    standing.data() + 3 * (size_t)c->rank));
+  if (W > 1) {
+    RC_TRY(lbmdem_comm_allreduce_bits(c, keys.data(), sizeof(long long) * keys.size()));
+    RC_TRY(lbmdem_comm_allreduce_bits(c, vals.data(), sizeof(double) * vals.size()));
+    RC_TRY(lbmdem_comm_allreduce_bits(c, standing.data(), sizeof(double) * standing.size()));
+  }
+  double out[3];
+  for (int k = 0; k < 3; ++k) {
+    out[k] = standing[k];   // rank 0's
+    long long b0 = 0, b1 = 0;
+    for (int r = 0; r < W; ++r) {
+      const long long k0 = keys[6 * (size_t)r + 2 * k], k1 = keys[6 * (size_t)r + 2 * k + 1];
+      if (k0 > b0 || (k0 == b0 && k0 != 0 && k1 > b1)) { b0 = k0; b1 = k1; out[k] = vals[3 * (size_t)r + k]; }
+    }
+  }
+  return lbmdem_dist_set_carries(h, out);
 } catch (const std::bad_alloc&) {
   return fail(LBMDEM_ENOMEM, "host memory allocation failed");
 }

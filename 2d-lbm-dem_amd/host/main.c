@@ -208,8 +208,11 @@ static int run(int argc, char** argv) {
     cfg.x_end = (int)((long)(g_rank + 1) * lx / g_world);
     cfg.halo = g_world > 1 ? 2 : 0;
     cfg.device = device + g_rank;
-    if (ckpt_in || ckpt_out) { fprintf(stderr, "checkpoints are single-GPU\n"); return EXIT_FAILURE; }
   }
+  /* with several strips every rank keeps its own checkpoint file: FILE.rank<k> */
+  char ckpt_in_rank[4096], ckpt_out_rank[4096];
+  if (g_use_comm && ckpt_in) { snprintf(ckpt_in_rank, sizeof ckpt_in_rank, "%s.rank%d", ckpt_in, g_rank); ckpt_in = ckpt_in_rank; }
+  if (g_use_comm && ckpt_out) { snprintf(ckpt_out_rank, sizeof ckpt_out_rank, "%s.rank%d", ckpt_out, g_rank); ckpt_out = ckpt_out_rank; }
   SAY("no space %le\n", cfg.dx);
   {
     double rMin = r[0];
@@ -220,10 +223,14 @@ static int run(int argc, char** argv) {
   lbmdem_handle* h = NULL;
   long nbsteps = 0;
   if (ckpt_in) {
-    DIE(lbmdem_checkpoint_load(ckpt_in, device, &h), "checkpoint_load");
+    DIE(lbmdem_checkpoint_load(ckpt_in, g_use_comm ? device + g_rank : device, &h), "checkpoint_load");
     DIE(lbmdem_get_config(h, &cfg), "get_config");
+    if (g_use_comm && (cfg.x_begin != (int)((long)g_rank * cfg.lx / g_world) || cfg.x_end != (int)((long)(g_rank + 1) * cfg.lx / g_world))) {
+      fprintf(stderr, "%s holds rows [%d, %d): written by a run with another number of strips\n", ckpt_in, cfg.x_begin, cfg.x_end);
+      return EXIT_FAILURE;
+    }
     nbsteps = lbmdem_nbsteps(h);
-    printf("Restarted from %s at step %ld\n", ckpt_in, nbsteps);
+    SAY("Restarted from %s at step %ld\n", ckpt_in, nbsteps);
   } else {
     DIE(lbmdem_create(&cfg, r, x1, x2, &h), "create");
   }
@@ -231,7 +238,7 @@ static int run(int argc, char** argv) {
   if (g_use_comm) {
     unsigned char id[LBMDEM_COMM_ID_BYTES];
     if (share_id(id) != 0) { fprintf(stderr, "rank %d: no RCCL id: %s\n", g_rank, lbmdem_last_error()); return EXIT_FAILURE; }
-    DIE(lbmdem_dist_enable(h, 0), "dist_enable");
+    if (!ckpt_in) DIE(lbmdem_dist_enable(h, 0), "dist_enable");   /* a restarted strip comes back distributed */
     DIE(lbmdem_comm_create(id, g_rank, g_world, cfg.device, &comm), "comm_create");
     DIE(lbmdem_comm_selftest(comm, 4096), "comm_selftest");   /* one rank: to itself; several: with both neighbours */
   }
@@ -300,7 +307,10 @@ static int run(int argc, char** argv) {
   } while (!stop && (max_steps < 0 || nbsteps < max_steps));
   DIE(lbmdem_sync(h), "sync");
   clock_gettime(CLOCK_MONOTONIC, &t1);
-  if (ckpt_out) DIE(lbmdem_checkpoint_save(h, ckpt_out), "checkpoint_save");
+  if (ckpt_out) {
+    if (comm) DIE(lbmdem_comm_sync_carries(h, comm), "comm_sync_carries");
+    DIE(lbmdem_checkpoint_save(h, ckpt_out), "checkpoint_save");
+  }
   double sum = serial_density(h, comm);
   double secs = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
   if (comm) { /* the slowest rank's time */

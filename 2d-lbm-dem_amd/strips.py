@@ -210,6 +210,20 @@ def merge_exports(exports):
     return state.view(np.float64), vals, has
 
 
+def merge_carries(exports):
+    """exports: per rank LbmDem.dist_export_carries() -> the carries every rank installs (dist_set_carries) before the
+    ranks write their checkpoints: per carry the youngest record over all ranks, else rank 0's standing value."""
+    import numpy as np
+    out = np.array(exports[0][2], dtype=np.float64)
+    for c in range(3):
+        best = (0, 0)
+        for keys, vals, _ in exports:
+            k = (int(keys[c, 0]), int(keys[c, 1]))
+            if k[0] != 0 and k > best:
+                best, out[c] = k, vals[c]
+    return out
+
+
 STEP_STROB = 4000     # write_DEM / write_forces cadence (main.c:142, 1773)
 
 
@@ -309,16 +323,20 @@ class GpuStripBackend:
     exchange buffers. torch is plumbing here: device memory for the buffers and the process group."""
 
     def __init__(self, pkg, torch, lx, ly, r, x1, x2, strip, halo, device, force_mode=0, distributed=False,
-                 margin=0, poison=False):
+                 margin=0, poison=False, restart_from=None):
         self.torch = torch
         dev = torch.device("cuda", device)
-        self.sim = pkg.LbmDem(lx, ly, r, x1, x2, device=device, strip=strip, halo=halo)
-        self.sim.set_force_mode(force_mode)
+        if restart_from is not None:     # this rank's checkpoint file: the strip comes back as it was (distributed or not)
+            self.sim = pkg.LbmDem.checkpoint_load(restart_from, device)
+        else:
+            self.sim = pkg.LbmDem(lx, ly, r, x1, x2, device=device, strip=strip, halo=halo)
+            self.sim.set_force_mode(force_mode)
         self.msg = {}
         if distributed:
-            self.sim.dist_enable(margin)
-            if poison:
-                self.sim.dist_set_poison(True)
+            if restart_from is None:
+                self.sim.dist_enable(margin)
+                if poison:
+                    self.sim.dist_set_poison(True)
             for kind in (KIN, FHF, TABLES):
                 nd = self.sim.dist_message_doubles(kind)
                 self.msg[kind] = ([torch.zeros(nd, dtype=torch.float64, device=dev) for _ in range(2)],

@@ -308,6 +308,14 @@ int lbmdem_dist_table_substep(lbmdem_handle* h, const double* state12_full, cons
 int lbmdem_vtk_place_owned(lbmdem_handle* h, float* fields11);
 int lbmdem_write_vtk_fields(const char* dir, int nfile, int lx, int ly, const float* fields11);
 int lbmdem_comm_write_vtk(lbmdem_handle* h, lbmdem_comm* c, const char* dir, int nfile);
+/* Checkpoints of a strip decomposition: every rank saves its own handle (lbmdem_checkpoint_save: its strip, the grains
+ * as it holds them, ownership masks, message capacities) and lbmdem_checkpoint_load brings it back with the grains
+ * distributed again. The "previous contact" carries are agreed over the ranks first: lbmdem_dist_export_carries gives
+ * a rank's youngest records and its standing values, lbmdem_dist_set_carries installs the result (per carry the
+ * greatest key pair over all ranks, else rank 0's standing value); lbmdem_comm_sync_carries = both over RCCL. */
+int lbmdem_dist_export_carries(lbmdem_handle* h, long long* carry_keys, double* carry_vals, double* carry_standing);
+int lbmdem_dist_set_carries(lbmdem_handle* h, const double* carry3);
+int lbmdem_comm_sync_carries(lbmdem_handle* h, lbmdem_comm* c);
 /* bitwise merge (integer sum) of host buffers whose non-zero bits are disjoint across the ranks; in place */
 int lbmdem_comm_allreduce_bits(lbmdem_comm* c, void* host_buf, size_t nbytes);
 /* sum of host values over the ranks (check_density / final_density; not on the step path) */

@@ -50,18 +50,21 @@ def test_run_matches_oracle_and_writes_a_frame(po, tmp_path):
     assert re.search(r"steps 8000 steps .* KE [0-9.e+-]+ PE [0-9.e+-]+ SE", out.stdout)
 
 
-def test_checkpoint_and_restart_from_the_command_line(po, tmp_path):
+@pytest.mark.parametrize("comm", [[], ["--comm"]])
+def test_checkpoint_and_restart_from_the_command_line(po, tmp_path, comm):
+    """--checkpoint / --restart; with --comm (the code path of --gpus N) every rank keeps its own file, FILE.rank<k>"""
     c = gu.CASES["G4_coupled_256x200"]
     sample = tmp_path / "packing.data"
     po.write_sample(str(sample), c["r_mm"], c["x_mm"], c["y_mm"])
-    base = [EXE, str(sample), "--lx", "256", "--ly", "200"]
+    base = [EXE, str(sample), "--lx", "256", "--ly", "200"] + comm
     full = subprocess.run(base + ["--steps", "150"], capture_output=True, text=True, cwd=tmp_path, timeout=300)
     a = subprocess.run(base + ["--steps", "67", "--checkpoint", "half.ckpt"], capture_output=True, text=True,
                        cwd=tmp_path, timeout=300)
     b = subprocess.run(base + ["--steps", "150", "--restart", "half.ckpt"], capture_output=True, text=True,
                        cwd=tmp_path, timeout=300)
     assert full.returncode == 0 and a.returncode == 0 and b.returncode == 0, (a.stderr[-300:], b.stderr[-300:])
-    assert "Restarted from half.ckpt at step 67" in b.stdout
+    assert ("Restarted from half.ckpt.rank0 at step 67" if comm else "Restarted from half.ckpt at step 67") in b.stdout
+    assert os.path.exists(tmp_path / ("half.ckpt.rank0" if comm else "half.ckpt"))
     fd = lambda out: re.search(r"final_density: ([0-9.]+)", out.stderr).group(1)
     assert fd(full) == fd(b)
 
