@@ -1149,7 +1149,15 @@ __device__ __forceinline__ void lds_dma16_tok(const char*& gsrc, unsigned lds_ds
                : "=&s"(keep), "+v"(gsrc) : "s"(lds_dst) : "memory");
 }
 
-template <int LX, int MINW, int WW, int NBUF>
+// COOP = true: the four wavefronts of a workgroup own 256 consecutive, tile-ALIGNED columns (64 each, all 64 lanes
+// produce: every load and store of a wave-row is four whole 16-node tiles -- the bare access pattern runs 11 % faster
+// than with 62-lane windows offset by -1, scripts/micro/stream_pattern.hip) and hand each other the three populations +
+// `act` flag of their edge columns through a small LDS ring, one raw s_barrier per row; the two columns just outside
+// the workgroup's window are computed once per segment by a pre-pass (wave 0: left, wave 3: right; one lane per row).
+// `nstrips` then counts 256-column windows and `nwork` workgroups.
+struct SeamEntry { double a, b, c; int act; int pad; };
+
+template <int LX, int MINW, int WW, int NBUF, bool COOP = false>
 __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restrict__ fin, double* __restrict__ fout,
                                                    const int* __restrict__ ob_old,
                                                    const int* __restrict__ ob_new, LatticeView L,
@@ -1161,15 +1169,17 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
     const int per = gridDim.x >> 3;
     blk = (blk & 7) * per + (blk >> 3);
   }
-  const int w = blk * 4 + (threadIdx.x >> 6);
-  if (w >= nwork) return;  // whole wave
+  const int wv = threadIdx.x >> 6;
+  const int w = COOP ? blk : blk * 4 + wv;
+  if (w >= nwork) return;  // whole wave (COOP: whole workgroup -- every wave of a workgroup passes the same barriers)
   const int strip = w % nstrips, seg = w / nstrips;
-  constexpr int OFF = (64 - WW) / 2;
-  static_assert(OFF >= 1, "the end lanes only feed their neighbours");
-  const int y = strip * WW - OFF + lane;
+  constexpr int OFF = COOP ? 0 : (64 - WW) / 2;
+  static_assert(COOP ? WW == 64 : OFF >= 1, "without the seam exchange the end lanes only feed their neighbours");
+  const int y0w = COOP ? strip * 256 + wv * 64 : strip * WW - OFF;   // column of lane 0
+  const int y = y0w + lane;
   const bool yin = y >= 0 && y < L.ly;
   const bool writer = lane >= OFF && lane < OFF + WW && yin;
-  const bool deep_y = strip * WW >= 2 && strip * WW + WW - 1 <= L.ly - 3;
+  const bool deep_y = y0w + OFF >= 2 && y0w + OFF + WW - 1 <= L.ly - 3;
   const int rows_per_wave = LX > 0 ? LX : seg_rows;
   const int xs = L.xo0 + seg * seg_stride;
   const int xe = xs + rows_per_wave < L.xo1 ? xs + rows_per_wave : L.xo1;
@@ -1178,7 +1188,6 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
   __shared__ double2 sLrec[4 * 4 * 64];
   __shared__ double sPay[4 * 64 * 4];
   __shared__ int sDesc[4 * 64];
-  const int wv = threadIdx.x >> 6;
   double2* const lrec = sLrec + wv * (4 * 64);
   double* const pay = sPay + wv * (64 * 4);
   int* const desc = sDesc + wv * 64;
@@ -1216,6 +1225,47 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
   auto rr_uy = [&](const RRec& r, int xl) { return r.b.y + ((L.gx0 + xl) * L.dx + L.Mgx - r.a.x) * r.v3; };  // wall_uy
   auto grain_rec = [&](int id) { return load_gp(G, (id < 0 || id >= L.n) ? 0 : id); };
 
+  // ---- COOP: the seams. Boundary b (0..4) lies left of wave b's lane 0. sFromLeft[b][row & 3] = {f*[7], f*[8], f*[1], act}
+  // of the column just LEFT of it (what wave b's lane 0 pulls from), sFromRight[b][row & 3] = {f*[5], f*[4], f*[3], act} of
+  // the column just RIGHT of it (for wave b-1's lane 63). Boundaries 0 and 4 are the workgroup's own edges: their outside
+  // columns come from the pre-pass, one entry per row of the segment (index row - (xs - 1)).
+  __shared__ SeamEntry sFromLeft[COOP ? 5 * 4 : 1], sFromRight[COOP ? 5 * 4 : 1], sHaloL[COOP ? 64 : 1], sHaloR[COOP ? 64 : 1];
+  auto seam_publish = [&](int row, const double (&f)[9], bool act) {
+    if (lane == 0) sFromRight[wv * 4 + (row & 3)] = SeamEntry{f[5], f[4], f[3], act ? 1 : 0, 0};
+    if (lane == 63) sFromLeft[(wv + 1) * 4 + (row & 3)] = SeamEntry{f[7], f[8], f[1], act ? 1 : 0, 0};
+  };
+  auto seam_left = [&](int row) -> const SeamEntry& { return wv == 0 ? sHaloL[row - (xs - 1)] : sFromLeft[wv * 4 + (row & 3)]; };
+  auto seam_right = [&](int row) -> const SeamEntry& { return wv == 3 ? sHaloR[row - (xs - 1)] : sFromRight[(wv + 1) * 4 + (row & 3)]; };
+  // f* and `act` of the node (row, yh), yh a column just outside the workgroup's window: what the neighbouring workgroup
+  // computes for it, with the same functions (pre-pass, one lane per row)
+  auto halo_prepass = [&](int yh, SeamEntry* dst, bool left) {
+    const int row = xs - 1 + lane;
+    SeamEntry e{0.0, 0.0, 0.0, 0, 0};
+    if (lane < xe - xs + 2 && yh >= 0 && yh < L.ly && row >= 0 && row < L.nxl) {
+      const int gxr = L.gx0 + row;
+      const bool in = gxr >= 1 && gxr <= L.lx - 2 && yh >= 1 && yh <= L.ly - 2;
+      const long node = (long)row * L.sy + yh;
+      double f[9];
+      const long fb = fbase(node);
+#pragma unroll
+      for (int q = 0; q < 9; ++q) f[q] = fin[fb + q * F_QSTRIDE(L)];
+      const int oo = ob_old[node];
+      const Ids3 ia = load_ids(ob_new, L, row - 1, yh), ib = load_ids(ob_new, L, row, yh), ic = load_ids(ob_new, L, row + 1, yh);
+      if (in && oo != -1) grain_equilibrium(L, grain_rec(oo), gxr, yh, f);
+      if (in && ib.c == -1) mrt_collide(L, f);
+      const bool act = ib.c != -1 && node_active(L, G, ia, ib, ic, gxr, yh, [&] { return grain_rec(ib.c); });
+      e = left ? SeamEntry{f[7], f[8], f[1], act ? 1 : 0, 0} : SeamEntry{f[5], f[4], f[3], act ? 1 : 0, 0};
+    }
+    dst[lane] = e;
+  };
+  auto seam_barrier = [&] {   // LDS writes of this wave done, then the workgroup's rendezvous; vector-memory queue untouched
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  if (COOP) {
+    if (wv == 0) halo_prepass(strip * 256 - 1, sHaloL, true);
+    if (wv == 3) halo_prepass(strip * 256 + 256, sHaloR, false);
+  }
+
   double Fm[9], F0[9], Fp[9], bufA[9], bufB[9];   // NBUF = 1: only bufA
 
   IdsRow iB = load_ids_row(ob_new, L, xs - 1, y, lane);
@@ -1236,6 +1286,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
     const Ids3 a3 = iA.all(), b3 = iB.all(), c3 = iC.all(), d3 = iD.all();   // DPP: outside the divergent &&
     actm = iB.c != -1 && node_active(L, G, a3, b3, c3, L.gx0 + xs - 1, y, [&] { return grain_rec(iB.c); });
     act0 = iC.c != -1 && node_active(L, G, b3, c3, d3, L.gx0 + xs, y, [&] { return grain_rec(iC.c); });
+    if (COOP) { seam_publish(xs - 1, Fm, actm); seam_publish(xs, F0, act0); }
   }
   int oo1 = load_old(xs + 1);   // previous-map ids of rows x+1, x+2
   int oo2 = load_old(xs + 2);
@@ -1315,6 +1366,12 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
     load_raw(x + 1 + NBUF, buf);
     __builtin_amdgcn_sched_barrier(0);
     make_fstar(x + 1, Fp, oo1, re_ux, re_uy, iD.c);
+    const Ids3 a3 = iC.all(), b3 = iD.all(), c3 = iE.all();   // DPP: outside the divergent &&
+    const bool actp = iD.c != -1 && node_active(L, G, a3, b3, c3, L.gx0 + x + 1, y, [&] { return grain_rec(iD.c); });
+    if (COOP) {
+      seam_publish(x + 1, Fp, actp);
+      seam_barrier();
+    }
 
     // the six cross-lane moves of a pull. DPP reads nothing from a lane that is switched off, so these run here, in
     // wave-uniform control flow, never inside a divergent branch.
@@ -1328,6 +1385,19 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
     In[3] = dpp_up1(Fm[7]);   // (-1,-1): lane-1
     In[4] = dpp_up1(F0[8]);   // ( 0,-1)
     In[5] = dpp_up1(Fp[1]);   // ( 1,-1)
+    int seam_pk_up = 0, seam_pk_dn = 0;   // COOP: act bits (rows x-1, x, x+1) of the columns outside the wave
+    if (COOP) {
+      if (lane == 63) {
+        const SeamEntry &em = seam_right(x - 1), &e0 = seam_right(x), &ep = seam_right(x + 1);
+        In[1] = em.a; In[8] = e0.b; In[7] = ep.c;
+        seam_pk_up = em.act | (e0.act << 1) | (ep.act << 2);
+      }
+      if (lane == 0) {
+        const SeamEntry &em = seam_left(x - 1), &e0 = seam_left(x), &ep = seam_left(x + 1);
+        In[3] = em.a; In[4] = e0.b; In[5] = ep.c;
+        seam_pk_dn = em.act | (e0.act << 1) | (ep.act << 2);
+      }
+    }
     const long node = (long)x * L.sy + y;
     // ---- (2) the payloads of the bounce-back links to LDS (the first 64 links of the row; a row with more: see (5))
     auto write_pay = [&](int base, const double (&in)[9]) {
@@ -1351,16 +1421,18 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
     // ---- (3) the reinit record of row x+2: requested late, converted at the top of the next iteration
     gre = reinit_rec(oo2);
     // ---- (4) everything but the bounce-back links: computed and stored
-    const Ids3 a3 = iC.all(), b3 = iD.all(), c3 = iE.all();   // DPP: outside the divergent &&
-    const bool actp = iD.c != -1 && node_active(L, G, a3, b3, c3, L.gx0 + x + 1, y, [&] { return grain_rec(iD.c); });
     {
       RegCtx3 C;
 #pragma unroll
       for (int q = 0; q < 9; ++q) { C.Fo[q] = F0[q]; C.onb[q] = onb[q]; C.In[q] = In[q]; }
       C.o0 = iC.c;
       const int pack = (actm ? 1 : 0) | (act0 ? 2 : 0) | (actp ? 4 : 0);
-      const int pk_up = dpp_dn1(pack);   // lane+1 (y+1)
-      const int pk_dn = dpp_up1(pack);   // lane-1 (y-1)
+      int pk_up = dpp_dn1(pack);   // lane+1 (y+1)
+      int pk_dn = dpp_up1(pack);   // lane-1 (y-1)
+      if (COOP) {
+        if (lane == 63) pk_up = seam_pk_up;
+        if (lane == 0) pk_dn = seam_pk_dn;
+      }
       C.act = (((pk_up >> 0) & 1u) << 1) | (((pack >> 0) & 1u) << 2) | (((pk_dn >> 0) & 1u) << 3) |
               (((pk_dn >> 1) & 1u) << 4) | (((pk_dn >> 2) & 1u) << 5) | (((pack >> 2) & 1u) << 6) |
               (((pk_up >> 2) & 1u) << 7) | (((pk_up >> 1) & 1u) << 8);
@@ -2396,7 +2468,21 @@ static int march_segment_rows(int rows, int nstrips) {
   return seg_rows;
 }
 
-// which marching kernel: 2 = k_cs_march (two waves per SIMD), 3 = k_cs_march3 (three)
+// The cooperative form of the marching kernel (k_cs_march3<..., COOP>): one workgroup per 256-column window and segment.
+template <int LX, int NBUF>
+static void launch_coop(const double* fin, double* fout, const int* obst_old, const int* obst_new, const LatticeView& L,
+                        const GrainFluidView& G, const ForceSlots& S, int remap, hipStream_t st) {
+  const int rows = L.xo1 - L.xo0;
+  const int nwin = (L.ly + 255) / 256;
+  const int nseg = (rows + LX - 1) / LX;
+  const int nwork = nwin * nseg;
+  int grid = nwork;
+  if (remap) grid = ((grid + 7) / 8) * 8;
+  hipLaunchKernelGGL((k_cs_march3<LX, 2, 64, NBUF, true>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, L, G,
+                     S, nwin, nwork, remap, LX, LX);
+}
+
+// which marching kernel: 2 = k_cs_march (two waves per SIMD), 3 = k_cs_march3 (three), 4 = cooperative aligned windows
 #ifndef LBMDEM_MARCH_DEFAULT
 #define LBMDEM_MARCH_DEFAULT 2
 #endif
@@ -2431,6 +2517,10 @@ static void launch_march(const double* fin, double* fout, const int* obst_old, c
   int grid = (nwork + 3) / 4;
   if (remap) grid = ((grid + 7) / 8) * 8;
 #ifdef LBMDEM_AB   // k_cs_march3 (measured slower) only exists in the experiment build
+  if (LX > 0 && LX <= 62 && WW == 62) {
+    if (march_kernel() == 4) { launch_coop<LX, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return; }
+    if (march_kernel() == 41) { launch_coop<LX, 1>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return; }
+  }
   switch (march_kernel()) {
     case 3:
       hipLaunchKernelGGL((k_cs_march3<LX, 3, WW, 1>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, L, G,
