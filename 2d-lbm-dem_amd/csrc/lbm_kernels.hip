@@ -1149,12 +1149,13 @@ __device__ __forceinline__ void lds_dma16_tok(const char*& gsrc, unsigned lds_ds
                : "=&s"(keep), "+v"(gsrc) : "s"(lds_dst) : "memory");
 }
 
-// COOP = true: the four wavefronts of a workgroup own 256 consecutive, tile-ALIGNED columns (64 each, all 64 lanes
-// produce: every load and store of a wave-row is four whole 16-node tiles -- the bare access pattern runs 11 % faster
-// than with 62-lane windows offset by -1, scripts/micro/stream_pattern.hip) and hand each other the three populations +
-// `act` flag of their edge columns through a small LDS ring, one raw s_barrier per row; the two columns just outside
-// the workgroup's window are computed once per segment by a pre-pass (wave 0: left, wave 3: right; one lane per row).
-// `nstrips` then counts 256-column windows and `nwork` workgroups.
+// COOP = true ("aligned"): a wavefront owns 64 consecutive, tile-ALIGNED columns and all 64 lanes produce: every load and
+// store of a wave-row is four whole 16-node tiles (the bare access pattern runs 11 % faster than with 62-lane windows
+// offset by -1, scripts/micro/stream_pattern.hip). The wavefronts stay INDEPENDENT (a cooperative form -- four waves
+// handing each other their edge columns through LDS with a barrier per row -- ran 12 % slower than independent waves:
+// the per-row rendezvous costs more than the pattern gains): the three populations + `act` flag a wave needs of the two
+// columns just outside its window are computed by the wave itself, once per segment, in a pre-pass with one lane per
+// row (lanes 0..31: left column, lanes 32..63: right column; hence at most 30 rows per segment) and kept in 2 KB of LDS.
 struct SeamEntry { double a, b, c; int act; int pad; };
 
 template <int LX, int MINW, int WW, int NBUF, bool COOP = false>
@@ -1170,12 +1171,12 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
     blk = (blk & 7) * per + (blk >> 3);
   }
   const int wv = threadIdx.x >> 6;
-  const int w = COOP ? blk : blk * 4 + wv;
-  if (w >= nwork) return;  // whole wave (COOP: whole workgroup -- every wave of a workgroup passes the same barriers)
+  const int w = blk * 4 + wv;
+  if (w >= nwork) return;  // whole wave
   const int strip = w % nstrips, seg = w / nstrips;
   constexpr int OFF = COOP ? 0 : (64 - WW) / 2;
-  static_assert(COOP ? WW == 64 : OFF >= 1, "without the seam exchange the end lanes only feed their neighbours");
-  const int y0w = COOP ? strip * 256 + wv * 64 : strip * WW - OFF;   // column of lane 0
+  static_assert(COOP ? (WW == 64 && LX <= 30) : OFF >= 1, "without the halo pre-pass the end lanes only feed their neighbours");
+  const int y0w = strip * WW - OFF;   // column of lane 0 (COOP: WW = 64, OFF = 0)
   const int y = y0w + lane;
   const bool yin = y >= 0 && y < L.ly;
   const bool writer = lane >= OFF && lane < OFF + WW && yin;
@@ -1225,23 +1226,24 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
   auto rr_uy = [&](const RRec& r, int xl) { return r.b.y + ((L.gx0 + xl) * L.dx + L.Mgx - r.a.x) * r.v3; };  // wall_uy
   auto grain_rec = [&](int id) { return load_gp(G, (id < 0 || id >= L.n) ? 0 : id); };
 
-  // ---- COOP: the seams. Boundary b (0..4) lies left of wave b's lane 0. sFromLeft[b][row & 3] = {f*[7], f*[8], f*[1], act}
-  // of the column just LEFT of it (what wave b's lane 0 pulls from), sFromRight[b][row & 3] = {f*[5], f*[4], f*[3], act} of
-  // the column just RIGHT of it (for wave b-1's lane 63). Boundaries 0 and 4 are the workgroup's own edges: their outside
-  // columns come from the pre-pass, one entry per row of the segment (index row - (xs - 1)).
-  __shared__ SeamEntry sFromLeft[COOP ? 5 * 4 : 1], sFromRight[COOP ? 5 * 4 : 1], sHaloL[COOP ? 64 : 1], sHaloR[COOP ? 64 : 1];
-  auto seam_publish = [&](int row, const double (&f)[9], bool act) {
-    if (lane == 0) sFromRight[wv * 4 + (row & 3)] = SeamEntry{f[5], f[4], f[3], act ? 1 : 0, 0};
-    if (lane == 63) sFromLeft[(wv + 1) * 4 + (row & 3)] = SeamEntry{f[7], f[8], f[1], act ? 1 : 0, 0};
-  };
-  auto seam_left = [&](int row) -> const SeamEntry& { return wv == 0 ? sHaloL[row - (xs - 1)] : sFromLeft[wv * 4 + (row & 3)]; };
-  auto seam_right = [&](int row) -> const SeamEntry& { return wv == 3 ? sHaloR[row - (xs - 1)] : sFromRight[(wv + 1) * 4 + (row & 3)]; };
-  // f* and `act` of the node (row, yh), yh a column just outside the workgroup's window: what the neighbouring workgroup
-  // computes for it, with the same functions (pre-pass, one lane per row)
-  auto halo_prepass = [&](int yh, SeamEntry* dst, bool left) {
-    const int row = xs - 1 + lane;
+  // ---- COOP: sHalo[wave][side * 32 + (row - (xs - 1))]: {f*[7], f*[8], f*[1], act} of the column left of the window (side 0),
+  // {f*[5], f*[4], f*[3], act} of the column right of it (side 1), rows xs-1 .. xe
+  __shared__ SeamEntry sHalo[COOP ? 4 * 64 : 1];
+  SeamEntry* const halo = sHalo + (COOP ? wv * 64 : 0);
+  auto seam_left = [&](int row) -> const SeamEntry& { return halo[(row - (xs - 1)) & 31]; };
+  auto seam_right = [&](int row) -> const SeamEntry& { return halo[32 + ((row - (xs - 1)) & 31)]; };
+  // f* and `act` of the nodes (row, y0w - 1) and (row, y0w + 64): what the neighbouring waves compute for them, with the same
+  // functions
+  if (COOP) {
+    const bool left = lane < 32;
+    const int yh = left ? y0w - 1 : y0w + 64;
+    const int row = xs - 1 + (lane & 31);
     SeamEntry e{0.0, 0.0, 0.0, 0, 0};
-    if (lane < xe - xs + 2 && yh >= 0 && yh < L.ly && row >= 0 && row < L.nxl) {
+#ifdef M3_NOHALO   /* timing experiment only (wrong results): what the aligned pattern alone is worth */
+    if (false) {
+#else
+    if ((lane & 31) < xe - xs + 2 && yh >= 0 && yh < L.ly && row >= 0 && row < L.nxl) {
+#endif
       const int gxr = L.gx0 + row;
       const bool in = gxr >= 1 && gxr <= L.lx - 2 && yh >= 1 && yh <= L.ly - 2;
       const long node = (long)row * L.sy + yh;
@@ -1256,14 +1258,8 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
       const bool act = ib.c != -1 && node_active(L, G, ia, ib, ic, gxr, yh, [&] { return grain_rec(ib.c); });
       e = left ? SeamEntry{f[7], f[8], f[1], act ? 1 : 0, 0} : SeamEntry{f[5], f[4], f[3], act ? 1 : 0, 0};
     }
-    dst[lane] = e;
-  };
-  auto seam_barrier = [&] {   // LDS writes of this wave done, then the workgroup's rendezvous; vector-memory queue untouched
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  };
-  if (COOP) {
-    if (wv == 0) halo_prepass(strip * 256 - 1, sHaloL, true);
-    if (wv == 3) halo_prepass(strip * 256 + 256, sHaloR, false);
+    halo[lane] = e;
+    __builtin_amdgcn_wave_barrier();
   }
 
   double Fm[9], F0[9], Fp[9], bufA[9], bufB[9];   // NBUF = 1: only bufA
@@ -1286,7 +1282,6 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
     const Ids3 a3 = iA.all(), b3 = iB.all(), c3 = iC.all(), d3 = iD.all();   // DPP: outside the divergent &&
     actm = iB.c != -1 && node_active(L, G, a3, b3, c3, L.gx0 + xs - 1, y, [&] { return grain_rec(iB.c); });
     act0 = iC.c != -1 && node_active(L, G, b3, c3, d3, L.gx0 + xs, y, [&] { return grain_rec(iC.c); });
-    if (COOP) { seam_publish(xs - 1, Fm, actm); seam_publish(xs, F0, act0); }
   }
   int oo1 = load_old(xs + 1);   // previous-map ids of rows x+1, x+2
   int oo2 = load_old(xs + 2);
@@ -1368,10 +1363,6 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
     make_fstar(x + 1, Fp, oo1, re_ux, re_uy, iD.c);
     const Ids3 a3 = iC.all(), b3 = iD.all(), c3 = iE.all();   // DPP: outside the divergent &&
     const bool actp = iD.c != -1 && node_active(L, G, a3, b3, c3, L.gx0 + x + 1, y, [&] { return grain_rec(iD.c); });
-    if (COOP) {
-      seam_publish(x + 1, Fp, actp);
-      seam_barrier();
-    }
 
     // the six cross-lane moves of a pull. DPP reads nothing from a lane that is switched off, so these run here, in
     // wave-uniform control flow, never inside a divergent branch.
@@ -1386,7 +1377,11 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
     In[4] = dpp_up1(F0[8]);   // ( 0,-1)
     In[5] = dpp_up1(Fp[1]);   // ( 1,-1)
     int seam_pk_up = 0, seam_pk_dn = 0;   // COOP: act bits (rows x-1, x, x+1) of the columns outside the wave
+#ifdef M3_NOHALO
+    if (false) {
+#else
     if (COOP) {
+#endif
       if (lane == 63) {
         const SeamEntry &em = seam_right(x - 1), &e0 = seam_right(x), &ep = seam_right(x + 1);
         In[1] = em.a; In[8] = e0.b; In[7] = ep.c;
@@ -2468,21 +2463,21 @@ static int march_segment_rows(int rows, int nstrips) {
   return seg_rows;
 }
 
-// The cooperative form of the marching kernel (k_cs_march3<..., COOP>): one workgroup per 256-column window and segment.
+// The aligned form of the marching kernel (k_cs_march3<..., COOP>): 64-column windows, at most 30 rows per segment.
 template <int LX, int NBUF>
-static void launch_coop(const double* fin, double* fout, const int* obst_old, const int* obst_new, const LatticeView& L,
-                        const GrainFluidView& G, const ForceSlots& S, int remap, hipStream_t st) {
+static void launch_aligned(const double* fin, double* fout, const int* obst_old, const int* obst_new, const LatticeView& L,
+                           const GrainFluidView& G, const ForceSlots& S, int remap, hipStream_t st) {
   const int rows = L.xo1 - L.xo0;
-  const int nwin = (L.ly + 255) / 256;
+  const int nwin = (L.ly + 63) / 64;
   const int nseg = (rows + LX - 1) / LX;
   const int nwork = nwin * nseg;
-  int grid = nwork;
+  int grid = (nwork + 3) / 4;
   if (remap) grid = ((grid + 7) / 8) * 8;
   hipLaunchKernelGGL((k_cs_march3<LX, 2, 64, NBUF, true>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, L, G,
                      S, nwin, nwork, remap, LX, LX);
 }
 
-// which marching kernel: 2 = k_cs_march (two waves per SIMD), 3 = k_cs_march3 (three), 4 = cooperative aligned windows
+// which marching kernel: 2 = k_cs_march (two waves per SIMD), 3 = k_cs_march3 (three), 4 = aligned 64-lane windows
 #ifndef LBMDEM_MARCH_DEFAULT
 #define LBMDEM_MARCH_DEFAULT 2
 #endif
@@ -2517,9 +2512,10 @@ static void launch_march(const double* fin, double* fout, const int* obst_old, c
   int grid = (nwork + 3) / 4;
   if (remap) grid = ((grid + 7) / 8) * 8;
 #ifdef LBMDEM_AB   // k_cs_march3 (measured slower) only exists in the experiment build
-  if (LX > 0 && LX <= 62 && WW == 62) {
-    if (march_kernel() == 4) { launch_coop<LX, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return; }
-    if (march_kernel() == 41) { launch_coop<LX, 1>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return; }
+  if (LX == 32 && WW == 62) {
+    if (march_kernel() == 4) { launch_aligned<30, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return; }
+    if (march_kernel() == 41) { launch_aligned<30, 1>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return; }
+    if (march_kernel() == 42) { launch_aligned<16, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return; }
   }
   switch (march_kernel()) {
     case 3:
