@@ -1149,16 +1149,7 @@ __device__ __forceinline__ void lds_dma16_tok(const char*& gsrc, unsigned lds_ds
                : "=&s"(keep), "+v"(gsrc) : "s"(lds_dst) : "memory");
 }
 
-// COOP = true ("aligned"): a wavefront owns 64 consecutive, tile-ALIGNED columns and all 64 lanes produce: every load and
-// store of a wave-row is four whole 16-node tiles (the bare access pattern runs 11 % faster than with 62-lane windows
-// offset by -1, scripts/micro/stream_pattern.hip). The wavefronts stay INDEPENDENT (a cooperative form -- four waves
-// handing each other their edge columns through LDS with a barrier per row -- ran 12 % slower than independent waves:
-// the per-row rendezvous costs more than the pattern gains): the three populations + `act` flag a wave needs of the two
-// columns just outside its window are computed by the wave itself, once per segment, in a pre-pass with one lane per
-// row (lanes 0..31: left column, lanes 32..63: right column; hence at most 30 rows per segment) and kept in 2 KB of LDS.
-struct SeamEntry { double a, b, c; int act; int pad; };
-
-template <int LX, int MINW, int WW, int NBUF, bool COOP = false>
+template <int LX, int MINW, int WW, int NBUF>
 __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restrict__ fin, double* __restrict__ fout,
                                                    const int* __restrict__ ob_old,
                                                    const int* __restrict__ ob_new, LatticeView L,
@@ -1170,17 +1161,15 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
     const int per = gridDim.x >> 3;
     blk = (blk & 7) * per + (blk >> 3);
   }
-  const int wv = threadIdx.x >> 6;
-  const int w = blk * 4 + wv;
+  const int w = blk * 4 + (threadIdx.x >> 6);
   if (w >= nwork) return;  // whole wave
   const int strip = w % nstrips, seg = w / nstrips;
-  constexpr int OFF = COOP ? 0 : (64 - WW) / 2;
-  static_assert(COOP ? (WW == 64 && LX <= 30) : OFF >= 1, "without the halo pre-pass the end lanes only feed their neighbours");
-  const int y0w = strip * WW - OFF;   // column of lane 0 (COOP: WW = 64, OFF = 0)
-  const int y = y0w + lane;
+  constexpr int OFF = (64 - WW) / 2;
+  static_assert(OFF >= 1, "the end lanes only feed their neighbours");
+  const int y = strip * WW - OFF + lane;
   const bool yin = y >= 0 && y < L.ly;
   const bool writer = lane >= OFF && lane < OFF + WW && yin;
-  const bool deep_y = y0w + OFF >= 2 && y0w + OFF + WW - 1 <= L.ly - 3;
+  const bool deep_y = strip * WW >= 2 && strip * WW + WW - 1 <= L.ly - 3;
   const int rows_per_wave = LX > 0 ? LX : seg_rows;
   const int xs = L.xo0 + seg * seg_stride;
   const int xe = xs + rows_per_wave < L.xo1 ? xs + rows_per_wave : L.xo1;
@@ -1189,6 +1178,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
   __shared__ double2 sLrec[4 * 4 * 64];
   __shared__ double sPay[4 * 64 * 4];
   __shared__ int sDesc[4 * 64];
+  const int wv = threadIdx.x >> 6;
   double2* const lrec = sLrec + wv * (4 * 64);
   double* const pay = sPay + wv * (64 * 4);
   int* const desc = sDesc + wv * 64;
@@ -1225,42 +1215,6 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
   auto rr_ux = [&](const RRec& r) { return r.b.x - (y * L.dx + L.Mby - r.a.y) * r.v3; };        // wall_ux
   auto rr_uy = [&](const RRec& r, int xl) { return r.b.y + ((L.gx0 + xl) * L.dx + L.Mgx - r.a.x) * r.v3; };  // wall_uy
   auto grain_rec = [&](int id) { return load_gp(G, (id < 0 || id >= L.n) ? 0 : id); };
-
-  // ---- COOP: sHalo[wave][side * 32 + (row - (xs - 1))]: {f*[7], f*[8], f*[1], act} of the column left of the window (side 0),
-  // {f*[5], f*[4], f*[3], act} of the column right of it (side 1), rows xs-1 .. xe
-  __shared__ SeamEntry sHalo[COOP ? 4 * 64 : 1];
-  SeamEntry* const halo = sHalo + (COOP ? wv * 64 : 0);
-  auto seam_left = [&](int row) -> const SeamEntry& { return halo[(row - (xs - 1)) & 31]; };
-  auto seam_right = [&](int row) -> const SeamEntry& { return halo[32 + ((row - (xs - 1)) & 31)]; };
-  // f* and `act` of the nodes (row, y0w - 1) and (row, y0w + 64): what the neighbouring waves compute for them, with the same
-  // functions
-  if (COOP) {
-    const bool left = lane < 32;
-    const int yh = left ? y0w - 1 : y0w + 64;
-    const int row = xs - 1 + (lane & 31);
-    SeamEntry e{0.0, 0.0, 0.0, 0, 0};
-#ifdef M3_NOHALO   /* timing experiment only (wrong results): what the aligned pattern alone is worth */
-    if (false) {
-#else
-    if ((lane & 31) < xe - xs + 2 && yh >= 0 && yh < L.ly && row >= 0 && row < L.nxl) {
-#endif
-      const int gxr = L.gx0 + row;
-      const bool in = gxr >= 1 && gxr <= L.lx - 2 && yh >= 1 && yh <= L.ly - 2;
-      const long node = (long)row * L.sy + yh;
-      double f[9];
-      const long fb = fbase(node);
-#pragma unroll
-      for (int q = 0; q < 9; ++q) f[q] = fin[fb + q * F_QSTRIDE(L)];
-      const int oo = ob_old[node];
-      const Ids3 ia = load_ids(ob_new, L, row - 1, yh), ib = load_ids(ob_new, L, row, yh), ic = load_ids(ob_new, L, row + 1, yh);
-      if (in && oo != -1) grain_equilibrium(L, grain_rec(oo), gxr, yh, f);
-      if (in && ib.c == -1) mrt_collide(L, f);
-      const bool act = ib.c != -1 && node_active(L, G, ia, ib, ic, gxr, yh, [&] { return grain_rec(ib.c); });
-      e = left ? SeamEntry{f[7], f[8], f[1], act ? 1 : 0, 0} : SeamEntry{f[5], f[4], f[3], act ? 1 : 0, 0};
-    }
-    halo[lane] = e;
-    __builtin_amdgcn_wave_barrier();
-  }
 
   double Fm[9], F0[9], Fp[9], bufA[9], bufB[9];   // NBUF = 1: only bufA
 
@@ -1361,8 +1315,6 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
     load_raw(x + 1 + NBUF, buf);
     __builtin_amdgcn_sched_barrier(0);
     make_fstar(x + 1, Fp, oo1, re_ux, re_uy, iD.c);
-    const Ids3 a3 = iC.all(), b3 = iD.all(), c3 = iE.all();   // DPP: outside the divergent &&
-    const bool actp = iD.c != -1 && node_active(L, G, a3, b3, c3, L.gx0 + x + 1, y, [&] { return grain_rec(iD.c); });
 
     // the six cross-lane moves of a pull. DPP reads nothing from a lane that is switched off, so these run here, in
     // wave-uniform control flow, never inside a divergent branch.
@@ -1376,23 +1328,6 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
     In[3] = dpp_up1(Fm[7]);   // (-1,-1): lane-1
     In[4] = dpp_up1(F0[8]);   // ( 0,-1)
     In[5] = dpp_up1(Fp[1]);   // ( 1,-1)
-    int seam_pk_up = 0, seam_pk_dn = 0;   // COOP: act bits (rows x-1, x, x+1) of the columns outside the wave
-#ifdef M3_NOHALO
-    if (false) {
-#else
-    if (COOP) {
-#endif
-      if (lane == 63) {
-        const SeamEntry &em = seam_right(x - 1), &e0 = seam_right(x), &ep = seam_right(x + 1);
-        In[1] = em.a; In[8] = e0.b; In[7] = ep.c;
-        seam_pk_up = em.act | (e0.act << 1) | (ep.act << 2);
-      }
-      if (lane == 0) {
-        const SeamEntry &em = seam_left(x - 1), &e0 = seam_left(x), &ep = seam_left(x + 1);
-        In[3] = em.a; In[4] = e0.b; In[5] = ep.c;
-        seam_pk_dn = em.act | (e0.act << 1) | (ep.act << 2);
-      }
-    }
     const long node = (long)x * L.sy + y;
     // ---- (2) the payloads of the bounce-back links to LDS (the first 64 links of the row; a row with more: see (5))
     auto write_pay = [&](int base, const double (&in)[9]) {
@@ -1416,18 +1351,16 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
     // ---- (3) the reinit record of row x+2: requested late, converted at the top of the next iteration
     gre = reinit_rec(oo2);
     // ---- (4) everything but the bounce-back links: computed and stored
+    const Ids3 a3 = iC.all(), b3 = iD.all(), c3 = iE.all();   // DPP: outside the divergent &&
+    const bool actp = iD.c != -1 && node_active(L, G, a3, b3, c3, L.gx0 + x + 1, y, [&] { return grain_rec(iD.c); });
     {
       RegCtx3 C;
 #pragma unroll
       for (int q = 0; q < 9; ++q) { C.Fo[q] = F0[q]; C.onb[q] = onb[q]; C.In[q] = In[q]; }
       C.o0 = iC.c;
       const int pack = (actm ? 1 : 0) | (act0 ? 2 : 0) | (actp ? 4 : 0);
-      int pk_up = dpp_dn1(pack);   // lane+1 (y+1)
-      int pk_dn = dpp_up1(pack);   // lane-1 (y-1)
-      if (COOP) {
-        if (lane == 63) pk_up = seam_pk_up;
-        if (lane == 0) pk_dn = seam_pk_dn;
-      }
+      const int pk_up = dpp_dn1(pack);   // lane+1 (y+1)
+      const int pk_dn = dpp_up1(pack);   // lane-1 (y-1)
       C.act = (((pk_up >> 0) & 1u) << 1) | (((pack >> 0) & 1u) << 2) | (((pk_dn >> 0) & 1u) << 3) |
               (((pk_dn >> 1) & 1u) << 4) | (((pk_dn >> 2) & 1u) << 5) | (((pack >> 2) & 1u) << 6) |
               (((pk_up >> 2) & 1u) << 7) | (((pk_up >> 1) & 1u) << 8);
@@ -2463,21 +2396,7 @@ static int march_segment_rows(int rows, int nstrips) {
   return seg_rows;
 }
 
-// The aligned form of the marching kernel (k_cs_march3<..., COOP>): 64-column windows, at most 30 rows per segment.
-template <int LX, int NBUF>
-static void launch_aligned(const double* fin, double* fout, const int* obst_old, const int* obst_new, const LatticeView& L,
-                           const GrainFluidView& G, const ForceSlots& S, int remap, hipStream_t st) {
-  const int rows = L.xo1 - L.xo0;
-  const int nwin = (L.ly + 63) / 64;
-  const int nseg = (rows + LX - 1) / LX;
-  const int nwork = nwin * nseg;
-  int grid = (nwork + 3) / 4;
-  if (remap) grid = ((grid + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_cs_march3<LX, 2, 64, NBUF, true>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, L, G,
-                     S, nwin, nwork, remap, LX, LX);
-}
-
-// which marching kernel: 2 = k_cs_march (two waves per SIMD), 3 = k_cs_march3 (three), 4 = aligned 64-lane windows
+// which marching kernel: 2 = k_cs_march (two waves per SIMD), 3 = k_cs_march3 (three)
 #ifndef LBMDEM_MARCH_DEFAULT
 #define LBMDEM_MARCH_DEFAULT 2
 #endif
@@ -2512,11 +2431,6 @@ static void launch_march(const double* fin, double* fout, const int* obst_old, c
   int grid = (nwork + 3) / 4;
   if (remap) grid = ((grid + 7) / 8) * 8;
 #ifdef LBMDEM_AB   // k_cs_march3 (measured slower) only exists in the experiment build
-  if (LX == 32 && WW == 62) {
-    if (march_kernel() == 4) { launch_aligned<30, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return; }
-    if (march_kernel() == 41) { launch_aligned<30, 1>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return; }
-    if (march_kernel() == 42) { launch_aligned<16, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return; }
-  }
   switch (march_kernel()) {
     case 3:
       hipLaunchKernelGGL((k_cs_march3<LX, 3, WW, 1>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, L, G,
