@@ -756,6 +756,7 @@ struct RegCtx {
   __device__ __forceinline__ bool act_nb(int d) const { return (act >> d) & 1u; }
 };
 
+#ifdef LBMDEM_AB   /* k_cs_march3 and its helpers only exist in the experiment build */
 // the same context for k_cs_march3 (no record ring: the classification never asks for a record)
 struct RegCtx3 {
   double Fo[9];
@@ -789,6 +790,8 @@ __device__ __forceinline__ void classify_store_all(const RegCtx3& C, const Latti
   LBM_CLASSIFY_ALL(5) LBM_CLASSIFY_ALL(6) LBM_CLASSIFY_ALL(7) LBM_CLASSIFY_ALL(8)
 #undef LBM_CLASSIFY_ALL
 }
+
+#endif  // LBMDEM_AB
 
 // All nine pulls of a node except the interpolated bounce-back links: the others are stored right away,
 // the bounce-back links are only flagged: bit q of `ibb` = link (P, q) needs ibb_eval; `nnm` / `hzm` =
@@ -1093,6 +1096,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
   }
 }
 
+#ifdef LBMDEM_AB
 // ---------------------------------------------------------------------------------------------
 // the fused fluid kernel, marching form for THREE wavefronts per SIMD (round 3)
 // ---------------------------------------------------------------------------------------------
@@ -1441,6 +1445,8 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
     }
   }
 }
+
+#endif  // LBMDEM_AB
 
 // ---------------------------------------------------------------------------------------------
 // hydrodynamic force and torque (main.c:1285-1333)
@@ -2400,7 +2406,7 @@ static int march_segment_rows(int rows, int nstrips) {
 #ifndef LBMDEM_MARCH_DEFAULT
 #define LBMDEM_MARCH_DEFAULT 2
 #endif
-static int march_kernel() {
+__attribute__((unused)) static int march_kernel() {
 #ifdef LBMDEM_AB
   static const int v = getenv("LBMDEM_MARCH") ? atoi(getenv("LBMDEM_MARCH")) : LBMDEM_MARCH_DEFAULT;
   return v;

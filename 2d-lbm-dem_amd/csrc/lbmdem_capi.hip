@@ -8,6 +8,7 @@
 #include "lbmdem_internal.h"
 
 #include <ctype.h>
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -103,6 +104,38 @@ struct lbmdem_handle {
   std::vector<hipEvent_t> ev0, ev1;
   size_t ev_used = 0;
 };
+
+// Named ranges for rocprofv3 --marker-trace around the phases of a step (obstacle map, fused fluid kernel, hydrodynamic
+// forces, Verlet rebuild, DEM sub-step). libroctx64.so is looked up once, lazily, and only when LBMDEM_ROCTX is set:
+// without a profiler attached the ranges cost nothing.
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  bool tried = false;
+};
+Roctx g_roctx;
+void roctx_init() {
+  g_roctx.tried = true;
+  const char* e = getenv("LBMDEM_ROCTX");
+  if (!e || !*e || *e == '0') return;
+  void* lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) return;
+  g_roctx.push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+  g_roctx.pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+  if (!g_roctx.push || !g_roctx.pop) { g_roctx.push = nullptr; g_roctx.pop = nullptr; }
+}
+struct PhaseRange {
+  bool on;
+  explicit PhaseRange(const char* name) {
+    if (!g_roctx.tried) roctx_init();
+    on = g_roctx.push != nullptr;
+    if (on) g_roctx.push(name);
+  }
+  ~PhaseRange() { if (on) g_roctx.pop(); }
+};
+}  // namespace
 
 static GrainFluidView gview(const lbmdem_handle* h) {
   const Kin& K = h->kin[h->kcur];
@@ -446,6 +479,7 @@ int lbmdem_destroy(lbmdem_handle* h) {
 
 int lbmdem_obst_construction(lbmdem_handle* h) {
   CHECK_H(h);
+  PhaseRange range_("lbmdem:obst_construction");
   if (h->dist && !h->dist_period_open)
     return fail(LBMDEM_EINVAL, "distributed grains: lbmdem_dist_begin_period comes before the fluid step");
   if (h->cs_interior_pending) return fail(LBMDEM_EINVAL, "lbmdem_collide_stream_part(LBMDEM_CS_INTERIOR) has not been called after LBMDEM_CS_EDGES");
@@ -485,6 +519,7 @@ static int prof_begin(lbmdem_handle* h, hipEvent_t* e1) {
 
 int lbmdem_collide_stream(lbmdem_handle* h) try {
   CHECK_H(h);
+  PhaseRange range_("lbmdem:collide_stream");
   CHECK_NOT_SPLIT(h);
   const int* ob_old = h->obst[h->ocur];
   const int* ob_new = h->obst_pending ? h->obst[1 - h->ocur] : h->obst[h->ocur];
@@ -506,6 +541,7 @@ int lbmdem_collide_stream(lbmdem_handle* h) try {
 
 int lbmdem_collide_stream_part(lbmdem_handle* h, int part) try {
   CHECK_H(h);
+  PhaseRange range_("lbmdem:collide_stream_part");
   const LatticeView& L = h->L;
   if (part == LBMDEM_CS_EDGES) {
     CHECK_NOT_SPLIT(h);
@@ -554,6 +590,7 @@ int lbmdem_collide_stream_part(lbmdem_handle* h, int part) try {
 
 int lbmdem_forces_fluid(lbmdem_handle* h) {
   CHECK_H(h);
+  PhaseRange range_("lbmdem:forces_fluid");
   CHECK_NOT_SPLIT(h);
   const int* ob = h->obst_pending ? h->obst[1 - h->ocur] : h->obst[h->ocur];
   {
@@ -629,6 +666,7 @@ int lbmdem_lbm_step(lbmdem_handle* h) {
 
 int lbmdem_verlet_rebuild(lbmdem_handle* h) {
   CHECK_H(h);
+  PhaseRange range_("lbmdem:verlet_rebuild");
   // VerletWall moves the right/top DEM walls: main.c:1555-1561
   lbmdem_config& c = h->cfg;
   if (h->nbsteps * c.dt < c.phys.dtt) {
@@ -650,6 +688,7 @@ int lbmdem_verlet_rebuild(lbmdem_handle* h) {
 
 int lbmdem_dem_substep(lbmdem_handle* h) {
   CHECK_H(h);
+  PhaseRange range_("lbmdem:dem_substep");
   CHECK_NOT_SPLIT(h);
   if (!h->verlet_ok) return fail(LBMDEM_EINVAL, "lbmdem_dem_substep before the first lbmdem_verlet_rebuild");
   if (*h->ovf_host) return fail(LBMDEM_ENOMEM, "Verlet list overflow (more than %ld symmetric entries)", h->V.cap);

@@ -38,7 +38,21 @@ import __graft_entry__ as ge  # noqa: E402
 import samples  # noqa: E402
 
 BYTES_PER_LUP = 148.0   # 9x8 B read + 9x8 B write + 4 B obstacle id
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # PMC-measured HBM bytes per launch (static: measured once, scripts/pmc_traffic.sh)
+# PMC-measured HBM bytes per launch of the fused kernel (scripts/pmc_traffic.sh: rocprofv3 cannot run inside this process).
+# The file names the sources the measured library was built from (SHA-256); a number measured on other sources is NOT reported.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+
+
+def library_source_sha256():
+    """SHA-256 over the sources the library is built from (the .so itself is git-ignored and rebuilt by build())"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "2d-lbm-dem_amd", "csrc")
+    for name in sorted(os.listdir(d)) + ["../../include/lbmdem_hip.h"]:
+        path = os.path.join(d, name)
+        if os.path.isfile(path):
+            h.update(name.encode()); h.update(open(path, "rb").read())
+    return h.hexdigest()
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -284,9 +298,16 @@ def main():
         cfgd = sim.config()
         rows = cfgd.x_end - cfgd.x_begin
         achieved = BYTES_PER_LUP * rows * ly / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_source = None, None
         if args.gpus == 1 and args.workload == "metric" and os.path.exists(TRAFFIC_FILE):
-            traffic = round(json.load(open(TRAFFIC_FILE))["traffic_bytes_per_launch"])   # same workload + kernel
+            tf = json.load(open(TRAFFIC_FILE))
+            if tf.get("source_sha256") == library_source_sha256():       # same workload, same kernel, same sources
+                traffic = round(tf["traffic_bytes_per_launch"])
+                traffic_source = "measured on a library built from these sources by scripts/pmc_traffic.sh: " + os.path.relpath(TRAFFIC_FILE, ROOT)
+            else:
+                traffic_source = ("none: " + os.path.relpath(TRAFFIC_FILE, ROOT) + " was measured on another build of the "
+                                  "library (" + f"{tf['traffic_bytes_per_launch'] / 1e9:.3f} GB per launch, "
+                                  f"{tf.get('traffic_over_algorithmic', 0):.3f} x algorithmic)")
         out = {
             "metric": f"MLUPS (D2Q9 collide+stream, coupled LBM-DEM step) on {w['short']}",
             "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": args.gpus, "steps": args.steps,
@@ -314,11 +335,11 @@ def main():
             "collide_stream_kernel_mlups": round(1e-6 * rows * ly / (kernel_ms * 1e-3), 1) if kernel_ms > 0 else None,
             "roofline": {"bound": "hbm", "kernel": "k_cs_march (fused reinit+collide+IBB+stream)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "traffic_source": "static: " + os.path.relpath(TRAFFIC_FILE, ROOT) if traffic else None,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "bytes_per_lup": BYTES_PER_LUP, "launches_timed": launches,
                          "note": "achieved = algorithmic 148 B/LUP x lattice nodes per launch / mean HIP-event "
                                  "duration; traffic = HBM bytes per launch from rocprofv3 FETCH_SIZE + WRITE_SIZE "
-                                 "(separate passes, calibrated on copy kernels; measured once for this kernel and workload, not in this run)"},
+                                 "(separate passes, calibrated on copy kernels) -- reported only when the file was measured on this very library binary"},
             "fast_force_mode": fast,
             "total_mass": mass,
         }

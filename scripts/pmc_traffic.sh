@@ -27,7 +27,10 @@ print(json.dumps(out, indent=1))
 json.dump(out, open(f"{O}/summary.json","w"), indent=1)
 # the file bench.py reads (copy to profiles/rNN_pmc_traffic.json)
 fb=out["FETCH_SIZE"]["march_bytes_calibrated_8B"]; wb=out["WRITE_SIZE"]["march_bytes_calibrated_8B"]; alg=148*4096*4096
-json.dump({"_what": "HBM traffic of k_cs_march per launch, 4096x4096/50k grains (bench.py default workload), rocprofv3 PMC FETCH_SIZE and "
+import sys
+sys.path.insert(0, "$GRAFT_REPO_ROOT")
+import bench
+json.dump({"source_sha256": bench.library_source_sha256(), "_what": "HBM traffic of k_cs_march per launch, 4096x4096/50k grains (bench.py default workload), rocprofv3 PMC FETCH_SIZE and "
            "WRITE_SIZE in separate passes (scripts/pmc_traffic.sh), calibrated on copy kernels of known size",
            "fetch_bytes": fb, "write_bytes": wb, "fetch_bytes_per_unit": out["FETCH_SIZE"]["bytes_per_unit_copy8"],
            "write_bytes_per_unit": out["WRITE_SIZE"]["bytes_per_unit_copy8"], "traffic_bytes_per_launch": fb+wb,
