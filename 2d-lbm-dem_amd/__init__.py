@@ -51,13 +51,25 @@ class Config(C.Structure):
 
 
 _lib = None
+_lib_sp = None
+SP_LIB_PATH = os.path.join(_HERE, "liblbmdem_hip_sp.so")   # `real` = float: the reference's -DSINGLE_PRECISION mode
 
 
-def load_library():
-    """dlopen liblbmdem_hip.so; fails loudly when it has not been built."""
-    global _lib
+def load_library(precision="f64"):
+    """dlopen liblbmdem_hip.so (precision "f32": liblbmdem_hip_sp.so, same ABI); fails loudly when it has not been built."""
+    global _lib, _lib_sp
+    if precision == "f32":
+        if _lib_sp is None:
+            load_library()       # runtime set-up (torch first, kernel arguments) happens with the default library
+            _lib_sp = _open_library(SP_LIB_PATH)
+        return _lib_sp
     if _lib is not None:
         return _lib
+    _lib = _open_library(LIB_PATH)
+    return _lib
+
+
+def _open_library(LIB_PATH):
     if not os.path.exists(LIB_PATH):
         raise LbmDemError(-2, f"{LIB_PATH} not built -- run __graft_entry__.build() "
                               "(make -C 2d-lbm-dem_amd/csrc); there is no CPU fallback")
@@ -147,7 +159,6 @@ def load_library():
     L.lbmdem_get_config.argtypes = [C.c_void_p, C.POINTER(Config)]
     L.lbmdem_read_sample.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_double)),
                                      C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.POINTER(C.c_double))]
-    _lib = L
     return L
 
 
@@ -172,16 +183,21 @@ def exported_symbols():
 
 def _chk(rc):
     if rc != 0:
-        raise LbmDemError(rc, load_library().lbmdem_last_error().decode(errors="replace"))
+        msg = load_library().lbmdem_last_error().decode(errors="replace")
+        if _lib_sp is not None:      # the float build keeps its own error text
+            sp = _lib_sp.lbmdem_last_error().decode(errors="replace")
+            msg = sp if not msg else (msg if not sp else f"{msg} | f32 library: {sp}")
+        raise LbmDemError(rc, msg)
 
 
 def _vp(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def read_sample(path):
-    """read_sample (main.c:609-639) -> (r, x1, x2) in metres."""
-    L = load_library()
+def read_sample(path, precision="f64"):
+    """read_sample (main.c:609-639) -> (r, x1, x2) in metres. precision "f32": parsed as the reference's
+    -DSINGLE_PRECISION build parses it (text -> float, times the float 1e-3)."""
+    L = load_library(precision)
     n = C.c_int(0)
     pr, p1, p2 = C.POINTER(C.c_double)(), C.POINTER(C.c_double)(), C.POINTER(C.c_double)()
     _chk(L.lbmdem_read_sample(os.fsencode(path), C.byref(n), C.byref(pr), C.byref(p1), C.byref(p2)))
@@ -191,9 +207,9 @@ def read_sample(path):
     return out
 
 
-def derive(lx, ly, r, scale=1.0, physics: Physics | None = None) -> Config:
-    """Time-step derivation of main.c:1836-1860 (host arithmetic, bit-identical)."""
-    L = load_library()
+def derive(lx, ly, r, scale=1.0, physics: Physics | None = None, precision="f64") -> Config:
+    """Time-step derivation of main.c:1836-1860 (host arithmetic, bit-identical; "f32": in the float build's types)."""
+    L = load_library(precision)
     cfg = Config()
     if physics is None:
         _chk(L.lbmdem_physics_defaults(C.byref(cfg.phys)))
@@ -257,9 +273,12 @@ class LbmDem:
     >>> f = sim.f            # [lx][ly][9], the reference's host layout
     """
 
-    def __init__(self, lx, ly, r, x1, x2, scale=1.0, device=0, strip=None, halo=0, physics=None):
-        L = load_library()
+    def __init__(self, lx, ly, r, x1, x2, scale=1.0, device=0, strip=None, halo=0, physics=None, precision="f64"):
+        """precision "f32": the float build of the library (the reference's -DSINGLE_PRECISION mode, main.c:34-40): same
+        methods, host arrays stay float64 (holding float values); step path and state transfers only."""
+        L = load_library(precision)
         self._L = L
+        self.precision = precision
         self._h = C.c_void_p()
         r = np.ascontiguousarray(r, dtype=np.float64)
         x1 = np.ascontiguousarray(x1, dtype=np.float64)
@@ -267,7 +286,7 @@ class LbmDem:
         if not (len(r) == len(x1) == len(x2)) or len(r) < 1:
             raise LbmDemError(-1, "r, x1, x2 must be equally long, at least one grain "
                                   "(the reference cannot run with 0 grains either: main.c:220)")
-        cfg = derive(lx, ly, r, scale, physics)
+        cfg = derive(lx, ly, r, scale, physics, precision)
         cfg.device = int(device)
         if strip is not None:
             cfg.x_begin, cfg.x_end, cfg.halo = int(strip[0]), int(strip[1]), int(halo)

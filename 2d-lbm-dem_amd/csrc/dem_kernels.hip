@@ -26,18 +26,18 @@
 
 namespace {
 
-struct Force3 { double f1, f2, f3, fn, ft, xij, yij, vt; };  // fn, ft, branch vector, vt: for the diagnostics
+struct Force3 { real f1, f2, f3, fn, ft, xij, yij, vt; };  // fn, ft, branch vector, vt: for the diagnostics
 
-__device__ __forceinline__ double maxt(double x, double y) { return (x < y) ? 0. : y; }  // main.c:211-216
+__device__ __forceinline__ real maxt(real x, real y) { return (x < y) ? 0. : y; }  // main.c:211-216
 
-struct GrainState { double x1, x2, v1, v2, v3, r; };
+struct GrainState { real x1, x2, v1, v2, v3, r; };
 
 // drifted + half-kicked state of grain j from the previous sub-step's state: main.c:1748-1753
-__device__ __forceinline__ GrainState advance(const Kin& K, const double* __restrict__ r, int j,
+__device__ __forceinline__ GrainState advance(const Kin& K, const real* __restrict__ r, int j,
                                               const DemParams& P) {
   GrainState s;
-  const double a1 = K.a1[j], a2 = K.a2[j], a3 = K.a3[j];
-  const double v1 = K.v1[j], v2 = K.v2[j], v3 = K.v3[j];
+  const real a1 = K.a1[j], a2 = K.a2[j], a3 = K.a3[j];
+  const real v1 = K.v1[j], v2 = K.v2[j], v3 = K.v3[j];
   s.x1 = K.x1[j] + P.dt * v1 + P.dt2 * a1 / 2.;
   s.x2 = K.x2[j] + P.dt * v2 + P.dt2 * a2 / 2.;
   s.v1 = v1 + P.dt * a1 / 2.;
@@ -53,36 +53,44 @@ template <bool FILM>
 __device__ __forceinline__ Force3 contact(const GrainState& A, const GrainState& B, const DemParams& P,
                                           bool& touched) {
   Force3 F = {0., 0., 0., 0., 0., 0., 0., 0.};
-  const double xij = A.x1 - B.x1;
-  const double yij = A.x2 - B.x2;
-  const double dist = sqrt(xij * xij + yij * yij);
-  const double dn = dist - A.r - B.r;
+  const real xij = A.x1 - B.x1;
+  const real yij = A.x2 - B.x2;
+  const real dist = (real)sqrt((double)(xij * xij + yij * yij));   // <math.h>'s double sqrt, rounded to real (main.c:742)
+  const real dn = dist - A.r - B.r;
   touched = !(dn >= 0);
   if (dn >= 0) return F;
-  const double vx = A.v1 - B.v1;
-  const double vy = A.v2 - B.v2;
-  const double xn = xij / dist;
-  const double yn = yij / dist;
-  const double vn = vx * xn + vy * yn;
-  const double vt = -vx * yn + vy * xn - A.v3 * A.r - B.v3 * B.r;
-  double fn = -P.kg * dn - P.nug * vn;
-  if (fn < 0) fn = 0.0;
-  double ft;
+  const real vx = A.v1 - B.v1;
+  const real vy = A.v2 - B.v2;
+  const real xn = xij / dist;
+  const real yn = yij / dist;
+  const real vn = vx * xn + vy * yn;
+  const real vt = -vx * yn + vy * xn - A.v3 * A.r - B.v3 * B.r;
   if (!FILM) {
-    ft = -P.kt * vt * P.dt;
-    const double ftest = P.mu * fn;
+    // force_grains declares `double fn, ft` (main.c:736) whatever `real` is: f1, f2 and the arguments of Maxt are formed
+    // in double and rounded to real once (fn and ft themselves always hold real values)
+    double fn = -P.kg * dn - P.nug * vn;
+    if (fn < 0) fn = 0.0;
+    double ft = -P.kt * vt * P.dt;
+    const real ftest = P.mu * fn;
     if (fabs(ft) > ftest) ft = (ft < 0.0) ? ftest : -ftest;
-    F.f3 = -maxt(ft * A.r, fn * P.murf * A.r * B.r);
+    F.f3 = -maxt((real)(ft * A.r), (real)(fn * P.murf * A.r * B.r));
+    F.f1 = fn * xn - ft * yn;
+    F.f2 = fn * yn + ft * xn;
+    F.fn = fn;
+    F.ft = ft;
   } else {
-    ft = P.kt * vt * P.dt;
-    const double ftest = P.mu * ft;  // sic, main.c:1385
-    if (fabs(ft) > ftest) ft = (ft > 0.0) ? ftest : -ftest;
+    // the inline film law uses acceleration_grains' own `real fn, ft` (main.c:1340)
+    real fn = -P.kg * dn - P.nug * vn;
+    if (fn < 0) fn = 0.0;
+    real ft = P.kt * vt * P.dt;
+    const real ftest = P.mu * ft;  // sic, main.c:1385
+    if (fabs((double)ft) > ftest) ft = (ft > 0.0) ? ftest : -ftest;
     F.f3 = -ft * A.r * P.murf;
+    F.f1 = fn * xn - ft * yn;
+    F.f2 = fn * yn + ft * xn;
+    F.fn = fn;
+    F.ft = ft;
   }
-  F.f1 = fn * xn - ft * yn;
-  F.f2 = fn * yn + ft * xn;
-  F.fn = fn;
-  F.ft = ft;
   F.xij = xij;
   F.yij = yij;
   F.vt = vt;
@@ -93,21 +101,21 @@ __device__ __forceinline__ Force3 contact(const GrainState& A, const GrainState&
 // (main.c:1455-1508); wf = the grain's wall candidate flags (VerletWall, main.c:1563-1593).
 // what the wall laws leave for the "previous contact" carries (CarryTrack): which walls the grain touched and the ft
 // (bottom: also f3) the reference assigns to pft / pff / pf there (main.c:842-843, 919, 942, 1466, 1494)
-struct WallHits { unsigned mask = 0; double ftB = 0., f3B = 0., ftL = 0., ftR = 0.; };
+struct WallHits { unsigned mask = 0; real ftB = 0., f3B = 0., ftL = 0., ftR = 0.; };
 
 template <bool DIAG>
-__device__ __forceinline__ void walls(const GrainState& me, unsigned wf, const DemParams& P, double& a1,
-                                      double& a2, double& a3, double& pr, double& ds, double& df1, int& dz,
-                                      double& dM11, double& dM12, double& dM21, double& dM22, WallHits& wh) {
+__device__ __forceinline__ void walls(const GrainState& me, unsigned wf, const DemParams& P, real& a1,
+                                      real& a2, real& a3, real& pr, real& ds, real& df1, int& dz,
+                                      real& dM11, real& dM12, real& dM21, real& dM22, WallHits& wh) {
   if (wf & 1u) {
-    const double dn = me.x2 - me.r - P.Mby;
+    const real dn = me.x2 - me.r - P.Mby;
     if (dn < 0) {  // force_WallB, main.c:809-828
-      const double vn = me.v2, vt = me.v1;
-      double fn = -P.km * dn - P.num * vn;
+      const real vn = me.v2, vt = me.v1;
+      real fn = -P.km * dn - P.num * vn;
       if (fn < 0) fn = 0.;
-      double ft = P.ktm * vt;
-      const double ftest = P.mumb * fn;
-      if (fabs(ft) > ftest) ft = (ft < 0.0) ? ftest : -ftest;
+      real ft = P.ktm * vt;
+      const real ftest = P.mumb * fn;
+      if (fabs((double)ft) > ftest) ft = (ft < 0.0) ? ftest : -ftest;
       a1 = a1 + ft; a2 = a2 + fn; a3 = a3 + (-(ft * me.r * P.murf));
       wh.mask |= 1u; wh.ftB = ft; wh.f3B = -(ft * me.r * P.murf);
       pr += fn;
@@ -115,14 +123,14 @@ __device__ __forceinline__ void walls(const GrainState& me, unsigned wf, const D
     }
   }
   if (wf & 2u) {
-    const double dn = -me.x2 - me.r + P.Mhy;
+    const real dn = -me.x2 - me.r + P.Mhy;
     if (dn < 0) {  // force_WallT, main.c:846-871
-      const double vn = me.v2;
-      double fn = P.km * dn - P.num * vn;
+      const real vn = me.v2;
+      real fn = P.km * dn - P.num * vn;
       if (fn > 0.) fn = 0.;
-      const double vt = me.v1 + me.v3 * me.r - P.wallT_vel;
-      double ft = fabs(P.ktm * vt);
-      double ftmax;
+      const real vt = me.v1 + me.v3 * me.r - P.wallT_vel;   // wallT_vel = amp * freq * cos(freq * t) is a double (main.c:855)
+      real ft = fabs((double)(P.ktm * vt));
+      real ftmax;
       if (vt >= 0) ftmax = P.mumb * fn - P.nugt * vt; else ftmax = P.mumb * fn + P.nugt * vt;
       if (ft > ftmax) ft = ftmax;
       if (vt > 0) ft = -ft;
@@ -133,13 +141,13 @@ __device__ __forceinline__ void walls(const GrainState& me, unsigned wf, const D
     }
   }
   if (wf & 4u) {
-    const double dn = me.x1 - me.r - P.Mgx;
+    const real dn = me.x1 - me.r - P.Mgx;
     if (dn < 0) {  // force_WallL, main.c:888-904
-      const double vn = me.v1;
-      double fn = -P.km * dn + P.num * vn;
+      const real vn = me.v1;
+      real fn = -P.km * dn + P.num * vn;
       if (fn < 0.) fn = 0.;
-      const double vt = me.v2;
-      double ft = P.mum * fn;
+      const real vt = me.v2;
+      real ft = P.mum * fn;
       if (vt > 0) ft = -ft;
       a1 = a1 + fn; a2 = a2 + ft; a3 = a3 + ft * me.r * P.murf;
       wh.mask |= 4u; wh.ftL = ft;
@@ -149,12 +157,12 @@ __device__ __forceinline__ void walls(const GrainState& me, unsigned wf, const D
     }
   }
   if (wf & 8u) {
-    const double dn = -me.x1 - me.r + P.Mdx;
+    const real dn = -me.x1 - me.r + P.Mdx;
     if (dn < 0) {  // force_WallR, main.c:923-936 (ft from the unclamped fn)
-      const double vn = me.v1;
-      double fn = P.km * dn - P.num * vn;
-      const double vt = me.v2;
-      double ft = P.mum * fn;
+      const real vn = me.v1;
+      real fn = P.km * dn - P.num * vn;
+      const real vt = me.v2;
+      real ft = P.mum * fn;
       if (vt > 0) ft = -ft;
       wh.mask |= 8u; wh.ftR = ft;
       if (fn > 0.) fn = 0.;
@@ -167,27 +175,27 @@ __device__ __forceinline__ void walls(const GrainState& me, unsigned wf, const D
 
 // Per-grain contact diagnostics of one sub-step (the fields write_DEM prints, main.c:413-420), in the
 // reference's accumulation order. Only produced when DIAG (the sub-step before an output).
-struct DiagOut { double *s, *f1, *f2, *ifm, *M11, *M12, *M21, *M22; int *z, *zz; DiagExtra X; };
+struct DiagOut { real *s, *f1, *f2, *ifm, *M11, *M12, *M21, *M22; int *z, *zz; DiagExtra X; };
 
 template <bool FILM, bool DIAG>
-__global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, const double* __restrict__ m,
-                              const double* __restrict__ It, const double* __restrict__ fhf,
+__global__ void k_dem_substep(Kin in, Kin out, const real* __restrict__ r, const real* __restrict__ m,
+                              const real* __restrict__ It, const real* __restrict__ fhf,
                               const int* __restrict__ offsets, const int* __restrict__ nbr,
-                              const unsigned char* __restrict__ wallflags, double* __restrict__ pout,
+                              const unsigned char* __restrict__ wallflags, real* __restrict__ pout,
                               DiagOut D, DemParams P, const unsigned char* __restrict__ active) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
   if (active && !active[i]) return;  // strip decomposition: a grain another rank integrates
   const GrainState me = advance(in, r, i, P);
-  const double x3 = in.x3[i] + P.dt * in.v3[i] + P.dt2 * in.a3[i] / 2.;
+  const real x3 = in.x3[i] + P.dt * in.v3[i] + P.dt2 * in.a3[i] / 2.;
 
   // acceleration_grains: start from the hydrodynamic force (main.c:1429-1431)
-  double a1 = fhf[i], a2 = fhf[P.n + i], a3 = fhf[2 * P.n + i];
+  real a1 = fhf[i], a2 = fhf[P.n + i], a3 = fhf[2 * P.n + i];
   // grain pressure g.p (main.c:1734, 776-777, 830, 880, 912, 938): reset every sub-step, += fn per
   // contact in the same order as the accelerations; a separated pair (dn >= 0) adds nothing
-  double pr = 0.0;
+  real pr = 0.0;
   bool touched;
-  double ds = 0., df1 = 0., df2 = 0., difm = 0., dM11 = 0., dM12 = 0., dM21 = 0., dM22 = 0.;
+  real ds = 0., df1 = 0., df2 = 0., difm = 0., dM11 = 0., dM12 = 0., dM21 = 0., dM22 = 0.;
   int dz = 0, dzz = 0;
   const int k0 = offsets[i], k1 = offsets[i + 1];
   for (int k = k0; k < k1; ++k) {
@@ -225,7 +233,7 @@ __global__ void k_dem_substep(Kin in, Kin out, const double* __restrict__ r, con
   WallHits wh;
   walls<DIAG>(me, wallflags[i], P, a1, a2, a3, pr, ds, df1, dz, dM11, dM12, dM21, dM22, wh);
   // main.c:1511-1515 (mw = 0: SURVEY.md hard part 5)
-  const double mi = m[i], mw = 0.0;
+  const real mi = m[i], mw = 0.0;
   a1 = a1 / mi + ((mi - mw) / mi) * P.xG;
   a2 = (a2 / mi) + ((mi - mw) / mi) * P.yG;
   a3 = a3 / It[i];
@@ -262,17 +270,17 @@ constexpr int DEM_GRAINS = DEM_TILE;  // grains per workgroup
 constexpr int DEM_ENTRIES = 512;  // list entries staged per round (8 per grain; denser lists take more rounds)
 
 template <bool FILM>
-__global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const double* __restrict__ r,
-                                                     const double* __restrict__ m,
-                                                     const double* __restrict__ It,
-                                                     const double* __restrict__ fhf,
+__global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const real* __restrict__ r,
+                                                     const real* __restrict__ m,
+                                                     const real* __restrict__ It,
+                                                     const real* __restrict__ fhf,
                                                      const int* __restrict__ offsets,
                                                      const int* __restrict__ nbr, const int* __restrict__ own,
                                                      const unsigned char* __restrict__ wallflags,
-                                                     double* __restrict__ pout, DemParams P,
+                                                     real* __restrict__ pout, DemParams P,
                                                      const unsigned char* __restrict__ active, CarryTrack T,
                                                      long long stamp, const unsigned char* __restrict__ owner) {
-  __shared__ double sF1[DEM_ENTRIES], sF2[DEM_ENTRIES], sF3[DEM_ENTRIES], sFn[DEM_ENTRIES];
+  __shared__ real sF1[DEM_ENTRIES], sF2[DEM_ENTRIES], sF3[DEM_ENTRIES], sFn[DEM_ENTRIES];
   __shared__ unsigned char sTouched[DEM_ENTRIES];
   __shared__ int sLast;   // highest list entry of this tile that is a touching contact in the reference's frame
   const int tid = threadIdx.x;
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const doub
   if (active && !__syncthreads_or(mine ? 1 : 0)) return;
   const int e0 = offsets[g0], e1 = offsets[g1];
   GrainState me{};
-  double x3 = 0., a1 = 0., a2 = 0., a3 = 0., pr = 0.0, mi = 1., Iti = 1.;
+  real x3 = 0., a1 = 0., a2 = 0., a3 = 0., pr = 0.0, mi = 1., Iti = 1.;
   int k0 = 0, k1 = 0;
   unsigned wf = 0;
   if (mine) {
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const doub
     mi = m[i]; Iti = It[i];
   }
   int last_e = -1;            // this thread's youngest touching contact (own < partner: the reference evaluates it there)
-  double last_ft = 0., last_f3 = 0.;
+  real last_ft = 0., last_f3 = 0.;
   long long last_who = 0;     // ... and the pair, (own << 32) | partner: the reference's contact order, whatever the list
   // strips with distributed grains: a rank only vouches for (and records) the contacts of the grains it OWNS -- every
   // contact is evaluated in the frame of its lower grain, so exactly one rank records it
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const doub
     }
   }
   if (tid >= 64) return;   // the first wavefront holds the tile's grains
-  double ds = 0., df1 = 0., dM11 = 0., dM12 = 0., dM21 = 0., dM22 = 0.;
+  real ds = 0., df1 = 0., dM11 = 0., dM12 = 0., dM21 = 0., dM22 = 0.;
   int dz = 0;
   WallHits wh;
   if (mine) walls<false>(me, wf, P, a1, a2, a3, pr, ds, df1, dz, dM11, dM12, dM21, dM22, wh);
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const doub
     }
   }
   if (!mine) return;
-  const double mw = 0.0;
+  const real mw = 0.0;
   a1 = a1 / mi + ((mi - mw) / mi) * P.xG;
   a2 = (a2 / mi) + ((mi - mw) / mi) * P.yG;
   a3 = a3 / Iti;
@@ -397,25 +405,25 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const doub
 // per-tile records of its last contacts (CarryTrack, lbmdem_internal.h) from which k_carry_resolve rebuilds the
 // carries exactly before the next diagnostic sub-step.
 
-__global__ __launch_bounds__(1024) void k_diag_scan(DiagExtra X, const int* __restrict__ offsets, int n, double kt) {
-  __shared__ double sFt[1024], sF3[1024];
+__global__ __launch_bounds__(1024) void k_diag_scan(DiagExtra X, const int* __restrict__ offsets, int n, real kt) {
+  __shared__ real sFt[1024], sF3[1024];
   __shared__ unsigned char sHas[1024];
   const int t = threadIdx.x;
   const int E = offsets[n];
   const int chunk = (E + 1023) / 1024;
   const int b = t * chunk, e = b + chunk < E ? b + chunk : E;
   bool has = false;
-  double lft = 0., lf3 = 0.;
+  real lft = 0., lf3 = 0.;
   for (int k = b; k < e; ++k)
     if (X.e_touched[k]) { has = true; lft = X.e_ft[k]; lf3 = X.e_f3[k]; }
   sHas[t] = has; sFt[t] = lft; sF3[t] = lf3;
   __syncthreads();
-  double pft = X.carry[0], pff = X.carry[1];
+  real pft = X.carry[0], pff = X.carry[1];
   for (int u = t - 1; u >= 0; --u)
     if (sHas[u]) { pft = sFt[u]; pff = sF3[u]; break; }
   for (int k = b; k < e; ++k) {
     if (!X.e_touched[k]) continue;
-    const double ft = X.e_ft[k], f3 = X.e_f3[k];
+    const real ft = X.e_ft[k], f3 = X.e_f3[k];
     X.e_dslip[k] = fabs(ft) * (X.e_avt[k] + (fabs(ft - pft)) / kt);
     X.e_drw[k] = fabs(f3) * (X.e_av3[k] + (fabs(f3 - pff)) / kt);
     pft = ft; pff = f3;
@@ -431,7 +439,7 @@ template <bool FILM>
 __global__ void k_diag_accum(DiagExtra X, const int* __restrict__ offsets, const int* __restrict__ nbr, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  double slip = 0., rw = 0.;
+  real slip = 0., rw = 0.;
   for (int k = offsets[i]; k < offsets[i + 1]; ++k) {
     const int j = nbr[k];
     int e = k;
@@ -464,25 +472,25 @@ __global__ __launch_bounds__(256) void k_diag_wall_lists(DiagExtra X, const unsi
   if (lane == 0) X.wcount[w] = cnt;
 }
 
-__global__ void k_diag_walls(DiagExtra X, Kin in, const double* __restrict__ r, DemParams P) {
+__global__ void k_diag_walls(DiagExtra X, Kin in, const real* __restrict__ r, DemParams P) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   const int n = P.n;
-  double pft = X.carry[0], pff = X.carry[1], pf = X.carry[2], ic = 0.0;  // ic: reset every sub-step (main.c:1743)
+  real pft = X.carry[0], pff = X.carry[1], pf = X.carry[2], ic = 0.0;  // ic: reset every sub-step (main.c:1743)
   const int *LB = X.wlist, *LT = X.wlist + n, *LL = X.wlist + 2 * (size_t)n, *LR = X.wlist + 3 * (size_t)n;
   // g[k].v1 and g[k].a1 of the reference at this point: drifted velocity, force sum so far (k = list position)
   auto v1_of = [&](int g) { return in.v1[g] + P.dt * in.a1[g] / 2.; };
   for (int k = 0; k < X.wcount[0]; ++k) {  // bottom: main.c:1455-1468, force_WallB 809-845
     const int i = LB[k];
     const GrainState me = advance(in, r, i, P);
-    const double dn = me.x2 - me.r - P.Mby;
+    const real dn = me.x2 - me.r - P.Mby;
     if (!(dn < 0)) continue;
-    const double vn = me.v2, vt = me.v1;
-    double fn = -P.km * dn - P.num * vn;
+    const real vn = me.v2, vt = me.v1;
+    real fn = -P.km * dn - P.num * vn;
     if (fn < 0) fn = 0.;
-    double ft = P.ktm * vt;
-    const double ftest = P.mumb * fn;
+    real ft = P.ktm * vt;
+    const real ftest = P.mumb * fn;
     if (fabs(ft) > ftest) ft = (ft < 0.0) ? ftest : -ftest;
-    const double f1 = ft, f3 = -(ft * me.r * P.murf);
+    const real f1 = ft, f3 = -(ft * me.r * P.murf);
     X.rw[i] += fabs(f3) * (fabs(me.v3 * P.dt) + (fabs(f3 - pff)) / P.kt);
     X.fr[i] += fabs(ft) * (fabs(vt * P.dt) + (fabs(ft - pft)) / P.kt);
     pff = f3; pft = ft;
@@ -493,15 +501,15 @@ __global__ void k_diag_walls(DiagExtra X, Kin in, const double* __restrict__ r, 
   for (int k = 0; k < X.wcount[1]; ++k) {  // top: main.c:1470-1480, force_WallT 846-887
     const int i = LT[k];
     const GrainState me = advance(in, r, i, P);
-    const double dn = -me.x2 - me.r + P.Mhy;
+    const real dn = -me.x2 - me.r + P.Mhy;
     if (!(dn < 0)) continue;
-    const double vn = me.v2;
-    double fn = P.km * dn - P.num * vn;
+    const real vn = me.v2;
+    real fn = P.km * dn - P.num * vn;
     ic += P.num * vn * vn * P.dt;
     if (fn > 0.) fn = 0.;
-    const double vt = me.v1 + me.v3 * me.r - P.wallT_vel;
-    double ft = fabs(P.ktm * vt);
-    double ftmax;
+    const real vt = me.v1 + me.v3 * me.r - P.wallT_vel;
+    real ft = fabs(P.ktm * vt);
+    real ftmax;
     if (vt >= 0) ftmax = P.mumb * fn - P.nugt * vt; else ftmax = P.mumb * fn + P.nugt * vt;
     if (ft > ftmax) ft = ftmax;
     if (vt > 0) ft = -ft;
@@ -510,16 +518,16 @@ __global__ void k_diag_walls(DiagExtra X, Kin in, const double* __restrict__ r, 
   for (int k = 0; k < X.wcount[2]; ++k) {  // left: main.c:1482-1496, force_WallL 888-921
     const int i = LL[k];
     const GrainState me = advance(in, r, i, P);
-    const double dn = me.x1 - me.r - P.Mgx;
+    const real dn = me.x1 - me.r - P.Mgx;
     if (!(dn < 0)) continue;
-    const double vn = me.v1;
-    double fn = -P.km * dn + P.num * vn;
+    const real vn = me.v1;
+    real fn = -P.km * dn + P.num * vn;
     ic += P.num * vn * vn * P.dt;
     if (fn < 0.) fn = 0.;
-    const double vt = me.v2;
-    double ft = P.mum * fn;
+    const real vt = me.v2;
+    real ft = P.mum * fn;
     if (vt > 0) ft = -ft;
-    const double f1 = fn, f2 = ft, f3 = ft * me.r * P.murf;
+    const real f1 = fn, f2 = ft, f3 = ft * me.r * P.murf;
     X.ice[i] += ic;
     X.rw[i] += fabs(f3) * fabs(me.v3 * P.dt);
     X.fr[i] += fabs(ft) * (fabs(vt * P.dt) + (fabs(ft - pft)) / P.kt);
@@ -531,12 +539,12 @@ __global__ void k_diag_walls(DiagExtra X, Kin in, const double* __restrict__ r, 
   for (int k = 0; k < X.wcount[3]; ++k) {  // right: main.c:1498-1508, force_WallR 923-951
     const int i = LR[k];
     const GrainState me = advance(in, r, i, P);
-    const double dn = -me.x1 - me.r + P.Mdx;
+    const real dn = -me.x1 - me.r + P.Mdx;
     if (!(dn < 0)) continue;
-    const double vn = me.v1;
-    const double fn = P.km * dn - P.num * vn;
-    const double vt = me.v2;
-    double ft = P.mum * fn;
+    const real vn = me.v1;
+    const real fn = P.km * dn - P.num * vn;
+    const real vt = me.v2;
+    real ft = P.mum * fn;
     if (vt > 0) ft = -ft;
     pft = ft;
     X.a1gc[i] = X.a1gc[i] + ((fn > 0.) ? 0. : fn);
@@ -585,13 +593,13 @@ __global__ __launch_bounds__(256) void k_carry_resolve(CarryTrack T, long long m
 // Verlet list
 // ---------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ int cell_coord(double x, double o, double cs, int nc) {
+__device__ __forceinline__ int cell_coord(real x, real o, real cs, int nc) {
   int c = (int)floor((x - o) / cs);
   return c < 0 ? 0 : (c >= nc ? nc - 1 : c);
 }
 
-__global__ void k_cell_keys(int n, const double* __restrict__ x1, const double* __restrict__ x2, double ox,
-                            double oy, double cs, int ncx, int ncy, unsigned int* __restrict__ keys,
+__global__ void k_cell_keys(int n, const real* __restrict__ x1, const real* __restrict__ x2, real ox,
+                            real oy, real cs, int ncx, int ncy, unsigned int* __restrict__ keys,
                             int* __restrict__ vals) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -609,26 +617,27 @@ __global__ void k_cell_bounds(int n, const unsigned int* __restrict__ keys, int*
 }
 
 // the reference's candidate test (main.c:1527-1532), lo < hi
-__device__ __forceinline__ bool verlet_pair(double x1l, double x2l, double rl, double x1h, double x2h,
-                                            double rh, double dV) {
-  const double ddx = x1l - x1h;
-  const double ddy = x2l - x2h;
-  if (((fabs(ddx) - rl - rh) <= dV) && ((fabs(ddy) - rl - rh) <= dV))
-    return (sqrt(ddx * ddx + ddy * ddy) - rl - rh) <= dV;
+__device__ __forceinline__ bool verlet_pair(real x1l, real x2l, real rl, real x1h, real x2h,
+                                            real rh, real dV) {
+  const real ddx = x1l - x1h;
+  const real ddy = x2l - x2h;
+  // main.c:1529-1532: fabs() and sqrt() make the left-hand sides double sums in either build
+  if (((fabs((double)ddx) - rl - rh) <= dV) && ((fabs((double)ddy) - rl - rh) <= dV))
+    return (sqrt((double)(ddx * ddx + ddy * ddy)) - rl - rh) <= dV;
   return false;
 }
 
 // MODE 0: count partners; MODE 1: write them (then sort ascending) -- one thread per grain
 template <int MODE>
-__global__ void k_verlet_scan(int n, const double* __restrict__ x1, const double* __restrict__ x2,
-                              const double* __restrict__ r, double ox, double oy, double cs, int ncx, int ncy,
+__global__ void k_verlet_scan(int n, const real* __restrict__ x1, const real* __restrict__ x2,
+                              const real* __restrict__ r, real ox, real oy, real cs, int ncx, int ncy,
                               const int* __restrict__ cell_start, const int* __restrict__ cell_end,
-                              const int* __restrict__ sorted, double dV, int* __restrict__ counts,
+                              const int* __restrict__ sorted, real dV, int* __restrict__ counts,
                               const int* __restrict__ offsets, int* __restrict__ nbr, int* __restrict__ own,
                               long cap, int* __restrict__ overflow) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const double xi = x1[i], yi = x2[i], ri = r[i];
+  const real xi = x1[i], yi = x2[i], ri = r[i];
   const int cx = cell_coord(xi, ox, cs, ncx), cy = cell_coord(yi, oy, cs, ncy);
   int cnt = 0;
   const int base = MODE ? offsets[i] : 0;
@@ -666,8 +675,8 @@ __global__ void k_verlet_scan(int n, const double* __restrict__ x1, const double
 }
 
 // wall candidate lists as per-grain flags: main.c:1563-1593
-__global__ void k_wall_flags(int n, const double* __restrict__ x1, const double* __restrict__ x2,
-                             const double* __restrict__ r, DemParams P, unsigned char* __restrict__ flags) {
+__global__ void k_wall_flags(int n, const real* __restrict__ x1, const real* __restrict__ x2,
+                             const real* __restrict__ r, DemParams P, unsigned char* __restrict__ flags) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   unsigned f = 0;
@@ -713,13 +722,13 @@ int carry_track_alloc(CarryTrack& T, int n) {
   if (T.tiles >= (1 << 24)) return -1;
   const size_t recs = (size_t)T.tiles * 4;
   if (hipMalloc((void**)&T.stamp, sizeof(long long) * recs) != hipSuccess) return -1;
-  if (hipMalloc((void**)&T.val, sizeof(double) * (2 * recs + 3)) != hipSuccess) { carry_track_free(T); return -1; }
+  if (hipMalloc((void**)&T.val, sizeof(real) * (2 * recs + 3)) != hipSuccess) { carry_track_free(T); return -1; }
   if (hipMalloc((void**)&T.who, sizeof(long long) * (recs + 6)) != hipSuccess) { carry_track_free(T); return -1; }
   if (hipMemset(T.who, 0, sizeof(long long) * (recs + 6)) != hipSuccess) { carry_track_free(T); return -1; }
   T.best_key = T.who + recs;
   T.carry = T.val + 2 * recs;
   if (hipMemset(T.stamp, 0xFF, sizeof(long long) * recs) != hipSuccess ||
-      hipMemset(T.val, 0, sizeof(double) * (2 * recs + 3)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+      hipMemset(T.val, 0, sizeof(real) * (2 * recs + 3)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
     carry_track_free(T);
     return -1;
   }
@@ -738,7 +747,7 @@ void launch_carry_resolve(const CarryTrack& T, long long min_stamp, hipStream_t 
 }
 
 
-int verlet_alloc(VerletDevice& V, int n, double cs, double ox, double oy, double wx, double wy) {
+int verlet_alloc(VerletDevice& V, int n, real cs, real ox, real oy, real wx, real wy) {
   V = VerletDevice{};
   V.cs = cs; V.ox = ox; V.oy = oy;
   V.ncx = (int)ceil(wx / cs) + 1; if (V.ncx < 1) V.ncx = 1;
@@ -776,7 +785,7 @@ void verlet_free(VerletDevice& V) {
   V = VerletDevice{};
 }
 
-int launch_verlet_rebuild(VerletDevice& V, const Kin& K, const double* r, const DemParams& P,
+int launch_verlet_rebuild(VerletDevice& V, const Kin& K, const real* r, const DemParams& P,
                           hipStream_t st) {
   hipError_t e = hipSuccess;
   const int n = P.n;
@@ -804,15 +813,15 @@ int launch_verlet_rebuild(VerletDevice& V, const Kin& K, const double* r, const 
   return (int)hipGetLastError();
 }
 
-int diag_extra_alloc(DiagExtra& X, int n, long cap, double* carry) {
+int diag_extra_alloc(DiagExtra& X, int n, long cap, real* carry) {
   X = DiagExtra{};
-  double* d = nullptr;
+  real* d = nullptr;
   const size_t nd = 5 * (size_t)n + 6 * (size_t)cap;
-  if (hipMalloc((void**)&d, sizeof(double) * nd) != hipSuccess) return -1;
+  if (hipMalloc((void**)&d, sizeof(real) * nd) != hipSuccess) return -1;
   X.fr = d;   // from here on diag_extra_free() releases whatever was allocated
-  if (hipMemset(d, 0, sizeof(double) * nd) != hipSuccess) { diag_extra_free(X); return -1; }
+  if (hipMemset(d, 0, sizeof(real) * nd) != hipSuccess) { diag_extra_free(X); return -1; }
   X.fr = d; X.ice = d + n; X.slip = d + 2 * (size_t)n; X.rw = d + 3 * (size_t)n; X.a1gc = d + 4 * (size_t)n;
-  double* e = d + 5 * (size_t)n;
+  real* e = d + 5 * (size_t)n;
   X.e_ft = e; X.e_f3 = e + cap; X.e_avt = e + 2 * cap; X.e_av3 = e + 3 * cap; X.e_dslip = e + 4 * cap; X.e_drw = e + 5 * cap;
   X.carry = carry;   // lives with the handle's CarryTrack
   if (hipMalloc((void**)&X.e_touched, (size_t)cap) != hipSuccess) { diag_extra_free(X); return -1; }
@@ -831,7 +840,7 @@ void diag_extra_free(DiagExtra& X) {
   X = DiagExtra{};
 }
 
-void launch_diag_extra(const DiagExtra& X, const Kin& in, const double* r, const VerletDevice& V,
+void launch_diag_extra(const DiagExtra& X, const Kin& in, const real* r, const VerletDevice& V,
                        const DemParams& P, int film, hipStream_t st) {
   const int n = P.n;
   hipLaunchKernelGGL(k_diag_scan, dim3(1), dim3(1024), 0, st, X, V.offsets, n, P.kt);
@@ -847,9 +856,9 @@ void launch_fill_own(const VerletDevice& V, int n, hipStream_t st) {
   hipLaunchKernelGGL(k_fill_own, dim3((n + 255) / 256), dim3(256), 0, st, n, V.offsets, V.own);
 }
 
-void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const double* m,
-                        const double* It, const double* fhf, const VerletDevice& V, double* pout,
-                        const DemParams& P, int film, double* diag, const DiagExtra* X, const unsigned char* active,
+void launch_dem_substep(const Kin& in, const Kin& out, const real* r, const real* m,
+                        const real* It, const real* fhf, const VerletDevice& V, real* pout,
+                        const DemParams& P, int film, real* diag, const DiagExtra* X, const unsigned char* active,
                         const CarryTrack* track, long long stamp, const unsigned char* owner, hipStream_t st) {
   const int n = P.n;
   const CarryTrack T = track ? *track : CarryTrack{};

@@ -21,8 +21,8 @@ namespace {
 constexpr int ERR_LIST_OVERFLOW = 4;   // more grains near a cut than the message capacity
 constexpr int ERR_MERGE_CLASH = 8;     // two ranks produced the same link sum
 
-__global__ __launch_bounds__(1024) void k_dist_classify(DistDevice D, DistGeom Gm, int n, const double* __restrict__ x1,
-                                                       const double* __restrict__ r, const double* __restrict__ rLB,
+__global__ __launch_bounds__(1024) void k_dist_classify(DistDevice D, DistGeom Gm, int n, const real* __restrict__ x1,
+                                                       const real* __restrict__ r, const real* __restrict__ rLB,
                                                        unsigned char* __restrict__ owner, int* __restrict__ error) {
   __shared__ int sCnt[5], sBase[5];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -30,11 +30,11 @@ __global__ __launch_bounds__(1024) void k_dist_classify(DistDevice D, DistGeom G
   if (blockIdx.x == 0 && threadIdx.x < 8) D.counters_alt[threadIdx.x] = 0;
   const bool in = i < n;
   const bool act = in && D.active[i] != 0;   // integrated during the last period: exact wherever it matters below
-  const double xc = in ? (x1[i] - Gm.Mgx) / Gm.dx : 0.0;   // the rasteriser's lattice coordinate of the centre (main.c:1009)
+  const real xc = in ? (x1[i] - Gm.Mgx) / Gm.dx : 0.0;   // the rasteriser's lattice coordinate of the centre (main.c:1009)
   const bool own = act && (Gm.first || xc >= Gm.lo) && (Gm.last || xc < Gm.hi);
   // grains that may cover nodes of this rank's rows (+ halo) or have links ending there
-  const double reach = in ? r[i] / Gm.dx + 3.0 : 0.0;
-  const bool near = act && xc + reach >= (double)Gm.gx0 && xc - reach <= (double)(Gm.gx0 + Gm.nxl);
+  const real reach = in ? r[i] / Gm.dx + 3.0 : 0.0;
+  const bool near = act && xc + reach >= (real)Gm.gx0 && xc - reach <= (real)(Gm.gx0 + Gm.nxl);
   if (in) {
     owner[i] = own ? 1 : 0;
     D.active[i] = own ? 1 : 0;           // the margin joins when the neighbours' messages are unpacked
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(1024) void k_dist_classify(DistDevice D, DistGeom G
   }
   // one global atomic per workgroup and list (same-address atomics from hundreds of wavefronts serialise at ~30 ns
   // each on this GPU); the order within a list is immaterial
-  const double ring = in ? rLB[i] + 2.0 : 0.0;   // reduced disc + one node: the grain's ring of boundary links
+  const real ring = in ? rLB[i] + 2.0 : 0.0;   // reduced disc + one node: the grain's ring of boundary links
   const bool want[5] = {own && Gm.has_lo && xc < Gm.lo + Gm.margin,                      // kinematics to the low neighbour
                         own && Gm.has_hi && xc >= Gm.hi - Gm.margin,                     // ... the high neighbour
                         act && !own && Gm.has_lo && xc < Gm.lo && xc + ring >= Gm.lo,    // its link sums reach this rank's rows
@@ -69,20 +69,20 @@ __global__ __launch_bounds__(1024) void k_dist_classify(DistDevice D, DistGeom G
 
 // The per-side kernels below take both sides in one launch: blockIdx.y = side (0 low, 1 high); a null buffer
 // skips the side.
-struct Buf2 { double* p[2]; };
-struct CBuf2 { const double* p[2]; };
+struct Buf2 { real* p[2]; };
+struct CBuf2 { const real* p[2]; };
 
 __global__ void k_pack_kin(DistDevice D, Kin K, Buf2 B) {
   const int side = blockIdx.y;
-  double* __restrict__ buf = B.p[side];
+  real* __restrict__ buf = B.p[side];
   if (!buf) return;
   const int* __restrict__ list = D.send_list[side];
   const int cnt = D.counters[side] < D.cap_g ? D.counters[side] : D.cap_g;   // an overflow is flagged by k_dist_classify
-  if (blockIdx.x == 0 && threadIdx.x == 0) buf[0] = (double)cnt;
+  if (blockIdx.x == 0 && threadIdx.x == 0) buf[0] = (real)cnt;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) {
     const int i = list[k];
-    double* o = buf + 1 + (long)k * 10;
-    o[0] = (double)i;
+    real* o = buf + 1 + (long)k * 10;
+    o[0] = (real)i;
     o[1] = K.x1[i]; o[2] = K.x2[i]; o[3] = K.x3[i]; o[4] = K.v1[i]; o[5] = K.v2[i]; o[6] = K.v3[i];
     o[7] = K.a1[i]; o[8] = K.a2[i]; o[9] = K.a3[i];
   }
@@ -90,7 +90,7 @@ __global__ void k_pack_kin(DistDevice D, Kin K, Buf2 B) {
 
 __global__ void k_unpack_kin(DistDevice D, CBuf2 B, Kin K, int n, int* __restrict__ error) {
   const int side = blockIdx.y;
-  const double* __restrict__ buf = B.p[side];
+  const real* __restrict__ buf = B.p[side];
   if (!buf) return;
   const int cap = D.cap_g;
   unsigned char* __restrict__ active = D.active;
@@ -100,7 +100,7 @@ __global__ void k_unpack_kin(DistDevice D, CBuf2 B, Kin K, int n, int* __restric
   if (cnt < 0 || cnt > cap) { cnt = 0; if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(error, ERR_LIST_OVERFLOW); }
   if (blockIdx.x == 0 && threadIdx.x == 0) *recv_count = cnt;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) {
-    const double* o = buf + 1 + (long)k * 10;
+    const real* o = buf + 1 + (long)k * 10;
     const int i = (int)o[0];
     if (i < 0 || i >= n) continue;
     recv_ids[k] = i;
@@ -110,9 +110,9 @@ __global__ void k_unpack_kin(DistDevice D, CBuf2 B, Kin K, int n, int* __restric
   }
 }
 
-__global__ void k_pack_fhf(DistDevice D, const double* __restrict__ fhf, int n, Buf2 B) {
+__global__ void k_pack_fhf(DistDevice D, const real* __restrict__ fhf, int n, Buf2 B) {
   const int side = blockIdx.y;
-  double* __restrict__ buf = B.p[side];
+  real* __restrict__ buf = B.p[side];
   if (!buf) return;
   const int* __restrict__ list = D.send_list[side];
   const int cnt = D.counters[side] < D.cap_g ? D.counters[side] : D.cap_g;   // an overflow is flagged by k_dist_classify
@@ -122,9 +122,9 @@ __global__ void k_pack_fhf(DistDevice D, const double* __restrict__ fhf, int n, 
   }
 }
 
-__global__ void k_unpack_fhf(DistDevice D, double* __restrict__ fhf, int n, CBuf2 B) {
+__global__ void k_unpack_fhf(DistDevice D, real* __restrict__ fhf, int n, CBuf2 B) {
   const int side = blockIdx.y;
-  const double* __restrict__ buf = B.p[side];
+  const real* __restrict__ buf = B.p[side];
   if (!buf) return;
   const int* __restrict__ ids = D.recv_ids[side];
   const int cnt = D.counters[4 + side];
@@ -136,7 +136,7 @@ __global__ void k_unpack_fhf(DistDevice D, double* __restrict__ fhf, int n, CBuf
 
 // the neighbour's part of the link-sum tables of grains this rank owns: slot by slot into the local table
 __global__ void k_merge_tables(ForceSlots S, CBuf2 B, int cap) {
-  const double* __restrict__ buf = B.p[blockIdx.y];
+  const real* __restrict__ buf = B.p[blockIdx.y];
   if (!buf) return;
   int cnt = (int)buf[0];
   if (cnt < 0 || cnt > cap) { cnt = 0; if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(S.error, ERR_LIST_OVERFLOW); }
@@ -147,7 +147,7 @@ __global__ void k_merge_tables(ForceSlots S, CBuf2 B, int cap) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   for (int e = wave; e < cnt; e += nwaves) {
     const unsigned long long* ent = b + 1 + (long)e * (1 + nslot);
-    const int i = (int)reinterpret_cast<const double*>(ent)[0];
+    const int i = (int)reinterpret_cast<const real*>(ent)[0];
     if (i < 0) continue;   // the sender could not complete this grain (flagged on its side)
     for (int k = lane; k < nslot; k += 64) {
       const unsigned long long v = ent[1 + k];
@@ -163,7 +163,7 @@ __global__ void k_merge_tables(ForceSlots S, CBuf2 B, int cap) {
 __global__ void k_poison(const unsigned char* __restrict__ active, Kin a, Kin b, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || active[i]) return;
-  const double q = __longlong_as_double(0x7FF8000000000BADll);
+  const real q = __longlong_as_double(0x7FF8000000000BADll);
   a.x1[i] = a.x2[i] = a.x3[i] = a.v1[i] = a.v2[i] = a.v3[i] = a.a1[i] = a.a2[i] = a.a3[i] = q;
   b.x1[i] = b.x2[i] = b.x3[i] = b.v1[i] = b.v2[i] = b.v3[i] = b.a1[i] = b.a2[i] = b.a3[i] = q;
 }
@@ -198,31 +198,31 @@ void dist_free(DistDevice& D) {
   D = DistDevice{};
 }
 
-void launch_dist_classify(const DistDevice& D, const DistGeom& Gm, int n, const double* x1, const double* r,
-                          const double* rLB, unsigned char* owner, int* error, hipStream_t st) {
+void launch_dist_classify(const DistDevice& D, const DistGeom& Gm, int n, const real* x1, const real* r,
+                          const real* rLB, unsigned char* owner, int* error, hipStream_t st) {
   // D.counters is all zero here: the classification of the period before cleared it (the received counts [4], [5] are
   // SET by the next unpack). The counts may exceed the capacities (flagged): every reader clamps.
   hipLaunchKernelGGL(k_dist_classify, dim3((n + 1023) / 1024), dim3(1024), 0, st, D, Gm, n, x1, r, rLB, owner, error);
 }
 
-void launch_dist_pack_kin(const DistDevice& D, const Kin& K, double* lo, double* hi, hipStream_t st) {
+void launch_dist_pack_kin(const DistDevice& D, const Kin& K, real* lo, real* hi, hipStream_t st) {
   hipLaunchKernelGGL(k_pack_kin, dim3(32, 2), dim3(256), 0, st, D, K, Buf2{{lo, hi}});
 }
 
-void launch_dist_unpack_kin(const DistDevice& D, const Kin& K, const double* lo, const double* hi, int n, int* error,
+void launch_dist_unpack_kin(const DistDevice& D, const Kin& K, const real* lo, const real* hi, int n, int* error,
                             hipStream_t st) {
   hipLaunchKernelGGL(k_unpack_kin, dim3(32, 2), dim3(256), 0, st, D, CBuf2{{lo, hi}}, K, n, error);
 }
 
-void launch_dist_pack_fhf(const DistDevice& D, const double* fhf, int n, double* lo, double* hi, hipStream_t st) {
+void launch_dist_pack_fhf(const DistDevice& D, const real* fhf, int n, real* lo, real* hi, hipStream_t st) {
   hipLaunchKernelGGL(k_pack_fhf, dim3(32, 2), dim3(256), 0, st, D, fhf, n, Buf2{{lo, hi}});
 }
 
-void launch_dist_unpack_fhf(const DistDevice& D, double* fhf, int n, const double* lo, const double* hi, hipStream_t st) {
+void launch_dist_unpack_fhf(const DistDevice& D, real* fhf, int n, const real* lo, const real* hi, hipStream_t st) {
   hipLaunchKernelGGL(k_unpack_fhf, dim3(32, 2), dim3(256), 0, st, D, fhf, n, CBuf2{{lo, hi}});
 }
 
-void launch_dist_merge_tables(const ForceSlots& S, const double* lo, const double* hi, int cap, hipStream_t st) {
+void launch_dist_merge_tables(const ForceSlots& S, const real* lo, const real* hi, int cap, hipStream_t st) {
   hipLaunchKernelGGL(k_merge_tables, dim3(32, 2), dim3(256), 0, st, S, CBuf2{{lo, hi}}, cap);
 }
 

@@ -11,7 +11,7 @@
 //   bounce-back and the grain interpolated bounce-back (Bouzidi, moving wall) on the fly. The wall
 //   distance delta (main.c:1054-1058) and the `act` flag (main.c:1039-1052) are recomputed from the
 //   obstacle map and the grain centres instead of being stored (the reference spends most of
-//   obst_construction clearing a 9-double-per-node delta array).
+//   obst_construction clearing a 9-real-per-node delta array).
 //
 // Bit parity with the reference's serial loops is a design constraint: expression association is
 // kept, the file is compiled with -ffp-contract=off, and the one order-dependent read of the
@@ -35,8 +35,8 @@ __host__ __device__ constexpr int EYq(int q) {
   return (q == 1 || q == 7 || q == 8) ? 1 : ((q == 3 || q == 4 || q == 5) ? -1 : 0);
 }
 __host__ __device__ constexpr int OPPq(int q) { return q == 0 ? 0 : (q <= 4 ? q + 4 : q - 4); }
-__host__ __device__ constexpr double Wq(int q) {
-  return q == 0 ? 4. / 9 : ((q & 1) ? 1. / 36 : 1. / 9);
+__host__ __device__ constexpr real Wq(int q) {   // real _w[Q] = {4. / 9, 1. / 36, 1. / 9, ...}: the double quotient, rounded to real
+  return (real)(q == 0 ? 4. / 9 : ((q & 1) ? 1. / 36 : 1. / 9));
 }
 
 // Populations are stored in tiles of 16 consecutive y: f[x][y / 16][q][y % 16]. The nine 128-byte cache lines
@@ -48,8 +48,11 @@ __host__ __device__ constexpr double Wq(int q) {
 #define LBMDEM_F_TILES 1   // 0: nine planes f[q][x][y] (A/B builds only: scripts/ab_layout.sh)
 #endif
 #if LBMDEM_F_TILES
-__device__ __forceinline__ long fbase(long node) { return (node >> 4) * 144 + (node & 15); }
-#define F_QSTRIDE(L) 16L
+// (LBMDEM_TILE_Y = 16 nodes for double, 32 for float: one 128-byte line per tile and direction either way)
+__device__ __forceinline__ long fbase(long node) {
+  return (node / LBMDEM_TILE_Y) * (9 * LBMDEM_TILE_Y) + (node % LBMDEM_TILE_Y);
+}
+#define F_QSTRIDE(L) ((long)LBMDEM_TILE_Y)
 #else
 __device__ __forceinline__ long fbase(long node) { return node; }
 #define F_QSTRIDE(L) ((L).plane)
@@ -57,11 +60,11 @@ __device__ __forceinline__ long fbase(long node) { return node; }
 #define fidx(q, node) (fbase(node) + (q) * F_QSTRIDE(L))   // needs the LatticeView `L` in scope
 
 // the fluid-side record of one grain
-struct GP { double x1, x2, v1, v2, v3, xc, yc, r2; };
+struct GP { real x1, x2, v1, v2, v3, xc, yc, r2; };
 
 __device__ __forceinline__ GP load_gp(const GrainFluidView& G, int i) {
-  const double2* p = reinterpret_cast<const double2*>(G.pk + (long)i * 8);
-  const double2 a = p[0], b = p[1], c = p[2], d = p[3];
+  const real2* p = reinterpret_cast<const real2*>(G.pk + (long)i * 8);
+  const real2 a = p[0], b = p[1], c = p[2], d = p[3];
   return GP{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
 }
 
@@ -73,10 +76,10 @@ __device__ __forceinline__ int min_cover(const GrainFluidView& G, long node, int
 }
 
 // rigid-body velocity of a grain at global node (x, y): main.c:974-975,1172-1173
-__device__ __forceinline__ double wall_ux(const LatticeView& L, const GP& g, int y) {
+__device__ __forceinline__ real wall_ux(const LatticeView& L, const GP& g, int y) {
   return g.v1 - (y * L.dx + L.Mby - g.x2) * g.v3;
 }
-__device__ __forceinline__ double wall_uy(const LatticeView& L, const GP& g, int x) {
+__device__ __forceinline__ real wall_uy(const LatticeView& L, const GP& g, int x) {
   return g.v2 + (x * L.dx + L.Mgx - g.x1) * g.v3;
 }
 
@@ -87,41 +90,47 @@ __device__ __forceinline__ double wall_uy(const LatticeView& L, const GP& g, int
 // from 1e-290). r == 0 means q is already the exact quotient (this also keeps the sign of a zero).
 // One division costs ~30 fp64 instructions on gfx950; this costs 3 + a select. The fused kernel is
 // issue-bound, not bandwidth-bound, so instructions are what counts.
-__device__ __forceinline__ double exact_div(double a, double b, double y) {
-  const double q = a * y;
-  const double r = __builtin_fma(-b, q, a);
-  return r == 0.0 ? q : __builtin_fma(r, y, q);
+__device__ __forceinline__ real exact_div(real a, real b, real y) {
+  const real q = a * y;
+  const real r = __builtin_fma(-b, q, a);     // (the float overload for float operands: exact there too)
+  return r == (real)0.0 ? q : (real)__builtin_fma(r, y, q);
 }
-__device__ __forceinline__ bool significand_all_ones(double v) {
+#ifdef LBMDEM_SINGLE_PRECISION
+__device__ __forceinline__ bool significand_all_ones(real v) { return (__float_as_int(v) & 0x7FFFFF) == 0x7FFFFF; }
+// numerators for which exact_div cannot underflow (divisors here are O(1) .. O(1e8))
+__device__ __forceinline__ bool div_safe(real a) { return a == 0.0f || (fabsf(a) > 1e-20f && fabsf(a) < 1e20f); }
+#else
+__device__ __forceinline__ bool significand_all_ones(real v) {
   return (__double_as_longlong(v) & 0xFFFFFFFFFFFFFll) == 0xFFFFFFFFFFFFFll;
 }
 // numerators for which exact_div cannot underflow (divisors here are O(1) .. O(1e8))
-__device__ __forceinline__ bool div_safe(double a) { return a == 0.0 || (fabs(a) > 1e-200 && fabs(a) < 1e200); }
+__device__ __forceinline__ bool div_safe(real a) { return a == 0.0 || (fabs(a) > 1e-200 && fabs(a) < 1e200); }
+#endif
 
 // main.c:1082-1116, in registers
-__device__ __forceinline__ void mrt_collide(const LatticeView& L, double (&f)[9]) {
-  const double a = 1. / 36;
-  const double f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3], f4 = f[4], f5 = f[5], f6 = f[6],
+__device__ __forceinline__ void mrt_collide(const LatticeView& L, real (&f)[9]) {
+  const real a = 1. / 36;
+  const real f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3], f4 = f[4], f5 = f[5], f6 = f[6],
                f7 = f[7], f8 = f[8];
-  const double rho = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + f8;
-  const double e = -4 * f0 + 2 * f1 - f2 + 2 * f3 - f4 + 2 * f5 - f6 + 2 * f7 - f8;
-  const double eps = 4 * f0 + f1 - 2 * f2 + f3 - 2 * f4 + f5 - 2 * f6 + f7 - 2 * f8;
-  const double j_x = f5 + f6 + f7 - f1 - f2 - f3;
-  const double q_x = -f1 + 2 * f2 - f3 + f5 - 2 * f6 + f7;
-  const double j_y = f1 + f8 + f7 - f3 - f4 - f5;
-  const double q_y = f1 - f3 + 2 * f4 - f5 + f7 - 2 * f8;
-  const double p_xx = f2 - f4 + f6 - f8;
-  const double p_xy = -f1 + f3 - f5 + f7;
+  const real rho = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + f8;
+  const real e = -4 * f0 + 2 * f1 - f2 + 2 * f3 - f4 + 2 * f5 - f6 + 2 * f7 - f8;
+  const real eps = 4 * f0 + f1 - 2 * f2 + f3 - 2 * f4 + f5 - 2 * f6 + f7 - 2 * f8;
+  const real j_x = f5 + f6 + f7 - f1 - f2 - f3;
+  const real q_x = -f1 + 2 * f2 - f3 + f5 - 2 * f6 + f7;
+  const real j_y = f1 + f8 + f7 - f3 - f4 - f5;
+  const real q_y = f1 - f3 + 2 * f4 - f5 + f7 - 2 * f8;
+  const real p_xx = f2 - f4 + f6 - f8;
+  const real p_xy = -f1 + f3 - f5 + f7;
 
-  const double j_x2 = j_x * j_x;
-  const double j_y2 = j_y * j_y;
+  const real j_x2 = j_x * j_x;
+  const real j_y2 = j_y * j_y;
 
   // three quotients by the same rho: one true division (the reciprocal) + three exact_div
-  double d1, d2, d3;  // 3 * (j_x2 + j_y2) / rho, (j_x2 - j_y2) / rho, j_x * j_y / rho
-  const double n1 = 3 * (j_x2 + j_y2), n2 = j_x2 - j_y2, n3 = j_x * j_y;
+  real d1, d2, d3;  // 3 * (j_x2 + j_y2) / rho, (j_x2 - j_y2) / rho, j_x * j_y / rho
+  const real n1 = 3 * (j_x2 + j_y2), n2 = j_x2 - j_y2, n3 = j_x * j_y;
   if (L.recip_ok && !significand_all_ones(rho) && rho > 1e-8 && rho < 1e8 && div_safe(n1) && div_safe(n2) &&
       div_safe(n3)) {
-    const double y = 1.0 / rho;
+    const real y = 1.0 / rho;
     d1 = exact_div(n1, rho, y);
     d2 = exact_div(n2, rho, y);
     d3 = exact_div(n3, rho, y);
@@ -130,12 +139,12 @@ __device__ __forceinline__ void mrt_collide(const LatticeView& L, double (&f)[9]
     d2 = (j_x2 - j_y2) / rho;
     d3 = j_x * j_y / rho;
   }
-  const double eO = e - L.s2 * (e + 2 * rho - d1);
-  const double epsO = eps - L.s3 * (eps - rho + d1);
-  const double q_xO = q_x - L.s5 * (q_x + j_x);
-  const double q_yO = q_y - L.s7 * (q_y + j_y);
-  const double p_xxO = p_xx - L.s8 * (p_xx - d2);
-  const double p_xyO = p_xy - L.s9 * (p_xy - d3);
+  const real eO = e - L.s2 * (e + 2 * rho - d1);
+  const real epsO = eps - L.s3 * (eps - rho + d1);
+  const real q_xO = q_x - L.s5 * (q_x + j_x);
+  const real q_yO = q_y - L.s7 * (q_y + j_y);
+  const real p_xxO = p_xx - L.s8 * (p_xx - d2);
+  const real p_xyO = p_xy - L.s9 * (p_xy - d3);
 
   f[0] = a * (4 * rho - 4 * eO + 4 * epsO);
   f[2] = a * (4 * rho - eO - 2 * epsO - 6 * j_x + 6 * q_xO + 9 * p_xxO);
@@ -153,8 +162,8 @@ __device__ __forceinline__ void mrt_collide(const LatticeView& L, double (&f)[9]
 // exactly negated numerators (negation and IEEE rounding commute), so eu[q+4] == -eu[q] bit for bit;
 // products with ex, ey in {0, +-1} are exact (a 0*u term only decides the sign of a zero sum, which
 // 1. + 3*eu and eu*eu then erase). Hence four divisions instead of nine, same bits.
-__device__ __forceinline__ void grain_equilibrium_u(const LatticeView& L, double ux, double uy, double (&f)[9]) {
-  double u_squ, e1, e2, e3, e4;
+__device__ __forceinline__ void grain_equilibrium_u(const LatticeView& L, real ux, real uy, real (&f)[9]) {
+  real u_squ, e1, e2, e3, e4;
   if (L.recip_ok && div_safe(ux * ux) && div_safe(uy * uy)) {  // divisions by the run constants c and c*c
     u_squ = exact_div(ux * ux + uy * uy, L.cc, L.rcc);
     e1 = exact_div(-ux + uy, L.c, L.rc);
@@ -168,6 +177,8 @@ __device__ __forceinline__ void grain_equilibrium_u(const LatticeView& L, double
     e3 = (-ux + (-uy)) / L.c;  // q = 3: (-1,-1)
     e4 = (-uy) / L.c;          // q = 4: ( 0,-1)
   }
+  // main.c:980: w * (1. + 3 * eu + 4.5 * eu * eu - 1.5 * u_squ) -- the literals 1., 4.5, 1.5 make the bracket a double
+  // sum in either build (3 * eu is an int times a real: a real); the product with w is rounded to real once
   const double k = 1.5 * u_squ;
   f[0] = Wq(0) * (1. + 0.0 - k);          // eu = 0: 1. + 3*0 + 4.5*0*0 == 1.
   f[1] = Wq(1) * (1. + 3 * e1 + 4.5 * e1 * e1 - k);
@@ -180,18 +191,19 @@ __device__ __forceinline__ void grain_equilibrium_u(const LatticeView& L, double
   f[8] = Wq(8) * (1. + 3 * (-e4) + 4.5 * e4 * e4 - k);
 }
 __device__ __forceinline__ void grain_equilibrium(const LatticeView& L, const GP& g, int x, int y,
-                                                  double (&f)[9]) {
+                                                  real (&f)[9]) {
   grain_equilibrium_u(L, wall_ux(L, g, y), wall_uy(L, g, x), f);
 }
 
 // wall distance along link q from solid node (x, y) of a disc (xc, yc, r2): main.c:1054-1058
 template <int q>
-__device__ __forceinline__ double link_delta(int x, int y, double xc, double yc, double r2) {
+__device__ __forceinline__ real link_delta(int x, int y, real xc, real yc, real r2) {
   constexpr int ex = EXq(q), ey = EYq(q);
-  const double aa = (double)(ex < 0 ? -ex : ex) + (double)(ey < 0 ? -ey : ey);
-  const double bb = (x + ex - xc) * ex + (y + ey - yc) * ey;
-  const double cc = (x + ex - xc) * (x + ex - xc) + (y + ey - yc) * (y + ey - yc) - r2;
-  return (bb - sqrt(fabs(bb * bb - aa * cc))) / aa;
+  const real aa = (real)(ex < 0 ? -ex : ex) + (real)(ey < 0 ? -ey : ey);
+  const real bb = (x + ex - xc) * ex + (y + ey - yc) * ey;
+  const real cc = (x + ex - xc) * (x + ex - xc) + (y + ey - yc) * (y + ey - yc) - r2;
+  // main.c:1058: fabs() and sqrt() are <math.h>'s double functions: everything right of `bb -` is double in either build
+  return (real)((bb - sqrt(fabs((double)(bb * bb - aa * cc)))) / aa);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -228,15 +240,16 @@ __global__ void k_obst_fill(int* __restrict__ obst, LatticeView L) {
 // whatever the order of the painters).
 // (Measured alternative: plain stores, then a second launch that re-reads the nodes and settles overlaps with atomics
 // only where they occur -- 37 + 30 us against 52 us: the kernel is bound by its 50 000 short waves, not by atomics.)
-__global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const double* __restrict__ x1,
-                             const double* __restrict__ x2, const double* __restrict__ r,
-                             const double* __restrict__ rLB, const double* __restrict__ v1,
-                             const double* __restrict__ v2, const double* __restrict__ v3,
-                             double* __restrict__ oxc, double* __restrict__ oyc, double* __restrict__ or2,
-                             double* __restrict__ orbl0, double* __restrict__ pk,
+__global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const real* __restrict__ x1,
+                             const real* __restrict__ x2, const real* __restrict__ r,
+                             const real* __restrict__ rLB, const real* __restrict__ v1,
+                             const real* __restrict__ v2, const real* __restrict__ v3,
+                             real* __restrict__ oxc, real* __restrict__ oyc, real* __restrict__ or2,
+                             real* __restrict__ orbl0, real* __restrict__ pk,
                              unsigned char* __restrict__ touched, const unsigned char* __restrict__ mask,
                              unsigned* __restrict__ mincov, unsigned epoch, const int* __restrict__ list,
-                             const int* __restrict__ list_count, int list_cap) {
+                             const int* __restrict__ list_count, int list_cap, const int* __restrict__ voff,
+                             const int* __restrict__ vnbr) {
   const int lane = threadIdx.x & 63;
   int i = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (list) {                    // strip decomposition: only the grains that can reach this rank's rows
@@ -245,14 +258,14 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
   }
   if (i >= n) return;
   if (mask && !mask[i]) return;
-  const double gx1 = x1[i], gx2 = x2[i];
-  const double xc = (gx1 - L.Mgx) / L.dx, yc = (gx2 - L.Mby) / L.dx, r2 = rLB[i] * rLB[i], rbl0 = r[i] / L.dx;
+  const real gx1 = x1[i], gx2 = x2[i];
+  const real xc = (gx1 - L.Mgx) / L.dx, yc = (gx2 - L.Mby) / L.dx, r2 = rLB[i] * rLB[i], rbl0 = r[i] / L.dx;
   if (lane == 0) {
     oxc[i] = xc; oyc[i] = yc; or2[i] = r2; orbl0[i] = rbl0;
-    double* o = pk + (long)i * 8;
+    real* o = pk + (long)i * 8;
     o[0] = gx1; o[1] = gx2; o[2] = v1[i]; o[3] = v2[i]; o[4] = v3[i]; o[5] = xc; o[6] = yc; o[7] = r2;
   }
-  const double R2 = rbl0 * rbl0;
+  const real R2 = rbl0 * rbl0;
   int xi = (int)(xc - rbl0), xf = (int)(xc + rbl0);
   if (xi < 1) xi = 1;
   if (xf >= L.lx - 1) xf = L.lx - 2;
@@ -265,9 +278,42 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
   if (xi > xf || yi > yf) return;
   const int ny = yf - yi + 1;
   auto in_disc = [&](int x, int y) {
-    const double d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc);
+    const real d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc);
     return d2 <= R2 && d2 <= r2;
   };
+  // Round 3: reduced discs of a physical packing do not overlap, so nearly all of the ~10 M returning atomicMax per
+  // step had nobody to arbitrate with (they were what set this kernel's time: profiles/r02_l_sq_counters.txt). A disc that
+  // is at least 1.5 nodes clear of every partner in the grain's Verlet list (symmetric: every pair within distVerlet of
+  // touching at the last rebuild, which is far more than reduced discs need to meet) shares no node with another disc:
+  // plain stores, no flags. Everything else -- and every grain while there is no list (voff == null: before the first
+  // rebuild, strips with distributed grains) -- keeps the atomic path.
+  bool alone = false;
+  if (voff) {
+    const int k0 = voff[i], k1 = voff[i + 1];
+    bool near = false;
+    const real ri = rLB[i];
+    for (int k = k0 + lane; k < k1; k += 64) {
+      const int j = vnbr[k];
+      const real ddx = (x1[j] - gx1) / L.dx, ddy = (x2[j] - gx2) / L.dx, rr = ri + rLB[j] + 1.5;
+      near |= !(ddx * ddx + ddy * ddy >= rr * rr);   // also true for a NaN
+    }
+    alone = !__any(near);
+  }
+  if (alone) {
+    if (ny <= 32) {
+      const int y = yi + (lane & 31);
+      if ((lane & 31) < ny)
+        for (int x = xi + (lane >> 5); x <= xf; x += 2)
+          if (in_disc(x, y)) obst[(long)(x - L.gx0) * L.sy + y] = i;
+    } else {
+      const int total = (xf - xi + 1) * ny;
+      for (int k = lane; k < total; k += 64) {
+        const int x = xi + k / ny, y = yi + k % ny;
+        if (in_disc(x, y)) obst[(long)(x - L.gx0) * L.sy + y] = i;
+      }
+    }
+    return;
+  }
   auto overlap = [&](long node, int old) {   // the node was somebody else's: rare
     if (old >= 0 && old < n && old != i) {
       touched[i] = 1; touched[old] = 1;
@@ -318,9 +364,9 @@ template <int TX, int TY>
 struct Tile {
   static constexpr int RX = TX + 2, RY = TY + 2;  // staged populations: halo 1
   static constexpr int OX = TX + 4, OY = TY + 4;  // staged obstacle ids: halo 2 (act of halo-1 nodes)
-  double* sF;  // [9][RX][RY]
+  real* sF;  // [9][RX][RY]
   int* sO;     // [OX][OY]
-  __device__ __forceinline__ double& F(int q, int tx, int ty) const {
+  __device__ __forceinline__ real& F(int q, int tx, int ty) const {
     return sF[(q * RX + (tx + 1)) * RY + (ty + 1)];
   }
   __device__ __forceinline__ int O(int tx, int ty) const { return sO[(tx + 2) * OY + (ty + 2)]; }
@@ -342,14 +388,14 @@ struct Tile {
       higher |= (o > oS && o != L.n);
     }
     if (!higher) return false;
-    const double xc = G.xc[oS], yc = G.yc[oS], r2 = G.r2[oS], rb = G.rbl0[oS];
-    const double R2 = rb * rb;
+    const real xc = G.xc[oS], yc = G.yc[oS], r2 = G.r2[oS], rb = G.rbl0[oS];
+    const real R2 = rb * rb;
 #pragma unroll
     for (int q = 1; q < 9; ++q) {
       const int o = O(tx + EXq(q), ty + EYq(q));
       if (o > oS && o != L.n) {
         const int x = gx + EXq(q), y = gy + EYq(q);
-        const double d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc);
+        const real d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc);
         if (!(d2 <= R2 && d2 <= r2) && min_cover(G, (long)(x - L.gx0) * L.sy + y, o) > oS) return true;
       }
     }
@@ -359,7 +405,7 @@ struct Tile {
 
 // Interpolated bounce-back (Bouzidi, moving wall) at solid node S = (sx, sy) of grain i for link q
 // towards the fluid node N = S + e_q: main.c:1166-1185 / 1198-1217.
-struct IbbLink { double d, uw; };
+struct IbbLink { real d, uw; };
 
 template <int q>
 __device__ __forceinline__ IbbLink ibb_link(const LatticeView& L, const GP& g, int sx, int sy) {
@@ -373,14 +419,14 @@ __device__ __forceinline__ bool ibb_far(const IbbLink& k) { return k.d >= 0.5; }
 __device__ __forceinline__ bool ibb_near(const IbbLink& k) { return k.d > 0. && k.d < 0.5; }
 // delta >= 1/2: fN_opp = f*[N][opp q], fN_q = f*[N][q]
 template <int q>
-__device__ __forceinline__ double ibb_far_value(const LatticeView& L, const IbbLink& k, double fN_opp,
-                                                double fN_q) {
+__device__ __forceinline__ real ibb_far_value(const LatticeView& L, const IbbLink& k, real fN_opp,
+                                                real fN_q) {
   return fN_opp / (2 * k.d) + (2 * k.d - 1) * fN_q / (2 * k.d) + 3 * (Wq(q) / L.c) * k.uw / k.d;
 }
 // 0 < delta < 1/2: f2 = the population read two links out, f[N + e_q][opp q]
 template <int q>
-__device__ __forceinline__ double ibb_near_value(const LatticeView& L, const IbbLink& k, double fN_opp,
-                                                 double f2) {
+__device__ __forceinline__ real ibb_near_value(const LatticeView& L, const IbbLink& k, real fN_opp,
+                                                 real f2) {
   return 2 * k.d * fN_opp + (1 - 2 * k.d) * f2 + 6 * (Wq(q) / L.c) * k.uw;
 }
 
@@ -396,7 +442,7 @@ __device__ __forceinline__ double ibb_near_value(const LatticeView& L, const Ibb
 // Everything of a pull except the interpolated bounce-back itself. Returns true when (P, q) IS an
 // interpolated-bounce-back link (P fluid, source S an interior grain node) -- `out` is then not set.
 template <int q, bool EDGE = true, class Ctx>
-__device__ __forceinline__ bool pull_classify(const Ctx& C, const LatticeView& L, int gx, int gy, double& out) {
+__device__ __forceinline__ bool pull_classify(const Ctx& C, const LatticeView& L, int gx, int gy, real& out) {
   constexpr int ex = EXq(q), ey = EYq(q), qo = OPPq(q);
   const int sxg = gx - ex, syg = gy - ey;  // source node S = P - e_q
   if (EDGE && (sxg < 0 || sxg >= L.lx || syg < 0 || syg >= L.ly)) {  // array edge: main.c:1237
@@ -443,7 +489,7 @@ __device__ __forceinline__ bool nn_interior(const LatticeView& L, int gx, int gy
 
 // The interpolated bounce-back value of link (P, q): P fluid, S = P - e_q an (active) node of a grain.
 template <int q, bool EDGE = true, class Ctx>
-__device__ __forceinline__ double ibb_eval(const Ctx& C, const LatticeView& L, int gx, int gy) {
+__device__ __forceinline__ real ibb_eval(const Ctx& C, const LatticeView& L, int gx, int gy) {
   constexpr int ex = EXq(q), ey = EYq(q), qo = OPPq(q);
   const int sxg = gx - ex, syg = gy - ey;
   const IbbLink k = ibb_link<q>(L, C.gp_nb(qo), sxg, syg);
@@ -451,7 +497,7 @@ __device__ __forceinline__ double ibb_eval(const Ctx& C, const LatticeView& L, i
   if (!ibb_near(k)) return C.in(qo);  // neither branch fires: slot keeps its value
 
   // 0 < delta < 1/2: the reference reads f[NN][opp q], NN = P + e_q, *in place* (main.c:1181,1213).
-  double f2;
+  real f2;
   const int nxg = gx + ex, nyg = gy + ey;
   if (!nn_interior<q, EDGE>(L, gx, gy)) {
     f2 = C.own(q);  // edge wall node: its slot opp q was set by the edge copy to f*[P][q]
@@ -471,9 +517,9 @@ __device__ __forceinline__ double ibb_eval(const Ctx& C, const LatticeView& L, i
 }
 
 template <int q, bool EDGE = true, class Ctx>
-__device__ __forceinline__ double pull_one(const Ctx& C, const LatticeView& L, const GrainFluidView& G,
+__device__ __forceinline__ real pull_one(const Ctx& C, const LatticeView& L, const GrainFluidView& G,
                                            int gx, int gy) {
-  double out;
+  real out;
   if (!pull_classify<q, EDGE>(C, L, gx, gy, out)) return out;
   return ibb_eval<q, EDGE>(C, L, gx, gy);
 }
@@ -485,33 +531,33 @@ __device__ __forceinline__ double pull_one(const Ctx& C, const LatticeView& L, c
 struct RtLink {
   int q;                 // 1..8
   int gx, gy;            // P
-  double own_qo, own_q;  // f*[P][opp q], f*[P][q]
-  double in_q, in_qo;    // f*[P + e_q][opp q], f*[P - e_q][q]
+  real own_qo, own_q;  // f*[P][opp q], f*[P][q]
+  real in_q, in_qo;    // f*[P + e_q][opp q], f*[P - e_q][q]
   bool nn_int, hazard;   // NN interior; NN solid and q <= 4 (its own update precedes S's)
 };
-__device__ __forceinline__ double link_delta_rt(int x, int y, int ex, int ey, double xc, double yc, double r2) {
+__device__ __forceinline__ real link_delta_rt(int x, int y, int ex, int ey, real xc, real yc, real r2) {
   const int aai = (ex < 0 ? -ex : ex) + (ey < 0 ? -ey : ey);
-  const double aa = (double)aai;
-  const double bb = (x + ex - xc) * ex + (y + ey - yc) * ey;
-  const double cc = (x + ex - xc) * (x + ex - xc) + (y + ey - yc) * (y + ey - yc) - r2;
-  const double t = bb - sqrt(fabs(bb * bb - aa * cc));
-  return aai == 2 ? t * 0.5 : t;  // == t / aa exactly
+  const real aa = (real)aai;
+  const real bb = (x + ex - xc) * ex + (y + ey - yc) * ey;
+  const real cc = (x + ex - xc) * (x + ex - xc) + (y + ey - yc) * (y + ey - yc) - r2;
+  const double t = bb - sqrt(fabs((double)(bb * bb - aa * cc)));   // double in either build, see link_delta
+  return (real)(aai == 2 ? t * 0.5 : t);  // == t / aa exactly
 }
 // wc_diag = Wq(1) / L.c, wc_axis = Wq(2) / L.c (what ibb_*_value<q> form as Wq(q) / L.c)
 // Lattice line through node (x, y) parallel to e = (ex, ey), numbered relative to the grain centre (xc, yc):
 // the index of a link's slot in the ForceSlots table. Producer (fused kernel) and consumer (force kernel) both
 // call this with the same doubles.
-__device__ __forceinline__ int slot_line(int x, int y, int ex, int ey, double xc, double yc) {
+__device__ __forceinline__ int slot_line(int x, int y, int ex, int ey, real xc, real yc) {
   return ey * (x - (int)xc) - ex * (y - (int)yc);
 }
 
 template <class RecFn>
-__device__ __forceinline__ double ibb_eval_rt(const LatticeView& L, const RtLink& k, double wc_diag,
-                                              double wc_axis, RecFn rec_of) {
+__device__ __forceinline__ real ibb_eval_rt(const LatticeView& L, const RtLink& k, real wc_diag,
+                                              real wc_axis, RecFn rec_of) {
   const int q = k.q;
   const int ex = (q >= 1 && q <= 3) ? -1 : ((q >= 5 && q <= 7) ? 1 : 0);
   const int ey = (q == 1 || q >= 7) ? 1 : ((q >= 3 && q <= 5) ? -1 : 0);
-  const double wc = (q & 1) ? wc_diag : wc_axis;
+  const real wc = (q & 1) ? wc_diag : wc_axis;
   const int sx = k.gx - ex, sy = k.gy - ey;
   const GP g = rec_of(-ex, -ey);  // record of the grain that owns S = P - e_q
   IbbLink a;
@@ -519,7 +565,7 @@ __device__ __forceinline__ double ibb_eval_rt(const LatticeView& L, const RtLink
   a.uw = ex * wall_ux(L, g, sy) + ey * wall_uy(L, g, sx);
   if (a.d >= 0.5) return k.own_qo / (2 * a.d) + (2 * a.d - 1) * k.own_q / (2 * a.d) + 3 * wc * a.uw / a.d;
   if (!(a.d > 0. && a.d < 0.5)) return k.in_qo;
-  double f2;
+  real f2;
   if (!k.nn_int) {
     f2 = k.own_q;
   } else {
@@ -544,8 +590,8 @@ struct TileCtx {
   const LatticeView& L;
   const GrainFluidView& G;
   int px, py, gx, gy;
-  __device__ __forceinline__ double own(int q) const { return T.F(q, px, py); }
-  __device__ __forceinline__ double in(int d) const { return T.F(OPPq(d), px + EXq(d), py + EYq(d)); }
+  __device__ __forceinline__ real own(int q) const { return T.F(q, px, py); }
+  __device__ __forceinline__ real in(int d) const { return T.F(OPPq(d), px + EXq(d), py + EYq(d)); }
   __device__ __forceinline__ int o_own() const { return T.O(px, py); }
   __device__ __forceinline__ int o_nb(int d) const { return T.O(px + EXq(d), py + EYq(d)); }
   __device__ __forceinline__ bool act_nb(int d) const {
@@ -555,14 +601,14 @@ struct TileCtx {
 };
 
 template <int TX, int TY>
-__global__ __launch_bounds__(256) void k_collide_stream(const double* __restrict__ fin,
-                                                        double* __restrict__ fout,
+__global__ __launch_bounds__(256) void k_collide_stream(const real* __restrict__ fin,
+                                                        real* __restrict__ fout,
                                                         const int* __restrict__ ob_old,
                                                         const int* __restrict__ ob_new, LatticeView L,
                                                         GrainFluidView G, int tiles_y, int ntiles,
                                                         int xcd_remap) {
   using TT = Tile<TX, TY>;
-  __shared__ double sF[9 * TT::RX * TT::RY];
+  __shared__ real sF[9 * TT::RX * TT::RY];
   __shared__ int sO[TT::OX * TT::OY];
   TT T{sF, sO};
   const int tid = threadIdx.x;
@@ -597,7 +643,7 @@ __global__ __launch_bounds__(256) void k_collide_stream(const double* __restrict
     const int gx = L.gx0 + xl;
     const long node = (long)xl * L.sy + y;
     const bool interior = gx >= 1 && gx <= L.lx - 2 && y >= 1 && y <= L.ly - 2;
-    double f[9];
+    real f[9];
     // reinit_obst_density (main.c:966-986) acts on the PREVIOUS obstacle map with the current grain
     // state: nodes that were solid restart from the grain's equilibrium
     const int oo = interior ? ob_old[node] : -1;
@@ -692,7 +738,7 @@ __device__ __forceinline__ bool node_active(const LatticeView& L, const GrainFlu
   for (int q = 1; q < 9; ++q) {
     if (nb[q] > o && nb[q] != L.n) {
       const int x = gx + EXq(q), y = gy + EYq(q);
-      const double d2 = (x - g.xc) * (x - g.xc) + (y - g.yc) * (y - g.yc);
+      const real d2 = (x - g.xc) * (x - g.xc) + (y - g.yc) * (y - g.yc);
       if (!(d2 <= g.r2)) cand |= 1u << q;
     }
   }
@@ -719,38 +765,38 @@ __device__ __forceinline__ bool node_active(const LatticeView& L, const GrainFlu
 // in-order vmcnt pipeline of the row prefetch, and no load sits inside a divergent path.
 constexpr int REC_RING = 4;
 struct RecRing {
-  double2* base;  // this wave's [REC_RING][4][64] double2
+  real2* base;  // this wave's [REC_RING][4][64] real2
   __device__ __forceinline__ void put(int row, int lane, const GP& g) const {
-    double2* p = base + (row & (REC_RING - 1)) * 4 * 64 + lane;
-    p[0] = make_double2(g.x1, g.x2);
-    p[64] = make_double2(g.v1, g.v2);
-    p[128] = make_double2(g.v3, g.xc);
-    p[192] = make_double2(g.yc, g.r2);
+    real2* p = base + (row & (REC_RING - 1)) * 4 * 64 + lane;
+    p[0] = make_real2(g.x1, g.x2);
+    p[64] = make_real2(g.v1, g.v2);
+    p[128] = make_real2(g.v3, g.xc);
+    p[192] = make_real2(g.yc, g.r2);
   }
   // only the lattice-unit centre (xc, yc) of that record
-  __device__ __forceinline__ void get_centre(int row, int lane, double& xc, double& yc) const {
-    const double* p = reinterpret_cast<const double*>(base + (row & (REC_RING - 1)) * 4 * 64 + lane);
+  __device__ __forceinline__ void get_centre(int row, int lane, real& xc, real& yc) const {
+    const real* p = reinterpret_cast<const real*>(base + (row & (REC_RING - 1)) * 4 * 64 + lane);
     xc = p[2 * 128 + 1];
     yc = p[2 * 192];
   }
   __device__ __forceinline__ GP get(int row, int lane) const {
-    const double2* p = base + (row & (REC_RING - 1)) * 4 * 64 + lane;
-    const double2 a = p[0], b = p[64], c = p[128], d = p[192];
+    const real2* p = base + (row & (REC_RING - 1)) * 4 * 64 + lane;
+    const real2 a = p[0], b = p[64], c = p[128], d = p[192];
     return GP{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
   }
 };
 
 struct RegCtx {
-  double Fo[9];   // f*[P][q]
-  double In[9];   // f*[P + e_d][opp d]
+  real Fo[9];   // f*[P][q]
+  real In[9];   // f*[P + e_d][opp d]
   int o0;
   int onb[9];
   unsigned act;   // bit d: act of the neighbour in direction d
   RecRing ring;
   int row, lane;  // local row of P and this lane
   __device__ __forceinline__ GP gp_nb(int d) const { return ring.get(row + EXq(d), lane + EYq(d)); }
-  __device__ __forceinline__ double own(int q) const { return Fo[q]; }
-  __device__ __forceinline__ double in(int d) const { return In[d]; }
+  __device__ __forceinline__ real own(int q) const { return Fo[q]; }
+  __device__ __forceinline__ real in(int d) const { return In[d]; }
   __device__ __forceinline__ int o_own() const { return o0; }
   __device__ __forceinline__ int o_nb(int d) const { return onb[d]; }
   __device__ __forceinline__ bool act_nb(int d) const { return (act >> d) & 1u; }
@@ -759,13 +805,13 @@ struct RegCtx {
 #ifdef LBMDEM_AB   /* k_cs_march3 and its helpers only exist in the experiment build */
 // the same context for k_cs_march3 (no record ring: the classification never asks for a record)
 struct RegCtx3 {
-  double Fo[9];
-  double In[9];
+  real Fo[9];
+  real In[9];
   int o0;
   int onb[9];
   unsigned act;
-  __device__ __forceinline__ double own(int q) const { return Fo[q]; }
-  __device__ __forceinline__ double in(int d) const { return In[d]; }
+  __device__ __forceinline__ real own(int q) const { return Fo[q]; }
+  __device__ __forceinline__ real in(int d) const { return In[d]; }
   __device__ __forceinline__ int o_own() const { return o0; }
   __device__ __forceinline__ int o_nb(int d) const { return onb[d]; }
   __device__ __forceinline__ bool act_nb(int d) const { return (act >> d) & 1u; }
@@ -777,12 +823,12 @@ struct RegCtx3 {
 // the pass that reads the records has a fixed length, so the wait for the records never covers the row prefetch.
 template <bool EDGE>
 __device__ __forceinline__ void classify_store_all(const RegCtx3& C, const LatticeView& L, int gx, int y,
-                                                   double* __restrict__ fout, long node) {
+                                                   real* __restrict__ fout, long node) {
   const long fb = fbase(node);
   fout[fb] = C.own(0);
 #define LBM_CLASSIFY_ALL(Q)                                       \
   {                                                               \
-    double o_;                                                    \
+    real o_;                                                    \
     if (pull_classify<Q, EDGE>(C, L, gx, y, o_)) o_ = C.own(Q);   \
     fout[fb + Q * F_QSTRIDE(L)] = o_;                             \
   }
@@ -798,13 +844,13 @@ __device__ __forceinline__ void classify_store_all(const RegCtx3& C, const Latti
 // that link's NN is interior / is a solid node whose own update precedes S's (q <= 4).
 template <bool EDGE, class Ctx>
 __device__ __forceinline__ void classify_store_row(const Ctx& C, const LatticeView& L, int gx, int y,
-                                                   double* __restrict__ fout, long node, unsigned& ibb,
+                                                   real* __restrict__ fout, long node, unsigned& ibb,
                                                    unsigned& nnm, unsigned& hzm) {
   const long fb = fbase(node);
   fout[fb] = C.own(0);
 #define LBM_CLASSIFY(Q)                                                   \
   {                                                                       \
-    double o_;                                                            \
+    real o_;                                                            \
     if (pull_classify<Q, EDGE>(C, L, gx, y, o_)) {                        \
       ibb |= 1u << Q;                                                     \
       if (nn_interior<Q, EDGE>(L, gx, y)) {                               \
@@ -839,26 +885,31 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
 // a lane that is switched off: only call these in wave-uniform control flow.
 __device__ __forceinline__ int dpp_up1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int dpp_dn1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
-__device__ __forceinline__ double dpp_up1(double v) {
+#ifdef LBMDEM_SINGLE_PRECISION
+__device__ __forceinline__ real dpp_up1(real v) { return __int_as_float(dpp_up1(__float_as_int(v))); }
+__device__ __forceinline__ real dpp_dn1(real v) { return __int_as_float(dpp_dn1(__float_as_int(v))); }
+#else
+__device__ __forceinline__ real dpp_up1(real v) {
   return __hiloint2double(dpp_up1(__double2hiint(v)), dpp_up1(__double2loint(v)));
 }
-__device__ __forceinline__ double dpp_dn1(double v) {
+__device__ __forceinline__ real dpp_dn1(real v) {
   return __hiloint2double(dpp_dn1(__double2hiint(v)), dpp_dn1(__double2loint(v)));
 }
+#endif
 #ifdef MARCH_BPERMUTE   /* experiment builds: the round-2 form (ds_bpermute) */
-__device__ __forceinline__ double shfl_up1(double v) { return __shfl_up(v, 1, 64); }
-__device__ __forceinline__ double shfl_dn1(double v) { return __shfl_down(v, 1, 64); }
+__device__ __forceinline__ real shfl_up1(real v) { return __shfl_up(v, 1, 64); }
+__device__ __forceinline__ real shfl_dn1(real v) { return __shfl_down(v, 1, 64); }
 __device__ __forceinline__ int shfl_up1(int v) { return __shfl_up(v, 1, 64); }
 __device__ __forceinline__ int shfl_dn1(int v) { return __shfl_down(v, 1, 64); }
 #else
-__device__ __forceinline__ double shfl_up1(double v) { return dpp_up1(v); }
-__device__ __forceinline__ double shfl_dn1(double v) { return dpp_dn1(v); }
+__device__ __forceinline__ real shfl_up1(real v) { return dpp_up1(v); }
+__device__ __forceinline__ real shfl_dn1(real v) { return dpp_dn1(v); }
 __device__ __forceinline__ int shfl_up1(int v) { return dpp_up1(v); }
 __device__ __forceinline__ int shfl_dn1(int v) { return dpp_dn1(v); }
 #endif
 
 template <int LX, int MINW, int WW>
-__global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict__ fin, double* __restrict__ fout,
+__global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__ fin, real* __restrict__ fout,
                                                   const int* __restrict__ ob_old,
                                                   const int* __restrict__ ob_new, LatticeView L,
                                                   GrainFluidView G, ForceSlots S, int nstrips, int nwork,
@@ -895,14 +946,14 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
   //   (3) the nine stores of row x.
   // gfx9 retires vector-memory operations in issue order (one vmcnt counter), so data must be consumed
   // in the order it was requested; no other global load exists inside the loop.
-  __shared__ double2 sRec[4 * REC_RING * 4 * 64];
+  __shared__ real2 sRec[4 * REC_RING * 4 * 64];
   const RecRing ring{sRec + (threadIdx.x >> 6) * (REC_RING * 4 * 64)};
   // wave-private scratch for the compacted bounce-back evaluation: 64 link slots
-  __shared__ double sPay[4 * 64 * 4];
+  __shared__ real sPay[4 * 64 * 4];
   __shared__ int sDesc[4 * 64];
-  double* const pay = sPay + (threadIdx.x >> 6) * (64 * 4);
+  real* const pay = sPay + (threadIdx.x >> 6) * (64 * 4);
   int* const desc = sDesc + (threadIdx.x >> 6) * 64;
-  const double wc_diag = L.wc_diag, wc_axis = L.wc_axis;  // kernel arguments: scalar registers
+  const real wc_diag = L.wc_diag, wc_axis = L.wc_axis;  // kernel arguments: scalar registers
   auto row_ok = [&](int xl) { return yin && xl >= 0 && xl < L.nxl; };
   const int ycl = y < 0 ? 0 : (y >= L.ly ? L.ly - 1 : y);
   auto node_of = [&](int xl) {  // clamped: always a valid address
@@ -915,7 +966,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
   auto load_old = [&](int xl) { return ob_old[node_of(xl)]; };
   // off-lattice positions load a clamped neighbour's values; they are never used (pull_one tests the
   // bounds of the source node before touching its populations)
-  auto load_raw = [&](int xl, double (&raw)[9]) {
+  auto load_raw = [&](int xl, real (&raw)[9]) {
     const long fb = fbase(node_of(xl));
 #pragma unroll
     for (int q = 0; q < 9; ++q) raw[q] = fin[fb + q * F_QSTRIDE(L)];
@@ -925,14 +976,14 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
     return row_ok(xl) && gx >= 1 && gx <= L.lx - 2 && y >= 1 && y <= L.ly - 2;
   };
   // f* of one node: reinit (previous map) + collide (current map)
-  auto make_fstar = [&](int xl, double (&f)[9], int oo, const GP& g, int on) {
+  auto make_fstar = [&](int xl, real (&f)[9], int oo, const GP& g, int on) {
     const bool in = interior(xl);
     if (in && oo != -1) grain_equilibrium(L, g, L.gx0 + xl, y, f);
     if (in && on == -1) mrt_collide(L, f);
   };
   auto grain_rec = [&](int id) { return load_gp(G, (id < 0 || id >= L.n) ? 0 : id); };
 
-  double Fm[9], F0[9], Fp[9], bufA[9], bufB[9];
+  real Fm[9], F0[9], Fp[9], bufA[9], bufB[9];
 
   Ids3 iA = load_ids(ob_new, L, xs - 2, y);  // row x-2 (only needed for act of row x-1)
   Ids3 iB = load_ids(ob_new, L, xs - 1, y);  // row x-1
@@ -964,7 +1015,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
   bool act0 = iC.c != -1 && node_active(L, G, iB, iC, iD, L.gx0 + xs, y, [&] { return ring.get(xs, lane); });
 
   // one iteration; `buf` holds row x+1 on entry and is refilled with row x+3
-  auto iterate = [&](int x, double (&buf)[9]) {
+  auto iterate = [&](int x, real (&buf)[9]) {
 #pragma unroll
     for (int q = 0; q < 9; ++q) Fp[q] = buf[q];
     make_fstar(x + 1, Fp, oo1, gre, iD.c);
@@ -1055,7 +1106,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
           k.nn_int = (d >> 12) & 1;
           k.hazard = (d >> 13) & 1;
           // the result goes straight to the population it belongs to: node of lane `src`, plane q
-          const double out =
+          const real out =
               ibb_eval_rt(L, k, wc_diag, wc_axis, [&](int dx, int dy) { return ring.get(x + dx, src + dy); });
           fout[fidx(k.q, node - lane + src)] = out;
           // ... and the link's momentum-exchange sum f_new[S][opp q] + f_new[P][q] (main.c:1313-1316; the first
@@ -1063,7 +1114,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const double* __restrict
           if (S.tab != nullptr) {
             const int ex = (k.q >= 1 && k.q <= 3) ? -1 : ((k.q >= 5 && k.q <= 7) ? 1 : 0);
             const int ey = (k.q == 1 || k.q >= 7) ? 1 : ((k.q >= 3 && k.q <= 5) ? -1 : 0);
-            double cx, cy;
+            real cx, cy;
             ring.get_centre(x - ex, src - ey, cx, cy);
             const int rel = slot_line(k.gx - ex, k.gy - ey, ex, ey, cx, cy) + S.half;
             if ((unsigned)rel < (unsigned)S.spd)
@@ -1154,7 +1205,7 @@ __device__ __forceinline__ void lds_dma16_tok(const char*& gsrc, unsigned lds_ds
 }
 
 template <int LX, int MINW, int WW, int NBUF>
-__global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restrict__ fin, double* __restrict__ fout,
+__global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict__ fin, real* __restrict__ fout,
                                                    const int* __restrict__ ob_old,
                                                    const int* __restrict__ ob_new, LatticeView L,
                                                    GrainFluidView G, ForceSlots S, int nstrips, int nwork,
@@ -1179,15 +1230,15 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
   const int xe = xs + rows_per_wave < L.xo1 ? xs + rows_per_wave : L.xo1;
 
   // wave-private LDS: link descriptors, link payloads, link grain records (DMA target: [part][dense lane])
-  __shared__ double2 sLrec[4 * 4 * 64];
-  __shared__ double sPay[4 * 64 * 4];
+  __shared__ real2 sLrec[4 * 4 * 64];
+  __shared__ real sPay[4 * 64 * 4];
   __shared__ int sDesc[4 * 64];
   const int wv = threadIdx.x >> 6;
-  double2* const lrec = sLrec + wv * (4 * 64);
-  double* const pay = sPay + wv * (64 * 4);
+  real2* const lrec = sLrec + wv * (4 * 64);
+  real* const pay = sPay + wv * (64 * 4);
   int* const desc = sDesc + wv * 64;
   const unsigned lrec_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lrec);
-  const double wc_diag = L.wc_diag, wc_axis = L.wc_axis;
+  const real wc_diag = L.wc_diag, wc_axis = L.wc_axis;
   auto row_ok = [&](int xl) { return yin && xl >= 0 && xl < L.nxl; };
   const int ycl = y < 0 ? 0 : (y >= L.ly ? L.ly - 1 : y);
   auto node_of = [&](int xl) {
@@ -1195,7 +1246,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
     return (long)xc * L.sy + ycl;
   };
   auto load_old = [&](int xl) { return ob_old[node_of(xl)]; };
-  auto load_raw = [&](int xl, double (&raw)[9]) {
+  auto load_raw = [&](int xl, real (&raw)[9]) {
     const long fb = fbase(node_of(xl));
 #pragma unroll
     for (int q = 0; q < 9; ++q) raw[q] = fin[fb + q * F_QSTRIDE(L)];
@@ -1205,22 +1256,22 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
     return row_ok(xl) && gx >= 1 && gx <= L.lx - 2 && y >= 1 && y <= L.ly - 2;
   };
   // f* of one node: reinit (previous map; the old owner's rigid-body velocity at the node) + collide (current map)
-  auto make_fstar = [&](int xl, double (&f)[9], int oo, double ux, double uy, int on) {
+  auto make_fstar = [&](int xl, real (&f)[9], int oo, real ux, real uy, int on) {
     const bool in = interior(xl);
     if (in && oo != -1) grain_equilibrium_u(L, ux, uy, f);
     if (in && on == -1) mrt_collide(L, f);
   };
   // what the re-initialisation needs of a record: x1, x2, v1, v2, v3
-  struct RRec { double2 a, b; double v3; };
+  struct RRec { real2 a, b; real v3; };
   auto reinit_rec = [&](int id) {
-    const double* p = G.pk + (long)((id < 0 || id >= L.n) ? 0 : id) * 8;
-    return RRec{*reinterpret_cast<const double2*>(p), *reinterpret_cast<const double2*>(p + 2), p[4]};
+    const real* p = G.pk + (long)((id < 0 || id >= L.n) ? 0 : id) * 8;
+    return RRec{*reinterpret_cast<const real2*>(p), *reinterpret_cast<const real2*>(p + 2), p[4]};
   };
   auto rr_ux = [&](const RRec& r) { return r.b.x - (y * L.dx + L.Mby - r.a.y) * r.v3; };        // wall_ux
   auto rr_uy = [&](const RRec& r, int xl) { return r.b.y + ((L.gx0 + xl) * L.dx + L.Mgx - r.a.x) * r.v3; };  // wall_uy
   auto grain_rec = [&](int id) { return load_gp(G, (id < 0 || id >= L.n) ? 0 : id); };
 
-  double Fm[9], F0[9], Fp[9], bufA[9], bufB[9];   // NBUF = 1: only bufA
+  real Fm[9], F0[9], Fp[9], bufA[9], bufB[9];   // NBUF = 1: only bufA
 
   IdsRow iB = load_ids_row(ob_new, L, xs - 1, y, lane);
   IdsRow iC = load_ids_row(ob_new, L, xs, y, lane);
@@ -1248,11 +1299,11 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
   if (NBUF == 2) load_raw(xs + 2, bufB);
 
   // one iteration: `buf` holds row x+1 on entry and is refilled with row x+1+NBUF
-  auto iterate = [&](int x, double (&buf)[9]) {
+  auto iterate = [&](int x, real (&buf)[9]) {
     const int gx = L.gx0 + x;
     const bool deep = deep_y && gx >= 2 && gx <= L.lx - 3;   // wave-uniform
     // the old owner's velocity at (x+1, y): frees the record's registers before anything else is requested
-    const double re_ux = rr_ux(gre), re_uy = rr_uy(gre, x + 1);
+    const real re_ux = rr_ux(gre), re_uy = rr_uy(gre, x + 1);
     int onb[9];
     {
       const Ids3 b = iB.all(), c = iC.all(), d = iD.all();
@@ -1322,7 +1373,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
 
     // the six cross-lane moves of a pull. DPP reads nothing from a lane that is switched off, so these run here, in
     // wave-uniform control flow, never inside a divergent branch.
-    double In[9];
+    real In[9];
     In[0] = 0.0;
     In[2] = Fm[6];            // (-1, 0): same lane, row x-1, slot opp(2) = 6
     In[6] = Fp[2];            // ( 1, 0)
@@ -1334,7 +1385,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
     In[5] = dpp_up1(Fp[1]);   // ( 1,-1)
     const long node = (long)x * L.sy + y;
     // ---- (2) the payloads of the bounce-back links to LDS (the first 64 links of the row; a row with more: see (5))
-    auto write_pay = [&](int base, const double (&in)[9]) {
+    auto write_pay = [&](int base, const real (&in)[9]) {
       int t = t0 - base;
 #pragma unroll
       for (int q = 1; q < 9; ++q) {
@@ -1386,7 +1437,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
         // x+1 and the ids; the cross-lane moves are repeated, in wave-uniform control flow)
         const Ids3 b = iB.all(), c = iC.all(), d = iD.all();
         const int nb[9] = {0, b.p, b.c, b.m, c.m, d.m, d.c, d.p, c.p};
-        const double in2[9] = {0.0, dpp_dn1(Fm[5]), Fm[6], dpp_up1(Fm[7]), dpp_up1(F0[8]), dpp_up1(Fp[1]), Fp[2],
+        const real in2[9] = {0.0, dpp_dn1(Fm[5]), Fm[6], dpp_up1(Fm[7]), dpp_up1(F0[8]), dpp_up1(Fp[1]), Fp[2],
                                dpp_dn1(Fp[3]), dpp_dn1(F0[4])};
         write_desc(base, nb);
         write_pay(base, in2);
@@ -1410,12 +1461,12 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
         k.hazard = k.nn_int && ((d >> 13) & 1);
         GP g;
         if (base == 0) {
-          const double2 ra = lrec[lane], rb = lrec[64 + lane], rc = lrec[128 + lane], re = lrec[192 + lane];
+          const real2 ra = lrec[lane], rb = lrec[64 + lane], rc = lrec[128 + lane], re = lrec[192 + lane];
           g = GP{ra.x, ra.y, rb.x, rb.y, rc.x, rc.y, re.x, re.y};
         } else {
           g = load_gp(G, (int)((unsigned)d >> 14));
         }
-        const double out = ibb_eval_rt(L, k, wc_diag, wc_axis, [&](int dx, int dy) {
+        const real out = ibb_eval_rt(L, k, wc_diag, wc_axis, [&](int dx, int dy) {
           if (dx == -ex && dy == -ey) return g;
           // the hazard partner: the grain that owns NN = P + e_q (rare; its loads stay inside this branch)
           return load_gp(G, ob_new[(long)(x + dx) * L.sy + (k.gy + dy)]);
@@ -1454,8 +1505,8 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const double* __restric
 
 __device__ __forceinline__ bool grain_box(const LatticeView& L, const GrainFluidView& G, int i, int& xi,
                                           int& xf, int& yi, int& yf) {
-  const double xc = G.xc[i], yc = G.yc[i], rbl0 = G.rbl0[i];
-  xi = (int)(xc - rbl0); if (xi < 1) xi = 1;                 // int max(double->int, 1): main.c:1300
+  const real xc = G.xc[i], yc = G.yc[i], rbl0 = G.rbl0[i];
+  xi = (int)(xc - rbl0); if (xi < 1) xi = 1;                 // int max(real->int, 1): main.c:1300
   xf = (int)(xc + rbl0); if (xf > L.lx - 2) xf = L.lx - 2;   // main.c:1301
   yi = (int)(yc - rbl0); if (yi < 1) yi = 1;
   yf = (int)(yc + rbl0); if (yf > L.ly - 2) yf = L.ly - 2;
@@ -1464,10 +1515,10 @@ __device__ __forceinline__ bool grain_box(const LatticeView& L, const GrainFluid
 
 // A grain is computed by the rank that owns the lattice column of its centre (first/last rank also
 // take centres left/right of the lattice). On one GPU every grain is owned.
-__device__ __forceinline__ bool grain_owned(const LatticeView& L, double xc) {
+__device__ __forceinline__ bool grain_owned(const LatticeView& L, real xc) {
   const int lo = L.gx0 + L.xo0, hi = L.gx0 + L.xo1;  // owned global rows [lo, hi)
   const bool first = (lo == 0), last = (hi == L.lx);
-  return (first || xc >= (double)lo) && (last || xc < (double)hi);
+  return (first || xc >= (real)lo) && (last || xc < (real)hi);
 }
 
 // Parity kernel: ONE WAVEFRONT PER GRAIN, bit-exact with the reference's serial x -> y -> q
@@ -1489,7 +1540,7 @@ constexpr int FORCE_BN_CAP = 512;    // boundary nodes kept per grain before a f
 constexpr int FORCE_TERMS_CAP = 128; // terms replayed per batch
 
 struct ForceLds {
-  double sT[FORCE_TERMS_CAP * 4 + 2];             // [term][fnx, fny, -p1, p2], then a zero slot
+  real sT[FORCE_TERMS_CAP * 4 + 2];             // [term][fnx, fny, -p1, p2], then a zero slot
   unsigned char sIn[FORCE_TILE * FORCE_TILE];     // 1 = node belongs to grain i
   unsigned short sBnK[FORCE_BN_CAP];              // boundary node: index in the bounding box
   unsigned char sBnM[FORCE_BN_CAP];               //                link mask (bit q-1)
@@ -1498,8 +1549,8 @@ struct ForceLds {
 // Phase B for up to 64 boundary nodes, one per lane (in scan order): `mask` = the node's links (bit q-1),
 // fx/fy[q-1] = fnx, fny of link q, (wx, wy) = (x - xc, y - yc). Terms go to LDS in scan order, three lanes
 // replay the additions. `h` is the running accumulator of lanes 0..2. One-wave workgroup: barriers are cheap.
-__device__ __forceinline__ void force_replay(ForceLds& sh, int lane, unsigned mask, const double (&fx)[8],
-                                             const double (&fy)[8], double wx, double wy, double& h) {
+__device__ __forceinline__ void force_replay(ForceLds& sh, int lane, unsigned mask, const real (&fx)[8],
+                                             const real (&fy)[8], real wx, real wy, real& h) {
   const int zero_slot = FORCE_TERMS_CAP * 4;
   const int a_off = lane < 3 ? lane : 0;  // fnx | fny | -p1
   const int cnt = __popc(mask);
@@ -1518,7 +1569,7 @@ __device__ __forceinline__ void force_replay(ForceLds& sh, int lane, unsigned ma
     for (int q = 0; q < 8; ++q) {
       if (mask & (1u << q)) {
         if (p >= lo && p < lo + FORCE_TERMS_CAP) {
-          double* t = &sh.sT[(p - lo) * 4];
+          real* t = &sh.sT[(p - lo) * 4];
           t[0] = fx[q];
           t[1] = fy[q];
           t[2] = fx[q] * (-wy);
@@ -1535,7 +1586,7 @@ __device__ __forceinline__ void force_replay(ForceLds& sh, int lane, unsigned ma
     if (lane < 3) {
       const int b_off = lane == 2 ? 3 : -1;
       for (int t = 0; t < nb8; t += 8) {
-        double a[8], b[8];
+        real a[8], b[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {  // loads do not depend on h: issue them ahead of the chain
           a[u] = sh.sT[(t + u) * 4 + a_off];
@@ -1550,10 +1601,10 @@ __device__ __forceinline__ void force_replay(ForceLds& sh, int lane, unsigned ma
 
 // The ordered sums of one grain gathered from the obstacle map and the lattice (phases A0, A1, A2, B above).
 // Returns h (lanes 0..2).
-__device__ __forceinline__ double force_gather(ForceLds& sh, const double* __restrict__ f,
-                                               const int* __restrict__ obst, const LatticeView& L, int i, double xc,
-                                               double yc, int xi, int xf, int yi, int yf, int lane) {
-  double h = 0.0;
+__device__ __forceinline__ real force_gather(ForceLds& sh, const real* __restrict__ f,
+                                               const int* __restrict__ obst, const LatticeView& L, int i, real xc,
+                                               real yc, int xi, int xf, int yi, int yf, int lane) {
+  real h = 0.0;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const int nx = xf - xi + 1, ny = yf - yi + 1;
   const int total = nx * ny;
@@ -1607,8 +1658,8 @@ __device__ __forceinline__ double force_gather(ForceLds& sh, const double* __res
     for (int b0 = 0; b0 < nbn; b0 += 64) {
       const int bi = b0 + lane;
       unsigned mask = 0;
-      double fx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      double wx = 0.0, wy = 0.0;
+      real fx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      real wx = 0.0, wy = 0.0;
       if (bi < nbn) {
         const int k = sh.sBnK[bi];
         mask = sh.sBnM[bi];
@@ -1621,7 +1672,7 @@ __device__ __forceinline__ double force_gather(ForceLds& sh, const double* __res
           if (mask & (1u << (q - 1))) {
             const int qo = OPPq(q);
             const long nodeN = (long)(x + EXq(q) - L.gx0) * L.sy + (y + EYq(q));
-            const double s = f[fidx(qo, nodeP)] + f[fidx(q, nodeN)];
+            const real s = f[fidx(qo, nodeP)] + f[fidx(q, nodeN)];
             fx[q - 1] = s * EXq(qo);
             fy[q - 1] = s * EYq(qo);
           }
@@ -1636,17 +1687,17 @@ __device__ __forceinline__ double force_gather(ForceLds& sh, const double* __res
   return h;
 }
 
-__global__ __launch_bounds__(64) void k_forces_parity(const double* __restrict__ f,
+__global__ __launch_bounds__(64) void k_forces_parity(const real* __restrict__ f,
                                                       const int* __restrict__ obst, LatticeView L,
                                                       GrainFluidView G, double scale12, double scale3,
-                                                      double* __restrict__ fhf,
+                                                      real* __restrict__ fhf,
                                                       unsigned char* __restrict__ owner) {
   __shared__ ForceLds sh;
   const int lane = threadIdx.x;
   const int i = blockIdx.x;
-  const double xc = G.xc[i], yc = G.yc[i];
+  const real xc = G.xc[i], yc = G.yc[i];
   const bool own = grain_owned(L, xc);
-  double h = 0.0;  // lanes 0,1,2 hold h1,h2,h3
+  real h = 0.0;  // lanes 0,1,2 hold h1,h2,h3
   if (lane == 0) sh.sT[FORCE_TERMS_CAP * 4] = 0.0;
   int xi, xf, yi, yf;
   if (own && grain_box(L, G, i, xi, xf, yi, yf)) h = force_gather(sh, f, obst, L, i, xc, yc, xi, xf, yi, yf, lane);
@@ -1689,20 +1740,20 @@ constexpr unsigned long long M_YDIR = 0x8888888888888888ull;  // q = 4, 8 (ex = 
 constexpr int FT_WAVES = 4;  // waves per workgroup of k_forces_table
 
 // FT_PACK takes both neighbours in one launch: blockIdx.y = side (0 low, 1 high); a null buffer skips the side
-struct PackSides { const int* list[2]; const int* count[2]; double* buf[2]; };
+struct PackSides { const int* list[2]; const int* count[2]; real* buf[2]; };
 
 template <int GW, int PASSES>
-__global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __restrict__ f, const int* __restrict__ obst,
+__global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const real* __restrict__ f, const int* __restrict__ obst,
                                                                 LatticeView L, GrainFluidView G, ForceSlots S, int cap1,
                                                                 int cap3, int nw64, double scale12, double scale3,
-                                                                double* __restrict__ fhf,
+                                                                real* __restrict__ fhf,
                                                                 unsigned char* __restrict__ owner, int mode,
                                                                 const int* __restrict__ list,
                                                                 const int* __restrict__ list_count,
                                                                 PackSides sides,
                                                                 const unsigned char* __restrict__ mask, int list_cap) {
-  extern __shared__ double sDyn[];
-  double* __restrict__ packbuf = nullptr;
+  extern __shared__ real sDyn[];
+  real* __restrict__ packbuf = nullptr;
   if (mode == FT_PACK) {
     packbuf = sides.buf[blockIdx.y];
     if (!packbuf) return;
@@ -1752,8 +1803,8 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
       local = mask[i] != 0;      // strip decomposition: the grains the rasteriser saw (the others' geometry is stale)
       if (!local) gid[g] = -1;
     } else if (i >= 0) {
-      const double xc = G.xc[i], rbl0 = G.rbl0[i];
-      local = xc + rbl0 + 2.0 >= (double)L.gx0 && xc - rbl0 - 2.0 <= (double)(L.gx0 + L.nxl);
+      const real xc = G.xc[i], rbl0 = G.rbl0[i];
+      local = xc + rbl0 + 2.0 >= (real)L.gx0 && xc - rbl0 - 2.0 <= (real)(L.gx0 + L.nxl);
     }
     unsigned long long* tg = reinterpret_cast<unsigned long long*>(S.tab) + (long)(i >= 0 ? i : 0) * 8 * spd;
 #pragma unroll
@@ -1781,7 +1832,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
     n1[g] = n2[g] = n3[g] = 0;
     own[g] = false;
     if (i < 0) continue;
-    const double xc = G.xc[i], yc = G.yc[i], r2 = G.r2[i];
+    const real xc = G.xc[i], yc = G.yc[i], r2 = G.r2[i];
     own[g] = grain_owned(L, xc);
     const bool was_touched = S.touched[i] != 0;
     if (was_touched && lane == 0 && consume) S.touched[i] = 0;  // the rasteriser sets it again while it applies
@@ -1798,7 +1849,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
     for (int w = lane; w < nw64; w += 64) bm[w] = 0ull;
     __builtin_amdgcn_wave_barrier();
     bool bad = false;
-    double h1 = 0.0, h2 = 0.0, h3 = 0.0;  // FT_FAST: this lane's part of the three sums
+    real h1 = 0.0, h2 = 0.0, h3 = 0.0;  // FT_FAST: this lane's part of the three sums
     int keyf[PASSES], keyb[PASSES];  // -1: no link; else ((bx * B + by) * 8 + q - 1) | bx << 20 | by << 26
 #pragma unroll
     for (int j = 0; j < PASSES; ++j) {
@@ -1806,11 +1857,11 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
       const int ex = fam_ex(fm), ey = fam_ey(fm), q = fam_q(fm);
       // a node of the line slot_line() == c, and the line's nodes: (px0 + m ex, py0 + m ey)
       const int px0 = X0 + ey * c, py0 = Y0 - (ey == 0 ? ex * c : 0);
-      const double ax = px0 - xc, ay = py0 - yc;
-      const double inv_ee = (ex != 0 && ey != 0) ? 0.5 : 1.0;
-      const double ee = (ex != 0 && ey != 0) ? 2.0 : 1.0;
-      const double be = ax * ex + ay * ey;
-      double disc = be * be - ee * (ax * ax + ay * ay - r2);
+      const real ax = px0 - xc, ay = py0 - yc;
+      const real inv_ee = (ex != 0 && ey != 0) ? 0.5 : 1.0;
+      const real ee = (ex != 0 && ey != 0) ? 2.0 : 1.0;
+      const real be = ax * ex + ay * ey;
+      real disc = be * be - ee * (ax * ax + ay * ay - r2);
       const bool far = disc < -4.0;
       // The rasteriser's test (x - xc)^2 + (y - yc)^2 <= r2 and this chord can only disagree about a node whose d2 is
       // within rounding (~1e-13) of r2, i.e. a node within 1e-13 / (2 sqrt(disc)) of a chord end: with disc >= 1e-6
@@ -1819,9 +1870,9 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
       const bool tangent = disc > -1e-6 && disc < 1e-6;
       const bool cuts = disc >= 1e-6;
       if (disc < 0.0) disc = 0.0;
-      const double sq = sqrt(disc);
-      const double mf = (sq - be) * inv_ee, mb = (-sq - be) * inv_ee;  // chord ends, in steps of e
-      const double ff = floor(mf), cb = ceil(mb);
+      const real sq = sqrt(disc);
+      const real mf = (sq - be) * inv_ee, mb = (-sq - be) * inv_ee;  // chord ends, in steps of e
+      const real ff = floor(mf), cb = ceil(mb);
       // a chord end within rounding distance of a lattice node: let the gather path decide
       // (mf - ff and cb - mb lie in [0, 1): near 0 or near 1 <=> far from 1/2)
       const bool shaky = fabs((mf - ff) - 0.5) > 0.5 - 1e-9 || fabs((cb - mb) - 0.5) > 0.5 - 1e-9;
@@ -1855,7 +1906,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
           const int ql = side == 0 ? q : q - 4, qlo = side == 0 ? q - 4 : q;
           const long nodeP = (long)(px - L.gx0) * L.sy + py, nodeN = (long)(nx - L.gx0) * L.sy + ny;
           if (obst[nodeP] != i || obst[nodeN] == -1) { bad = true; continue; }  // the table should have had it
-          const double sum = f[fidx(qlo, nodeP)] + f[fidx(ql, nodeN)];
+          const real sum = f[fidx(qlo, nodeP)] + f[fidx(ql, nodeN)];
           if (side == 0) { fw[g][j] = (unsigned long long)__double_as_longlong(sum); ffill = true; }
           else { bw[g][j] = (unsigned long long)__double_as_longlong(sum); bfill = true; }
         }
@@ -1864,10 +1915,10 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
       keyf[j] = keyb[j] = -1;
       if (meets && mode == FT_FAST) {
         // forward link: direction q out of node kf, momentum along the opposite direction (main.c:1315-1318)
-        const double sf = __longlong_as_double((long long)fw[g][j]), sb = __longlong_as_double((long long)bw[g][j]);
-        const double wxf = px0 + kf * ex - xc, wyf = py0 + kf * ey - yc;
-        const double wxb = px0 + kb * ex - xc, wyb = py0 + kb * ey - yc;
-        const double fxf = sf * -ex, fyf = sf * -ey, fxb = sb * ex, fyb = sb * ey;
+        const real sf = __longlong_as_double((long long)fw[g][j]), sb = __longlong_as_double((long long)bw[g][j]);
+        const real wxf = px0 + kf * ex - xc, wyf = py0 + kf * ey - yc;
+        const real wxb = px0 + kb * ex - xc, wyb = py0 + kb * ey - yc;
+        const real fxf = sf * -ex, fyf = sf * -ey, fxb = sb * ex, fyb = sb * ey;
         h1 = h1 + fxf + fxb;
         h2 = h2 + fyf + fyb;
         h3 = h3 - fxf * wyf + fyf * wxf - fxb * wyb + fyb * wxb;
@@ -1912,7 +1963,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
     if (mode == FT_PACK) {  // {id, slots} to the message; the owner merges
       const int nslot = 8 * spd;
       unsigned long long* e = reinterpret_cast<unsigned long long*>(packbuf) + 1 + (long)(g0 + g) * (1 + nslot);
-      if (lane == 0) reinterpret_cast<double*>(e)[0] = (double)i;
+      if (lane == 0) reinterpret_cast<real*>(e)[0] = (real)i;
       for (int k = lane; k < nslot; k += 64) e[1 + k] = LBMDEM_SLOT_EMPTY;
       __builtin_amdgcn_wave_barrier();  // one wave's stores to the same address keep their order
       __threadfence_block();
@@ -1958,9 +2009,9 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
     }
     if (n1[g] > cap1 || n2[g] > cap1 || n3[g] > cap3) { n1[g] = -1; continue; }
     __builtin_amdgcn_wave_barrier();
-    double* const l1 = sDyn + (size_t)(gslot0 + g) * per_grain;
-    double* const l2 = l1 + cap1;
-    double* const l3 = l2 + cap1;
+    real* const l1 = sDyn + (size_t)(gslot0 + g) * per_grain;
+    real* const l2 = l1 + cap1;
+    real* const l3 = l2 + cap1;
     // (exo, eyo): the direction opposite to the link's, along which its momentum is exchanged
     auto emit = [&](int keyp, unsigned long long slot, int exo, int eyo) {
       const int key = keyp & 0xFFFFF;
@@ -1969,9 +2020,9 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
       const unsigned long long below = bm[w] & ((1ull << (key & 63)) - 1ull);
       const int bd = __popcll(below & M_DIAG), bx = __popcll(below & M_XDIR), by = __popcll(below & M_YDIR);
       const int r1 = pw[w] + bd + bx, r2_ = pw[nw64 + w] + bd + by, r3 = pw[2 * nw64 + w] + 2 * bd + bx + by;
-      const double sum = __longlong_as_double((long long)slot);
-      const double fnx = sum * exo, fny = sum * eyo;  // main.c:1315-1316
-      const double wx = x - xc, wy = y - yc;
+      const real sum = __longlong_as_double((long long)slot);
+      const real fnx = sum * exo, fny = sum * eyo;  // main.c:1315-1316
+      const real wx = x - xc, wy = y - yc;
       int r3b = r3;
       if (exo != 0) { l1[r1] = fnx; l3[r3b++] = fnx * (-wy); }   // - fnx * (y - yc)
       if (eyo != 0) { l2[r2_] = fny; l3[r3b] = fny * wx; }        // + fny * (x - xc)
@@ -2008,7 +2059,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
     }
   }
   if (mode == FT_PACK) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) packbuf[0] = (double)ntodo;
+    if (blockIdx.x == 0 && threadIdx.x == 0) packbuf[0] = (real)ntodo;
     return;
   }
   __syncthreads();
@@ -2035,13 +2086,13 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
       const int v = __shfl_xor(longest, off, 64);
       longest = v > longest ? v : longest;
     }
-    const double* tl = sDyn + (size_t)(g < NG ? g : 0) * per_grain + (a == 0 ? 0 : (a == 1 ? cap1 : 2 * cap1));
-    double h = 0.0;
+    const real* tl = sDyn + (size_t)(g < NG ? g : 0) * per_grain + (a == 0 ? 0 : (a == 1 ? cap1 : 2 * cap1));
+    real h = 0.0;
     for (int t = 0; t < longest; t += 8) {  // wave-uniform trip count
       if (t < mine) {
-        double2 v[4];
+        real2 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const double2*>(tl + t)[u];  // issued ahead of the chain
+        for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const real2*>(tl + t)[u];  // issued ahead of the chain
 #pragma unroll
         for (int u = 0; u < 4; ++u) { h = h + v[u].x; h = h + v[u].y; }
       }
@@ -2051,9 +2102,9 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const double* __
 }
 
 // The queued grains, gathered from obst and f: one wavefront per grain, a fixed grid strides over the queue.
-__global__ __launch_bounds__(64) void k_forces_gather_queue(const double* __restrict__ f, const int* __restrict__ obst,
+__global__ __launch_bounds__(64) void k_forces_gather_queue(const real* __restrict__ f, const int* __restrict__ obst,
                                                             LatticeView L, GrainFluidView G, ForceSlots S,
-                                                            double scale12, double scale3, double* __restrict__ fhf) {
+                                                            double scale12, double scale3, real* __restrict__ fhf) {
   __shared__ ForceLds sh;
   const int lane = threadIdx.x;
   const int count = *S.gathered;
@@ -2067,22 +2118,22 @@ __global__ __launch_bounds__(64) void k_forces_gather_queue(const double* __rest
       if (lane == 0) atomicOr(S.error, 2);
       continue;
     }
-    const double h = force_gather(sh, f, obst, L, i, G.xc[i], G.yc[i], xi, xf, yi, yf, lane);
+    const real h = force_gather(sh, f, obst, L, i, G.xc[i], G.yc[i], xi, xf, yi, yf, lane);
     if (lane < 3) fhf[lane * L.n + i] = h * (lane == 2 ? scale3 : scale12);
   }
 }
 
 // Fast kernel: one wavefront per grain, lanes take bounding-box nodes, cross-lane shuffle reduction.
 // Same terms as the parity kernel, different summation tree (differs in the last bits).
-__global__ void k_forces_fast(const double* __restrict__ f, const int* __restrict__ obst, LatticeView L,
+__global__ void k_forces_fast(const real* __restrict__ f, const int* __restrict__ obst, LatticeView L,
                               GrainFluidView G, double scale12, double scale3,
-                              double* __restrict__ fhf, unsigned char* __restrict__ owner) {
+                              real* __restrict__ fhf, unsigned char* __restrict__ owner) {
   const int lane = threadIdx.x & 63;
   const int i = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (i >= L.n) return;
-  const double xc = G.xc[i], yc = G.yc[i];
+  const real xc = G.xc[i], yc = G.yc[i];
   const bool own = grain_owned(L, xc);
-  double h1 = 0, h2 = 0, h3 = 0;
+  real h1 = 0, h2 = 0, h3 = 0;
   int xi, xf, yi, yf;
   if (own && grain_box(L, G, i, xi, xf, yi, yf)) {
     const int ny = yf - yi + 1;
@@ -2096,9 +2147,9 @@ __global__ void k_forces_fast(const double* __restrict__ f, const int* __restric
         const int ex = EXq(q), ey = EYq(q), qo = OPPq(q);
         const long nodeN = (long)(x + ex - L.gx0) * L.sy + (y + ey);
         if (obst[nodeN] == i) continue;
-        const double s = f[fidx(qo, rowP + y)] + f[fidx(q, nodeN)];
-        const double fnx = s * EXq(qo);
-        const double fny = s * EYq(qo);
+        const real s = f[fidx(qo, rowP + y)] + f[fidx(q, nodeN)];
+        const real fnx = s * EXq(qo);
+        const real fny = s * EYq(qo);
         h1 = h1 + fnx;
         h2 = h2 + fny;
         h3 = h3 - fnx * (y - yc) + fny * (x - xc);
@@ -2125,7 +2176,7 @@ __global__ void k_forces_fast(const double* __restrict__ f, const int* __restric
 
 // host AoS rows [nxl][ly][9] (reference layout, main.c:56) -> device planes. One thread per
 // (node, q) element read coalesced from the AoS side through LDS-free index math; init-time only.
-__global__ void k_aos_to_soa(const double* __restrict__ aos, double* __restrict__ f, LatticeView L) {
+__global__ void k_aos_to_soa(const real* __restrict__ aos, real* __restrict__ f, LatticeView L) {
   const long total = (long)L.nxl * L.ly * 9;
   for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (long)gridDim.x * blockDim.x) {
     const int q = (int)(k % 9);
@@ -2134,7 +2185,7 @@ __global__ void k_aos_to_soa(const double* __restrict__ aos, double* __restrict_
     f[fidx(q, (long)xl * L.sy + y)] = aos[k];
   }
 }
-__global__ void k_soa_to_aos(const double* __restrict__ f, double* __restrict__ aos, LatticeView L, int xl0,
+__global__ void k_soa_to_aos(const real* __restrict__ f, real* __restrict__ aos, LatticeView L, int xl0,
                              int nrows) {
   const long total = (long)nrows * L.ly * 9;
   for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (long)gridDim.x * blockDim.x) {
@@ -2146,11 +2197,11 @@ __global__ void k_soa_to_aos(const double* __restrict__ f, double* __restrict__ 
 }
 
 // init_density (main.c:716-724): f = w[q] everywhere
-__global__ void k_fill_equilibrium(double* __restrict__ f, LatticeView L) {
+__global__ void k_fill_equilibrium(real* __restrict__ f, LatticeView L) {
   const long total = 9 * L.plane;
   for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (long)gridDim.x * blockDim.x) {
 #if LBMDEM_F_TILES
-    const int q = (int)((k % 144) >> 4);  // f[tile][q][16]
+    const int q = (int)((k % (9 * LBMDEM_TILE_Y)) / LBMDEM_TILE_Y);  // f[tile][q][TILE_Y]
 #else
     const int q = (int)(k / L.plane);
 #endif
@@ -2159,16 +2210,16 @@ __global__ void k_fill_equilibrium(double* __restrict__ f, LatticeView L) {
 }
 
 // rho, rho*u sums in the order write_vtk forms them (main.c:315-319)
-__global__ void k_macro(const double* __restrict__ f, LatticeView L, int xl0, int nrows,
-                        double* __restrict__ rho, double* __restrict__ ux, double* __restrict__ uy) {
+__global__ void k_macro(const real* __restrict__ f, LatticeView L, int xl0, int nrows,
+                        real* __restrict__ rho, real* __restrict__ ux, real* __restrict__ uy) {
   const long total = (long)nrows * L.ly;
   for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (long)gridDim.x * blockDim.x) {
     const int y = (int)(k % L.ly), xr = (int)(k / L.ly);
     const long node = (long)(xl0 + xr) * L.sy + y;
-    double s = 0.0, sx = 0.0, sy = 0.0;
+    real s = 0.0, sx = 0.0, sy = 0.0;
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-      const double v = f[fidx(q, node)];
+      const real v = f[fidx(q, node)];
       s += v;
       sx += v * EXq(q);
       sy += v * EYq(q);
@@ -2179,7 +2230,7 @@ __global__ void k_macro(const double* __restrict__ f, LatticeView L, int xl0, in
 
 // Total mass, per-block partial sums over the owned rows (check_density, main.c:1249-1261).
 // Summation order differs from the reference's serial sweep; compared with a tolerance.
-__global__ void k_density_partial(const double* __restrict__ f, LatticeView L, double* __restrict__ partial) {
+__global__ void k_density_partial(const real* __restrict__ f, LatticeView L, double* __restrict__ partial) {
   __shared__ double red[256];
   const long rows = L.xo1 - L.xo0;
   const long total = rows * L.ly;
@@ -2209,7 +2260,7 @@ __global__ void k_density_partial(const double* __restrict__ f, LatticeView L, d
 // sum and the flags; the host walks the rows with the exact running sum and replays a row element by element (in
 // the reference's order) whenever the shortcut does not apply: the rows where the sum crosses a power of two (~13 of
 // 4096 at 4096^2), tie rows (~1), and whatever the first pass could not classify.
-__global__ void k_density_rowsum(const double* __restrict__ f, LatticeView L, double* __restrict__ rowsum) {
+__global__ void k_density_rowsum(const real* __restrict__ f, LatticeView L, double* __restrict__ rowsum) {
   __shared__ double red[256];
   const long row = L.xo0 + blockIdx.x;
   double s = 0.0;
@@ -2227,8 +2278,9 @@ __global__ void k_density_rowsum(const double* __restrict__ f, LatticeView L, do
   if (threadIdx.x == 0) rowsum[blockIdx.x] = red[0];
 }
 
-// quanta[row] = sum over the row of RN(a / 2^(kexp[row] - 52)); flags[row] != 0: the shortcut does not apply
-__global__ void k_density_rowquanta(const double* __restrict__ f, LatticeView L, const int* __restrict__ kexp,
+// quanta[row] = sum over the row of RN(a / u), u = 2^(kexp[row] - (p - 1)) the quantum of a running sum in binade kexp[row]
+// (p = LBMDEM_REAL_MANT significand bits of `real`); flags[row] != 0: the shortcut does not apply
+__global__ void k_density_rowquanta(const real* __restrict__ f, LatticeView L, const int* __restrict__ kexp,
                                     unsigned long long* __restrict__ quanta, int* __restrict__ flags) {
   __shared__ unsigned long long red[256];
   __shared__ int bad;
@@ -2243,9 +2295,9 @@ __global__ void k_density_rowquanta(const double* __restrict__ f, LatticeView L,
     const long node = row * L.sy + y;
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-      const double a = f[fidx(q, node)];
+      const double a = f[fidx(q, node)];   // (a float is a double: the quantum arithmetic below is exact in double for either type)
       if (!(a > 0.0) || !(a < top)) { mybad = 1; continue; }   // also NaN
-      const double t = ldexp(a, 52 - k);   // a / u, exact (a power-of-two scaling; a tiny a may underflow to 0: n = 0, right)
+      const double t = ldexp(a, (LBMDEM_REAL_MANT - 1) - k);   // a / u, exact (a power-of-two scaling; a tiny a may underflow to 0: n = 0, right)
       const double fl = floor(t);
       if (t - fl == 0.5) mybad = 1;        // a tie: the rounding depends on the running sum
       n += (unsigned long long)rint(t);
@@ -2263,10 +2315,10 @@ __global__ void k_density_rowquanta(const double* __restrict__ f, LatticeView L,
 
 // halo rows <-> contiguous buffer [9][nrows][ly]; blockIdx.y = side: rows from xl0a (low) / xl0b (high), a null buffer
 // skips the side
-__global__ void k_halo_pack(const double* __restrict__ f, LatticeView L, int xl0a, int xl0b, int nrows,
-                            double* __restrict__ bufa, double* __restrict__ bufb) {
+__global__ void k_halo_pack(const real* __restrict__ f, LatticeView L, int xl0a, int xl0b, int nrows,
+                            real* __restrict__ bufa, real* __restrict__ bufb) {
   const int xl0 = blockIdx.y ? xl0b : xl0a;
-  double* __restrict__ buf = blockIdx.y ? bufb : bufa;
+  real* __restrict__ buf = blockIdx.y ? bufb : bufa;
   if (!buf) return;
   const long per = (long)nrows * L.ly, total = 9 * per;
   for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (long)gridDim.x * blockDim.x) {
@@ -2276,10 +2328,10 @@ __global__ void k_halo_pack(const double* __restrict__ f, LatticeView L, int xl0
     buf[k] = f[fidx(q, (long)(xl0 + xr) * L.sy + y)];
   }
 }
-__global__ void k_halo_unpack(double* __restrict__ f, LatticeView L, int xl0a, int xl0b, int nrows,
-                              const double* __restrict__ bufa, const double* __restrict__ bufb) {
+__global__ void k_halo_unpack(real* __restrict__ f, LatticeView L, int xl0a, int xl0b, int nrows,
+                              const real* __restrict__ bufa, const real* __restrict__ bufb) {
   const int xl0 = blockIdx.y ? xl0b : xl0a;
-  const double* __restrict__ buf = blockIdx.y ? bufb : bufa;
+  const real* __restrict__ buf = blockIdx.y ? bufb : bufa;
   if (!buf) return;
   const long per = (long)nrows * L.ly, total = 9 * per;
   for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (long)gridDim.x * blockDim.x) {
@@ -2291,12 +2343,12 @@ __global__ void k_halo_unpack(double* __restrict__ f, LatticeView L, int xl0a, i
 }
 
 // The five fields write_vtk builds per node (main.c:284-323), float32, in [y][x] order (x fastest), for
-// the owned rows (x offset = first owned row). Fluid sums are accumulated in FLOAT with a double
-// intermediate per addition, exactly as `float += double` does in the reference.
-__global__ void k_vtk_fields(const double* __restrict__ f, const int* __restrict__ obst, LatticeView L,
-                             const double* __restrict__ gp, const double* __restrict__ v1,
-                             const double* __restrict__ v2, const double* __restrict__ a1,
-                             const double* __restrict__ a2, double rho_moy, float* __restrict__ grain_pressure,
+// the owned rows (x offset = first owned row). Fluid sums are accumulated in FLOAT with a real
+// intermediate per addition, exactly as `float += real` does in the reference.
+__global__ void k_vtk_fields(const real* __restrict__ f, const int* __restrict__ obst, LatticeView L,
+                             const real* __restrict__ gp, const real* __restrict__ v1,
+                             const real* __restrict__ v2, const real* __restrict__ a1,
+                             const real* __restrict__ a2, real rho_moy, float* __restrict__ grain_pressure,
                              float* __restrict__ grain_velocity, float* __restrict__ grain_acceleration,
                              float* __restrict__ fluid_pressure, float* __restrict__ fluid_velocity) {
   const int nx = L.xo1 - L.xo0;
@@ -2313,12 +2365,12 @@ __global__ void k_vtk_fields(const double* __restrict__ f, const int* __restrict
     } else {
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
-        const double v = f[fidx(q, node)];
-        fp = (float)((double)fp + v);
-        fv0 = (float)((double)fv0 + v * EXq(q));
-        fv1 = (float)((double)fv1 + v * EYq(q));
+        const real v = f[fidx(q, node)];
+        fp = (float)((real)fp + v);
+        fv0 = (float)((real)fv0 + v * EXq(q));
+        fv1 = (float)((real)fv1 + v * EYq(q));
       }
-      fp = (float)((1. / 3.) * rho_moy * ((double)fp - 1.));
+      fp = (float)((1. / 3.) * rho_moy * ((real)fp - 1.));
     }
     grain_pressure[k] = gpr;
     grain_velocity[3 * k] = gv0; grain_velocity[3 * k + 1] = gv1; grain_velocity[3 * k + 2] = 0.f;
@@ -2345,14 +2397,15 @@ void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st) {
   hipLaunchKernelGGL(k_obst_fill, dim3(grid_for((long)L.nxl * L.sy / 4)), dim3(256), 0, st, obst, L);
 }
 
-void launch_obst_paint(int* obst, const LatticeView& L, int n, const double* x1, const double* x2, const double* r,
-                       const double* rLB, const double* v1, const double* v2, const double* v3, double* xc,
-                       double* yc, double* r2, double* rbl0, double* pk, unsigned char* touched,
+void launch_obst_paint(int* obst, const LatticeView& L, int n, const real* x1, const real* x2, const real* r,
+                       const real* rLB, const real* v1, const real* v2, const real* v3, real* xc,
+                       real* yc, real* r2, real* rbl0, real* pk, unsigned char* touched,
                        const unsigned char* mask, unsigned* mincov, unsigned epoch, const int* list,
-                       const int* list_count, int list_cap, hipStream_t st) {
+                       const int* list_count, int list_cap, const int* voff, const int* vnbr, hipStream_t st) {
   const long threads = (long)(list ? list_cap : n) * 64;
   hipLaunchKernelGGL(k_obst_paint, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, obst, L, n, x1, x2, r,
-                     rLB, v1, v2, v3, xc, yc, r2, rbl0, pk, touched, mask, mincov, epoch, list, list_count, list_cap);
+                     rLB, v1, v2, v3, xc, yc, r2, rbl0, pk, touched, mask, mincov, epoch, list, list_count, list_cap, voff,
+                     vnbr);
 }
 
 void launch_slots_clear(const ForceSlots& S, int n, hipStream_t st) {
@@ -2362,7 +2415,7 @@ void launch_slots_clear(const ForceSlots& S, int n, hipStream_t st) {
 }
 
 template <int TX, int TY>
-static void launch_cs(const double* fin, double* fout, const int* obst_old, const int* obst_new,
+static void launch_cs(const real* fin, real* fout, const int* obst_old, const int* obst_new,
                       const LatticeView& L, const GrainFluidView& G, int remap, hipStream_t st) {
   const int rows = L.xo1 - L.xo0;
   const int tiles_y = (L.ly + TY - 1) / TY, tiles_x = (rows + TX - 1) / TX;
@@ -2416,7 +2469,7 @@ __attribute__((unused)) static int march_kernel() {
 }
 
 template <int LX, int MINW, int WW = 62>
-static void launch_march(const double* fin, double* fout, const int* obst_old, const int* obst_new,
+static void launch_march(const real* fin, real* fout, const int* obst_old, const int* obst_new,
                          const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, int remap,
                          hipStream_t st) {
   const int rows = L.xo1 - L.xo0;
@@ -2459,7 +2512,7 @@ static void launch_march(const double* fin, double* fout, const int* obst_old, c
 
 // Two row ranges of equal width w <= 32 (the rows next to the two cuts of a strip) in ONE launch: two segments of w rows,
 // the second `stride` rows after the first.
-static void launch_march_two_ranges(const double* fin, double* fout, const int* obst_old, const int* obst_new,
+static void launch_march_two_ranges(const real* fin, real* fout, const int* obst_old, const int* obst_new,
                                     const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, int lo0, int w,
                                     int hi0, hipStream_t st) {
   constexpr int WW = 62;
@@ -2483,7 +2536,7 @@ static void launch_march_two_ranges(const double* fin, double* fout, const int* 
 // LDS-tile kernel, which does not fill the slot table.
 bool collide_stream_fills_slots(const LatticeView& L) { return L.reduced_lt1 != 0; }
 
-void launch_collide_stream(const double* fin, double* fout, const int* obst_old, const int* obst_new,
+void launch_collide_stream(const real* fin, real* fout, const int* obst_old, const int* obst_new,
                            const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, hipStream_t st) {
 #ifdef LBMDEM_AB
   if (getenv("LBMDEM_CS_VARIANT")) {   // experiments with other kernel shapes; without the variable: the product's choice
@@ -2511,7 +2564,7 @@ void launch_collide_stream(const double* fin, double* fout, const int* obst_old,
   else launch_cs<4, 64>(fin, fout, obst_old, obst_new, L, G, 0, st);
 }
 
-void launch_collide_stream_edges(const double* fin, double* fout, const int* obst_old, const int* obst_new,
+void launch_collide_stream_edges(const real* fin, real* fout, const int* obst_old, const int* obst_new,
                                  const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, int lo0, int lo1,
                                  int hi0, int hi1, hipStream_t st) {
   bool one_launch = lo1 > lo0 && hi1 > hi0 && lo1 - lo0 == hi1 - hi0 && lo1 - lo0 <= 32 && lo1 <= hi0 && L.reduced_lt1;
@@ -2527,15 +2580,15 @@ void launch_collide_stream_edges(const double* fin, double* fout, const int* obs
   if (hi1 > hi0) { Ls.xo0 = hi0; Ls.xo1 = hi1; launch_collide_stream(fin, fout, obst_old, obst_new, Ls, G, S, st); }
 }
 
-void launch_forces_parity(const double* f, const int* obst, const LatticeView& L,
-                          const GrainFluidView& G, double scale12, double scale3, double* fhf,
+void launch_forces_parity(const real* f, const int* obst, const LatticeView& L,
+                          const GrainFluidView& G, double scale12, double scale3, real* fhf,
                           unsigned char* owner, hipStream_t st) {
   hipLaunchKernelGGL(k_forces_parity, dim3(L.n), dim3(64), 0, st, f, obst, L, G, scale12, scale3, fhf, owner);
 }
 
 template <int GW, int PASSES>
-static void launch_forces_table_t(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
-                                  const ForceSlots& S, double scale12, double scale3, double* fhf, unsigned char* owner,
+static void launch_forces_table_t(const real* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
+                                  const ForceSlots& S, double scale12, double scale3, real* fhf, unsigned char* owner,
                                   int fast, hipStream_t st) {
   const int HB = S.hb, B = 2 * HB + 1;
   const int nw64 = (B * B * 8 + 63) / 64;
@@ -2553,9 +2606,9 @@ static void launch_forces_table_t(const double* f, const int* obst, const Lattic
   hipLaunchKernelGGL(k_forces_gather_queue, dim3(grid), dim3(64), 0, st, f, obst, L, G, S, scale12, scale3, fhf);
 }
 
-void launch_forces_table_pack(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
+void launch_forces_table_pack(const real* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
                               const ForceSlots& S, const int* const list[2], const int* const list_count[2], int cap,
-                              double* const buf[2], hipStream_t st) {
+                              real* const buf[2], hipStream_t st) {
   const int HB = S.hb, B = 2 * HB + 1;
   const int nw64 = (B * B * 8 + 63) / 64;
   const int cap1 = (4 * S.spd + 2 * B + 7) & ~7, cap3 = (8 * S.spd + 4 * B + 7) & ~7;
@@ -2564,16 +2617,16 @@ void launch_forces_table_pack(const double* f, const int* obst, const LatticeVie
   const PackSides P{{list[0], list[1]}, {list_count[0], list_count[1]}, {buf[0], buf[1]}};
   if (S.spd <= 32)
     hipLaunchKernelGGL((k_forces_table<1, 2>), dim3(blocks, 2), dim3(64 * FT_WAVES), lds, st, f, obst, L, G, S, cap1, cap3,
-                       nw64, 0.0, 0.0, (double*)nullptr, (unsigned char*)nullptr, (int)FT_PACK, (const int*)nullptr,
+                       nw64, 0.0, 0.0, (real*)nullptr, (unsigned char*)nullptr, (int)FT_PACK, (const int*)nullptr,
                        (const int*)nullptr, P, S.mask, cap);
   else
     hipLaunchKernelGGL((k_forces_table<1, 4>), dim3(blocks, 2), dim3(64 * FT_WAVES), lds, st, f, obst, L, G, S, cap1, cap3,
-                       nw64, 0.0, 0.0, (double*)nullptr, (unsigned char*)nullptr, (int)FT_PACK, (const int*)nullptr,
+                       nw64, 0.0, 0.0, (real*)nullptr, (unsigned char*)nullptr, (int)FT_PACK, (const int*)nullptr,
                        (const int*)nullptr, P, S.mask, cap);
 }
 
-void launch_forces_slots(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
-                         const ForceSlots& S, double scale12, double scale3, double* fhf, unsigned char* owner,
+void launch_forces_slots(const real* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
+                         const ForceSlots& S, double scale12, double scale3, real* fhf, unsigned char* owner,
                          int fast, hipStream_t st) {
 #ifdef LBMDEM_AB
   static const int gw = getenv("LBMDEM_FORCE_GW") ? atoi(getenv("LBMDEM_FORCE_GW")) : 1;
@@ -2594,49 +2647,49 @@ void launch_forces_slots(const double* f, const int* obst, const LatticeView& L,
   }
 }
 
-void launch_forces_fast(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
-                        double scale12, double scale3, double* fhf, unsigned char* owner,
+void launch_forces_fast(const real* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
+                        double scale12, double scale3, real* fhf, unsigned char* owner,
                         hipStream_t st) {
   const long threads = (long)L.n * 64;
   hipLaunchKernelGGL(k_forces_fast, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, f, obst, L,
                      G, scale12, scale3, fhf, owner);
 }
 
-void launch_aos_to_soa(const double* aos_rows, double* f, const LatticeView& L, hipStream_t st) {
+void launch_aos_to_soa(const real* aos_rows, real* f, const LatticeView& L, hipStream_t st) {
   hipLaunchKernelGGL(k_aos_to_soa, dim3(grid_for((long)L.nxl * L.ly * 9)), dim3(256), 0, st, aos_rows, f, L);
 }
-void launch_soa_to_aos(const double* f, double* aos_rows, const LatticeView& L, int xl0, int nrows,
+void launch_soa_to_aos(const real* f, real* aos_rows, const LatticeView& L, int xl0, int nrows,
                        hipStream_t st) {
   hipLaunchKernelGGL(k_soa_to_aos, dim3(grid_for((long)nrows * L.ly * 9)), dim3(256), 0, st, f, aos_rows, L,
                      xl0, nrows);
 }
-void launch_fill_equilibrium(double* f, const LatticeView& L, hipStream_t st) {
+void launch_fill_equilibrium(real* f, const LatticeView& L, hipStream_t st) {
   hipLaunchKernelGGL(k_fill_equilibrium, dim3(grid_for(9 * L.plane)), dim3(256), 0, st, f, L);
 }
-void launch_macro(const double* f, const LatticeView& L, int xl0, int nrows, double* rho, double* ux,
-                  double* uy, hipStream_t st) {
+void launch_macro(const real* f, const LatticeView& L, int xl0, int nrows, real* rho, real* ux,
+                  real* uy, hipStream_t st) {
   hipLaunchKernelGGL(k_macro, dim3(grid_for((long)nrows * L.ly)), dim3(256), 0, st, f, L, xl0, nrows, rho,
                      ux, uy);
 }
-void launch_density_partial(const double* f, const LatticeView& L, double* partial, int nblocks,
+void launch_density_partial(const real* f, const LatticeView& L, double* partial, int nblocks,
                             hipStream_t st) {
   hipLaunchKernelGGL(k_density_partial, dim3(nblocks), dim3(256), 0, st, f, L, partial);
 }
-void launch_density_rowsum(const double* f, const LatticeView& L, double* rowsum, hipStream_t st) {
+void launch_density_rowsum(const real* f, const LatticeView& L, double* rowsum, hipStream_t st) {
   hipLaunchKernelGGL(k_density_rowsum, dim3(L.xo1 - L.xo0), dim3(256), 0, st, f, L, rowsum);
 }
-void launch_density_rowquanta(const double* f, const LatticeView& L, const int* kexp, unsigned long long* quanta,
+void launch_density_rowquanta(const real* f, const LatticeView& L, const int* kexp, unsigned long long* quanta,
                               int* flags, hipStream_t st) {
   hipLaunchKernelGGL(k_density_rowquanta, dim3(L.xo1 - L.xo0), dim3(256), 0, st, f, L, kexp, quanta, flags);
 }
-void launch_halo_pack(const double* f, const LatticeView& L, int xl0_lo, int xl0_hi, int nrows, double* buf_lo,
-                      double* buf_hi, hipStream_t st) {
+void launch_halo_pack(const real* f, const LatticeView& L, int xl0_lo, int xl0_hi, int nrows, real* buf_lo,
+                      real* buf_hi, hipStream_t st) {
   hipLaunchKernelGGL(k_halo_pack, dim3(grid_for(9L * nrows * L.ly), 2), dim3(256), 0, st, f, L, xl0_lo, xl0_hi, nrows,
                      buf_lo, buf_hi);
 }
-void launch_vtk_fields(const double* f, const int* obst, const LatticeView& L, const double* gp,
-                       const double* v1, const double* v2, const double* a1, const double* a2,
-                       double rho_moy, float* grain_pressure, float* grain_velocity,
+void launch_vtk_fields(const real* f, const int* obst, const LatticeView& L, const real* gp,
+                       const real* v1, const real* v2, const real* a1, const real* a2,
+                       real rho_moy, float* grain_pressure, float* grain_velocity,
                        float* grain_acceleration, float* fluid_pressure, float* fluid_velocity,
                        hipStream_t st) {
   hipLaunchKernelGGL(k_vtk_fields, dim3(grid_for((long)(L.xo1 - L.xo0) * L.ly)), dim3(256), 0, st, f, obst, L, gp,
@@ -2644,8 +2697,8 @@ void launch_vtk_fields(const double* f, const int* obst, const LatticeView& L, c
                      fluid_pressure, fluid_velocity);
 }
 
-void launch_halo_unpack(double* f, const LatticeView& L, int xl0_lo, int xl0_hi, int nrows, const double* buf_lo,
-                        const double* buf_hi, hipStream_t st) {
+void launch_halo_unpack(real* f, const LatticeView& L, int xl0_lo, int xl0_hi, int nrows, const real* buf_lo,
+                        const real* buf_hi, hipStream_t st) {
   hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(9L * nrows * L.ly), 2), dim3(256), 0, st, f, L, xl0_lo, xl0_hi, nrows,
                      buf_lo, buf_hi);
 }

@@ -45,7 +45,7 @@ struct lbmdem_handle {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   // lattice
-  double* f[2] = {nullptr, nullptr};
+  real* f[2] = {nullptr, nullptr};
   int fcur = 0;
   int* obst[2] = {nullptr, nullptr};
   int ocur = 0;           // map the current f was produced with ("old" for the next collide_stream)
@@ -53,20 +53,20 @@ struct lbmdem_handle {
   // collide_stream in two parts (lbmdem_collide_stream_part): after EDGES the interior rows of f[fcur] are
   // still missing; the operands of the launch are kept for INTERIOR
   bool cs_interior_pending = false;
-  const double* cs_fin = nullptr;
+  const real* cs_fin = nullptr;
   const int *cs_ob_old = nullptr, *cs_ob_new = nullptr;
   int cs_lo_end = 0, cs_hi_begin = 0;  // interior = local rows [cs_lo_end, cs_hi_begin)
   ForceSlots cs_slots{};
   // grains
   int n = 0;
-  double* gbuf = nullptr;  // one allocation, carved below
+  real* gbuf = nullptr;  // one allocation, carved below
   Kin kin[2];
   int kcur = 0;
-  double *r = nullptr, *m = nullptr, *It = nullptr, *rLB = nullptr;
-  double *xc = nullptr, *yc = nullptr, *r2 = nullptr, *rbl0 = nullptr;
-  double* pk = nullptr;   // [n][8] packed fluid-side grain records
-  double* gp = nullptr;   // [n] grain pressure g.p of the last DEM sub-step (main.c:187,776)
-  double* diag = nullptr; // [8][n] doubles s f1 f2 ifm M11 M12 M21 M22, then [2][n] ints z zz
+  real *r = nullptr, *m = nullptr, *It = nullptr, *rLB = nullptr;
+  real *xc = nullptr, *yc = nullptr, *r2 = nullptr, *rbl0 = nullptr;
+  real* pk = nullptr;   // [n][8] packed fluid-side grain records
+  real* gp = nullptr;   // [n] grain pressure g.p of the last DEM sub-step (main.c:187,776)
+  real* diag = nullptr; // [8][n] reals s f1 f2 ifm M11 M12 M21 M22, then [2][n] ints z zz
   bool diag_always = false;
   DiagExtra dx{};          // buffers of the order-dependent diagnostics fr, ice, slip, rw (allocated on first use)
   bool dx_ready = false;
@@ -74,7 +74,7 @@ struct lbmdem_handle {
   long long substep_seq = 0;  // sequence number of the next sub-step (the records' stamps)
   long long carry_from = 0;   // ct.carry is as of the sub-step before this one; only younger records override it
   bool diag_valid = false; // the last sub-step produced diagnostics
-  double* fhf = nullptr;  // [3][n]
+  real* fhf = nullptr;  // [3][n]
   unsigned char* owner = nullptr;
   unsigned* mincov = nullptr;   // GrainFluidView::mincov
   unsigned paint_epoch = 0;
@@ -92,6 +92,7 @@ struct lbmdem_handle {
   DistDevice dd{};
   VerletDevice V{};
   bool verlet_ok = false;
+  bool verlet_tracks_positions = false;  // the positions have only moved by DEM sub-steps since the list was built (no upload)
   volatile int* ovf_host = nullptr;  // pinned mirror of V.overflow, refreshed (asynchronously) after every rebuild
   volatile int* ferr_host = nullptr; // pinned mirror of fs.error (strip decomposition), refreshed after every period's forces
   long nbsteps = 0;
@@ -137,6 +138,40 @@ struct PhaseRange {
 };
 }  // namespace
 
+// Host buffers at the ABI are double in both builds; the device holds `real`. (Every float is a double: downloads are
+// exact; uploads of values that are not floats are rounded to nearest, like an assignment to `real` in the reference.)
+static hipError_t h2d_real(real* dst, const double* src, size_t n, hipStream_t st) {
+#ifdef LBMDEM_SINGLE_PRECISION
+  std::vector<real> tmp(n);
+  for (size_t k = 0; k < n; ++k) tmp[k] = (real)src[k];
+  hipError_t e = hipMemcpyAsync(dst, tmp.data(), sizeof(real) * n, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);   // tmp dies here
+  return e;
+#else
+  return hipMemcpyAsync(dst, src, sizeof(real) * n, hipMemcpyHostToDevice, st);
+#endif
+}
+static hipError_t d2h_real(double* dst, const real* src, size_t n, hipStream_t st) {
+#ifdef LBMDEM_SINGLE_PRECISION
+  std::vector<real> tmp(n);
+  hipError_t e = hipMemcpyAsync(tmp.data(), src, sizeof(real) * n, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e == hipSuccess) for (size_t k = 0; k < n; ++k) dst[k] = tmp[k];
+  return e;
+#else
+  hipError_t e = hipMemcpyAsync(dst, src, sizeof(real) * n, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  return e;
+#endif
+}
+// The float build covers the step path and the state transfers (what its parity tests and its bench line use); the
+// file writers, checkpoints, the strip decomposition and the RCCL transport exist in the double build only.
+#ifdef LBMDEM_SINGLE_PRECISION
+#define SP_UNAVAILABLE(what) return fail(LBMDEM_EINVAL, what " is not available in the single-precision build of the library")
+#else
+#define SP_UNAVAILABLE(what) do { } while (0)
+#endif
+
 static GrainFluidView gview(const lbmdem_handle* h) {
   const Kin& K = h->kin[h->kcur];
   return GrainFluidView{K.x1, K.x2, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0, h->pk, h->mincov, h->paint_epoch};
@@ -146,13 +181,16 @@ static DemParams dem_params(const lbmdem_handle* h) {
   const lbmdem_config& c = h->cfg;
   const lbmdem_physics& p = c.phys;
   DemParams P;
-  P.n = h->n; P.dt = c.dt; P.dt2 = c.dt2;
-  P.kg = p.kg; P.nug = p.nug; P.kt = p.kt; P.mu = p.mu; P.murf = p.murf;
-  P.km = p.km; P.num = p.num; P.ktm = p.ktm; P.mumb = p.mumb; P.mum = p.mum; P.nugt = p.nugt;
-  P.Mgx = c.Mgx; P.Mdx = c.Mdx; P.Mby = c.Mby; P.Mhy = c.Mhy;
-  P.wallT_vel = p.amp * p.freq * cos(p.freq * p.t);
-  P.xG = c.xG; P.yG = c.yG;
-  P.distVerlet = p.distVerlet;
+  P.n = h->n; P.dt = (real)c.dt; P.dt2 = (real)c.dt2;
+  P.kg = (real)p.kg; P.nug = (real)p.nug; P.kt = (real)p.kt; P.mu = (real)p.mu; P.murf = (real)p.murf;
+  P.km = (real)p.km; P.num = (real)p.num; P.ktm = (real)p.ktm; P.mumb = (real)p.mumb; P.mum = (real)p.mum; P.nugt = (real)p.nugt;
+  P.Mgx = (real)c.Mgx; P.Mdx = (real)c.Mdx; P.Mby = (real)c.Mby; P.Mhy = (real)c.Mhy;
+  {
+    const real amp = (real)p.amp, freq = (real)p.freq, t = (real)p.t;   // main.c:163-165
+    P.wallT_vel = amp * freq * cos((double)(freq * t));                 // main.c:855: cos() is <math.h>'s
+  }
+  P.xG = (real)c.xG; P.yG = (real)c.yG;
+  P.distVerlet = (real)p.distVerlet;
   return P;
 }
 
@@ -182,23 +220,29 @@ int lbmdem_derive(lbmdem_config* cfg, int lx, int ly, double scale, int nbgrains
     return fail(LBMDEM_EINVAL, "lbmdem_derive: bad arguments");
   const lbmdem_physics& p = cfg->phys;
   cfg->lx = lx; cfg->ly = ly; cfg->scale = scale; cfg->nbgrains = nbgrains;
+  // The reference's globals are `real` (main.c:52, 97-118, 201-204): locals of that type + the reference's own
+  // expressions give its promotions in either build (sin, cos, sqrt are <math.h>'s double functions there).
+  const real G = (real)p.G, angleG = (real)p.angleG, iterDEM = (real)p.iterDEM, kg = (real)p.kg, tau = (real)p.tau,
+             nu = (real)p.nu;
   // main.c:1836-1842
-  cfg->Mgx = 0.;
-  cfg->Mdx = 1.e-3 * lx / 10;
-  cfg->Mhy = 1.e-3 * ly / 10;
-  cfg->Mby = 0.;
-  cfg->xG = -p.G * sin(p.angleG);
-  cfg->yG = -p.G * cos(p.angleG);
+  const real Mgx = 0.;
+  const real Mdx = 1.e-3 * lx / 10;
+  const real Mhy = 1.e-3 * ly / 10;
+  const real Mby = 0.;
+  const real xG = -G * sin((double)angleG);
+  const real yG = -G * cos((double)angleG);
   // main.c:1844-1854
-  cfg->dx = (1. / scale) * (cfg->Mdx - cfg->Mgx) / (lx - 1);
-  double rMin = r[0];
-  for (int i = 1; i <= nbgrains - 1; i++) rMin = fmin(rMin, r[i]);
-  const double dtmax = (1 / p.iterDEM) * REF_PI * rMin * sqrt(REF_PI * RHO_S / p.kg);
-  cfg->dtLB = cfg->dx * cfg->dx * (p.tau - 0.5) / (3 * p.nu);
-  cfg->npDEM = (int)(cfg->dtLB / dtmax + 1);
-  cfg->c = cfg->dx / cfg->dtLB;
-  cfg->dt = cfg->dtLB / cfg->npDEM;
-  cfg->dt2 = cfg->dt * cfg->dt;
+  const real dx = (1. / scale) * (Mdx - Mgx) / (lx - 1);
+  real rMin = (real)r[0];
+  for (int i = 1; i <= nbgrains - 1; i++) rMin = (real)fmin((double)rMin, (double)(real)r[i]);
+  const real dtmax = (1 / iterDEM) * REF_PI * rMin * sqrt((double)(REF_PI * RHO_S / kg));
+  const real dtLB = dx * dx * (tau - 0.5) / (3 * nu);
+  const int npDEM = (dtLB / dtmax + 1);
+  const real c = dx / dtLB;
+  const real dt = dtLB / npDEM;
+  const real dt2 = dt * dt;
+  cfg->Mgx = Mgx; cfg->Mdx = Mdx; cfg->Mhy = Mhy; cfg->Mby = Mby; cfg->xG = xG; cfg->yG = yG;
+  cfg->dx = dx; cfg->dtLB = dtLB; cfg->npDEM = npDEM; cfg->c = c; cfg->dt = dt; cfg->dt2 = dt2;
   return LBMDEM_OK;
 }
 
@@ -216,14 +260,14 @@ int lbmdem_read_sample(const char* path, int* nbgrains, double** r_out, double**
   double* x1 = (double*)malloc(sizeof(double) * n);
   double* x2 = (double*)malloc(sizeof(double) * n);
   if (!r || !x1 || !x2) { fclose(fp); free(r); free(x1); free(x2); return fail(LBMDEM_ENOMEM, "host alloc"); }
-  const double unit = 1e-3;  // main.c:114
+  const real unit = 1e-3;  // `real r = 1e-3`, main.c:114
   for (int i = 0; i < n; ++i) {
-    double v[3];
+    real v[3];   // fscanf(FLOAT_FORMAT, &g[i].r, ...): the text is converted straight to `real` (main.c:36,39,619)
     for (int k = 0; k < 3; ++k) {
       int ch;
       while ((ch = fgetc(fp)) != EOF && (isspace(ch) || ch == ';')) {}
       if (ch != EOF) ungetc(ch, fp);
-      if (ch == EOF || fscanf(fp, "%le", &v[k]) != 1) {
+      if (ch == EOF || fscanf(fp, sizeof(real) == 4 ? "%e" : "%le", &v[k]) != 1) {
         fclose(fp); free(r); free(x1); free(x2);
         return fail(LBMDEM_EINVAL, "sample '%s' truncated at grain %d", path, i);
       }
@@ -253,7 +297,10 @@ static int paint_into(lbmdem_handle* h, int* obst) {
   launch_obst_paint(obst, h->L, h->n, K.x1, K.x2, h->r, h->rLB, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0, h->pk,
                     h->fs.touched, h->dist ? h->dd.fluidmask : nullptr, h->mincov, h->paint_epoch,
                     h->dist ? h->dd.local_list : nullptr, h->dist ? h->dd.counters + 6 : nullptr, h->dist ? h->dd.cap_l : 0,
-                    h->stream);
+                    // the pair list tells which discs cannot share a node with another one (plain stores instead of
+                    // atomics). Not with distributed grains: a rank's list is only right for the grains it integrates
+                    (h->verlet_ok && h->verlet_tracks_positions && !h->dist && !*h->ovf_host) ? h->V.offsets : nullptr,
+                    (h->verlet_ok && h->verlet_tracks_positions && !h->dist && !*h->ovf_host) ? h->V.nbr : nullptr, h->stream);
   h->slots_valid = false;  // the grain geometry the table is indexed with has changed
   HIP_TRY(hipGetLastError());
   return LBMDEM_OK;
@@ -297,34 +344,46 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
   if (gx1 > cfg->lx) gx1 = cfg->lx;
   L.nxl = gx1 - L.gx0;
   L.xo0 = cfg->x_begin - L.gx0; L.xo1 = cfg->x_end - L.gx0;
-  L.sy = (cfg->ly + 15) & ~15;
+  L.sy = ((cfg->ly + LBMDEM_TILE_Y - 1) / LBMDEM_TILE_Y) * LBMDEM_TILE_Y;
   L.plane = (long)L.nxl * L.sy;
   L.n = n;
-  L.dx = cfg->dx; L.c = cfg->c; L.Mgx = cfg->Mgx; L.Mby = cfg->Mby;
+  L.dx = (real)cfg->dx; L.c = (real)cfg->c; L.Mgx = (real)cfg->Mgx; L.Mby = (real)cfg->Mby;
   const lbmdem_physics& p = cfg->phys;
-  L.s2 = p.s2; L.s3 = p.s3; L.s5 = p.s5; L.s7 = p.s7; L.s8 = p.s8; L.s9 = p.s9;
+  L.s2 = (real)p.s2; L.s3 = (real)p.s3; L.s5 = (real)p.s5; L.s7 = (real)p.s7; L.s8 = (real)p.s8; L.s9 = (real)p.s9;
   L.reduced_lt1 = p.reductionR < 1.0 ? 1 : 0;
   {
-    const double cc = cfg->c * cfg->c;
-    L.rc = 1.0 / cfg->c;
-    L.rcc = 1.0 / cc;
+    const real cr = (real)cfg->c;
+    const real cc = cr * cr;                 // c * c of main.c:976 (real arithmetic)
+    L.rc = (real)(1.0 / cr);                 // RN(1 / b) in `real` for exact_div
+    L.rcc = (real)(1.0 / cc);
     L.cc = cc;
     L.lid6 = 0.0;
-    L.wc_diag = (1. / 36) / cfg->c;
-    L.wc_axis = (1. / 9) / cfg->c;
-    auto all_ones = [](double v) {
+    const real w_diag = 1. / 36, w_axis = 1. / 9;   // real _w[Q] (main.c:53-54)
+    L.wc_diag = w_diag / cr;                 // w[iLB] / c of main.c:1174 (real arithmetic)
+    L.wc_axis = w_axis / cr;
+    auto all_ones = [](real v) {
+#ifdef LBMDEM_SINGLE_PRECISION
+      uint32_t b;
+      memcpy(&b, &v, sizeof b);
+      return (b & 0x7FFFFFu) == 0x7FFFFFu;
+#else
       uint64_t b;
       memcpy(&b, &v, sizeof b);
       return (b & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull;
+#endif
     };
-    L.recip_ok = (!all_ones(cfg->c) && !all_ones(cc) && cfg->c > 1e-4 && cfg->c < 1e4) ? 1 : 0;
+    L.recip_ok = (!all_ones(cr) && !all_ones(cc) && cfg->c > 1e-4 && cfg->c < 1e4) ? 1 : 0;
 #ifdef LBMDEM_AB
     if (const char* e = getenv("LBMDEM_TRUE_DIVISIONS")) if (atoi(e)) L.recip_ok = 0;  // A/B switch
 #endif
   }
   // force scaling, main.c:1329-1331
-  h->fscale12 = p.rho_moy * 9 * p.nu * p.nu / (cfg->dx * (p.tau - 0.5) * (p.tau - 0.5));
-  h->fscale3 = cfg->dx * p.rho_moy * 9 * p.nu * p.nu / (cfg->dx * (p.tau - 0.5) * (p.tau - 0.5));
+  {  // `fhf1[i] *= rho_moy * 9 * nu * nu / (dx * (tau - 0.5) * (tau - 0.5))` with real globals: the numerator is a real
+     // product, `tau - 0.5` makes the denominator -- and the quotient, and the multiplication -- double
+    const real rho_moy = (real)p.rho_moy, nu = (real)p.nu, tau = (real)p.tau, dxr = (real)cfg->dx;
+    h->fscale12 = rho_moy * 9 * nu * nu / (dxr * (tau - 0.5) * (tau - 0.5));
+    h->fscale3 = dxr * rho_moy * 9 * nu * nu / (dxr * (tau - 0.5) * (tau - 0.5));
+  }
 
 #define CREATE_TRY(expr)                                                                             \
   do {                                                                                               \
@@ -339,17 +398,17 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
 
   CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
-  const size_t fbytes = sizeof(double) * 9 * (size_t)L.plane;
+  const size_t fbytes = sizeof(real) * 9 * (size_t)L.plane;
   CREATE_TRY(hipMalloc((void**)&h->f[0], fbytes));
   CREATE_TRY(hipMalloc((void**)&h->f[1], fbytes));
   CREATE_TRY(hipMalloc((void**)&h->obst[0], sizeof(int) * (size_t)L.plane));
   CREATE_TRY(hipMalloc((void**)&h->obst[1], sizeof(int) * (size_t)L.plane));
   // grains: 18 kinematic + r m It rLB xc yc r2 rbl0 + 3 fhf + 8 packed + p = 38 columns
   const size_t cols = 18 + 8 + 3 + 8 + 1 + 9;
-  CREATE_TRY(hipMalloc((void**)&h->gbuf, sizeof(double) * cols * n));
-  CREATE_TRY(hipMemset(h->gbuf, 0, sizeof(double) * cols * n));
+  CREATE_TRY(hipMalloc((void**)&h->gbuf, sizeof(real) * cols * n));
+  CREATE_TRY(hipMemset(h->gbuf, 0, sizeof(real) * cols * n));
   {
-    double* p0 = h->gbuf;
+    real* p0 = h->gbuf;
     for (int b = 0; b < 2; ++b) {
       Kin& K = h->kin[b];
       K.x1 = p0; K.x2 = p0 + n; K.x3 = p0 + 2 * n; K.v1 = p0 + 3 * n; K.v2 = p0 + 4 * n; K.v3 = p0 + 5 * n;
@@ -386,6 +445,9 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
     const int half = (int)ceil(1.4143 * p.reductionR * rmax / cfg->dx) + 2;
     const int spd = (2 * half + 1 + 3) & ~3;
     bool want = spd <= LBMDEM_SPD_MAX && collide_stream_fills_slots(L) && n < (1 << 18);  // grain id: 18 bits of a link descriptor
+#ifdef LBMDEM_SINGLE_PRECISION
+    want = false;   // the table kernel's chord geometry is calibrated for double rounding errors: float build gathers
+#endif
 #ifdef LBMDEM_AB
     if (const char* e = getenv("LBMDEM_NO_SLOTS")) if (atoi(e)) want = false;  // A/B: forces gathered from the lattice
 #endif
@@ -393,7 +455,7 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
       h->fs.half = half;
       h->fs.spd = spd;
       h->fs.hb = (int)ceil(p.reductionR * rmax / cfg->dx) + 1;
-      CREATE_TRY(hipMalloc((void**)&h->fs.tab, sizeof(double) * 8 * (size_t)spd * n));
+      CREATE_TRY(hipMalloc((void**)&h->fs.tab, sizeof(real) * 8 * (size_t)spd * n));
       launch_slots_clear(h->fs, n, h->stream);
       h->slots_clean = true;
     }
@@ -401,22 +463,26 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
   CREATE_TRY(hipMalloc((void**)&h->dpartial, sizeof(double) * 1024));
   {
     // per-grain constants on the host, reference arithmetic: main.c:624-626, 1859
-    std::vector<double> hm(n), hIt(n), hrLB(n);
+    std::vector<real> hr(n), hm(n), hIt(n), hrLB(n), hx1(n), hx2(n);
+    const real reductionR = (real)p.reductionR, dxr = (real)cfg->dx;
     for (int i = 0; i < n; ++i) {
-      hm[i] = RHO_S * REF_PI * r[i] * r[i];
-      hIt[i] = hm[i] * r[i] * r[i] / 2;
-      hrLB[i] = p.reductionR * r[i] / cfg->dx;
+      hr[i] = (real)r[i]; hx1[i] = (real)x1[i]; hx2[i] = (real)x2[i];
+      hm[i] = RHO_S * REF_PI * hr[i] * hr[i];      // rhoS * pi * r * r: a double product (pi), stored as real
+      hIt[i] = hm[i] * hr[i] * hr[i] / 2;          // real arithmetic
+      hrLB[i] = reductionR * hr[i] / dxr;
     }
-    CREATE_TRY(hipMemcpy(h->r, r, sizeof(double) * n, hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(h->m, hm.data(), sizeof(double) * n, hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(h->It, hIt.data(), sizeof(double) * n, hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(h->rLB, hrLB.data(), sizeof(double) * n, hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(h->kin[0].x1, x1, sizeof(double) * n, hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(h->kin[0].x2, x2, sizeof(double) * n, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->r, hr.data(), sizeof(real) * n, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->m, hm.data(), sizeof(real) * n, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->It, hIt.data(), sizeof(real) * n, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->rLB, hrLB.data(), sizeof(real) * n, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->kin[0].x1, hx1.data(), sizeof(real) * n, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->kin[0].x2, hx2.data(), sizeof(real) * n, hipMemcpyHostToDevice));
   }
   // Verlet grid over the fluid domain; grains outside are clamped into the edge cells
   {
-    const double cs = 2 * rmax + p.distVerlet;
+    // (cell edge: the float build's cell coordinates carry a relative error of ~1e-7; a hair more keeps every partner
+    // within the 3 x 3 cells that are scanned)
+    const double cs = (2 * rmax + p.distVerlet) * (sizeof(real) == 4 ? 1.001 : 1.0);
     const double wx = cfg->dx * (cfg->lx - 1), wy = cfg->dx * (cfg->ly - 1);
     if (verlet_alloc(h->V, n, cs, cfg->Mgx, cfg->Mby, wx, wy) != 0) {
       int rc = fail(LBMDEM_ENOMEM, "verlet_alloc failed");
@@ -683,6 +749,7 @@ int lbmdem_verlet_rebuild(lbmdem_handle* h) {
   // by the next sub-step that finds it set, by the next rebuild and by lbmdem_sync (no stall here)
   HIP_TRY(hipMemcpyAsync((void*)h->ovf_host, h->V.overflow, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   h->verlet_ok = true;
+  h->verlet_tracks_positions = true;
   return LBMDEM_OK;
 }
 
@@ -780,9 +847,9 @@ int lbmdem_upload_f(lbmdem_handle* h, const double* f_aos) {
   if (!f_aos) return fail(LBMDEM_EINVAL, "null buffer");
   const LatticeView& L = h->L;
   const size_t cnt = (size_t)L.nxl * L.ly * 9;
-  double* tmp = nullptr;
-  HIP_TRY(hipMalloc((void**)&tmp, sizeof(double) * cnt));
-  hipError_t e = hipMemcpyAsync(tmp, f_aos + (size_t)L.gx0 * L.ly * 9, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream);
+  real* tmp = nullptr;
+  HIP_TRY(hipMalloc((void**)&tmp, sizeof(real) * cnt));
+  hipError_t e = h2d_real(tmp, f_aos + (size_t)L.gx0 * L.ly * 9, cnt, h->stream);
   h->slots_valid = false;  // the populations the link sums were formed from are being replaced
   if (e == hipSuccess) { launch_aos_to_soa(tmp, h->f[h->fcur], L, h->stream); e = hipStreamSynchronize(h->stream); }
   (void)hipFree(tmp);
@@ -797,11 +864,10 @@ int lbmdem_download_f(lbmdem_handle* h, double* f_aos) {
   const LatticeView& L = h->L;
   const int rows = L.xo1 - L.xo0;
   const size_t cnt = (size_t)rows * L.ly * 9;
-  double* tmp = nullptr;
-  HIP_TRY(hipMalloc((void**)&tmp, sizeof(double) * cnt));
+  real* tmp = nullptr;
+  HIP_TRY(hipMalloc((void**)&tmp, sizeof(real) * cnt));
   launch_soa_to_aos(h->f[h->fcur], tmp, L, L.xo0, rows, h->stream);
-  hipError_t e = hipMemcpyAsync(f_aos + (size_t)(L.gx0 + L.xo0) * L.ly * 9, tmp, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  hipError_t e = d2h_real(f_aos + (size_t)(L.gx0 + L.xo0) * L.ly * 9, tmp, cnt, h->stream);
   (void)hipFree(tmp);
   HIP_TRY(e);
   return LBMDEM_OK;
@@ -826,14 +892,13 @@ int lbmdem_download_macro(lbmdem_handle* h, double* rho, double* ux, double* uy)
   const LatticeView& L = h->L;
   const int rows = L.xo1 - L.xo0;
   const size_t cnt = (size_t)rows * L.ly;
-  double* tmp = nullptr;
-  HIP_TRY(hipMalloc((void**)&tmp, sizeof(double) * cnt * 3));
+  real* tmp = nullptr;
+  HIP_TRY(hipMalloc((void**)&tmp, sizeof(real) * cnt * 3));
   launch_macro(h->f[h->fcur], L, L.xo0, rows, tmp, tmp + cnt, tmp + 2 * cnt, h->stream);
   const size_t off = (size_t)(L.gx0 + L.xo0) * L.ly;
-  hipError_t e = hipStreamSynchronize(h->stream);
-  if (e == hipSuccess) e = hipMemcpy(rho + off, tmp, sizeof(double) * cnt, hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(ux + off, tmp + cnt, sizeof(double) * cnt, hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(uy + off, tmp + 2 * cnt, sizeof(double) * cnt, hipMemcpyDeviceToHost);
+  hipError_t e = d2h_real(rho + off, tmp, cnt, h->stream);
+  if (e == hipSuccess) e = d2h_real(ux + off, tmp + cnt, cnt, h->stream);
+  if (e == hipSuccess) e = d2h_real(uy + off, tmp + 2 * cnt, cnt, h->stream);
   (void)hipFree(tmp);
   HIP_TRY(e);
   return LBMDEM_OK;
@@ -863,16 +928,17 @@ int lbmdem_total_density_serial(lbmdem_handle* h, double sum_in, double* sum_out
   if (!sum_out) return fail(LBMDEM_EINVAL, "null buffer");
   const LatticeView& L = h->L;
   const int rows = L.xo1 - L.xo0;
-  const double* f = h->f[h->fcur];
-  double* d_rowsum = nullptr; int* d_k = nullptr; unsigned long long* d_q = nullptr; int* d_flag = nullptr; double* d_row = nullptr;
-  std::vector<double> rowsum(rows), rowbuf((size_t)L.ly * 9);
+  const real* f = h->f[h->fcur];
+  double* d_rowsum = nullptr; int* d_k = nullptr; unsigned long long* d_q = nullptr; int* d_flag = nullptr; real* d_row = nullptr;
+  std::vector<double> rowsum(rows);
+  std::vector<real> rowbuf((size_t)L.ly * 9);
   std::vector<int> kexp(rows), flag(rows);
   std::vector<unsigned long long> quanta(rows);
   hipError_t e = hipMalloc((void**)&d_rowsum, sizeof(double) * rows);
   if (e == hipSuccess) e = hipMalloc((void**)&d_k, sizeof(int) * rows);
   if (e == hipSuccess) e = hipMalloc((void**)&d_q, sizeof(unsigned long long) * rows);
   if (e == hipSuccess) e = hipMalloc((void**)&d_flag, sizeof(int) * rows);
-  if (e == hipSuccess) e = hipMalloc((void**)&d_row, sizeof(double) * L.ly * 9);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_row, sizeof(real) * L.ly * 9);
   auto cleanup = [&] { (void)hipFree(d_rowsum); (void)hipFree(d_k); (void)hipFree(d_q); (void)hipFree(d_flag); (void)hipFree(d_row); };
   if (e != hipSuccess) { cleanup(); HIP_TRY(e); }
   // pass 1: approximate row sums -> the binade the running sum is (most probably) in when it reaches each row
@@ -899,26 +965,26 @@ int lbmdem_total_density_serial(lbmdem_handle* h, double sum_in, double* sum_out
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   if (e != hipSuccess) { cleanup(); HIP_TRY(e); }
   // the chain, with the exact running sum
-  volatile double s = sum_in;   // volatile: every addition rounded to double, whatever the host compiler's flags
+  volatile real s = (real)sum_in;   // the reference's accumulator is a `real` (main.c:1251); volatile: every addition rounded to it
   int replayed = 0;
   for (int r = 0; r < rows; ++r) {
     bool fast = false;
     const double sv = s;
-    if (!flag[r] && sv > 0.0 && isfinite(sv) && quanta[r] < (1ull << 53)) {
+    if (!flag[r] && sv > 0.0 && isfinite(sv) && quanta[r] < (1ull << LBMDEM_REAL_MANT)) {
       int ex = 0;
       (void)frexp(sv, &ex);
       if (ex - 1 == kexp[r]) {
-        const double u = ldexp(1.0, kexp[r] - 52);
-        const double add = (double)quanta[r] * u;          // exact: quanta < 2^53, u a power of two
+        const double u = ldexp(1.0, kexp[r] - (LBMDEM_REAL_MANT - 1));
+        const double add = (double)quanta[r] * u;          // exact: quanta < 2^p, u a power of two
         const double top = ldexp(1.0, kexp[r] + 1);
         const double t = sv + add;                          // exact while the result stays below 2^(k+1) (multiples of u)
-        if (t < top) { s = t; fast = true; }
+        if (t < top) { s = (real)t; fast = true; }
       }
     }
     if (fast) continue;
     // replay this row element by element in the reference's order (y, then q)
     launch_soa_to_aos(f, d_row, L, L.xo0 + r, 1, h->stream);
-    e = hipMemcpyAsync(rowbuf.data(), d_row, sizeof(double) * L.ly * 9, hipMemcpyDeviceToHost, h->stream);
+    e = hipMemcpyAsync(rowbuf.data(), d_row, sizeof(real) * L.ly * 9, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { cleanup(); HIP_TRY(e); }
     const size_t cnt = (size_t)L.ly * 9;
@@ -939,11 +1005,12 @@ int lbmdem_upload_kinematics(lbmdem_handle* h, const double* k9) try {
   CHECK_H(h);
   if (!k9) return fail(LBMDEM_EINVAL, "null buffer");
   const int n = h->n;
-  std::vector<double> soa(9 * (size_t)n);
+  std::vector<real> soa(9 * (size_t)n);
   for (int i = 0; i < n; ++i)
-    for (int c = 0; c < 9; ++c) soa[(size_t)c * n + i] = k9[(size_t)i * 9 + c];
+    for (int c = 0; c < 9; ++c) soa[(size_t)c * n + i] = (real)k9[(size_t)i * 9 + c];
   HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipMemcpy(h->kin[h->kcur].x1, soa.data(), sizeof(double) * 9 * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->kin[h->kcur].x1, soa.data(), sizeof(real) * 9 * n, hipMemcpyHostToDevice));
+  h->verlet_tracks_positions = false;   // the pair list no longer bounds which discs can meet (obst_construction: atomics)
   return LBMDEM_OK;
 } catch (const std::bad_alloc&) {
   return fail(LBMDEM_ENOMEM, "host memory allocation failed");
@@ -955,9 +1022,9 @@ int lbmdem_download_kinematics(lbmdem_handle* h, double* k9) try {
   CHECK_H(h);
   if (!k9) return fail(LBMDEM_EINVAL, "null buffer");
   const int n = h->n;
-  std::vector<double> soa(9 * (size_t)n);
+  std::vector<real> soa(9 * (size_t)n);
   HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipMemcpy(soa.data(), h->kin[h->kcur].x1, sizeof(double) * 9 * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(soa.data(), h->kin[h->kcur].x1, sizeof(real) * 9 * n, hipMemcpyDeviceToHost));
   for (int i = 0; i < n; ++i)
     for (int c = 0; c < 9; ++c) k9[(size_t)i * 9 + c] = soa[(size_t)c * n + i];
   return LBMDEM_OK;
@@ -971,9 +1038,9 @@ int lbmdem_download_fhf(lbmdem_handle* h, double* fhf3) try {
   CHECK_H(h);
   if (!fhf3) return fail(LBMDEM_EINVAL, "null buffer");
   const int n = h->n;
-  std::vector<double> soa(3 * (size_t)n);
+  std::vector<real> soa(3 * (size_t)n);
   HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipMemcpy(soa.data(), h->fhf, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(soa.data(), h->fhf, sizeof(real) * 3 * n, hipMemcpyDeviceToHost));
   for (int i = 0; i < n; ++i)
     for (int c = 0; c < 3; ++c) fhf3[(size_t)i * 3 + c] = soa[(size_t)c * n + i];
   return LBMDEM_OK;
@@ -985,6 +1052,7 @@ int lbmdem_download_fhf(lbmdem_handle* h, double* fhf3) try {
 
 int lbmdem_download_verlet(lbmdem_handle* h, int* cumul, int* neighbours, int cap, int* npairs,
                            int* wallflags) try {
+  SP_UNAVAILABLE("the Verlet list download");
   CHECK_H(h);
   if (!h->verlet_ok) return fail(LBMDEM_EINVAL, "no Verlet list built yet");
   const int n = h->n;
@@ -1025,8 +1093,7 @@ int lbmdem_download_verlet(lbmdem_handle* h, int* cumul, int* neighbours, int ca
 int lbmdem_download_grain_pressure(lbmdem_handle* h, double* p) {
   CHECK_H(h);
   if (!p) return fail(LBMDEM_EINVAL, "null buffer");
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipMemcpy(p, h->gp, sizeof(double) * h->n, hipMemcpyDeviceToHost));
+  HIP_TRY(d2h_real(p, h->gp, (size_t)h->n, h->stream));
   return LBMDEM_OK;
 }
 
@@ -1119,6 +1186,7 @@ int lbmdem_write_vtk(lbmdem_handle* h, const char* dir, int nfile) try {
 }
 
 int lbmdem_set_diagnostics(lbmdem_handle* h, int always) {
+  SP_UNAVAILABLE("the write_DEM diagnostics table");
   if (!h) return fail(LBMDEM_EINVAL, "null handle");
   h->diag_always = always != 0;
   return LBMDEM_OK;
@@ -1127,6 +1195,7 @@ int lbmdem_set_diagnostics(lbmdem_handle* h, int always) {
 // 30 columns per grain in the reference's struct order (main.c:182-197):
 // x1 x2 x3 v1 v2 v3 a1 a2 a3 r m mw It p s f1 f2 ifm fm fr ifr M11 M12 M21 M22 ice slip rw z zz
 int lbmdem_download_grain_table(lbmdem_handle* h, double* t) try {
+  SP_UNAVAILABLE("the write_DEM diagnostics table");
   CHECK_H(h);
   if (!t) return fail(LBMDEM_EINVAL, "null buffer");
   if (!h->diag_valid) return fail(LBMDEM_EINVAL, "no contact diagnostics for the last sub-step (lbmdem_set_diagnostics, or "
@@ -1168,6 +1237,7 @@ int lbmdem_download_grain_table(lbmdem_handle* h, double* t) try {
 // write_DEM, main.c:340-438: DEM%06d.dat (28 tab-separated columns per grain) and one line appended to
 // stats.data. energies8 (may be NULL): KE, PE, SE, IFR, WF, INCE, TSLIP, TRW.
 int lbmdem_write_dem(lbmdem_handle* h, const char* dir, int nfile, double* energies8) try {
+  SP_UNAVAILABLE("write_DEM");
   CHECK_H(h);
   const int n = h->n;
   std::vector<double> t(30 * (size_t)n), hf(3 * (size_t)n);
@@ -1234,6 +1304,7 @@ int lbmdem_write_dem(lbmdem_handle* h, const char* dir, int nfile, double* energ
 }
 
 int lbmdem_write_forces(lbmdem_handle* h, const char* dir, int nfile) try {
+  SP_UNAVAILABLE("write_forces");
   CHECK_H(h);
   const int n = h->n;
   std::vector<double> t(30 * (size_t)n);
@@ -1348,6 +1419,7 @@ static bool rd(FILE* fp, void* p, size_t n) { return fread(p, 1, n, fp) == n; }
 }  // namespace
 
 int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) try {
+  SP_UNAVAILABLE("checkpointing");
   CHECK_H(h);
   CHECK_NOT_SPLIT(h);
   if (!path) return fail(LBMDEM_EINVAL, "null path");
@@ -1408,6 +1480,7 @@ int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) try {
 }
 
 int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) try {
+  SP_UNAVAILABLE("checkpointing");
   if (!path || !out) return fail(LBMDEM_EINVAL, "null argument");
   *out = nullptr;
   FILE* fp = fopen(path, "rb");
@@ -1461,6 +1534,7 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
   }
   h->nbsteps = H.nbsteps;
   h->verlet_ok = H.verlet_ok != 0;
+  h->verlet_tracks_positions = h->verlet_ok;
   if (h->verlet_ok) {  // the entry -> grain map is derived from the offsets
     launch_fill_own(h->V, n, h->stream);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { lbmdem_destroy(h); return fail(LBMDEM_EHIP, "k_fill_own failed"); }
@@ -1541,18 +1615,20 @@ int lbmdem_profile_read(lbmdem_handle* h, double* mean_ms, long* launches) {
 long lbmdem_halo_doubles(lbmdem_handle* h) { return h ? 9L * h->cfg.halo * h->L.ly : -1; }
 
 int lbmdem_halo_pack2(lbmdem_handle* h, void* buf_lo, void* buf_hi) {
+  SP_UNAVAILABLE("the strip decomposition");
   CHECK_H(h);
   const LatticeView& L = h->L;
   const int H = h->cfg.halo;
   if (!buf_lo && !buf_hi) return LBMDEM_OK;
   if (H < 1) return fail(LBMDEM_EINVAL, "no halo on this handle");
   if (L.xo1 - L.xo0 < H) return fail(LBMDEM_EINVAL, "strip narrower than the halo");
-  launch_halo_pack(h->f[h->fcur], L, L.xo0, L.xo1 - H, H, (double*)buf_lo, (double*)buf_hi, h->stream);
+  launch_halo_pack(h->f[h->fcur], L, L.xo0, L.xo1 - H, H, (real*)buf_lo, (real*)buf_hi, h->stream);
   HIP_TRY(hipGetLastError());
   return LBMDEM_OK;
 }
 
 int lbmdem_halo_unpack2(lbmdem_handle* h, const void* buf_lo, const void* buf_hi) {
+  SP_UNAVAILABLE("the strip decomposition");
   CHECK_H(h);
   const LatticeView& L = h->L;
   const int H = h->cfg.halo;
@@ -1560,7 +1636,7 @@ int lbmdem_halo_unpack2(lbmdem_handle* h, const void* buf_lo, const void* buf_hi
   if (H < 1) return fail(LBMDEM_EINVAL, "no halo on this handle");
   if ((buf_lo && L.xo0 - H < 0) || (buf_hi && L.xo1 + H > L.nxl)) return fail(LBMDEM_EINVAL, "no halo rows on that side");
   if (!buf_lo && !buf_hi) return LBMDEM_OK;
-  launch_halo_unpack(h->f[h->fcur], L, L.xo0 - H, L.xo1, H, (const double*)buf_lo, (const double*)buf_hi, h->stream);
+  launch_halo_unpack(h->f[h->fcur], L, L.xo0 - H, L.xo1, H, (const real*)buf_lo, (const real*)buf_hi, h->stream);
   HIP_TRY(hipGetLastError());
   return LBMDEM_OK;
 }
@@ -1604,6 +1680,7 @@ static int dist_enable_caps(lbmdem_handle* h, int M, long cap_g, long cap_t, lon
 }
 
 int lbmdem_dist_enable(lbmdem_handle* h, int margin_rows) try {
+  SP_UNAVAILABLE("the strip decomposition with distributed grains");
   CHECK_H(h);
   const lbmdem_config& c = h->cfg;
   if (h->dist) return fail(LBMDEM_EINVAL, "already enabled");
@@ -1738,13 +1815,13 @@ int lbmdem_dist_pack2(lbmdem_handle* h, int kind, void* buf_lo, void* buf_hi) {
   CHECK_H(h);
   if (!h->dist) return fail(LBMDEM_EINVAL, "lbmdem_dist_enable first");
   if (!buf_lo && !buf_hi) return LBMDEM_OK;
-  if (kind == LBMDEM_MSG_KIN) launch_dist_pack_kin(h->dd, h->kin[h->kcur], (double*)buf_lo, (double*)buf_hi, h->stream);
-  else if (kind == LBMDEM_MSG_FHF) launch_dist_pack_fhf(h->dd, h->fhf, h->n, (double*)buf_lo, (double*)buf_hi, h->stream);
+  if (kind == LBMDEM_MSG_KIN) launch_dist_pack_kin(h->dd, h->kin[h->kcur], (real*)buf_lo, (real*)buf_hi, h->stream);
+  else if (kind == LBMDEM_MSG_FHF) launch_dist_pack_fhf(h->dd, h->fhf, h->n, (real*)buf_lo, (real*)buf_hi, h->stream);
   else if (kind == LBMDEM_MSG_TABLES) {
     CHECK_NOT_SPLIT(h);
     if (!h->slots_valid) return fail(LBMDEM_EINVAL, "table messages are packed between collide_stream and forces_fluid");
     // both neighbours in one launch (a null buffer skips the side)
-    double* const bufs[2] = {(double*)buf_lo, (double*)buf_hi};
+    real* const bufs[2] = {(real*)buf_lo, (real*)buf_hi};
     const int* const lists[2] = {h->dd.strad_list[0], h->dd.strad_list[1]};
     const int* const counts[2] = {h->dd.counters + 2, h->dd.counters + 3};
     launch_forces_table_pack(h->f[h->fcur], h->obst[h->ocur], h->L, gview(h), h->fs, lists, counts, h->dd.cap_t, bufs,
@@ -1759,11 +1836,11 @@ int lbmdem_dist_unpack2(lbmdem_handle* h, int kind, const void* buf_lo, const vo
   if (!h->dist) return fail(LBMDEM_EINVAL, "lbmdem_dist_enable first");
   if (!buf_lo && !buf_hi) return LBMDEM_OK;
   if (kind == LBMDEM_MSG_KIN)
-    launch_dist_unpack_kin(h->dd, h->kin[h->kcur], (const double*)buf_lo, (const double*)buf_hi, h->n, h->fs.error, h->stream);
+    launch_dist_unpack_kin(h->dd, h->kin[h->kcur], (const real*)buf_lo, (const real*)buf_hi, h->n, h->fs.error, h->stream);
   else if (kind == LBMDEM_MSG_FHF)
-    launch_dist_unpack_fhf(h->dd, h->fhf, h->n, (const double*)buf_lo, (const double*)buf_hi, h->stream);
+    launch_dist_unpack_fhf(h->dd, h->fhf, h->n, (const real*)buf_lo, (const real*)buf_hi, h->stream);
   else if (kind == LBMDEM_MSG_TABLES)
-    launch_dist_merge_tables(h->fs, (const double*)buf_lo, (const double*)buf_hi, h->dd.cap_t, h->stream);
+    launch_dist_merge_tables(h->fs, (const real*)buf_lo, (const real*)buf_hi, h->dd.cap_t, h->stream);
   else return fail(LBMDEM_EINVAL, "unknown message kind");
   HIP_TRY(hipGetLastError());
   return LBMDEM_OK;
@@ -1919,6 +1996,7 @@ int lbmdem_fhf_device(lbmdem_handle* h, void** fhf, void** owner_mask) {
 }
 
 int lbmdem_fhf_export(lbmdem_handle* h, void* dev_buf) {
+  SP_UNAVAILABLE("the strip decomposition");
   CHECK_H(h);
   if (!dev_buf) return fail(LBMDEM_EINVAL, "null buffer");
   HIP_TRY(hipMemcpyAsync(dev_buf, h->fhf, sizeof(double) * 3 * h->n, hipMemcpyDeviceToDevice, h->stream));
@@ -1926,6 +2004,7 @@ int lbmdem_fhf_export(lbmdem_handle* h, void* dev_buf) {
 }
 
 int lbmdem_fhf_import(lbmdem_handle* h, const void* dev_buf) {
+  SP_UNAVAILABLE("the strip decomposition");
   CHECK_H(h);
   if (!dev_buf) return fail(LBMDEM_EINVAL, "null buffer");
   HIP_TRY(hipMemcpyAsync(h->fhf, dev_buf, sizeof(double) * 3 * h->n, hipMemcpyDeviceToDevice, h->stream));
@@ -2029,6 +2108,7 @@ int lbmdem_comm_destroy(lbmdem_comm* c) {
 }
 
 int lbmdem_comm_create(const void* id128, int rank, int world, int device, lbmdem_comm** out) try {
+  SP_UNAVAILABLE("the RCCL transport");
   if (!id128 || !out || world < 1 || rank < 0 || rank >= world) return fail(LBMDEM_EINVAL, "bad lbmdem_comm_create arguments");
   *out = nullptr;
   int rc = rccl_load();

@@ -7,6 +7,27 @@
 #include <stdint.h>
 
 // ---------------------------------------------------------------------------------------------
+// `real` -- the reference's arithmetic type (main.c:34-40): double, or float when the reference is compiled
+// -DSINGLE_PRECISION. The library is built once per type (liblbmdem_hip.so / liblbmdem_hip_sp.so, csrc/Makefile SP=1);
+// every device formula is written with the reference's own literals and declarations, so that the usual arithmetic
+// conversions promote exactly where the reference's C does (an `1.`, `0.5` or `4.5` literal, sqrt(), fabs() make a
+// sub-expression double even in the float build; an int literal does not). Host buffers at the C ABI are double in
+// both builds (every float is a double).
+// ---------------------------------------------------------------------------------------------
+#ifdef LBMDEM_SINGLE_PRECISION
+typedef float real;
+typedef float2 real2;
+#define LBMDEM_REAL_MANT 24          /* significand bits incl. the hidden one */
+#define LBMDEM_TILE_Y 32             /* nodes per 128-byte line */
+#else
+typedef double real;
+typedef double2 real2;
+#define LBMDEM_REAL_MANT 53
+#define LBMDEM_TILE_Y 16
+#endif
+__host__ __device__ __forceinline__ real2 make_real2(real a, real b) { real2 v; v.x = a; v.y = b; return v; }
+
+// ---------------------------------------------------------------------------------------------
 // Device-side views (passed by value to kernels)
 // ---------------------------------------------------------------------------------------------
 
@@ -20,29 +41,29 @@ struct LatticeView {
   int nxl;       // local rows (owned + halo)
   int xo0, xo1;  // owned local rows [xo0, xo1)
   int sy;        // row pitch in elements
-  long plane;    // nxl * sy: nodes of the slab (a lattice is 9 * plane doubles)
+  long plane;    // nxl * sy: nodes of the slab (a lattice is 9 * plane reals)
   int n;         // nbgrains; also the obst code of the lattice-edge walls (main.c:676,681)
-  double dx, c, Mgx, Mby;
-  double s2, s3, s5, s7, s8, s9;
+  real dx, c, Mgx, Mby;
+  real s2, s3, s5, s7, s8, s9;
   int reduced_lt1;  // phys.reductionR < 1: reduced discs lie strictly inside the grains (always, in the reference)
   // x / c and x / (c*c) as correctly rounded quotients from the reciprocals (exact_div in lbm_kernels.hip);
   // recip_ok = 0 when a divisor's significand is all ones (the one case the construction does not cover)
-  double rc, rcc;
+  real rc, rcc;
   int recip_ok;
-  double lid6;               // EXTENSION: uw_h / 6 of the lid terms commented out at main.c:1129-1130; 0 = off
-  double cc;                 // c * c
-  double wc_diag, wc_axis;   // w_q / c for the diagonal and the axis directions (main.c:1174,1184)
+  real lid6;               // EXTENSION: uw_h / 6 of the lid terms commented out at main.c:1129-1130; 0 = off
+  real cc;                 // c * c
+  real wc_diag, wc_axis;   // w_q / c for the diagonal and the axis directions (main.c:1174,1184)
 };
 
 // Grain state used by the fluid kernels. xc, yc, r2, rbl0 are the lattice-unit centre, squared
 // reduced radius and unreduced radius (main.c:1009-1013), refreshed by every obst_construction.
 struct GrainFluidView {
-  const double* x1; const double* x2;
-  const double* v1; const double* v2; const double* v3;
-  const double* xc; const double* yc; const double* r2; const double* rbl0;
+  const real* x1; const real* x2;
+  const real* v1; const real* v2; const real* v3;
+  const real* xc; const real* yc; const real* r2; const real* rbl0;
   // the same eight values packed per grain, [n][8] = {x1, x2, v1, v2, v3, xc, yc, r2}: one 64-byte
   // record, fetched with four 16-byte loads by the fluid kernels
-  const double* pk;
+  const real* pk;
   // Lowest grain index covering a node, for nodes covered by MORE than one disc (written by the rasteriser when its
   // atomicMax finds a previous owner): (epoch & 0xFFF) << 20 | (0xFFFFF - index), valid when the epoch matches the
   // last rasterisation. Decides `act` where discs overlap (main.c:1039-1052 sees the map as it was when the OWNER was
@@ -61,7 +82,7 @@ struct GrainFluidView {
 // A slot holds LBMDEM_SLOT_EMPTY unless the fused kernel of this step wrote it. `touched[i]` = some node of grain
 // i's disc is also covered by another grain's disc (set by the rasteriser). tab == nullptr: feature off.
 struct ForceSlots {
-  double* tab;
+  real* tab;
   unsigned char* touched;
   int spd;   // slots per direction (2 * half + 1 rounded up)
   int half;
@@ -76,23 +97,23 @@ struct ForceSlots {
   const int* local_count;
   int local_cap;
 };
-#define LBMDEM_SLOT_EMPTY 0x7FF8C0DE5107E117ull  /* a quiet NaN no arithmetic produces */
+#define LBMDEM_SLOT_EMPTY 0x7FF8C0DE5107E117ull  /* a quiet NaN no arithmetic produces (double build; the float build has no table) */
 constexpr int LBMDEM_SPD_MAX = 64;               // larger grains (reduced radius > ~20 nodes): feature off
 
 struct DemParams {
   int n;
-  double dt, dt2;
-  double kg, nug, kt, mu, murf;            // grain-grain (main.c:104-113)
-  double km, num, ktm, mumb, mum, nugt;    // walls
-  double Mgx, Mdx, Mby, Mhy;               // DEM wall positions (main.c:201-204,1555-1561)
-  double wallT_vel;                        // amp*freq*cos(freq*t) (main.c:855)
-  double xG, yG;
-  double distVerlet;
+  real dt, dt2;
+  real kg, nug, kt, mu, murf;            // grain-grain (main.c:104-113)
+  real km, num, ktm, mumb, mum, nugt;    // walls
+  real Mgx, Mdx, Mby, Mhy;               // DEM wall positions (main.c:201-204,1555-1561)
+  double wallT_vel;                      // amp*freq*cos(freq*t) (main.c:855): cos() makes it a double in either build
+  real xG, yG;
+  real distVerlet;
 };
 
 // kinematic state, SoA; two copies ping-pong across DEM sub-steps
 struct Kin {
-  double *x1, *x2, *x3, *v1, *v2, *v3, *a1, *a2, *a3;
+  real *x1, *x2, *x3, *v1, *v2, *v3, *a1, *a2, *a3;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -102,30 +123,31 @@ struct Kin {
 // lbm_kernels.hip
 void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st);
 // fills xc, yc, r2, rbl0, pk (per-grain lattice geometry, main.c:1009-1013) and paints the reduced discs
-void launch_obst_paint(int* obst, const LatticeView& L, int n, const double* x1, const double* x2, const double* r,
-                       const double* rLB, const double* v1, const double* v2, const double* v3, double* xc,
-                       double* yc, double* r2, double* rbl0, double* pk, unsigned char* touched,
+void launch_obst_paint(int* obst, const LatticeView& L, int n, const real* x1, const real* x2, const real* r,
+                       const real* rLB, const real* v1, const real* v2, const real* v3, real* xc,
+                       real* yc, real* r2, real* rbl0, real* pk, unsigned char* touched,
                        const unsigned char* mask, unsigned* mincov, unsigned epoch, const int* list,
-                       const int* list_count, int list_cap, hipStream_t st);
-void launch_collide_stream(const double* fin, double* fout, const int* obst_old, const int* obst_new,
+                       const int* list_count, int list_cap, const int* verlet_offsets, const int* verlet_nbr,
+                       hipStream_t st);   // verlet_*: the symmetric pair list (null: every grain takes the atomic path)
+void launch_collide_stream(const real* fin, real* fout, const int* obst_old, const int* obst_new,
                            const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, hipStream_t st);
 // the two edge-row ranges [lo0, lo1) and [hi0, hi1) of a strip (either may be empty): one launch when they are equally
 // wide (two segments), else one launch_collide_stream each
-void launch_collide_stream_edges(const double* fin, double* fout, const int* obst_old, const int* obst_new,
+void launch_collide_stream_edges(const real* fin, real* fout, const int* obst_old, const int* obst_new,
                                  const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, int lo0, int lo1,
                                  int hi0, int hi1, hipStream_t st);
 // true when launch_collide_stream(..., S) with S.tab != nullptr fills the table (the marching kernel does)
 bool collide_stream_fills_slots(const LatticeView& L);
 void launch_slots_clear(const ForceSlots& S, int n, hipStream_t st);
 // parity forces from the slot table (resets it to empty); grains whose table is incomplete gather from f
-void launch_forces_slots(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
-                         const ForceSlots& S, double scale12, double scale3, double* fhf, unsigned char* owner,
+void launch_forces_slots(const real* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
+                         const ForceSlots& S, double scale12, double scale3, real* fhf, unsigned char* owner,
                          int fast, hipStream_t st);
 // strip decomposition: this rank's part of the tables of the listed grains (owned by a neighbour rank), completed
 // and written as {count; count x {id, 8 * spd slots}} to a message buffer
-void launch_forces_table_pack(const double* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
+void launch_forces_table_pack(const real* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
                               const ForceSlots& S, const int* const list[2], const int* const list_count[2], int cap,
-                              double* const buf[2], hipStream_t st);
+                              real* const buf[2], hipStream_t st);
 
 // dist_kernels.hip -- strip decomposition with the grains distributed over the ranks (strips.py)
 struct DistDevice {
@@ -139,49 +161,49 @@ struct DistDevice {
   int* counters_alt;         // the other set: zeroed during this period, used by the next (the host swaps the two)
   int cap_g, cap_t, cap_l;
 };
-struct DistGeom { double lo, hi, margin, dx, Mgx; int has_lo, has_hi, first, last, gx0, nxl; };
+struct DistGeom { real lo, hi, margin, dx, Mgx; int has_lo, has_hi, first, last, gx0, nxl; };
 int dist_alloc(DistDevice& D, int n, int cap_g, int cap_t, int cap_l);
 void dist_free(DistDevice& D);
 // ownership, masks and the send / straddler lists from the current positions of the grains that were active
-void launch_dist_classify(const DistDevice& D, const DistGeom& Gm, int n, const double* x1, const double* r,
-                          const double* rLB, unsigned char* owner, int* error, hipStream_t st);
+void launch_dist_classify(const DistDevice& D, const DistGeom& Gm, int n, const real* x1, const real* r,
+                          const real* rLB, unsigned char* owner, int* error, hipStream_t st);
 // messages: {count; count x {id, x1 x2 x3 v1 v2 v3 a1 a2 a3}} / {count x {fhf1 fhf2 fhf3}} in the order of that list
 // (both sides in one launch: `lo` / `hi` = the low / high neighbour's buffer, null to skip)
-void launch_dist_pack_kin(const DistDevice& D, const Kin& K, double* lo, double* hi, hipStream_t st);
-void launch_dist_unpack_kin(const DistDevice& D, const Kin& K, const double* lo, const double* hi, int n, int* error,
+void launch_dist_pack_kin(const DistDevice& D, const Kin& K, real* lo, real* hi, hipStream_t st);
+void launch_dist_unpack_kin(const DistDevice& D, const Kin& K, const real* lo, const real* hi, int n, int* error,
                             hipStream_t st);
-void launch_dist_pack_fhf(const DistDevice& D, const double* fhf, int n, double* lo, double* hi, hipStream_t st);
-void launch_dist_unpack_fhf(const DistDevice& D, double* fhf, int n, const double* lo, const double* hi, hipStream_t st);
-void launch_dist_merge_tables(const ForceSlots& S, const double* lo, const double* hi, int cap, hipStream_t st);
+void launch_dist_pack_fhf(const DistDevice& D, const real* fhf, int n, real* lo, real* hi, hipStream_t st);
+void launch_dist_unpack_fhf(const DistDevice& D, real* fhf, int n, const real* lo, const real* hi, hipStream_t st);
+void launch_dist_merge_tables(const ForceSlots& S, const real* lo, const real* hi, int cap, hipStream_t st);
 void launch_dist_poison(const DistDevice& D, const Kin& a, const Kin& b, int n, hipStream_t st);
-void launch_forces_parity(const double* f, const int* obst, const LatticeView& L,
-                          const GrainFluidView& G, double scale12, double scale3, double* fhf,
+void launch_forces_parity(const real* f, const int* obst, const LatticeView& L,
+                          const GrainFluidView& G, double scale12, double scale3, real* fhf,
                           unsigned char* owner, hipStream_t st);
-void launch_forces_fast(const double* f, const int* obst, const LatticeView& L,
-                        const GrainFluidView& G, double scale12, double scale3, double* fhf,
+void launch_forces_fast(const real* f, const int* obst, const LatticeView& L,
+                        const GrainFluidView& G, double scale12, double scale3, real* fhf,
                         unsigned char* owner, hipStream_t st);
-void launch_aos_to_soa(const double* aos_rows, double* f, const LatticeView& L, hipStream_t st);
-void launch_soa_to_aos(const double* f, double* aos_rows, const LatticeView& L, int xl0, int nrows,
+void launch_aos_to_soa(const real* aos_rows, real* f, const LatticeView& L, hipStream_t st);
+void launch_soa_to_aos(const real* f, real* aos_rows, const LatticeView& L, int xl0, int nrows,
                        hipStream_t st);
-void launch_fill_equilibrium(double* f, const LatticeView& L, hipStream_t st);
-void launch_macro(const double* f, const LatticeView& L, int xl0, int nrows, double* rho, double* ux,
-                  double* uy, hipStream_t st);
-void launch_density_partial(const double* f, const LatticeView& L, double* partial, int nblocks,
+void launch_fill_equilibrium(real* f, const LatticeView& L, hipStream_t st);
+void launch_macro(const real* f, const LatticeView& L, int xl0, int nrows, real* rho, real* ux,
+                  real* uy, hipStream_t st);
+void launch_density_partial(const real* f, const LatticeView& L, double* partial, int nblocks,
                             hipStream_t st);
 // the reference's serial total density (see k_density_rowquanta): per owned row an approximate sum, then the integer
 // number of quanta 2^(kexp[row] - 52) the row adds + a flag when the shortcut does not apply to the row
-void launch_density_rowsum(const double* f, const LatticeView& L, double* rowsum, hipStream_t st);
-void launch_density_rowquanta(const double* f, const LatticeView& L, const int* kexp, unsigned long long* quanta,
+void launch_density_rowsum(const real* f, const LatticeView& L, double* rowsum, hipStream_t st);
+void launch_density_rowquanta(const real* f, const LatticeView& L, const int* kexp, unsigned long long* quanta,
                               int* flags, hipStream_t st);
 // both sides in one launch; a null buffer skips the side
-void launch_halo_pack(const double* f, const LatticeView& L, int xl0_lo, int xl0_hi, int nrows, double* buf_lo,
-                      double* buf_hi, hipStream_t st);
-void launch_halo_unpack(double* f, const LatticeView& L, int xl0_lo, int xl0_hi, int nrows, const double* buf_lo,
-                        const double* buf_hi, hipStream_t st);
+void launch_halo_pack(const real* f, const LatticeView& L, int xl0_lo, int xl0_hi, int nrows, real* buf_lo,
+                      real* buf_hi, hipStream_t st);
+void launch_halo_unpack(real* f, const LatticeView& L, int xl0_lo, int xl0_hi, int nrows, const real* buf_lo,
+                        const real* buf_hi, hipStream_t st);
 // the five float32 fields of write_vtk (main.c:284-323), [ly][lx] order, owned rows only
-void launch_vtk_fields(const double* f, const int* obst, const LatticeView& L, const double* gp,
-                       const double* v1, const double* v2, const double* a1, const double* a2,
-                       double rho_moy, float* grain_pressure, float* grain_velocity,
+void launch_vtk_fields(const real* f, const int* obst, const LatticeView& L, const real* gp,
+                       const real* v1, const real* v2, const real* a1, const real* a2,
+                       real rho_moy, float* grain_pressure, float* grain_velocity,
                        float* grain_acceleration, float* fluid_pressure, float* fluid_velocity,
                        hipStream_t st);
 
@@ -189,7 +211,7 @@ void launch_vtk_fields(const double* f, const int* obst, const LatticeView& L, c
 struct VerletDevice {
   // uniform grid
   int ncx, ncy;
-  double ox, oy, cs;
+  real ox, oy, cs;
   unsigned int* keys_in; unsigned int* keys_out;
   int* vals_in; int* vals_out;
   int* cell_start; int* cell_end;
@@ -204,26 +226,26 @@ struct VerletDevice {
   unsigned char* wallflags;  // n
   int* overflow;             // device flag
 };
-int verlet_alloc(VerletDevice& V, int n, double cs, double ox, double oy, double wx, double wy);
+int verlet_alloc(VerletDevice& V, int n, real cs, real ox, real oy, real wx, real wy);
 void verlet_free(VerletDevice& V);
 // returns 0 or the hipError_t of the failing call (hipCUB sort / scan, memset, launch)
-int launch_verlet_rebuild(VerletDevice& V, const Kin& K, const double* r, const DemParams& P,
+int launch_verlet_rebuild(VerletDevice& V, const Kin& K, const real* r, const DemParams& P,
                           hipStream_t st);
 // Buffers of the order-dependent contact diagnostics fr, ice, slip, rw (main.c:782-789, 840-843, 851, 893,
 // 916-919, 942, 1462-1466, 1490-1494): they depend on "previous contact" carries (pft, pff, pf, ic,
 // main.c:130-131) that thread through the reference's serial contact loop. Only used by the rare sub-steps
 // that produce write_DEM's table (see launch_diag_extra).
 struct DiagExtra {
-  double *fr, *ice, *slip, *rw;          // [n] results
-  double* a1gc;                          // [n] a1 after the grain contacts; the wall pass keeps adding (= g[].a1 then)
-  double *e_ft, *e_f3, *e_avt, *e_av3;   // [cap] per list entry with own < partner: ft, f3, |vt dt|, |v3_own dt|
-  double *e_dslip, *e_drw;               // [cap] its contribution to slip / rw once the carries are known
+  real *fr, *ice, *slip, *rw;          // [n] results
+  real* a1gc;                          // [n] a1 after the grain contacts; the wall pass keeps adding (= g[].a1 then)
+  real *e_ft, *e_f3, *e_avt, *e_av3;   // [cap] per list entry with own < partner: ft, f3, |vt dt|, |v3_own dt|
+  real *e_dslip, *e_drw;               // [cap] its contribution to slip / rw once the carries are known
   unsigned char* e_touched;              // [cap] 1 = entry with own < partner and dn < 0
   int* wlist;                            // [4][n] wall candidate lists (bottom, top, left, right), grains ascending
   int* wcount;                           // [4]
-  double* carry;                         // pft, pff, pf: persist from sub-step to sub-step
+  real* carry;                         // pft, pff, pf: persist from sub-step to sub-step
 };
-int diag_extra_alloc(DiagExtra& X, int n, long cap, double* carry);
+int diag_extra_alloc(DiagExtra& X, int n, long cap, real* carry);
 
 // Where the carries come from when the sub-step before was not a diagnostic one: every ordinary sub-step leaves, per
 // tile of DEM_TILE consecutive grains and per kind of contact that assigns a carry (main.c:784-786/1410-1411 grain
@@ -235,8 +257,8 @@ constexpr int DEM_TILE = 64;
 enum : int { CARRY_GRAIN = 0, CARRY_BOTTOM = 1, CARRY_LEFT = 2, CARRY_RIGHT = 3 };
 struct CarryTrack {
   long long* stamp;  // [tiles][4] sequence number of the sub-step that wrote the record, -1: none
-  double* val;       // [tiles][4][2] ft, f3
-  double* carry;     // [3] pft, pff, pf
+  real* val;       // [tiles][4][2] ft, f3
+  real* carry;     // [3] pft, pff, pf
   int tiles;
   long long* who;       // [tiles][4] the contact of the record: (grain << 32) | partner (walls: partner 0)
   long long* best_key;  // [3][2] left by launch_carry_resolve: {(stamp + 1) * 4 + kind, who} of the record each carry came from
@@ -248,10 +270,10 @@ void launch_carry_resolve(const CarryTrack& T, long long min_stamp, hipStream_t 
 void diag_extra_free(DiagExtra& X);
 // after the DIAG sub-step kernel: carries scanned over the contacts in the reference's order, per-grain sums,
 // then the four wall loops replayed serially
-void launch_diag_extra(const DiagExtra& X, const Kin& in, const double* r, const VerletDevice& V,
+void launch_diag_extra(const DiagExtra& X, const Kin& in, const real* r, const VerletDevice& V,
                        const DemParams& P, int film, hipStream_t st);
 void launch_fill_own(const VerletDevice& V, int n, hipStream_t st);
-void launch_dem_substep(const Kin& in, const Kin& out, const double* r, const double* m,
-                        const double* It, const double* fhf, const VerletDevice& V, double* pout,
-                        const DemParams& P, int film, double* diag, const DiagExtra* X, const unsigned char* active,
+void launch_dem_substep(const Kin& in, const Kin& out, const real* r, const real* m,
+                        const real* It, const real* fhf, const VerletDevice& V, real* pout,
+                        const DemParams& P, int film, real* diag, const DiagExtra* X, const unsigned char* active,
                         const CarryTrack* track, long long stamp, const unsigned char* owner, hipStream_t st);

@@ -41,18 +41,18 @@ def reference_available() -> bool:
     return os.path.isfile(os.path.join(REF_ROOT, "src", "main.c"))
 
 
-def ref_lib_path(lx: int, ly: int, fast: bool = False) -> str:
-    return os.path.join(HERE, "_ref", f"libref_{'fast_' if fast else ''}{lx}x{ly}.so")
+def ref_lib_path(lx: int, ly: int, fast: bool = False, sp: bool = False) -> str:
+    return os.path.join(HERE, "_ref", f"libref_{'fast_' if fast else ''}{'sp_' if sp else ''}{lx}x{ly}.so")
 
 
-def build_ref(lx: int, ly: int, fast: bool = False) -> str | None:
-    """Compile the reference TU for one lattice size (only where /root/reference exists)."""
-    path = ref_lib_path(lx, ly, fast)
+def build_ref(lx: int, ly: int, fast: bool = False, sp: bool = False) -> str | None:
+    """Compile the reference TU for one lattice size (only where /root/reference exists). sp: -DSINGLE_PRECISION."""
+    path = ref_lib_path(lx, ly, fast, sp)
     if os.path.exists(path):
         return path
     if not reference_available():
         return None
-    subprocess.run(["make", "-s", "-C", HERE, "ref_fast" if fast else "ref", f"LX={lx}", f"LY={ly}"],
+    subprocess.run(["make", "-s", "-C", HERE, "ref_sp" if sp else ("ref_fast" if fast else "ref"), f"LX={lx}", f"LY={ly}"],
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return path if os.path.exists(path) else None
 
@@ -209,8 +209,8 @@ class Reference:
     """The unmodified reference TU, compiled for one (lx, ly). One instance per process:
     the reference keeps its state in globals."""
 
-    def __init__(self, lx, ly, sample_path, fast=False):
-        path = build_ref(lx, ly, fast)
+    def __init__(self, lx, ly, sample_path, fast=False, sp=False):
+        path = build_ref(lx, ly, fast, sp)
         if path is None:
             raise FileNotFoundError("reference build not available")
         self.L = C.CDLL(path)

@@ -144,13 +144,13 @@ def run_dem_case(sim, case):
     return out
 
 
-def _generate(name, case, q):
+def _generate(name, case, q, sp=False):
     import pyoracle as po
     lx, ly = case["lx"], case["ly"]
     tmp = tempfile.NamedTemporaryFile("w", suffix=".data", delete=False)
     tmp.close()
     po.write_sample(tmp.name, case["r_mm"], case["x_mm"], case["y_mm"], comment=f"#golden {name}")
-    R = po.Reference(lx, ly, tmp.name)
+    R = po.Reference(lx, ly, tmp.name, sp=sp)      # sp: the reference compiled -DSINGLE_PRECISION (main.c:34-40)
     os.unlink(tmp.name)
     if case["kind"] == "lbm":
         res = run_lbm_case(R, case)
@@ -251,15 +251,18 @@ REAL_CASES = {
 GRAINS_FROM = {"real_50000_8192x4096": "real_50000_4096x4096"}
 
 
-def _real_case(name, q):
+F32_REAL_CASES = {"real_a08d83_600x500_f32": ("a08d83.data", 600, 500, (1, 10, 20))}
+
+
+def _real_case(name, q, sp=False):
     """Runs in its own process: the reference on one of its shipped samples; returns the parsed grains
     (exactly the doubles the reference works with) and SHA-256 digests of its state."""
     import pyoracle as po
-    fname, lx, ly, dumps = REAL_CASES[name]
-    po.build_ref(lx, ly)
+    fname, lx, ly, dumps = (F32_REAL_CASES if sp else REAL_CASES)[name]
+    po.build_ref(lx, ly, sp=sp)
     devnull = os.open(os.devnull, os.O_WRONLY)
     os.dup2(devnull, 1)
-    R = po.Reference(lx, ly, os.path.join(po.REF_ROOT, "bin", fname))
+    R = po.Reference(lx, ly, os.path.join(po.REF_ROOT, "bin", fname), sp=sp)
     g0 = R.get_grains()
     s = R.scalars()
     out = dict(r=g0[:, po.COL["r"]].copy(), x1=g0[:, 0].copy(), x2=g0[:, 1].copy(),
@@ -295,10 +298,36 @@ def make_real_fixtures(only=None):
         print("wrote", name, {k: str(v)[:20] for k, v in res.items() if k.startswith(("sha_f", "mass"))})
 
 
+def make_f32_fixtures():
+    """<case>_f32.npz: the same cases on the reference compiled -DSINGLE_PRECISION (typedef float real, main.c:34-40):
+    the oracle of the float build of the library (liblbmdem_hip_sp.so). Stored as float64 arrays holding float values."""
+    for name, case in cases().items():
+        if case["kind"] == "output":
+            continue
+        q = mp.Queue()
+        p = mp.Process(target=_generate, args=(name, case, q, True))
+        p.start()
+        res = q.get()
+        p.join()
+        np.savez_compressed(os.path.join(HERE, name + "_f32.npz"), **pack(name, case, res))
+        print("wrote", name + "_f32")
+    for name in F32_REAL_CASES:
+        q = mp.Queue()
+        p = mp.Process(target=_real_case, args=(name, q, True))
+        p.start()
+        res = q.get()
+        p.join()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
+        print("wrote", name, {k: str(v)[:20] for k, v in res.items() if k.startswith(("sha_f", "mass"))})
+
+
 def main():
     import pyoracle as po
     if not po.reference_available():
         raise SystemExit("the reference is not present here; golden vectors can only be made in the build container")
+    if len(sys.argv) > 1 and sys.argv[1] == "--f32":
+        make_f32_fixtures()
+        return
     if len(sys.argv) > 1:      # python make_golden.py real_50000_8192x4096 ...: only these real-sample fixtures
         make_real_fixtures(sys.argv[1:])
         return

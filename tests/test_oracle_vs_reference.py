@@ -79,3 +79,29 @@ np.savez({str(tmp_path)!r} + "/" + mode + ".npz", f=f, g=g)
         subprocess.run([sys.executable, "-c", code, mode], check=True, stdout=subprocess.DEVNULL)
     a, b = np.load(tmp_path / "own.npz"), np.load(tmp_path / "real.npz")
     assert np.array_equal(a["f"], b["f"]) and np.array_equal(a["g"], b["g"])
+
+
+def test_f32_goldens_are_what_the_single_precision_reference_produces(po):
+    """tests/golden/*_f32.npz pin the float build of the library (liblbmdem_hip_sp.so). They are dumps of the reference
+    compiled -DSINGLE_PRECISION (typedef float real, main.c:34-40) through the same harness: regenerate one fluid case
+    and the DEM case here and compare with what is stored."""
+    import multiprocessing as mp
+    import golden_util as gu
+    if not po.reference_available():
+        pytest.skip("the reference is not present on this machine")
+    for name in ("G2_moving_grain_96x96", "G5_dem_64x48"):
+        case = gu.ALL_CASES[name]
+        q = mp.Queue()
+        p = mp.Process(target=gu.mg._generate, args=(name, case, q, True))
+        p.start()
+        res = q.get()
+        p.join()
+        stored = gu.load(name + "_f32")
+        fresh = gu.mg.pack(name, case, res)
+        assert set(fresh) == set(stored)
+        for k in fresh:
+            a, b = np.asarray(fresh[k]), np.asarray(stored[k])
+            assert np.array_equal(a, b, equal_nan=a.dtype.kind == "f"), (name, k)
+            if np.asarray(fresh[k]).dtype == np.float64 and k not in ("r_mm", "x_mm", "y_mm", "scalars"):
+                v = np.asarray(fresh[k])
+                assert np.array_equal(v, v.astype(np.float32).astype(np.float64), equal_nan=True), (name, k, "not floats")
