@@ -152,7 +152,6 @@ def _open_library(LIB_PATH):
     L.lbmdem_comm_run.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
     L.lbmdem_comm_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.lbmdem_comm_selftest.argtypes = [C.c_void_p, C.c_int]
-    L.lbmdem_comm_exchange_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.lbmdem_fhf_export.argtypes = [C.c_void_p, C.c_void_p]
     L.lbmdem_fhf_import.argtypes = [C.c_void_p, C.c_void_p]
     L.lbmdem_fhf_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
@@ -256,13 +255,6 @@ class Comm:
 
     def selftest(self, doubles=4096):
         _chk(self._L.lbmdem_comm_selftest(self._c, int(doubles)))
-
-    def exchange_probe(self, doubles, iters=200):
-        """(us with the exchange on a side stream, us without it, us with it in line on the main stream): one
-        critical-path exchange of `doubles` values to this rank itself."""
-        out = (C.c_double * 3)()
-        _chk(self._L.lbmdem_comm_exchange_probe(self._c, int(doubles), int(iters), out))
-        return float(out[0]), float(out[1]), float(out[2])
 
 
 class LbmDem:

@@ -1,0 +1,161 @@
+// lbmdem_checkpoint.hip -- checkpoint / restart of a handle (the reference cannot resume a run): single domain, or one
+// file per rank of a strip decomposition with distributed grains.
+
+#include "lbmdem_handle.h"
+
+#pragma GCC visibility push(default)
+extern "C" {
+// ---- checkpoint / restart ------------------------------------------------------------------------
+
+namespace {
+struct CkptHeader {
+  char magic[8];       // "LBMDEMC4"
+  double lid6;         // lbmdem_set_lid
+  int layout;          // device layout of the populations in the file: 1 = 16-node tiles f[x][y/16][q][y%16]
+  int force_mode, diag_always, has_carry;
+  double carry[3];     // pft, pff, pf of the order-dependent contact diagnostics (main.c:130-131), when has_carry
+  lbmdem_config cfg;   // incl. the wall positions VerletWall may have moved
+  long nbsteps;
+  int verlet_ok, nnbr; // symmetric list length
+  long plane;          // sanity: nxl * sy of the writer
+};
+struct CkptDist {       // follows the lattice when the writer had its grains distributed over strips
+  char magic[8];        // "LBMDIST1"
+  int margin, cap_g, cap_t, cap_l, poison, pad;
+};
+constexpr int CKPT_LAYOUT = 1;
+static bool wr(FILE* fp, const void* p, size_t n) { return fwrite(p, 1, n, fp) == n; }
+static bool rd(FILE* fp, void* p, size_t n) { return fread(p, 1, n, fp) == n; }
+}  // namespace
+
+int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) try {
+  SP_UNAVAILABLE("checkpointing");
+  CHECK_H(h);
+  CHECK_NOT_SPLIT(h);
+  if (!path) return fail(LBMDEM_EINVAL, "null path");
+  if (h->obst_pending) return fail(LBMDEM_EINVAL, "checkpoint between obst_construction and collide_stream");
+  // (a handle with distributed grains writes ITS strip, the grains as it holds them, its ownership masks and message
+  // capacities: one file per rank; the carries must have been agreed over the ranks first, lbmdem_comm_sync_carries)
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int n = h->n;
+  std::vector<int> off(n + 1, 0);
+  if (h->verlet_ok) HIP_TRY(hipMemcpy(off.data(), h->V.offsets, sizeof(int) * (n + 1), hipMemcpyDeviceToHost));
+  CkptHeader H;
+  memset(&H, 0, sizeof H);
+  memcpy(H.magic, "LBMDEMC4", 8);
+  H.lid6 = h->L.lid6;
+  H.layout = CKPT_LAYOUT; H.force_mode = h->force_mode; H.diag_always = h->diag_always ? 1 : 0;
+  H.has_carry = 1;
+  if (!h->dist && h->carry_from < h->substep_seq) {
+    launch_carry_resolve(h->ct, h->carry_from, h->stream);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  HIP_TRY(hipMemcpy(H.carry, h->ct.carry, sizeof H.carry, hipMemcpyDeviceToHost));
+  H.cfg = h->cfg; H.nbsteps = h->nbsteps; H.verlet_ok = h->verlet_ok ? 1 : 0; H.nnbr = off[n]; H.plane = h->L.plane;
+  FILE* fp = fopen(path, "wb");
+  if (!fp) return fail(LBMDEM_EINVAL, "cannot open '%s' for writing", path);
+  bool ok = wr(fp, &H, sizeof H);
+  auto dump = [&](const void* dev, size_t bytes) {
+    if (!ok || bytes == 0) return;
+    std::vector<char> buf(bytes);
+    if (hipMemcpy(buf.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; return; }
+    ok = wr(fp, buf.data(), bytes);
+  };
+  dump(h->r, sizeof(double) * n);
+  dump(h->kin[h->kcur].x1, sizeof(double) * 9 * n);
+  dump(h->fhf, sizeof(double) * 3 * n);
+  dump(h->gp, sizeof(double) * n);
+  dump(h->V.offsets, sizeof(int) * (n + 1));
+  dump(h->V.nbr, sizeof(int) * (size_t)H.nnbr);
+  dump(h->V.wallflags, n);
+  dump(h->obst[h->ocur], sizeof(int) * (size_t)h->L.plane);
+  for (int q = 0; q < 9 && ok; ++q)  // the lattice (device layout) in nine chunks: bounded host staging
+    dump(h->f[h->fcur] + (size_t)q * h->L.plane, sizeof(double) * (size_t)h->L.plane);
+  if (h->dist && ok) {   // optional trailing section
+    CkptDist D;
+    memset(&D, 0, sizeof D);
+    memcpy(D.magic, "LBMDIST1", 8);
+    D.margin = h->dist_margin; D.cap_g = h->dd.cap_g; D.cap_t = h->dd.cap_t; D.cap_l = h->dd.cap_l;
+    D.poison = h->dist_poison ? 1 : 0;
+    ok = wr(fp, &D, sizeof D);
+    dump(h->dd.active, n); dump(h->dd.fluidmask, n); dump(h->owner, n);
+  }
+  ok = (fclose(fp) == 0) && ok;
+  if (!ok) return fail(LBMDEM_EHIP, "writing checkpoint '%s' failed", path);
+  return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
+}
+
+int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) try {
+  SP_UNAVAILABLE("checkpointing");
+  if (!path || !out) return fail(LBMDEM_EINVAL, "null argument");
+  *out = nullptr;
+  FILE* fp = fopen(path, "rb");
+  if (!fp) return fail(LBMDEM_EINVAL, "cannot open checkpoint '%s'", path);
+  CkptHeader H;
+  if (!rd(fp, &H, sizeof H) || memcmp(H.magic, "LBMDEMC4", 8) != 0) { fclose(fp); return fail(LBMDEM_EINVAL, "'%s' is not a checkpoint of this library version", path); }
+  if (H.layout != CKPT_LAYOUT) { fclose(fp); return fail(LBMDEM_EINVAL, "checkpoint '%s' holds another device layout (%d)", path, H.layout); }
+  const int n = H.cfg.nbgrains;
+  std::vector<double> r(n), kin(9 * (size_t)n);
+  if (!rd(fp, r.data(), sizeof(double) * n) || !rd(fp, kin.data(), sizeof(double) * 9 * n)) { fclose(fp); return fail(LBMDEM_EINVAL, "checkpoint truncated"); }
+  lbmdem_config cfg = H.cfg;
+  cfg.device = device;
+  lbmdem_handle* h = nullptr;
+  int rc = lbmdem_create(&cfg, r.data(), kin.data(), kin.data() + n, &h);  // x1, x2 are the first two columns
+  if (rc != LBMDEM_OK) { fclose(fp); return rc; }
+  bool ok = h->L.plane == H.plane && H.nnbr >= 0 && H.nnbr <= h->V.cap;
+  auto fill = [&](void* dev, size_t bytes) {
+    if (!ok || bytes == 0) return;
+    std::vector<char> buf(bytes);
+    ok = rd(fp, buf.data(), bytes) && hipMemcpy(dev, buf.data(), bytes, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  if (ok) ok = hipMemcpy(h->kin[0].x1, kin.data(), sizeof(double) * 9 * n, hipMemcpyHostToDevice) == hipSuccess;
+  h->kcur = 0;
+  fill(h->fhf, sizeof(double) * 3 * n);
+  fill(h->gp, sizeof(double) * n);
+  fill(h->V.offsets, sizeof(int) * (n + 1));
+  fill(h->V.nbr, sizeof(int) * (size_t)H.nnbr);
+  fill(h->V.wallflags, n);
+  fill(h->obst[0], sizeof(int) * (size_t)h->L.plane);
+  h->ocur = 0; h->obst_pending = false;
+  for (int q = 0; q < 9 && ok; ++q) fill(h->f[0] + (size_t)q * h->L.plane, sizeof(double) * (size_t)h->L.plane);
+  h->fcur = 0;
+  if (ok) {   // a strip with distributed grains: masks and message capacities as the writer had them
+    CkptDist D;
+    if (rd(fp, &D, sizeof D)) {
+      ok = memcmp(D.magic, "LBMDIST1", 8) == 0 && lbmdem_dist_enable_caps(h, D.margin, D.cap_g, D.cap_t, D.cap_l) == LBMDEM_OK;
+      if (ok) { fill(h->dd.active, n); fill(h->dd.fluidmask, n); fill(h->owner, n); h->dist_poison = D.poison != 0; }
+    }
+  }
+  fclose(fp);
+  if (!ok) { lbmdem_destroy(h); return fail(LBMDEM_EINVAL, "checkpoint '%s' is truncated or from a different decomposition", path); }
+  h->cfg = cfg;  // wall positions as saved
+  h->force_mode = H.force_mode;
+  h->L.lid6 = H.lid6;
+  h->diag_always = H.diag_always != 0;
+  if (H.has_carry) {  // the "previous contact" carries continue across the restart (no records yet: ct.carry stands)
+    if (hipMemcpy(h->ct.carry, H.carry, sizeof H.carry, hipMemcpyHostToDevice) != hipSuccess) {
+      lbmdem_destroy(h);
+      return fail(LBMDEM_EHIP, "checkpoint: carries not restored");
+    }
+  }
+  h->nbsteps = H.nbsteps;
+  h->verlet_ok = H.verlet_ok != 0;
+  h->verlet_tracks_positions = h->verlet_ok;
+  if (h->verlet_ok) {  // the entry -> grain map is derived from the offsets
+    launch_fill_own(h->V, n, h->stream);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { lbmdem_destroy(h); return fail(LBMDEM_EHIP, "k_fill_own failed"); }
+  }
+  *out = h;
+  return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,172 @@
+// lbmdem_handle.h -- what the translation units of the C ABI share (lbmdem_capi.hip: handle, step driver, state
+// transfer; lbmdem_output.hip: the reference's file writers; lbmdem_checkpoint.hip; lbmdem_strips.hip: strip
+// decomposition; lbmdem_comm.hip: the RCCL transport). Not part of the public ABI.
+#pragma once
+
+#include "../../include/lbmdem_hip.h"
+#include "lbmdem_internal.h"
+
+#include <ctype.h>
+#include <dlfcn.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#define REF_PI 3.14159265358979 /* main.c:42 */
+#define RHO_S 2650              /* main.c:44 */
+
+// sets the text lbmdem_last_error() returns (thread-local) and returns `code`
+int lbmdem_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+#define fail lbmdem_fail
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(LBMDEM_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                  __LINE__);                                                                  \
+  } while (0)
+#define RC_TRY(expr) do { int rc_ = (expr); if (rc_ != LBMDEM_OK) return rc_; } while (0)
+
+struct lbmdem_handle {
+  lbmdem_config cfg;
+  LatticeView L;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  // lattice
+  real* f[2] = {nullptr, nullptr};
+  int fcur = 0;
+  int* obst[2] = {nullptr, nullptr};
+  int ocur = 0;           // map the current f was produced with ("old" for the next collide_stream)
+  bool obst_pending = false;  // obst[1 - ocur] holds a newer map not yet consumed by collide_stream
+  // collide_stream in two parts (lbmdem_collide_stream_part): after EDGES the interior rows of f[fcur] are
+  // still missing; the operands of the launch are kept for INTERIOR
+  bool cs_interior_pending = false;
+  const real* cs_fin = nullptr;
+  const int *cs_ob_old = nullptr, *cs_ob_new = nullptr;
+  int cs_lo_end = 0, cs_hi_begin = 0;  // interior = local rows [cs_lo_end, cs_hi_begin)
+  ForceSlots cs_slots{};
+  // grains
+  int n = 0;
+  real* gbuf = nullptr;  // one allocation, carved below
+  Kin kin[2];
+  int kcur = 0;
+  real *r = nullptr, *m = nullptr, *It = nullptr, *rLB = nullptr;
+  real *xc = nullptr, *yc = nullptr, *r2 = nullptr, *rbl0 = nullptr;
+  real* pk = nullptr;   // [n][8] packed fluid-side grain records
+  real* gp = nullptr;   // [n] grain pressure g.p of the last DEM sub-step (main.c:187,776)
+  real* diag = nullptr; // [8][n] reals s f1 f2 ifm M11 M12 M21 M22, then [2][n] ints z zz
+  bool diag_always = false;
+  DiagExtra dx{};          // buffers of the order-dependent diagnostics fr, ice, slip, rw (allocated on first use)
+  bool dx_ready = false;
+  CarryTrack ct{};            // "previous contact" carries: records left by every ordinary sub-step (single-domain handles)
+  long long substep_seq = 0;  // sequence number of the next sub-step (the records' stamps)
+  long long carry_from = 0;   // ct.carry is as of the sub-step before this one; only younger records override it
+  bool diag_valid = false; // the last sub-step produced diagnostics
+  real* fhf = nullptr;  // [3][n]
+  unsigned char* owner = nullptr;
+  unsigned* mincov = nullptr;   // GrainFluidView::mincov
+  unsigned paint_epoch = 0;
+  // link sums handed from the fused kernel to the force kernel (ForceSlots, lbmdem_internal.h)
+  ForceSlots fs{};
+  int* gathered2 = nullptr;   // both counters (fs.gathered / fs.gathered_next alternate between them)
+  bool slots_clean = false;  // every slot is empty
+  bool last_forces_from_table = false;
+  bool slots_valid = false;  // the table was filled by the collide_stream that produced f[fcur] with the current map
+  double rmax = 0.0, rmin = 0.0;
+  // strip decomposition with distributed grains (lbmdem_dist_*)
+  bool dist = false, dist_poison = false;
+  bool dist_period_open = false;   // lbmdem_dist_begin_period has classified the grains for the coming fluid step
+  int dist_margin = 0;
+  DistDevice dd{};
+  VerletDevice V{};
+  bool verlet_ok = false;
+  bool verlet_tracks_positions = false;  // the positions have only moved by DEM sub-steps since the list was built (no upload)
+  volatile int* ovf_host = nullptr;  // pinned mirror of V.overflow, refreshed (asynchronously) after every rebuild
+  volatile int* ferr_host = nullptr; // pinned mirror of fs.error (strip decomposition), refreshed after every period's forces
+  long nbsteps = 0;
+  int force_mode = 0;
+  // derived scalars
+  double fscale12 = 0, fscale3 = 0;
+  double* dpartial = nullptr;
+  // profiling of the dominant kernel
+  bool prof = false;
+  std::vector<hipEvent_t> ev0, ev1;
+  size_t ev_used = 0;
+};
+
+#define CHECK_H(h) do { if (!(h)) return fail(LBMDEM_EINVAL, "null handle"); HIP_TRY(hipSetDevice((h)->cfg.device)); } while (0)
+#define CHECK_NOT_SPLIT(h) do { if ((h)->cs_interior_pending) return fail(LBMDEM_EINVAL, "lbmdem_collide_stream_part(LBMDEM_CS_INTERIOR) has not been called after LBMDEM_CS_EDGES"); } while (0)
+
+// Named ranges for rocprofv3 --marker-trace around the phases of a step (LBMDEM_ROCTX=1; lbmdem_capi.hip)
+struct PhaseRange {
+  bool on;
+  explicit PhaseRange(const char* name);
+  ~PhaseRange();
+};
+
+// Host buffers at the ABI are double in both builds; the device holds `real`. (Every float is a double: downloads are
+// exact; uploads of values that are not floats are rounded to nearest, like an assignment to `real` in the reference.)
+static inline hipError_t h2d_real(real* dst, const double* src, size_t n, hipStream_t st) {
+#ifdef LBMDEM_SINGLE_PRECISION
+  std::vector<real> tmp(n);
+  for (size_t k = 0; k < n; ++k) tmp[k] = (real)src[k];
+  hipError_t e = hipMemcpyAsync(dst, tmp.data(), sizeof(real) * n, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);   // tmp dies here
+  return e;
+#else
+  return hipMemcpyAsync(dst, src, sizeof(real) * n, hipMemcpyHostToDevice, st);
+#endif
+}
+static inline hipError_t d2h_real(double* dst, const real* src, size_t n, hipStream_t st) {
+#ifdef LBMDEM_SINGLE_PRECISION
+  std::vector<real> tmp(n);
+  hipError_t e = hipMemcpyAsync(tmp.data(), src, sizeof(real) * n, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e == hipSuccess) for (size_t k = 0; k < n; ++k) dst[k] = tmp[k];
+  return e;
+#else
+  hipError_t e = hipMemcpyAsync(dst, src, sizeof(real) * n, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  return e;
+#endif
+}
+// The float build covers the step path and the state transfers (what its parity tests and its bench line use); the
+// file writers, checkpoints, the strip decomposition and the RCCL transport exist in the double build only.
+#ifdef LBMDEM_SINGLE_PRECISION
+#define SP_UNAVAILABLE(what) return fail(LBMDEM_EINVAL, what " is not available in the single-precision build of the library")
+#else
+#define SP_UNAVAILABLE(what) do { } while (0)
+#endif
+
+static inline GrainFluidView gview(const lbmdem_handle* h) {
+  const Kin& K = h->kin[h->kcur];
+  return GrainFluidView{K.x1, K.x2, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0, h->pk, h->mincov, h->paint_epoch};
+}
+
+static inline DemParams dem_params(const lbmdem_handle* h) {
+  const lbmdem_config& c = h->cfg;
+  const lbmdem_physics& p = c.phys;
+  DemParams P;
+  P.n = h->n; P.dt = (real)c.dt; P.dt2 = (real)c.dt2;
+  P.kg = (real)p.kg; P.nug = (real)p.nug; P.kt = (real)p.kt; P.mu = (real)p.mu; P.murf = (real)p.murf;
+  P.km = (real)p.km; P.num = (real)p.num; P.ktm = (real)p.ktm; P.mumb = (real)p.mumb; P.mum = (real)p.mum; P.nugt = (real)p.nugt;
+  P.Mgx = (real)c.Mgx; P.Mdx = (real)c.Mdx; P.Mby = (real)c.Mby; P.Mhy = (real)c.Mhy;
+  {
+    const real amp = (real)p.amp, freq = (real)p.freq, t = (real)p.t;   // main.c:163-165
+    P.wallT_vel = amp * freq * cos((double)(freq * t));                 // main.c:855: cos() is <math.h>'s
+  }
+  P.xG = (real)c.xG; P.yG = (real)c.yG;
+  P.distVerlet = (real)p.distVerlet;
+  return P;
+}
+
+// shared between the translation units
+#define LBMDEM_INTERNAL extern "C" __attribute__((visibility("hidden")))
+LBMDEM_INTERNAL int lbmdem_write_vtk_file(const char* path, int nx, int ny, const char* name, int dim, const float* data);
+LBMDEM_INTERNAL int lbmdem_dist_enable_caps(lbmdem_handle* h, int M, long cap_g, long cap_t, long cap_l);

@@ -157,6 +157,9 @@ def main():
                          "several ranks: gloo tests, RCCL self-exchange); c = lbmdem_comm_run (RCCL inside the library, "
                          "no Python on the step path -- has only ever run with ONE rank, no multi-GPU box was available: "
                          "opt-in until tests/test_gpu_multi.py has passed on real GPUs)")
+    ap.add_argument("--precision", choices=["f64", "f32"], default="f64",
+                    help="f64 = the reference's `real` (the headline); f32 = the float build of the library, the reference's "
+                         "-DSINGLE_PRECISION mode (one GPU, its own line: dtype f32, 76 B/LUP; never the headline)")
     ap.add_argument("--strips", action="store_true",
                     help="use the strip-decomposition driver (torch.distributed) even with one rank")
     args = ap.parse_args()
@@ -179,7 +182,9 @@ def main():
     lx, ly = w["lx"], w["ly"]
 
     if world == 1 and not args.strips:
-        sim = pkg.LbmDem(lx, ly, r, x1, x2, device=local_rank)
+        if args.precision == "f32" and (args.gpus != 1 or args.strips):
+            raise SystemExit("--precision f32 is a one-GPU, single-domain mode")
+        sim = pkg.LbmDem(lx, ly, r, x1, x2, device=local_rank, precision=args.precision)
         sim.set_force_mode(args.force_mode)
         npdem = sim.cfg.npDEM
 
@@ -270,7 +275,7 @@ def main():
     # informative: the fast (shuffle-tree) force kernel on the same state: drift against the parity kernel's
     # bits for one and the same lattice, and the coupled-step rate with it (SURVEY hard part 11)
     fast = None
-    if world == 1 and not args.strips and args.force_mode == 0:
+    if world == 1 and not args.strips and args.force_mode == 0 and args.precision == "f64":
         sim.forces_fluid(); fp = sim.fhf.copy()
         sim.set_force_mode(1); sim.forces_fluid(); ff = sim.fhf.copy()
         scale_f = np.abs(fp).max(axis=0)
@@ -297,9 +302,10 @@ def main():
         mlups = 1e-6 * lx * ly * args.steps / elapsed
         cfgd = sim.config()
         rows = cfgd.x_end - cfgd.x_begin
-        achieved = BYTES_PER_LUP * rows * ly / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        bytes_per_lup = BYTES_PER_LUP if args.precision == "f64" else 76.0   # 9x4 B read + 9x4 B write + 4 B obstacle id
+        achieved = bytes_per_lup * rows * ly / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic, traffic_source = None, None
-        if args.gpus == 1 and args.workload == "metric" and os.path.exists(TRAFFIC_FILE):
+        if args.gpus == 1 and args.workload == "metric" and os.path.exists(TRAFFIC_FILE) and args.precision == "f64":
             tf = json.load(open(TRAFFIC_FILE))
             if tf.get("source_sha256") == library_source_sha256():       # same workload, same kernel, same sources
                 traffic = round(tf["traffic_bytes_per_launch"])
@@ -312,7 +318,7 @@ def main():
             "metric": f"MLUPS (D2Q9 collide+stream, coupled LBM-DEM step) on {w['short']}",
             "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "scaling": "strong", "vs_baseline": None, "dtype": args.precision,
             "data": w["data"],
             "config": {"workload": w["name"], "lx": lx, "ly": ly, "grains": int(len(r)), "npDEM": int(npdem),
                        "step": "1 fluid step + npDEM DEM sub-steps (+ Verlet rebuild every 100 DEM steps)",
@@ -336,14 +342,19 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_cs_march (fused reinit+collide+IBB+stream)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_source,
-                         "bytes_per_lup": BYTES_PER_LUP, "launches_timed": launches,
+                         "bytes_per_lup": bytes_per_lup, "launches_timed": launches,
                          "note": "achieved = algorithmic 148 B/LUP x lattice nodes per launch / mean HIP-event "
                                  "duration; traffic = HBM bytes per launch from rocprofv3 FETCH_SIZE + WRITE_SIZE "
                                  "(separate passes, calibrated on copy kernels) -- reported only when the file was measured on this very library binary"},
             "fast_force_mode": fast,
             "total_mass": mass,
         }
-        if args.gpus == 1 and not args.no_cpu_baseline:
+        if args.precision == "f32":
+            out["metric"] += " -- float build (the reference's -DSINGLE_PRECISION mode), NOT the headline"
+            out["roofline"]["note"] = ("achieved = algorithmic 76 B/LUP x lattice nodes per launch / mean HIP-event duration; the "
+                                       "float build mirrors the reference's mixed float/double arithmetic and gathers the hydrodynamic "
+                                       "forces from the lattice (no link-sum table)")
+        if args.gpus == 1 and not args.no_cpu_baseline and args.precision == "f64":
             out["cpu_baseline"] = cpu_baseline(w, sample_mm, npdem)
         import ctypes
         ctypes.CDLL(None).fflush(None)      # RCCL prints through C stdio: whatever it buffered comes out BEFORE the line

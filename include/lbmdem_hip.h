@@ -324,11 +324,6 @@ int lbmdem_comm_allreduce_sum(lbmdem_comm* c, double* values, int n);
  * busy (the transport exercised on a one-GPU box); with several ranks also the step's own pattern: on every lane one
  * grouped exchange with both neighbours, all lanes in flight at once, payload checked. Collective over the ranks. */
 int lbmdem_comm_selftest(lbmdem_comm* c, int doubles);
-/* measurement helper (not on any step path): mean time in microseconds of one exchange as it sits on the step's
- * critical path -- producer kernel, event to a side stream, grouped send + receive of `doubles` values to this rank
- * itself, event back, consumer kernel -- us[0]; of the same loop without the exchange, us[1]; and with the send +
- * receive enqueued on the main stream itself, us[2] */
-int lbmdem_comm_exchange_probe(lbmdem_comm* c, int doubles, int iters, double* us);
 
 /* Device pointer to the 3*n hydrodynamic-force table (fhf1[n], fhf2[n], fhf3[n]) and to the
  * n-entry ownership mask (1 = this rank computed the grain) for the cross-rank combine. */

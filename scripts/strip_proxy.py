@@ -8,11 +8,12 @@ Prints one JSON line."""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "scripts")]
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 import torch
 import __graft_entry__ as ge, samples
 from strip_backends import LoopbackComm, lockstep_render_dist
+from exchange_probe import exchange_probe
 
 pkg = ge.load_package(); strips = pkg.strips_module()
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
@@ -65,7 +66,7 @@ for rank in sorted({0, world // 2}):
 comm = pkg.Comm(pkg.comm_unique_id(), 0, 1, 0)
 lat = {}
 for name, nd in (("tables", runners[world // 2].b.sim.dist_message_doubles(2)), ("fhf", runners[world // 2].b.sim.dist_message_doubles(1))):
-    w, wo, inline = comm.exchange_probe(nd, 300)
+    w, wo, inline = exchange_probe(pkg, comm, nd, 300)
     lat[name] = round(min(w, inline) - wo, 1)
     lat[name + "_loop_side_stream_without_inline_us"] = [round(w, 1), round(wo, 1), round(inline, 1)]
 out["rccl_self_exchange_us"] = lat

@@ -112,24 +112,35 @@ def test_rccl_path_of_the_c_driver_with_one_rank(po, tmp_path):
 
 def test_transport_selftest_and_exchange_probe_with_one_rank():
     """The library's RCCL transport from Python (one-rank communicator, in a fresh process: RCCL initialises once per
-    process): the self-test, and the probe that prices one critical-path exchange -- through a side stream with event
-    hand-overs, and in line on the main stream, which is how lbmdem_comm_lbm_step sends the link-sum tables and the
-    forces."""
+    process): the self-test, and -- with the experiment build, which alone carries the helper -- the probe that prices
+    one critical-path exchange: through a side stream with event hand-overs, and in line on the main stream, which is
+    how lbmdem_comm_lbm_step sends the link-sum tables and the forces."""
     import subprocess, sys
     code = r'''
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "scripts")]
 import __graft_entry__ as ge
 pkg = ge.load_package()
 c = pkg.Comm(pkg.comm_unique_id(), 0, 1, 0)
 c.selftest()
-side, without, inline = c.exchange_probe(20000, 100)
-assert 0 < without < inline < side, (side, without, inline)
-print("PROBE-OK %.1f %.1f %.1f" % (side, without, inline))
+assert not hasattr(pkg.load_library(), "lbmdem_comm_exchange_probe") or "_ab" in pkg.LIB_PATH
+if "_ab" in pkg.LIB_PATH:
+    from exchange_probe import exchange_probe
+    side, without, inline = exchange_probe(pkg, c, 20000, 100)
+    assert 0 < without < inline < side, (side, without, inline)
+    print("PROBE %.1f %.1f %.1f" % (side, without, inline))
+print("TRANSPORT-OK")
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and "PROBE-OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+    ab = os.path.join(root, "2d-lbm-dem_amd", "liblbmdem_hip_ab.so")
+    for lib in [None] + ([ab] if os.path.exists(ab) else []):
+        env = dict(os.environ)
+        env.pop("LBMDEM_HIP_LIBRARY", None)
+        if lib:
+            env["LBMDEM_HIP_LIBRARY"] = lib
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and "TRANSPORT-OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+        assert (lib is None) or "PROBE" in out.stdout
 
 
 def test_comm_driver_writes_the_same_files_as_the_single_gpu_driver(po, tmp_path):
