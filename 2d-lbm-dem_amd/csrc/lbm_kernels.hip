@@ -908,6 +908,28 @@ __device__ __forceinline__ int shfl_up1(int v) { return dpp_up1(v); }
 __device__ __forceinline__ int shfl_dn1(int v) { return dpp_dn1(v); }
 #endif
 
+#ifdef MARCH_TIMING   /* experiment builds: where a wavefront's cycles go (s_memtime between the phases of an iteration) */
+// MARCH_TIMING = k: only phase k is timed (one accumulator and one pending stamp: the kernel has no registers to spare --
+// with all eight phases timed at once it spills and runs twice as long); phase k lies between boundary
+// MT(k == 0 ? 7 : k - 1) and boundary MT(k); a stamp is only consumed at the end of its phase, so it adds no s_waitcnt
+// of its own in between. scripts/march_timing.py reads the sums.
+__device__ unsigned long long g_march_t[16];
+#define MT_FROM (MARCH_TIMING == 0 ? 7 : MARCH_TIMING - 1)
+#define MT_DECL unsigned long long mt_acc_ = 0, mt_from_ = __builtin_readcyclecounter(); const unsigned long long mt_start_ = mt_from_;
+#define MT(i) { if ((i) == MT_FROM) { __builtin_amdgcn_sched_barrier(0); mt_from_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } \
+                if ((i) == MARCH_TIMING) { __builtin_amdgcn_sched_barrier(0); mt_acc_ += __builtin_readcyclecounter() - mt_from_; __builtin_amdgcn_sched_barrier(0); } }
+#define MT_FLUSH if (lane == 0) { atomicAdd(&g_march_t[MARCH_TIMING], mt_acc_); atomicAdd(&g_march_t[8], __builtin_readcyclecounter() - mt_start_); atomicAdd(&g_march_t[9], 1ull); }
+extern "C" __attribute__((visibility("default"))) int lbmdem_ab_march_timing(unsigned long long* out) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_march_t), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  unsigned long long z[16] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_march_t), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#else
+#define MT_DECL
+#define MT(i)
+#define MT_FLUSH
+#endif
+
 template <int LX, int MINW, int WW>
 __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__ fin, real* __restrict__ fout,
                                                   const int* __restrict__ ob_old,
@@ -1014,11 +1036,19 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
   bool actm = iB.c != -1 && node_active(L, G, iA, iB, iC, L.gx0 + xs - 1, y, [&] { return ring.get(xs - 1, lane); });
   bool act0 = iC.c != -1 && node_active(L, G, iB, iC, iD, L.gx0 + xs, y, [&] { return ring.get(xs, lane); });
 
+  MT_DECL
   // one iteration; `buf` holds row x+1 on entry and is refilled with row x+3
   auto iterate = [&](int x, real (&buf)[9]) {
+    MT(7)   // loop head
 #pragma unroll
     for (int q = 0; q < 9; ++q) Fp[q] = buf[q];
+#ifdef MARCH_TIMING   /* phase 0 = the wait for the row's populations alone */
+#pragma unroll
+    for (int q = 0; q < 9; ++q) asm volatile("" ::"v"(Fp[q]));
+    MT(0)
+#endif
     make_fstar(x + 1, Fp, oo1, gre, iD.c);
+    MT(1)
     const Ids3 iF = inext;  // row x+3
     // ---- (1) small gathers
     oo1 = oo2;
@@ -1030,7 +1060,9 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
     // ---- (2) the big loads: populations of row x+3
     load_raw(x + 3, buf);
     __builtin_amdgcn_sched_barrier(0);
+    MT(2)
     const bool actp = iD.c != -1 && node_active(L, G, iC, iD, iE, L.gx0 + x + 1, y, [&] { return ring.get(x + 1, lane); });
+    MT(3)
 
     RegCtx C;
     C.ring = ring;
@@ -1068,6 +1100,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
         if (deep) classify_store_row<false>(C, L, gx, y, fout, node, ibb, nnm, hzm);
         else classify_store_row<true>(C, L, gx, y, fout, node, ibb, nnm, hzm);
       }
+      MT(4)
       // (b) the bounce-back links of the whole row (typically ~20, spread over all eight directions
       // and a few lanes) are compacted into dense lanes through LDS and evaluated in ONE pass with the
       // direction as data, instead of ~3.5 direction-specific divergent passes of ~130 instructions.
@@ -1123,6 +1156,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
         }
         __builtin_amdgcn_wave_barrier();
       }
+      MT(5)
     }
     // row x-1 is no longer needed: its ring slot takes the owner records of row x+3; then request
     // those of row x+4 (consumed at this point of the next iteration)
@@ -1133,6 +1167,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
     for (int q = 0; q < 9; ++q) { Fm[q] = F0[q]; F0[q] = Fp[q]; }
     iB = iC; iC = iD; iD = iE; iE = iF;
     actm = act0; act0 = actp;
+    MT(6)
   };
 
   // Both halves run unconditionally (a row >= xe stores nothing): with `if (x + 1 < xe)` around the second one the
@@ -1145,6 +1180,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
 #endif
     iterate(x + 1, bufB);
   }
+  MT_FLUSH
 }
 
 #ifdef LBMDEM_AB
@@ -2506,7 +2542,12 @@ static void launch_march(const real* fin, real* fout, const int* obst_old, const
     default: break;
   }
 #endif
-  hipLaunchKernelGGL((k_cs_march<LX, MINW, WW>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, L, G,
+  unsigned dyn_lds = 0;
+#ifdef LBMDEM_AB   // occupancy experiment: extra (unused) dynamic LDS so that only ONE workgroup fits a CU
+  static const int env_lds = getenv("LBMDEM_MARCH_DYNLDS") ? atoi(getenv("LBMDEM_MARCH_DYNLDS")) : 0;
+  dyn_lds = (unsigned)env_lds;
+#endif
+  hipLaunchKernelGGL((k_cs_march<LX, MINW, WW>), dim3(grid), dim3(256), dyn_lds, st, fin, fout, obst_old, obst_new, L, G,
                      S, nstrips, nwork, remap, seg_rows, seg_rows);
 }
 
