@@ -1240,6 +1240,16 @@ __device__ __forceinline__ void lds_dma16_tok(const char*& gsrc, unsigned lds_ds
                : "=&s"(keep), "+v"(gsrc) : "s"(lds_dst) : "memory");
 }
 
+#ifdef M3_DMAPOP
+// 16 bytes per lane from (sbase + voff) to LDS byte address lds_dst (wave-uniform) + 16 * lane; the per-lane offset also
+// comes OUT of the statement so that a later ordinary load can be tied to it (issued after the DMA)
+__device__ __forceinline__ void lds_dma16_s(const char* sbase, unsigned& voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep), "+v"(voff) : "s"(sbase), "s"(lds_dst) : "memory");
+}
+#endif
+
 template <int LX, int MINW, int WW, int NBUF>
 __global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict__ fin, real* __restrict__ fout,
                                                    const int* __restrict__ ob_old,
@@ -1274,6 +1284,48 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict_
   real* const pay = sPay + wv * (64 * 4);
   int* const desc = sDesc + wv * 64;
   const unsigned lrec_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lrec);
+#ifdef M3_DMAPOP
+  // The populations of the next row travel global -> LDS without a register landing (5 x global_load_lds_dwordx4 per
+  // row): chunk g = 64 k + lane (k = 0..4) is the 16-byte pair (y_c, y_c + 1), y_c = y0 - 1 + 2 (g % 33) (even: y0 is odd
+  // for WW = 62), of direction g / 33; it lands at staging byte 16 g, so direction q of lane l is double 66 q + l + 1.
+  static_assert(WW == 62 && NBUF == 1 && sizeof(real) == 8, "the DMA staging is laid out for the 62-column window of doubles");
+  __shared__ real sStage[4 * 640];
+  real* const stage = sStage + wv * 640;
+  const unsigned stage_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)stage);
+  unsigned dma_off[5];   // byte offset of this lane's chunk from the first tile of the row
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    int g = 64 * k + lane;
+    if (g > 296) g = 296;
+    const int q = g / 33, c = g % 33;
+    int yc = strip * WW - OFF - 1 + 2 * c;
+    yc = yc < 0 ? 0 : (yc > L.sy - 2 ? L.sy - 2 : yc);
+    dma_off[k] = (unsigned)(((yc / LBMDEM_TILE_Y) * (9 * LBMDEM_TILE_Y) + (yc % LBMDEM_TILE_Y) + q * LBMDEM_TILE_Y) * 8);
+  }
+  typedef const int __attribute__((address_space(1))) * gint_ptr_t;
+  // request row xl (clamped like node_of); returns the probe whose arrival means the row has landed
+  auto dma_row = [&](int xl) {
+    const int xc = xl < 0 ? 0 : (xl >= L.nxl ? L.nxl - 1 : xl);
+    // (wave-uniform, but derived from threadIdx.x >> 6: say so, the DMA wants its base in scalar registers)
+    const unsigned long long rbv =
+        (unsigned long long)(reinterpret_cast<const char*>(fin) + (long)xc * (L.sy / LBMDEM_TILE_Y) * (9 * LBMDEM_TILE_Y * 8));
+    const char* rb = reinterpret_cast<const char*>(
+        ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rbv >> 32)) << 32) |
+        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rbv));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads of the previous row out of the staging are over
+    lds_dma16_s(rb, dma_off[0], stage_lds);
+    lds_dma16_s(rb, dma_off[1], stage_lds + 1024);
+    lds_dma16_s(rb, dma_off[2], stage_lds + 2048);
+    lds_dma16_s(rb, dma_off[3], stage_lds + 3072);
+    lds_dma16_s(rb, dma_off[4], stage_lds + 4096);
+    return *(gint_ptr_t)(unsigned long long)(rb + dma_off[4]);
+  };
+  auto stage_read = [&](int probe, real (&f)[9]) {
+    asm volatile("" ::"v"(probe) : "memory");   // the compiler's counted wait for the probe: the DMA before it has landed
+#pragma unroll
+    for (int q = 0; q < 9; ++q) f[q] = stage[66 * q + lane + 1];
+  };
+#endif
   const real wc_diag = L.wc_diag, wc_axis = L.wc_axis;
   auto row_ok = [&](int xl) { return yin && xl >= 0 && xl < L.nxl; };
   const int ycl = y < 0 ? 0 : (y >= L.ly ? L.ly - 1 : y);
@@ -1331,8 +1383,12 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict_
   int oo1 = load_old(xs + 1);   // previous-map ids of rows x+1, x+2
   int oo2 = load_old(xs + 2);
   RRec gre = reinit_rec(oo1);   // reinit record of row x+1
+#ifdef M3_DMAPOP
+  int pop_probe = dma_row(xs + 1);
+#else
   load_raw(xs + 1, bufA);
   if (NBUF == 2) load_raw(xs + 2, bufB);
+#endif
 
   // one iteration: `buf` holds row x+1 on entry and is refilled with row x+1+NBUF
   auto iterate = [&](int x, real (&buf)[9]) {
@@ -1401,9 +1457,14 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict_
     // ---- (1) 12 unconditional loads: ids of row x+3 (2), previous-map id of row x+3 (1), populations of row x+2 (9)
     const IdsRow inext = load_ids_row(ob_new, L, x + 3, y, lane);
     const int oo3 = load_old(x + 3);
+#ifdef M3_DMAPOP
+    stage_read(pop_probe, Fp);
+    pop_probe = dma_row(x + 2);
+#else
 #pragma unroll
     for (int q = 0; q < 9; ++q) Fp[q] = buf[q];
     load_raw(x + 1 + NBUF, buf);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     make_fstar(x + 1, Fp, oo1, re_ux, re_uy, iD.c);
 
@@ -2525,7 +2586,20 @@ static void launch_march(const real* fin, real* fout, const int* obst_old, const
   const int nwork = nstrips * nseg;
   int grid = (nwork + 3) / 4;
   if (remap) grid = ((grid + 7) / 8) * 8;
-#ifdef LBMDEM_AB   // k_cs_march3 (measured slower) only exists in the experiment build
+#ifdef LBMDEM_AB   // k_cs_march3 only exists in the experiment build
+#ifdef M3_DMAPOP
+  if constexpr (WW == 62) {
+    if (march_kernel() == 3 || march_kernel() == 21) {
+      if (march_kernel() == 3)
+        hipLaunchKernelGGL((k_cs_march3<LX, 3, WW, 1>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, L, G,
+                           S, nstrips, nwork, remap, seg_rows, seg_rows);
+      else
+        hipLaunchKernelGGL((k_cs_march3<LX, 2, WW, 1>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, L, G,
+                           S, nstrips, nwork, remap, seg_rows, seg_rows);
+      return;
+    }
+  }
+#else
   switch (march_kernel()) {
     case 3:
       hipLaunchKernelGGL((k_cs_march3<LX, 3, WW, 1>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, L, G,
@@ -2541,6 +2615,7 @@ static void launch_march(const real* fin, real* fout, const int* obst_old, const
       return;
     default: break;
   }
+#endif
 #endif
   unsigned dyn_lds = 0;
 #ifdef LBMDEM_AB   // occupancy experiment: extra (unused) dynamic LDS so that only ONE workgroup fits a CU
