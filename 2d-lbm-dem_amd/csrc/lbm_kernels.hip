@@ -1256,18 +1256,30 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict_
                                                    const int* __restrict__ ob_new, LatticeView L,
                                                    GrainFluidView G, ForceSlots S, int nstrips, int nwork,
                                                    int xcd_remap, int seg_rows, int seg_stride) {
+#ifdef M3_UNIFORM
+  int lane = threadIdx.x & 63;   // (not const: re-declared opaque in every iteration, see iterate())
+#else
   const int lane = threadIdx.x & 63;
+#endif
   int blk = blockIdx.x;
   if (xcd_remap) {
     const int per = gridDim.x >> 3;
     blk = (blk & 7) * per + (blk >> 3);
   }
+#ifdef M3_UNIFORM   /* wave-uniform, said explicitly: the row counter and the row addresses then live in scalar registers */
+  const int w = __builtin_amdgcn_readfirstlane(blk * 4 + (int)(threadIdx.x >> 6));
+#else
   const int w = blk * 4 + (threadIdx.x >> 6);
+#endif
   if (w >= nwork) return;  // whole wave
   const int strip = w % nstrips, seg = w / nstrips;
   constexpr int OFF = (64 - WW) / 2;
   static_assert(OFF >= 1, "the end lanes only feed their neighbours");
+#ifdef M3_UNIFORM
+  int y = strip * WW - OFF + lane;
+#else
   const int y = strip * WW - OFF + lane;
+#endif
   const bool yin = y >= 0 && y < L.ly;
   const bool writer = lane >= OFF && lane < OFF + WW && yin;
   const bool deep_y = strip * WW >= 2 && strip * WW + WW - 1 <= L.ly - 3;
@@ -1333,7 +1345,34 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict_
     const int xc = xl < 0 ? 0 : (xl >= L.nxl ? L.nxl - 1 : xl);
     return (long)xc * L.sy + ycl;
   };
+#ifdef M3_UNIFORM
+  // scalar row base + 32-bit lane byte offset, the offset re-declared opaque at every use: otherwise the compiler folds it
+  // into a loop-invariant 64-bit per-lane pointer (two registers each, hoisted out of the loop and then spilled)
+  const int yo_ = lane == 0 ? y - 1 : (lane == 63 ? y + 1 : y);
+  const int co_ = yo_ < 0 ? 0 : (yo_ >= L.ly ? L.ly - 1 : yo_);
+  const unsigned ycl4 = 4u * (unsigned)ycl, co4 = 4u * (unsigned)co_;
+  const bool c_in = ycl == y, o_in = co_ == yo_;
+  auto opaque = [](unsigned v) { asm volatile("" : "+v"(v)); return v; };
+  auto row_of = [&](const int* ob, int xl) {
+    const int xc = xl < 0 ? 0 : (xl >= L.nxl ? L.nxl - 1 : xl);
+    return reinterpret_cast<const char*>(ob) + (long)xc * L.sy * 4;
+  };
+  auto load_old = [&](int xl) { return *reinterpret_cast<const int*>(row_of(ob_old, xl) + opaque(ycl4)); };
+  auto load_ids_row_u = [&](int xl) {
+    const bool rok = xl >= 0 && xl < L.nxl;
+    const char* row = row_of(ob_new, xl);
+    const int vc = *reinterpret_cast<const int*>(row + opaque(ycl4));
+    const int vo = *reinterpret_cast<const int*>(row + opaque(co4));
+    IdsRow r;
+    r.c = (rok && c_in) ? vc : L.n;
+    r.outer = (rok && o_in) ? vo : L.n;
+    return r;
+  };
+#define M3_LOAD_IDS(xl) load_ids_row_u(xl)
+#else
   auto load_old = [&](int xl) { return ob_old[node_of(xl)]; };
+#define M3_LOAD_IDS(xl) load_ids_row(ob_new, L, xl, y, lane)
+#endif
   auto load_raw = [&](int xl, real (&raw)[9]) {
     const long fb = fbase(node_of(xl));
 #pragma unroll
@@ -1361,13 +1400,13 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict_
 
   real Fm[9], F0[9], Fp[9], bufA[9], bufB[9];   // NBUF = 1: only bufA
 
-  IdsRow iB = load_ids_row(ob_new, L, xs - 1, y, lane);
-  IdsRow iC = load_ids_row(ob_new, L, xs, y, lane);
-  IdsRow iD = load_ids_row(ob_new, L, xs + 1, y, lane);
-  IdsRow iE = load_ids_row(ob_new, L, xs + 2, y, lane);
+  IdsRow iB = M3_LOAD_IDS(xs - 1);
+  IdsRow iC = M3_LOAD_IDS(xs);
+  IdsRow iD = M3_LOAD_IDS(xs + 1);
+  IdsRow iE = M3_LOAD_IDS(xs + 2);
   bool actm, act0;
   {
-    const IdsRow iA = load_ids_row(ob_new, L, xs - 2, y, lane);
+    const IdsRow iA = M3_LOAD_IDS(xs - 2);
     int oo = load_old(xs - 1);
     load_raw(xs - 1, Fm);
     RRec r = reinit_rec(oo);
@@ -1392,6 +1431,12 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict_
 
   // one iteration: `buf` holds row x+1 on entry and is refilled with row x+1+NBUF
   auto iterate = [&](int x, real (&buf)[9]) {
+#ifdef M3_UNIFORM
+    // Nothing derived from the lane or the column may be hoisted out of the loop: the compiler otherwise keeps dozens of
+    // trivial loop invariants (lane | q << 8, (double)(y +- 1), per-lane pointers) in registers it does not have, and
+    // spills them to scratch -- whose reloads sit in the same in-order queue as the row prefetch.
+    asm volatile("" : "+v"(lane), "+v"(y));
+#endif
     const int gx = L.gx0 + x;
     const bool deep = deep_y && gx >= 2 && gx <= L.lx - 3;   // wave-uniform
     // the old owner's velocity at (x+1, y): frees the record's registers before anything else is requested
@@ -1455,7 +1500,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict_
     const int probe = *(gint_ptr)(unsigned long long)rec_src;
     __builtin_amdgcn_sched_barrier(0);
     // ---- (1) 12 unconditional loads: ids of row x+3 (2), previous-map id of row x+3 (1), populations of row x+2 (9)
-    const IdsRow inext = load_ids_row(ob_new, L, x + 3, y, lane);
+    const IdsRow inext = M3_LOAD_IDS(x + 3);
     const int oo3 = load_old(x + 3);
 #ifdef M3_DMAPOP
     stage_read(pop_probe, Fp);
@@ -1600,6 +1645,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict_
 // hydrodynamic force and torque (main.c:1285-1333)
 // ---------------------------------------------------------------------------------------------
 
+#undef M3_LOAD_IDS
 __device__ __forceinline__ bool grain_box(const LatticeView& L, const GrainFluidView& G, int i, int& xi,
                                           int& xf, int& yi, int& yf) {
   const real xc = G.xc[i], yc = G.yc[i], rbl0 = G.rbl0[i];
