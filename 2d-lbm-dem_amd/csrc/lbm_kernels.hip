@@ -1240,6 +1240,35 @@ __device__ __forceinline__ void lds_dma16_tok(const char*& gsrc, unsigned lds_ds
                : "=&s"(keep), "+v"(gsrc) : "s"(lds_dst) : "memory");
 }
 
+#ifdef M3_MANUAL
+// Loads the compiler does not see as loads (asm): it places no s_waitcnt of its own for them -- a counted wait after a
+// run of conditional stores can only assume that none of them was issued, and so drains the queue -- and the kernel
+// waits by hand with the exact number of vector-memory operations it has issued since (gfx9 retires them in order).
+typedef int m3_v4i __attribute__((ext_vector_type(4)));
+typedef int m3_v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int m3_load_b32(const char* sbase, unsigned voff) {
+  int v;
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+  return v;
+}
+__device__ __forceinline__ m3_v4i m3_load_b128(const void* p) {
+  m3_v4i v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ m3_v4i m3_load_b128_16(const void* p) {
+  m3_v4i v;
+  asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ m3_v2i m3_load_b64_32(const void* p) {
+  m3_v2i v;
+  asm volatile("global_load_dwordx2 %0, %1, off offset:32" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ double m3_dbl(int lo, int hi) { return __hiloint2double(hi, lo); }
+#endif
+
 #ifdef M3_DMAPOP
 // 16 bytes per lane from (sbase + voff) to LDS byte address lds_dst (wave-uniform) + 16 * lane; the per-lane offset also
 // comes OUT of the statement so that a later ordinary load can be tied to it (issued after the DMA)
@@ -1330,10 +1359,16 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict_
     lds_dma16_s(rb, dma_off[2], stage_lds + 2048);
     lds_dma16_s(rb, dma_off[3], stage_lds + 3072);
     lds_dma16_s(rb, dma_off[4], stage_lds + 4096);
+#ifdef M3_MANUAL
+    return 0;
+#else
     return *(gint_ptr_t)(unsigned long long)(rb + dma_off[4]);
+#endif
   };
   auto stage_read = [&](int probe, real (&f)[9]) {
+#ifndef M3_MANUAL
     asm volatile("" ::"v"(probe) : "memory");   // the compiler's counted wait for the probe: the DMA before it has landed
+#endif
 #pragma unroll
     for (int q = 0; q < 9; ++q) f[q] = stage[66 * q + lane + 1];
   };
@@ -1422,7 +1457,30 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict_
   int oo1 = load_old(xs + 1);   // previous-map ids of rows x+1, x+2
   int oo2 = load_old(xs + 2);
   RRec gre = reinit_rec(oo1);   // reinit record of row x+1
-#ifdef M3_DMAPOP
+#ifdef M3_MANUAL
+  // what is in flight across an iteration boundary: ids + previous-map id of row x+2, the reinit record of row x+1
+  int pend_c, pend_o, pend_old;
+  m3_v4i pend_ra, pend_rb;
+  m3_v2i pend_rc;
+  auto request_ids = [&](int xl) {
+    const char* row = row_of(ob_new, xl);
+    pend_c = m3_load_b32(row, opaque(ycl4));
+    pend_o = m3_load_b32(row, opaque(co4));
+    pend_old = m3_load_b32(row_of(ob_old, xl), opaque(ycl4));
+  };
+  auto request_reinit = [&](int id) {
+    const real* p = G.pk + (long)((id < 0 || id >= L.n) ? 0 : id) * 8;
+    pend_ra = m3_load_b128(p);
+    pend_rb = m3_load_b128_16(p);
+    pend_rc = m3_load_b64_32(p);
+  };
+  request_ids(xs + 2);
+  request_reinit(oo1);
+  int pop_probe = dma_row(xs + 1);
+  // everything requested so far has landed before the first iteration (the counted waits inside the loop count the
+  // operations of ONE iteration)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pend_c), "+v"(pend_o), "+v"(pend_old), "+v"(pend_ra), "+v"(pend_rb), "+v"(pend_rc) :: "memory");
+#elif defined(M3_DMAPOP)
   int pop_probe = dma_row(xs + 1);
 #else
   load_raw(xs + 1, bufA);
@@ -1439,6 +1497,20 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict_
 #endif
     const int gx = L.gx0 + x;
     const bool deep = deep_y && gx >= 2 && gx <= L.lx - 3;   // wave-uniform
+#ifdef M3_MANUAL
+    // The operations issued since the requests that are consumed here (ids / previous-map id of row x+2 and the
+    // populations of row x+1: at the top of the previous iteration; the reinit record: in its middle) are its nine
+    // population stores and the stores of its bounce-back pass: at most nine operations outstanding <=> all of them landed.
+    asm volatile("s_waitcnt vmcnt(9)" : "+v"(pend_c), "+v"(pend_o), "+v"(pend_old), "+v"(pend_ra), "+v"(pend_rb), "+v"(pend_rc) :: "memory");
+    {
+      const bool rok = x + 2 >= 0 && x + 2 < L.nxl;
+      iE.c = (rok && c_in) ? pend_c : L.n;
+      iE.outer = (rok && o_in) ? pend_o : L.n;
+      oo2 = pend_old;
+      gre = RRec{make_real2(m3_dbl(pend_ra.x, pend_ra.y), m3_dbl(pend_ra.z, pend_ra.w)),
+                 make_real2(m3_dbl(pend_rb.x, pend_rb.y), m3_dbl(pend_rb.z, pend_rb.w)), m3_dbl(pend_rc.x, pend_rc.y)};
+    }
+#endif
     // the old owner's velocity at (x+1, y): frees the record's registers before anything else is requested
     const real re_ux = rr_ux(gre), re_uy = rr_uy(gre, x + 1);
     int onb[9];
@@ -1496,12 +1568,17 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict_
     // once the compiler's own counted wait for `probe` is over, the records have landed.
     // (an address that comes out of an asm statement has lost its address space: say "global", or the load becomes a
     // FLAT one and the compiler falls back to vmcnt(0) everywhere)
+#ifdef M3_MANUAL
+    const int probe = 0;
+    request_ids(x + 3);
+#else
     typedef const int __attribute__((address_space(1))) * gint_ptr;
     const int probe = *(gint_ptr)(unsigned long long)rec_src;
     __builtin_amdgcn_sched_barrier(0);
     // ---- (1) 12 unconditional loads: ids of row x+3 (2), previous-map id of row x+3 (1), populations of row x+2 (9)
     const IdsRow inext = M3_LOAD_IDS(x + 3);
     const int oo3 = load_old(x + 3);
+#endif
 #ifdef M3_DMAPOP
     stage_read(pop_probe, Fp);
     pop_probe = dma_row(x + 2);
@@ -1546,7 +1623,11 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict_
     };
     if (T > 0) write_pay(0, In);
     // ---- (3) the reinit record of row x+2: requested late, converted at the top of the next iteration
+#ifdef M3_MANUAL
+    request_reinit(oo2);
+#else
     gre = reinit_rec(oo2);
+#endif
     // ---- (4) everything but the bounce-back links: computed and stored
     const Ids3 a3 = iC.all(), b3 = iD.all(), c3 = iE.all();   // DPP: outside the divergent &&
     const bool actp = iD.c != -1 && node_active(L, G, a3, b3, c3, L.gx0 + x + 1, y, [&] { return grain_rec(iD.c); });
@@ -1573,7 +1654,12 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict_
 #endif
     for (int base = 0; base < (M3_OVERFLOW ? T : (T < 64 ? T : 64)); base += 64) {   // wave-uniform; more than one round only if the row has > 64 links
       if (base == 0) {
+#ifdef M3_MANUAL
+        // since the record DMA: 3 id loads, 5 population DMAs, 3 record loads, 9 population stores
+        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+#else
         asm volatile("" ::"v"(probe) : "memory");   // the compiler waits for `probe` here => the records are in LDS
+#endif
       } else {
         // rare: descriptors and payloads of the next 64 links, rebuilt from what is still in registers (rows x-1, x,
         // x+1 and the ids; the cross-lane moves are repeated, in wave-uniform control flow)
@@ -1624,8 +1710,13 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict_
     }
 #pragma unroll
     for (int q = 0; q < 9; ++q) { Fm[q] = F0[q]; F0[q] = Fp[q]; }
+#ifdef M3_MANUAL
+    iB = iC; iC = iD; iD = iE;   // (iE and oo2 are decoded at the top of the next iteration)
+    oo1 = oo2;
+#else
     iB = iC; iC = iD; iD = iE; iE = inext;
     oo1 = oo2; oo2 = oo3;
+#endif
     actm = act0; act0 = actp;
   };
   if (NBUF == 1) {
