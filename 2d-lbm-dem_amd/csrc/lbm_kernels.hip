@@ -551,6 +551,13 @@ __device__ __forceinline__ int slot_line(int x, int y, int ex, int ey, real xc, 
   return ey * (x - (int)xc) - ex * (y - (int)yc);
 }
 
+// delta >= 1/2 (main.c:1175-1177 / 1207-1209). (Round 3 measured the three quotients as one true reciprocal + three
+// exact_div: the same bits, ~50 instructions fewer, 2-4 % SLOWER -- the guards and selects lengthen the pass's dependent
+// chain; not kept.)
+__device__ __forceinline__ real ibb_far_rt(const LatticeView& L, const IbbLink& k, real fN_opp, real fN_q, real wc) {
+  return fN_opp / (2 * k.d) + (2 * k.d - 1) * fN_q / (2 * k.d) + 3 * wc * k.uw / k.d;
+}
+
 template <class RecFn>
 __device__ __forceinline__ real ibb_eval_rt(const LatticeView& L, const RtLink& k, real wc_diag,
                                               real wc_axis, RecFn rec_of) {
@@ -563,7 +570,7 @@ __device__ __forceinline__ real ibb_eval_rt(const LatticeView& L, const RtLink& 
   IbbLink a;
   a.d = link_delta_rt(sx, sy, ex, ey, g.xc, g.yc, g.r2);
   a.uw = ex * wall_ux(L, g, sy) + ey * wall_uy(L, g, sx);
-  if (a.d >= 0.5) return k.own_qo / (2 * a.d) + (2 * a.d - 1) * k.own_q / (2 * a.d) + 3 * wc * a.uw / a.d;
+  if (a.d >= 0.5) return ibb_far_rt(L, a, k.own_qo, k.own_q, wc);
   if (!(a.d > 0. && a.d < 0.5)) return k.in_qo;
   real f2;
   if (!k.nn_int) {
@@ -576,7 +583,7 @@ __device__ __forceinline__ real ibb_eval_rt(const LatticeView& L, const RtLink& 
       IbbLink b;
       b.d = link_delta_rt(nx, ny, -ex, -ey, gn.xc, gn.yc, gn.r2);
       b.uw = (-ex) * wall_ux(L, gn, ny) + (-ey) * wall_uy(L, gn, nx);
-      if (b.d >= 0.5) f2 = k.own_q / (2 * b.d) + (2 * b.d - 1) * k.own_qo / (2 * b.d) + 3 * wc * b.uw / b.d;
+      if (b.d >= 0.5) f2 = ibb_far_rt(L, b, k.own_q, k.own_qo, wc);
       else if (b.d > 0. && b.d < 0.5) f2 = 2 * b.d * k.own_q + (1 - 2 * b.d) * k.in_qo + 6 * wc * b.uw;
     }
   }
@@ -866,6 +873,37 @@ __device__ __forceinline__ void classify_store_row(const Ctx& C, const LatticeVi
 #undef LBM_CLASSIFY
 }
 
+#ifndef MARCH_BRANCHY   /* -DMARCH_BRANCHY (experiment builds) restores the branchy form for deep rows too */
+// classify_store_row for rows and lanes at least two nodes away from every lattice edge (S, P and NN all interior),
+// without a branch: the eight pulls differ only in WHICH value they take -- the streamed population, or the weight w_q
+// when both ends are solid and the source is an active node (main.c:1161-1162) -- and all of them are stored; the slot of
+// a bounce-back link gets the streamed value as a placeholder, which the compacted pass that follows overwrites (the
+// stores of one wavefront to one address keep their order; a link whose wall distance fires neither formula keeps exactly
+// this value, main.c:1166-1217). ~13 instructions per direction instead of three nested divergent branches: 1.6 % of the
+// kernel (A/B on one GPU, four interleaved pairs).
+template <class Ctx>
+__device__ __forceinline__ void classify_store_row_deep(const Ctx& C, const LatticeView& L, real* __restrict__ fout,
+                                                        long node, unsigned& ibb, unsigned& nnm, unsigned& hzm) {
+  const long fb = fbase(node);
+  fout[fb] = C.own(0);
+  const bool own_solid = C.o_own() != -1;
+#define LBM_CLASSIFY_DEEP(Q)                                                        \
+  {                                                                                 \
+    const bool src_solid = C.o_nb(OPPq(Q)) != -1;                                   \
+    const bool reset = src_solid & own_solid & C.act_nb(OPPq(Q));                   \
+    const real in_ = C.in(OPPq(Q));                                                 \
+    fout[fb + Q * F_QSTRIDE(L)] = reset ? Wq(Q) : in_;                              \
+    const unsigned link = (src_solid & !own_solid) ? 1u << Q : 0u;                  \
+    ibb |= link;                                                                    \
+    if (Q <= 4) hzm |= C.o_nb(Q) != -1 ? link : 0u;                                 \
+  }
+  LBM_CLASSIFY_DEEP(1) LBM_CLASSIFY_DEEP(2) LBM_CLASSIFY_DEEP(3) LBM_CLASSIFY_DEEP(4)
+  LBM_CLASSIFY_DEEP(5) LBM_CLASSIFY_DEEP(6) LBM_CLASSIFY_DEEP(7) LBM_CLASSIFY_DEEP(8)
+#undef LBM_CLASSIFY_DEEP
+  nnm = ibb;
+}
+#endif
+
 // number of set bits of `m` below this lane
 __device__ __forceinline__ unsigned mbcnt(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -971,10 +1009,13 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
   __shared__ real2 sRec[4 * REC_RING * 4 * 64];
   const RecRing ring{sRec + (threadIdx.x >> 6) * (REC_RING * 4 * 64)};
   // wave-private scratch for the compacted bounce-back evaluation: 64 link slots
-  __shared__ real sPay[4 * 64 * 4];
-  __shared__ int sDesc[4 * 64];
-  real* const pay = sPay + (threadIdx.x >> 6) * (64 * 4);
-  int* const desc = sDesc + (threadIdx.x >> 6) * 64;
+  // (Round 3 measured a spare 65th slot that lanes without a link write to, instead of sitting out the writes under an
+  // exec mask: eight mask round trips per row less, but 12 B of scratch and twice the scalar spill reloads: +1.7 %.)
+  constexpr int LINK_SLOTS = 64;
+  __shared__ real sPay[4 * LINK_SLOTS * 4];
+  __shared__ int sDesc[4 * LINK_SLOTS];
+  real* const pay = sPay + (threadIdx.x >> 6) * (LINK_SLOTS * 4);
+  int* const desc = sDesc + (threadIdx.x >> 6) * LINK_SLOTS;
   const real wc_diag = L.wc_diag, wc_axis = L.wc_axis;  // kernel arguments: scalar registers
   auto row_ok = [&](int xl) { return yin && xl >= 0 && xl < L.nxl; };
   const int ycl = y < 0 ? 0 : (y >= L.ly ? L.ly - 1 : y);
@@ -1097,7 +1138,11 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
       // (a) everything but the interpolated bounce-back links: computed and stored
       unsigned ibb = 0, nnm = 0, hzm = 0;
       if (writer && x < xe) {
+#ifndef MARCH_BRANCHY
+        if (deep) classify_store_row_deep(C, L, fout, node, ibb, nnm, hzm);
+#else
         if (deep) classify_store_row<false>(C, L, gx, y, fout, node, ibb, nnm, hzm);
+#endif
         else classify_store_row<true>(C, L, gx, y, fout, node, ibb, nnm, hzm);
       }
       MT(4)
