@@ -1102,7 +1102,12 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
     load_raw(x + 3, buf);
     __builtin_amdgcn_sched_barrier(0);
     MT(2)
-    const bool actp = iD.c != -1 && node_active(L, G, iC, iD, iE, L.gx0 + x + 1, y, [&] { return ring.get(x + 1, lane); });
+    // (the column re-declared opaque: otherwise (double)(y - 1), (double)y, (double)(y + 1) of node_active's rare path are
+    // hoisted out of the loop into six registers the kernel does not have, and one pair ends up in scratch -- whose reload
+    // drains the row prefetch)
+    int y_act = y;
+    asm volatile("" : "+v"(y_act));
+    const bool actp = iD.c != -1 && node_active(L, G, iC, iD, iE, L.gx0 + x + 1, y_act, [&] { return ring.get(x + 1, lane); });
     MT(3)
 
     RegCtx C;
