@@ -88,8 +88,11 @@ __device__ __forceinline__ real wall_uy(const LatticeView& L, const GP& g, int x
 // and RN(q + r * y) = RN(a / b) -- for every a, provided the significand of b is not all ones and
 // nothing under- or overflows (the callers check b; |a / b| here is a velocity ratio or a moment, far
 // from 1e-290). r == 0 means q is already the exact quotient (this also keeps the sign of a zero).
-// One division costs ~30 fp64 instructions on gfx950; this costs 3 + a select. The fused kernel is
-// issue-bound, not bandwidth-bound, so instructions are what counts.
+// One division costs ~30 fp64 instructions on gfx950; this costs 3 + a select. Round 1 measured -18 % VALU instructions
+// and -1 % time with it in the fused kernel; by round 3 (DPP shifts, branch-free classification) the guards, the selects
+// and the skipped fallback cost more than the divisions: true divisions are 0-4.7 % faster (six interleaved pairs on one
+// GPU, never slower), so the product uses them and this form only exists with -DLBMDEM_EXACT_RECIP.
+#ifdef LBMDEM_EXACT_RECIP
 __device__ __forceinline__ real exact_div(real a, real b, real y) {
   const real q = a * y;
   const real r = __builtin_fma(-b, q, a);     // (the float overload for float operands: exact there too)
@@ -106,6 +109,7 @@ __device__ __forceinline__ bool significand_all_ones(real v) {
 // numerators for which exact_div cannot underflow (divisors here are O(1) .. O(1e8))
 __device__ __forceinline__ bool div_safe(real a) { return a == 0.0 || (fabs(a) > 1e-200 && fabs(a) < 1e200); }
 #endif
+#endif  // LBMDEM_EXACT_RECIP
 
 // main.c:1082-1116, in registers
 __device__ __forceinline__ void mrt_collide(const LatticeView& L, real (&f)[9]) {
@@ -128,16 +132,19 @@ __device__ __forceinline__ void mrt_collide(const LatticeView& L, real (&f)[9]) 
   // three quotients by the same rho: one true division (the reciprocal) + three exact_div
   real d1, d2, d3;  // 3 * (j_x2 + j_y2) / rho, (j_x2 - j_y2) / rho, j_x * j_y / rho
   const real n1 = 3 * (j_x2 + j_y2), n2 = j_x2 - j_y2, n3 = j_x * j_y;
+#ifdef LBMDEM_EXACT_RECIP   /* experiment builds: the round-1 form (one reciprocal + three exact_div, guarded) */
   if (L.recip_ok && !significand_all_ones(rho) && rho > 1e-8 && rho < 1e8 && div_safe(n1) && div_safe(n2) &&
       div_safe(n3)) {
     const real y = 1.0 / rho;
     d1 = exact_div(n1, rho, y);
     d2 = exact_div(n2, rho, y);
     d3 = exact_div(n3, rho, y);
-  } else {
-    d1 = 3 * (j_x2 + j_y2) / rho;
-    d2 = (j_x2 - j_y2) / rho;
-    d3 = j_x * j_y / rho;
+  } else
+#endif
+  {
+    d1 = n1 / rho;
+    d2 = n2 / rho;
+    d3 = n3 / rho;
   }
   const real eO = e - L.s2 * (e + 2 * rho - d1);
   const real epsO = eps - L.s3 * (eps - rho + d1);
@@ -164,14 +171,17 @@ __device__ __forceinline__ void mrt_collide(const LatticeView& L, real (&f)[9]) 
 // 1. + 3*eu and eu*eu then erase). Hence four divisions instead of nine, same bits.
 __device__ __forceinline__ void grain_equilibrium_u(const LatticeView& L, real ux, real uy, real (&f)[9]) {
   real u_squ, e1, e2, e3, e4;
+#ifdef LBMDEM_EXACT_RECIP
   if (L.recip_ok && div_safe(ux * ux) && div_safe(uy * uy)) {  // divisions by the run constants c and c*c
     u_squ = exact_div(ux * ux + uy * uy, L.cc, L.rcc);
     e1 = exact_div(-ux + uy, L.c, L.rc);
     e2 = exact_div(-ux, L.c, L.rc);
     e3 = exact_div(-ux + (-uy), L.c, L.rc);
     e4 = exact_div(-uy, L.c, L.rc);
-  } else {
-    u_squ = (ux * ux + uy * uy) / (L.c * L.c);
+  } else
+#endif
+  {
+    u_squ = (ux * ux + uy * uy) / L.cc;   // L.cc = c * c in `real` arithmetic (host), main.c:976
     e1 = (-ux + uy) / L.c;     // q = 1: (-1, 1)
     e2 = (-ux) / L.c;          // q = 2: (-1, 0)
     e3 = (-ux + (-uy)) / L.c;  // q = 3: (-1,-1)
