@@ -157,6 +157,45 @@ def test_distributed_grain_protocol_bit_exact_over_gloo(po, tmp_path):
     assert ((x1 / dx < cut) != (want_g[:, 0] / dx < cut)).any(), "no grain crossed the cut: migration not exercised"
 
 
+def _bits_worker(rank, world, port, outdir):
+    sys.path[:0] = [ROOT, HERE]
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    strips = ge.load_package().strips_module()
+    comm = strips.TorchComm(dist)
+    n = 37                                           # not a multiple of 8 bytes for the uint8 array: the padding path
+    rng = np.random.default_rng(5)
+    full = rng.standard_normal((n, 12)) * 1e3
+    full[3, 4] = -0.0; full[5, 1] = np.inf; full[7, 7] = np.nan; full[9, 0] = 5e-324    # bit patterns, not values
+    owner = np.arange(n) % world                     # every grain has exactly one owner
+    st = np.where((owner == rank)[:, None], full, 0.0)
+    owned = (owner == rank).astype(np.uint8)
+    keys = np.zeros((world, 3, 2), np.int64); keys[rank] = [[rank + 1, -7], [0, 0], [1 << 40, (rank << 32) | 5]]
+    for a in (st, owned, keys):
+        comm.all_reduce_host_bits(a)
+    np.savez(os.path.join(outdir, f"bits{rank}.npz"), st=st, owned=owned, keys=keys, full=full)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bitwise_host_allreduce_over_gloo(tmp_path, world):
+    """TorchComm.all_reduce_host_bits -- the exchange behind the multi-rank write_DEM sub-step (DistStripRunner.table_substep):
+    arrays whose non-zero bits are disjoint across the ranks come back as their bit-wise union on every rank, whatever the
+    bit patterns (-0.0, inf, NaN, denormals, negative integers) and whatever the byte length."""
+    import torch.multiprocessing as tmp_mp
+    port = _free_port()
+    tmp_mp.spawn(_bits_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        z = np.load(tmp_path / f"bits{rank}.npz")
+        assert np.array_equal(z["st"].view(np.uint64), z["full"].view(np.uint64)), f"rank {rank}: state bits differ"
+        assert (z["owned"] == 1).all()
+        for r in range(world):
+            assert z["keys"][r].tolist() == [[r + 1, -7], [0, 0], [1 << 40, (r << 32) | 5]]
+
+
 def test_partition_and_halo(pkg):
     s = pkg.strips_module()
     assert s.partition(8192, 8) == [(1024 * k, 1024 * (k + 1)) for k in range(8)]
