@@ -582,7 +582,6 @@ int lbmdem_lbm_step(lbmdem_handle* h) {
 
 int lbmdem_verlet_rebuild(lbmdem_handle* h) {
   CHECK_H(h);
-  PhaseRange range_("lbmdem:verlet_rebuild");
   // VerletWall moves the right/top DEM walls: main.c:1555-1561
   lbmdem_config& c = h->cfg;
   if (h->nbsteps * c.dt < c.phys.dtt) {
@@ -592,6 +591,14 @@ int lbmdem_verlet_rebuild(lbmdem_handle* h) {
     c.Mdx = 1.e-3 * c.lx;
     c.Mhy = 1.e-3 * c.ly;
   }
+  return lbmdem_verlet_build_lists(h);
+}
+
+// the lists alone (pair list + the four wall lists against the walls WHERE THEY ARE): what a rebuild outside the
+// reference's updateVerlet cadence may do (the table sub-step of a strip decomposition, lbmdem_dist_table_substep)
+int lbmdem_verlet_build_lists(lbmdem_handle* h) {
+  CHECK_H(h);
+  PhaseRange range_("lbmdem:verlet_rebuild");
   if (*h->ovf_host) return fail(LBMDEM_ENOMEM, "Verlet list overflow at the previous rebuild (more than %ld symmetric entries)", h->V.cap);
   const int e = launch_verlet_rebuild(h->V, h->kin[h->kcur], h->r, dem_params(h), h->stream);
   if (e != 0) return fail(LBMDEM_EHIP, "Verlet rebuild failed: %s", hipGetErrorString((hipError_t)e));

@@ -9,7 +9,7 @@ extern "C" {
 
 namespace {
 struct CkptHeader {
-  char magic[8];       // "LBMDEMC4"
+  char magic[8];       // "LBMDEMC5"
   double lid6;         // lbmdem_set_lid
   int layout;          // device layout of the populations in the file: 1 = 16-node tiles f[x][y/16][q][y%16]
   int force_mode, diag_always, has_carry;
@@ -18,6 +18,7 @@ struct CkptHeader {
   long nbsteps;
   int verlet_ok, nnbr; // symmetric list length
   long plane;          // sanity: nxl * sy of the writer
+  int has_dist, pad;   // a CkptDist section follows the lattice (the writer had its grains distributed over strips)
 };
 struct CkptDist {       // follows the lattice when the writer had its grains distributed over strips
   char magic[8];        // "LBMDIST1"
@@ -26,6 +27,10 @@ struct CkptDist {       // follows the lattice when the writer had its grains di
 constexpr int CKPT_LAYOUT = 1;
 static bool wr(FILE* fp, const void* p, size_t n) { return fwrite(p, 1, n, fp) == n; }
 static bool rd(FILE* fp, void* p, size_t n) { return fread(p, 1, n, fp) == n; }
+struct FileCloser {   // closes on every exit path, exceptions included
+  FILE* fp;
+  ~FileCloser() { if (fp) fclose(fp); }
+};
 }  // namespace
 
 int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) try {
@@ -42,7 +47,7 @@ int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) try {
   if (h->verlet_ok) HIP_TRY(hipMemcpy(off.data(), h->V.offsets, sizeof(int) * (n + 1), hipMemcpyDeviceToHost));
   CkptHeader H;
   memset(&H, 0, sizeof H);
-  memcpy(H.magic, "LBMDEMC4", 8);
+  memcpy(H.magic, "LBMDEMC5", 8);
   H.lid6 = h->L.lid6;
   H.layout = CKPT_LAYOUT; H.force_mode = h->force_mode; H.diag_always = h->diag_always ? 1 : 0;
   H.has_carry = 1;
@@ -52,6 +57,7 @@ int lbmdem_checkpoint_save(lbmdem_handle* h, const char* path) try {
   }
   HIP_TRY(hipMemcpy(H.carry, h->ct.carry, sizeof H.carry, hipMemcpyDeviceToHost));
   H.cfg = h->cfg; H.nbsteps = h->nbsteps; H.verlet_ok = h->verlet_ok ? 1 : 0; H.nnbr = off[n]; H.plane = h->L.plane;
+  H.has_dist = h->dist ? 1 : 0;
   FILE* fp = fopen(path, "wb");
   if (!fp) return fail(LBMDEM_EINVAL, "cannot open '%s' for writing", path);
   bool ok = wr(fp, &H, sizeof H);
@@ -95,18 +101,26 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
   *out = nullptr;
   FILE* fp = fopen(path, "rb");
   if (!fp) return fail(LBMDEM_EINVAL, "cannot open checkpoint '%s'", path);
+  FileCloser closer{fp};
   CkptHeader H;
-  if (!rd(fp, &H, sizeof H) || memcmp(H.magic, "LBMDEMC4", 8) != 0) { fclose(fp); return fail(LBMDEM_EINVAL, "'%s' is not a checkpoint of this library version", path); }
-  if (H.layout != CKPT_LAYOUT) { fclose(fp); return fail(LBMDEM_EINVAL, "checkpoint '%s' holds another device layout (%d)", path, H.layout); }
+  if (!rd(fp, &H, sizeof H) || memcmp(H.magic, "LBMDEMC5", 8) != 0) return fail(LBMDEM_EINVAL, "'%s' is not a checkpoint of this library version", path);
+  if (H.layout != CKPT_LAYOUT) return fail(LBMDEM_EINVAL, "checkpoint '%s' holds another device layout (%d)", path, H.layout);
+  // the header is not trusted: sizes are checked before anything is allocated from them
+  const lbmdem_config& hc = H.cfg;
+  if (hc.nbgrains < 1 || hc.nbgrains > (1 << 28) || hc.lx < 3 || hc.ly < 3 || hc.lx > (1 << 24) || hc.ly > (1 << 24) ||
+      hc.x_begin < 0 || hc.x_end > hc.lx || hc.x_begin >= hc.x_end || hc.halo < 0 || hc.halo > hc.lx || hc.npDEM < 1 ||
+      H.nnbr < 0 || H.nbsteps < 0 || H.plane < 1 || (H.has_dist != 0 && H.has_dist != 1))
+    return fail(LBMDEM_EINVAL, "checkpoint '%s': implausible header (grains %d, lattice %d x %d, rows [%d, %d))", path,
+                hc.nbgrains, hc.lx, hc.ly, hc.x_begin, hc.x_end);
   const int n = H.cfg.nbgrains;
   std::vector<double> r(n), kin(9 * (size_t)n);
-  if (!rd(fp, r.data(), sizeof(double) * n) || !rd(fp, kin.data(), sizeof(double) * 9 * n)) { fclose(fp); return fail(LBMDEM_EINVAL, "checkpoint truncated"); }
+  if (!rd(fp, r.data(), sizeof(double) * n) || !rd(fp, kin.data(), sizeof(double) * 9 * n)) return fail(LBMDEM_EINVAL, "checkpoint truncated");
   lbmdem_config cfg = H.cfg;
   cfg.device = device;
   lbmdem_handle* h = nullptr;
   int rc = lbmdem_create(&cfg, r.data(), kin.data(), kin.data() + n, &h);  // x1, x2 are the first two columns
-  if (rc != LBMDEM_OK) { fclose(fp); return rc; }
-  bool ok = h->L.plane == H.plane && H.nnbr >= 0 && H.nnbr <= h->V.cap;
+  if (rc != LBMDEM_OK) return rc;
+  bool ok = h->L.plane == H.plane && H.nnbr <= h->V.cap;
   auto fill = [&](void* dev, size_t bytes) {
     if (!ok || bytes == 0) return;
     std::vector<char> buf(bytes);
@@ -123,14 +137,13 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
   h->ocur = 0; h->obst_pending = false;
   for (int q = 0; q < 9 && ok; ++q) fill(h->f[0] + (size_t)q * h->L.plane, sizeof(double) * (size_t)h->L.plane);
   h->fcur = 0;
-  if (ok) {   // a strip with distributed grains: masks and message capacities as the writer had them
-    CkptDist D;
-    if (rd(fp, &D, sizeof D)) {
-      ok = memcmp(D.magic, "LBMDIST1", 8) == 0 && lbmdem_dist_enable_caps(h, D.margin, D.cap_g, D.cap_t, D.cap_l) == LBMDEM_OK;
-      if (ok) { fill(h->dd.active, n); fill(h->dd.fluidmask, n); fill(h->owner, n); h->dist_poison = D.poison != 0; }
-    }
+  if (ok && H.has_dist) {   // a strip with distributed grains: masks and message capacities as the writer had them. A
+    CkptDist D;             // missing or short section fails the load HERE, not later inside a collective on one rank
+    ok = rd(fp, &D, sizeof D) && memcmp(D.magic, "LBMDIST1", 8) == 0 && D.margin > 0 && D.cap_g > 0 && D.cap_t > 0 &&
+         D.cap_l > 0 && D.cap_g <= n && D.cap_t <= n && D.cap_l <= n &&
+         lbmdem_dist_enable_caps(h, D.margin, D.cap_g, D.cap_t, D.cap_l) == LBMDEM_OK;
+    if (ok) { fill(h->dd.active, n); fill(h->dd.fluidmask, n); fill(h->owner, n); h->dist_poison = D.poison != 0; }
   }
-  fclose(fp);
   if (!ok) { lbmdem_destroy(h); return fail(LBMDEM_EINVAL, "checkpoint '%s' is truncated or from a different decomposition", path); }
   h->cfg = cfg;  // wall positions as saved
   h->force_mode = H.force_mode;

@@ -28,8 +28,16 @@ RcclApi g_rccl;
 
 int rccl_load() {
   if (g_rccl.lib) return LBMDEM_OK;
-  // a copy that is already in the process (PyTorch-ROCm ships its own as "librccl.so") is reused: one RCCL per process
-  void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+  // LBMDEM_RCCL_LIBRARY names the RCCL build to use (a non-standard install; the tests' several-ranks-on-one-GPU stand-in,
+  // tests/rccl_shim). Otherwise a copy that is already in the process (PyTorch-ROCm ships its own as "librccl.so") is
+  // reused: one RCCL per process
+  void* lib = nullptr;
+  const char* named = getenv("LBMDEM_RCCL_LIBRARY");
+  if (named && *named) {
+    lib = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return fail(LBMDEM_EHIP, "cannot load LBMDEM_RCCL_LIBRARY=%s: %s", named, dlerror());
+  }
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
   if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
   if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
   if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
@@ -67,6 +75,8 @@ struct lbmdem_comm {
   double* buf[4][2][2] = {};
   size_t count[4] = {};   // doubles per message: KIN, FHF, TABLES, halo
   double* scratch = nullptr;
+  float* vtk_dev = nullptr;   // staging of one strip's VTK fields (lbmdem_comm_write_vtk), kept between frames
+  size_t vtk_floats = 0;
 };
 
 #pragma GCC visibility push(default)
@@ -91,6 +101,7 @@ int lbmdem_comm_destroy(lbmdem_comm* c) {
   }
   for (auto& k : c->buf) for (auto& s : k) for (double*& p : s) if (p) (void)hipFree(p);
   if (c->scratch) (void)hipFree(c->scratch);
+  if (c->vtk_dev) (void)hipFree(c->vtk_dev);
   for (int l = 0; l < LANE_COUNT; ++l) if (c->nccl[l]) (void)g_rccl.CommDestroy(c->nccl[l]);
   delete c;
   return LBMDEM_OK;
@@ -303,16 +314,51 @@ int lbmdem_comm_run(lbmdem_handle* h, lbmdem_comm* c, long n_dem_steps) {
   return LBMDEM_OK;
 }
 
-// write_vtk (main.c:237-338) of the whole lattice: the strips' columns merged, rank 0 writes the five files.
+// write_vtk (main.c:237-338) of the whole lattice: every rank renders the five fields of its own columns and SENDS them
+// to rank 0 (point to point, one reused device staging buffer of the widest strip), which places them and writes the
+// five files. Only rank 0 holds lattice-sized host arrays (as the single-GPU writer does).
 int lbmdem_comm_write_vtk(lbmdem_handle* h, lbmdem_comm* c, const char* dir, int nfile) try {
   CHECK_H(h);
   if (!c) return fail(LBMDEM_EINVAL, "null communicator");
-  const size_t cnt = (size_t)h->cfg.lx * h->cfg.ly;
-  std::vector<float> fields(11 * cnt, 0.f);
-  RC_TRY(lbmdem_vtk_place_owned(h, fields.data()));
-  if (c->world > 1) RC_TRY(lbmdem_comm_allreduce_bits(c, fields.data(), sizeof(float) * fields.size()));
-  if (c->rank != 0) return LBMDEM_OK;
-  return lbmdem_write_vtk_fields(dir, nfile, h->cfg.lx, h->cfg.ly, fields.data());
+  const int lx = h->cfg.lx, ly = h->cfg.ly, W = c->world;
+  const LatticeView& L = h->L;
+  const int nx = L.xo1 - L.xo0, x0 = L.gx0 + L.xo0;
+  const size_t part = (size_t)nx * ly;
+  std::vector<float> loc(11 * part);
+  RC_TRY(lbmdem_download_vtk_fields(h, loc.data(), loc.data() + part, loc.data() + 4 * part, loc.data() + 7 * part, loc.data() + 8 * part));
+  // who owns which columns
+  std::vector<double> strips(2 * (size_t)W, 0.0);
+  strips[2 * (size_t)c->rank] = x0; strips[2 * (size_t)c->rank + 1] = nx;
+  if (W > 1) {
+    if (2 * W > 1024) return fail(LBMDEM_EINVAL, "too many ranks");
+    RC_TRY(lbmdem_comm_allreduce_sum(c, strips.data(), 2 * W));
+  }
+  size_t widest = 0, covered = 0;
+  for (int r = 0; r < W; ++r) { const size_t w = (size_t)strips[2 * (size_t)r + 1]; if (w > widest) widest = w; covered += w; }
+  if (covered != (size_t)lx) return fail(LBMDEM_EINVAL, "the ranks' strips cover %zu of %d columns", covered, lx);
+  if (W > 1 && c->vtk_floats < 11 * widest * ly) {
+    if (c->vtk_dev) { HIP_TRY(hipFree(c->vtk_dev)); c->vtk_dev = nullptr; c->vtk_floats = 0; }
+    HIP_TRY(hipMalloc((void**)&c->vtk_dev, sizeof(float) * 11 * widest * ly));
+    c->vtk_floats = 11 * widest * ly;
+  }
+  if (c->rank != 0) {
+    HIP_TRY(hipMemcpy(c->vtk_dev, loc.data(), sizeof(float) * loc.size(), hipMemcpyHostToDevice));
+    NCCL_TRY(g_rccl.Send(c->vtk_dev, loc.size(), ncclFloat, 0, c->nccl[0], c->side[0]));
+    HIP_TRY(hipStreamSynchronize(c->side[0]));
+    return LBMDEM_OK;
+  }
+  std::vector<float> fields(11 * (size_t)lx * ly, 0.f);
+  lbmdem_vtk_place_block(fields.data(), lx, ly, x0, nx, loc.data());
+  for (int r = 1; r < W; ++r) {
+    const int rx0 = (int)strips[2 * (size_t)r], rnx = (int)strips[2 * (size_t)r + 1];
+    const size_t n = 11 * (size_t)rnx * ly;
+    if (loc.size() < n) loc.resize(n);
+    NCCL_TRY(g_rccl.Recv(c->vtk_dev, n, ncclFloat, r, c->nccl[0], c->side[0]));
+    HIP_TRY(hipStreamSynchronize(c->side[0]));
+    HIP_TRY(hipMemcpy(loc.data(), c->vtk_dev, sizeof(float) * n, hipMemcpyDeviceToHost));
+    lbmdem_vtk_place_block(fields.data(), lx, ly, rx0, rnx, loc.data());
+  }
+  return lbmdem_write_vtk_fields(dir, nfile, lx, ly, fields.data());
 } catch (const std::bad_alloc&) {
   return fail(LBMDEM_ENOMEM, "host memory allocation failed");
 }

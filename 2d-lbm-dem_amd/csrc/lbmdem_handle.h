@@ -169,4 +169,6 @@ static inline DemParams dem_params(const lbmdem_handle* h) {
 // shared between the translation units
 #define LBMDEM_INTERNAL extern "C" __attribute__((visibility("hidden")))
 LBMDEM_INTERNAL int lbmdem_write_vtk_file(const char* path, int nx, int ny, const char* name, int dim, const float* data);
+LBMDEM_INTERNAL int lbmdem_verlet_build_lists(lbmdem_handle* h);
+LBMDEM_INTERNAL int lbmdem_vtk_place_block(float* fields11, int lx, int ly, int x0, int nx, const float* block11);
 LBMDEM_INTERNAL int lbmdem_dist_enable_caps(lbmdem_handle* h, int M, long cap_g, long cap_t, long cap_l);

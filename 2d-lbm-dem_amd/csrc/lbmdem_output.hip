@@ -301,6 +301,19 @@ int lbmdem_write_forces(lbmdem_handle* h, const char* dir, int nfile) try {
   return fail(LBMDEM_EINVAL, "unexpected C++ exception");
 }
 
+// a strip's five fields (block11: the layout of lbmdem_download_vtk_fields for nx columns, back to back) into the
+// lattice-sized arrays, columns [x0, x0 + nx)
+int lbmdem_vtk_place_block(float* fields11, int lx, int ly, int x0, int nx, const float* block11) {
+  const size_t part = (size_t)nx * ly, cnt = (size_t)lx * ly;
+  const float* lp[5] = {block11, block11 + part, block11 + 4 * part, block11 + 7 * part, block11 + 8 * part};
+  float* fp[5] = {fields11, fields11 + cnt, fields11 + 4 * cnt, fields11 + 7 * cnt, fields11 + 8 * cnt};
+  const int dims[5] = {1, 3, 3, 1, 3};
+  for (int k = 0; k < 5; ++k)
+    for (int y = 0; y < ly; ++y)
+      memcpy(fp[k] + ((size_t)y * lx + x0) * dims[k], lp[k] + (size_t)y * nx * dims[k], sizeof(float) * nx * dims[k]);
+  return LBMDEM_OK;
+}
+
 // write_vtk of a strip decomposition (main.c:237-338): every rank drops its owned columns into zero-initialised
 // lattice-sized arrays (fields11 = grain_pressure[cnt], grain_velocity[3 cnt], grain_acceleration[3 cnt],
 // fluid_pressure[cnt], fluid_velocity[3 cnt], cnt = lx * ly, each [ly][lx]); the caller merges the ranks' arrays
@@ -315,11 +328,8 @@ int lbmdem_vtk_place_owned(lbmdem_handle* h, float* fields11) try {
   float* lp[5] = {loc.data(), loc.data() + part, loc.data() + 4 * part, loc.data() + 7 * part, loc.data() + 8 * part};
   int rc = lbmdem_download_vtk_fields(h, lp[0], lp[1], lp[2], lp[3], lp[4]);
   if (rc != LBMDEM_OK) return rc;
-  float* fp[5] = {fields11, fields11 + cnt, fields11 + 4 * cnt, fields11 + 7 * cnt, fields11 + 8 * cnt};
-  const int dims[5] = {1, 3, 3, 1, 3};
-  for (int k = 0; k < 5; ++k)
-    for (int y = 0; y < L.ly; ++y)
-      memcpy(fp[k] + ((size_t)y * L.lx + x0) * dims[k], lp[k] + (size_t)y * nx * dims[k], sizeof(float) * nx * dims[k]);
+  (void)cnt;
+  lbmdem_vtk_place_block(fields11, L.lx, L.ly, x0, nx, loc.data());
   return LBMDEM_OK;
 } catch (const std::bad_alloc&) {
   return fail(LBMDEM_ENOMEM, "host memory allocation failed");

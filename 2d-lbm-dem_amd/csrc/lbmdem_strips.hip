@@ -139,7 +139,9 @@ int lbmdem_dist_enable(lbmdem_handle* h, int margin_rows) try {
 // The "previous contact" carries as agreed over all ranks (strip decomposition: before a checkpoint, see
 // lbmdem_comm_sync_carries): they stand until a younger contact is recorded.
 int lbmdem_dist_set_carries(lbmdem_handle* h, const double* carry3) {
+  SP_UNAVAILABLE("the strip decomposition with distributed grains");   // (ct.carry holds `real`s: 12 bytes in the float build)
   CHECK_H(h);
+  if (!h->dist) return fail(LBMDEM_EINVAL, "lbmdem_dist_enable first");
   if (!carry3) return fail(LBMDEM_EINVAL, "null buffer");
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(h->ct.carry, carry3, sizeof(double) * 3, hipMemcpyHostToDevice));
@@ -150,7 +152,9 @@ int lbmdem_dist_set_carries(lbmdem_handle* h, const double* carry3) {
 // this rank's youngest record per carry (keys {0,0} = none) and its carry[] as it stands (only meaningful on the rank
 // that ran the last table sub-step)
 int lbmdem_dist_export_carries(lbmdem_handle* h, long long* carry_keys, double* carry_vals, double* carry_standing) {
+  SP_UNAVAILABLE("the strip decomposition with distributed grains");
   CHECK_H(h);
+  if (!h->dist) return fail(LBMDEM_EINVAL, "lbmdem_dist_enable first");
   if (!carry_keys || !carry_vals || !carry_standing) return fail(LBMDEM_EINVAL, "null buffer");
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(carry_standing, h->ct.carry, sizeof(double) * 3, hipMemcpyDeviceToHost));
@@ -314,7 +318,9 @@ int lbmdem_dist_table_substep(lbmdem_handle* h, const double* state12_full, cons
   // a list over ALL grains from their exact positions (this rank's own list was built with whatever the grains it does
   // not integrate held). Every pair in contact is in any valid list, pairs that do not touch contribute nothing, and
   // partners are sorted by index: the sub-step's sums are those of the reference's list.
-  int rc = lbmdem_verlet_rebuild(h);
+  // (only the LISTS: VerletWall's move of the right/top walls happens every updateVerlet steps in the reference,
+  // main.c:1555-1561,1721 -- this extra rebuild must not move them early when dtt > 0)
+  int rc = lbmdem_verlet_build_lists(h);
   if (rc != LBMDEM_OK) return rc;
   if (!h->dx_ready) {
     HIP_TRY(hipStreamSynchronize(h->stream));

@@ -8,6 +8,8 @@
  * `#define duration 1.5`, main.c:27-32,47); here the same defaults apply and can be overridden at
  * run time: --lx N --ly N --scale S --duration SECONDS --steps N_DEM_STEPS --device K, and (absent in
  * the reference, which cannot resume) --checkpoint FILE (written at the end) / --restart FILE.
+ * --gpus N: one process per GPU, rank k on device K + k; --devices a,b,c names the device of every rank instead (the
+ * same device may appear twice: that is how the tests run several ranks on a one-GPU box, see tests/rccl_shim).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -27,6 +29,7 @@
  * through a file in a private temporary directory. Rank 0 prints and writes the VTK frames and DEM tables (merged over the ranks); checkpoints are single-GPU. */
 static int g_rank = 0, g_world = 1, g_use_comm = 0;
 static char g_iddir[256] = "";
+static int g_devices[64], g_ndevices = 0;   /* --devices */
 
 static int share_id(unsigned char* id) {
   char path[320], tmp[340];
@@ -96,7 +99,18 @@ int main(int argc, char** argv) {
   for (int a = 1; a < argc; ++a) {
     if (!strcmp(argv[a], "--gpus") && a + 1 < argc) gpus = atoi(argv[a + 1]);
     if (!strcmp(argv[a], "--comm")) g_use_comm = 1;   /* the RCCL path with a single rank */
+    if (!strcmp(argv[a], "--devices") && a + 1 < argc) {
+      for (const char* p = argv[a + 1]; *p && g_ndevices < 64;) {
+        char* end = NULL;
+        long v = strtol(p, &end, 10);
+        if (end == p || v < 0) { fprintf(stderr, "--devices: a comma-separated list of device ordinals\n"); return EXIT_FAILURE; }
+        g_devices[g_ndevices++] = (int)v;
+        p = (*end == ',') ? end + 1 : end;
+        if (*end && *end != ',') { fprintf(stderr, "--devices: a comma-separated list of device ordinals\n"); return EXIT_FAILURE; }
+      }
+    }
   }
+  if (g_ndevices > 0 && g_ndevices < gpus) { fprintf(stderr, "--devices names %d devices for %d ranks\n", g_ndevices, gpus); return EXIT_FAILURE; }
   if (gpus <= 1) return run(argc, argv);
   g_world = gpus; g_use_comm = 1;
   { /* every strip must be at least one margin wide (lbmdem_dist_enable would refuse on the ranks whose strip is one
@@ -173,12 +187,13 @@ static int run(int argc, char** argv) {
     else if (!strcmp(argv[a], "--checkpoint") && a + 1 < argc) ckpt_out = argv[++a];
     else if (!strcmp(argv[a], "--restart") && a + 1 < argc) ckpt_in = argv[++a];
     else if (!strcmp(argv[a], "--gpus") && a + 1 < argc) ++a;
+    else if (!strcmp(argv[a], "--devices") && a + 1 < argc) ++a;
     else if (!strcmp(argv[a], "--comm")) {}
     else if (argv[a][0] != '-' && !sample) sample = argv[a];
     else { sample = NULL; break; }
   }
   if (!sample) {
-    SAY("usage: usage %s <filename> [--lx N --ly N --scale S --duration T --steps N --device K --gpus N]\n", argv[0]);
+    SAY("usage: usage %s <filename> [--lx N --ly N --scale S --duration T --steps N --device K --gpus N --devices a,b,..]\n", argv[0]);
     exit(EXIT_FAILURE);
   }
   SAY("Opening file : %s\n", sample);
@@ -207,7 +222,7 @@ static int run(int argc, char** argv) {
     cfg.x_begin = (int)((long)g_rank * lx / g_world);
     cfg.x_end = (int)((long)(g_rank + 1) * lx / g_world);
     cfg.halo = g_world > 1 ? 2 : 0;
-    cfg.device = device + g_rank;
+    cfg.device = g_ndevices > 0 ? g_devices[g_rank] : device + g_rank;
   }
   /* with several strips every rank keeps its own checkpoint file: FILE.rank<k> */
   char ckpt_in_rank[4096], ckpt_out_rank[4096];
@@ -223,7 +238,7 @@ static int run(int argc, char** argv) {
   lbmdem_handle* h = NULL;
   long nbsteps = 0;
   if (ckpt_in) {
-    DIE(lbmdem_checkpoint_load(ckpt_in, g_use_comm ? device + g_rank : device, &h), "checkpoint_load");
+    DIE(lbmdem_checkpoint_load(ckpt_in, cfg.device, &h), "checkpoint_load");
     DIE(lbmdem_get_config(h, &cfg), "get_config");
     if (g_use_comm && (cfg.x_begin != (int)((long)g_rank * cfg.lx / g_world) || cfg.x_end != (int)((long)(g_rank + 1) * cfg.lx / g_world))) {
       fprintf(stderr, "%s holds rows [%d, %d): written by a run with another number of strips\n", ckpt_in, cfg.x_begin, cfg.x_end);

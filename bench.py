@@ -13,6 +13,12 @@ synthetic row packing of the same shape as bin/50000.data: radii 0.5-0.9 mm, ~34
 process per GPU (strong scaling of the case BASELINE.json's metric names: "4096^2 / 50k grains; 1/2/4/8
 MI355X"). `--workload configs4` runs BASELINE.json configs[4] (8192 x 4096, 50 000 grains) instead.
 
+`python bench.py --gpus N` with N > 1 and no launcher around it starts itself under torch.distributed.run (one rank per
+GPU); a node with fewer than N GPUs gets one clean message. At N > 1 the step is driven from C (lbmdem_comm_run: RCCL
+send/recv inside the library, no Python on the step path) after a watchdogged trial run in child processes has shown
+that this transport works on this node and reproduces the single-domain bits; otherwise the torch.distributed strip
+driver is measured instead -- `config.driver` says which one ran.
+
 Output: one JSON line on rank 0. `value` = lattice-node updates of the whole job per second / 1e6
 with all state resident in HBM. `roofline` prices the dominant kernel (k_collide_stream) from HIP
 events recorded on its own stream; `cpu_baseline` times the reference's serial C path (prebuilt
@@ -142,6 +148,123 @@ def cpu_baseline(w, sample_mm, npdem):
     return out
 
 
+def device_map(world):
+    """LBMDEM_BENCH_DEVICES="0,0": the device of every rank, for running several ranks on ONE GPU (the tests do, with
+    LBMDEM_RCCL_LIBRARY pointing at tests/rccl_shim -- real RCCL refuses two ranks on one device). Unset: rank k on GPU k."""
+    e = os.environ.get("LBMDEM_BENCH_DEVICES")
+    if not e:
+        return None
+    d = [int(t) for t in e.split(",")]
+    if len(d) < world:
+        raise SystemExit(f"LBMDEM_BENCH_DEVICES names {len(d)} devices for {world} ranks")
+    return d
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def relaunch_under_launcher(args):
+    """`python bench.py --gpus N`, N > 1, started without a launcher (as the driver starts it): replace this process by
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <the same arguments>`."""
+    if device_map(args.gpus) is None:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            print(f"bench.py --gpus {args.gpus}: needs {args.gpus} GPUs, this node has {have}", file=sys.stderr)
+            raise SystemExit(2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+TRIAL_PERIODS = 2
+
+
+def trial_parent(args, dist, rank, world, ctl):
+    """Watchdog around the C driver: every rank starts ONE child process (this script with --trial-child) -- the children
+    form their own group, run TRIAL_PERIODS fluid steps of the real workload through lbmdem_comm_run and compare with a
+    single-domain run -- and kills it after --trial-timeout seconds. A hang inside RCCL (ordering, topology, a driver
+    problem) therefore costs a timeout, not the bench run. -> (every rank's child passed, note)"""
+    import subprocess
+    import torch
+    port = torch.tensor([free_port() if rank == 0 else 0], dtype=torch.int64, device=ctl)
+    dist.broadcast(port, 0)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(int(port[0])), RANK=str(rank), WORLD_SIZE=str(world),
+               LOCAL_RANK=os.environ.get("LOCAL_RANK", str(rank)))
+    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--trial-child", "--gpus", str(world), "--workload", args.workload]
+    t0 = time.perf_counter()
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        out, err = child.communicate(timeout=args.trial_timeout)
+        ok = child.returncode == 0 and "TRIAL-OK" in out
+        why = "passed" if ok else ("exit code %d: %s" % (child.returncode, (err or out).strip().splitlines()[-1][:200] if (err or out).strip() else ""))
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.communicate()
+        ok, why = False, f"rank {rank}: no answer within {args.trial_timeout:.0f} s (killed)"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ctl)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    allok = int(flag[0]) == 1
+    note = (f"{TRIAL_PERIODS} fluid steps of this workload through lbmdem_comm_run in child processes, bit-equal to a "
+            f"single-domain run (owned grains' kinematics, serial lattice mass): {'passed' if allok else 'FAILED'} in "
+            f"{time.perf_counter() - t0:.1f} s" + ("" if allok else f" [{why}]"))
+    return allok, note
+
+
+def trial_child(args, rank, world, device):
+    """One rank of the C-driver trial (see trial_parent). Control plane: gloo among the children."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    pkg = ge.load_package()
+    strips = pkg.strips_module()
+    w = workload(args.workload)
+    (r, x1, x2), _ = make_sample(w)
+    lx, ly = w["lx"], w["ly"]
+    runner = strips.CCommRunner(pkg, dist, rank, world, device, lx, ly, r, x1, x2)
+    runner.comm.selftest()
+    sim = runner.sim
+    nsub = TRIAL_PERIODS * sim.cfg.npDEM
+    runner.render_scene(nsub)
+    sim.sync()
+    # the reference's serial mass chain through the strips in x order, and the kinematics of the grains this rank owns
+    s = torch.zeros(1, dtype=torch.float64)
+    for k in range(world):
+        if k == rank:
+            s[0] = sim.final_density(float(s[0]))
+        dist.broadcast(s, k)
+    kin = sim.kinematics
+    ref = torch.zeros((len(r), 9), dtype=torch.float64)
+    ref_mass = torch.zeros(1, dtype=torch.float64)
+    if rank == 0:
+        single = pkg.LbmDem(lx, ly, r, x1, x2, device=device)
+        single.renderScene(nsub)
+        ref[...] = torch.from_numpy(single.kinematics)
+        ref_mass[0] = single.final_density()
+        single.close()
+    dist.broadcast(ref, 0)
+    dist.broadcast(ref_mass, 0)
+    refk = ref.numpy()
+    x0, x1_ = strips.partition(lx, world)[rank]
+    xc = refk[:, 0] / sim.cfg.dx
+    own = ((x0 == 0) | (xc >= x0)) & ((x1_ == lx) | (xc < x1_))
+    ok = bool(np.array_equal(kin[own], refk[own])) and float(s[0]) == float(ref_mass[0])
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    print("TRIAL-OK" if int(flag[0]) == 1 else f"TRIAL-MISMATCH rank {rank}: own grains equal {bool(np.array_equal(kin[own], refk[own]))}, "
+          f"mass {float(s[0])!r} vs {float(ref_mass[0])!r}", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    raise SystemExit(0 if int(flag[0]) == 1 else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,11 +275,13 @@ def main():
     ap.add_argument("--workload", choices=["metric", "configs4", "real50k"], default="metric",
                     help="metric = 4096x4096 / 50k-grain synthetic packing (BASELINE.json's metric, every N); "
                          "configs4 = 8192x4096/50k; real50k = 4096x4096 with the reference's bin/50000.data geometry")
-    ap.add_argument("--driver", choices=["c", "torch"], default="torch",
-                    help="multi-GPU step driver: torch = strips.py over torch.distributed (the transport that has run on "
-                         "several ranks: gloo tests, RCCL self-exchange); c = lbmdem_comm_run (RCCL inside the library, "
-                         "no Python on the step path -- has only ever run with ONE rank, no multi-GPU box was available: "
-                         "opt-in until tests/test_gpu_multi.py has passed on real GPUs)")
+    ap.add_argument("--driver", choices=["auto", "c", "torch"], default="auto",
+                    help="multi-GPU step driver: c = lbmdem_comm_run (RCCL inside the library, no Python on the step path); "
+                         "torch = strips.py over torch.distributed (~30 library calls per period from Python); auto = c after "
+                         "a watchdogged trial of it (child processes, killed after --trial-timeout seconds, results compared "
+                         "with a single-domain run), else torch")
+    ap.add_argument("--trial-timeout", type=float, default=120.0)
+    ap.add_argument("--trial-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64",
                     help="f64 = the reference's `real` (the headline); f32 = the float build of the library, the reference's "
                          "-DSINGLE_PRECISION mode (one GPU, its own line: dtype f32, 76 B/LUP; never the headline)")
@@ -164,18 +289,27 @@ def main():
                     help="use the strip-decomposition driver (torch.distributed) even with one rank")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_launcher(args)        # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    devices = device_map(world)
+    if devices is None and torch.cuda.device_count() < world:
+        if rank == 0:
+            print(f"bench.py --gpus {world}: needs {world} GPUs, this node has {torch.cuda.device_count()}", file=sys.stderr)
+        raise SystemExit(2)
+    shared_gpu = devices is not None          # test mode: several ranks on one GPU (tests/rccl_shim)
+    local_rank = devices[rank] if shared_gpu else local_rank
     torch.cuda.set_device(local_rank)
+    if args.trial_child:
+        return trial_child(args, rank, world, local_rank)
     pkg = ge.load_package()
     w = workload(args.workload)
     (r, x1, x2), sample_mm = make_sample(w)
@@ -200,13 +334,29 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:      # RCCL refuses two ranks on one device: the control plane runs over gloo, the data plane is the
+            dist.init_process_group("gloo")      # library's own transport (pointed at the tests' stand-in)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        ctl = "cpu" if shared_gpu else "cuda"
         strips = pkg.strips_module()
         cfg0 = pkg.derive(lx, ly, r)
         margin = strips.default_margin(cfg0.npDEM, float(max(r)), cfg0.phys.distVerlet, cfg0.dx)
         wide = min(b - a for a, b in strips.partition(lx, world)) >= margin
         runner = None
-        if args.driver == "c" and args.force_mode == 0 and (wide or world == 1):
+        driver_note = None
+        want_c = args.driver in ("auto", "c") and args.force_mode == 0 and (wide or world == 1)
+        if shared_gpu and not want_c:
+            raise SystemExit("several ranks on one GPU: only the C driver (wide strips, parity forces) can run")
+        if want_c and args.driver == "auto" and world > 1:
+            ok, driver_note = trial_parent(args, dist, rank, world, ctl)
+            if not ok:
+                if shared_gpu:
+                    raise SystemExit("C-driver trial failed: " + driver_note)
+                if rank == 0:
+                    print("C-driver trial failed (" + driver_note + "): measuring the torch.distributed strip driver", file=sys.stderr)
+                want_c = False
+        if want_c:
             # grains distributed, the library's own RCCL transport, one C call per batch of steps
             # every rank must take the same path. The vote comes BEFORE the RCCL communicator is made: a rank that
             # fails in its local set-up would otherwise leave the others blocked inside ncclCommInitRank
@@ -216,9 +366,11 @@ def main():
             except Exception as e:
                 print(f"[rank {rank}] C driver unavailable: {e}", file=sys.stderr)
                 ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            flag = torch.tensor([ok], dtype=torch.int32, device=ctl)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag[0]) == 0:
+                if shared_gpu:
+                    raise SystemExit("C driver unavailable")
                 if rank == 0:
                     print("falling back to the torch.distributed strip driver on all ranks", file=sys.stderr)
                 runner = None
@@ -238,6 +390,7 @@ def main():
         def sync():
             sim.sync(); torch.cuda.synchronize()
         barrier = dist.barrier
+        reduce_dev = ctl
 
     run_steps(args.warmup)
     sync()
@@ -252,7 +405,7 @@ def main():
     sim.profile_enable(False)
     if world > 1 or args.strips:
         import torch.distributed as dist
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=reduce_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
@@ -291,7 +444,7 @@ def main():
     mass = sim.final_density()
     if world > 1 or args.strips:   # every rank holds the mass of its own rows
         import torch.distributed as dist
-        tm = torch.tensor([mass], dtype=torch.float64, device="cuda")
+        tm = torch.tensor([mass], dtype=torch.float64, device=reduce_dev)
         dist.all_reduce(tm, op=dist.ReduceOp.SUM)
         mass = float(tm[0])
     if not np.isfinite(mass):
@@ -323,8 +476,9 @@ def main():
             "config": {"workload": w["name"], "lx": lx, "ly": ly, "grains": int(len(r)), "npDEM": int(npdem),
                        "step": "1 fluid step + npDEM DEM sub-steps (+ Verlet rebuild every 100 DEM steps)",
                        "force_kernel": "parity" if args.force_mode == 0 else "fast",
-                       "driver": None if runner is None else ("C (lbmdem_comm_run, RCCL in the library)" if
-                                                                isinstance(runner, strips.CCommRunner) else "torch.distributed"),
+                       "driver": None if runner is None else ("C (lbmdem_comm_run, RCCL send/recv inside the library)" if
+                                                                isinstance(runner, strips.CCommRunner) else "torch.distributed (strips.py)"),
+                       "driver_trial": None if runner is None else driver_note,
                        "decomposition": "none" if args.gpus == 1 else (
                            f"{args.gpus} x-strips, halo 2 rows, grains owned by strips (margin integrated redundantly); per "
                            f"fluid step and neighbour: f halo rows and grain kinematics (both overlapped with the fluid "

@@ -2,7 +2,10 @@
 CPU oracle. MODE=distributed (default): grains owned by strips, neighbour messages only (kinematics of the margin,
 link-sum tables, forces), halo of 2 rows; MODE=ccomm: the same protocol driven from C (lbmdem_comm_run, the
 library's RCCL transport); MODE=replicated: every rank integrates all grains, one bit-exact
-all-reduce of the forces per fluid step. Used by tests/test_gpu_multi.py when the box has more than one GPU."""
+all-reduce of the forces per fluid step. Used by tests/test_gpu_multi.py when the box has more than one GPU.
+SHARED_GPU=1 (MODE=ccomm only): every rank on device 0, control plane over gloo, the library's transport pointed at the
+tests' RCCL stand-in (LBMDEM_RCCL_LIBRARY = tests/rccl_shim/librccl.so.1) -- the multi-rank code of lbmdem_comm.hip on a
+one-GPU box (tests/test_gpu_rccl_shim.py)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,8 +14,15 @@ import torch, torch.distributed as dist
 import __graft_entry__ as ge, samples
 
 rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+shared = os.environ.get("SHARED_GPU") == "1"
+if shared:
+    local = 0
 torch.cuda.set_device(local)
-dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+if shared:
+    dist.init_process_group("gloo")
+else:
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+ctl = "cpu" if shared else "cuda"
 pkg = ge.load_package(); strips = pkg.strips_module()
 mode = os.environ.get("MODE", "distributed")     # distributed | replicated | ccomm (distributed, driven from C)
 distributed = mode in ("distributed", "ccomm")
@@ -26,7 +36,7 @@ else:
     runner = strips.make_gpu_runner(pkg, dist, rank, world, local, lx, ly, r, x1, x2, distributed=distributed)
     assert isinstance(runner, strips.DistStripRunner) == distributed
 runner.sim.kinematics = k
-n = 5 * runner.sim.cfg.npDEM + 3
+n = int(os.environ.get("NSTEPS", 5 * runner.sim.cfg.npDEM + 3))
 runner.render_scene(n)
 runner.sim.sync(); torch.cuda.synchronize()
 got = np.full((lx, ly, 9), np.nan)
@@ -40,14 +50,14 @@ if rank == 0:
 else:
     ref_f = np.empty((lx, ly, 9)); ref_kin = np.empty((len(r), 9)); ref_fhf = np.empty((len(r), 3))
 for a in (ref_f, ref_kin, ref_fhf):                       # hand the oracle's result to every rank
-    t = torch.from_numpy(a).cuda(); dist.broadcast(t, 0); a[...] = t.cpu().numpy()
+    t = torch.from_numpy(a).to(ctl); dist.broadcast(t, 0); a[...] = t.cpu().numpy()
 own = np.ones(len(r), bool)
 if distributed:      # a rank answers for the grains whose centre lies in its rows
     xc = ref_kin[:, 0] / runner.sim.cfg.dx
     own = ((x0 == 0) | (xc >= x0)) & ((x1_ == lx) | (xc < x1_))
 ok = (np.array_equal(got[x0:x1_], ref_f[x0:x1_]) and np.array_equal(runner.sim.kinematics[own], ref_kin[own])
       and np.array_equal(runner.sim.fhf[own], ref_fhf[own]))
-flag = torch.tensor([1 if ok else 0], device="cuda"); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+flag = torch.tensor([1 if ok else 0], device=ctl); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 if rank == 0:
     print("MULTI-GPU-OK" if int(flag) == 1 else "MULTI-GPU-MISMATCH", world, mode, flush=True)
 dist.barrier(); dist.destroy_process_group()

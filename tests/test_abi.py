@@ -96,3 +96,21 @@ def test_documented_binding_compiles_and_links(pkg, tmp_path):
     # no temporary copy of the reference's source is left behind in the repository
     leftovers = [f for f in os.listdir(os.path.join(root, "oracle")) if f.endswith(".c") and "main" in f]
     assert leftovers == []
+
+
+def test_rccl_stand_in_exports_what_the_transport_binds():
+    """tests/rccl_shim/librccl.so.1 (test infrastructure: several ranks on the one GPU of the test box) defines exactly
+    the RCCL entry points lbmdem_comm.hip looks up with dlsym -- and the product never names it."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim = os.path.join(root, "tests", "rccl_shim", "librccl.so.1")
+    assert os.path.exists(shim), "run __graft_entry__.build()"
+    out = subprocess.run(["nm", "-D", "--defined-only", shim], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    comm_src = open(os.path.join(root, "2d-lbm-dem_amd", "csrc", "lbmdem_comm.hip")).read()
+    bound = set(re.findall(r'RCCL_SYM\(\w+, "(nccl\w+)"\)', comm_src))
+    assert len(bound) == 9 and bound == exported, (sorted(bound), sorted(exported))
+    for dirpath, _, files in os.walk(os.path.join(root, "2d-lbm-dem_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".c")):
+                assert "rccl_shim/librccl" not in open(os.path.join(dirpath, f), errors="replace").read(), f
