@@ -46,7 +46,7 @@ ok = True
 if rank == 0:
     po = ge.load_oracle()
     ora = po.Oracle(lx, ly, r, x1, x2); ora.set_kinematics(k); ora.steps(n)
-    ref_f, ref_kin, ref_fhf = ora.get_f(), ora.get_grains()[:, :9], ora.get_fhf()
+    ref_f, ref_kin, ref_fhf = (np.ascontiguousarray(a) for a in (ora.get_f(), ora.get_grains()[:, :9], ora.get_fhf()))
 else:
     ref_f = np.empty((lx, ly, 9)); ref_kin = np.empty((len(r), 9)); ref_fhf = np.empty((len(r), 3))
 for a in (ref_f, ref_kin, ref_fhf):                       # hand the oracle's result to every rank
@@ -55,8 +55,16 @@ own = np.ones(len(r), bool)
 if distributed:      # a rank answers for the grains whose centre lies in its rows
     xc = ref_kin[:, 0] / runner.sim.cfg.dx
     own = ((x0 == 0) | (xc >= x0)) & ((x1_ == lx) | (xc < x1_))
-ok = (np.array_equal(got[x0:x1_], ref_f[x0:x1_]) and np.array_equal(runner.sim.kinematics[own], ref_kin[own])
-      and np.array_equal(runner.sim.fhf[own], ref_fhf[own]))
+parts = (np.array_equal(got[x0:x1_], ref_f[x0:x1_]), np.array_equal(runner.sim.kinematics[own], ref_kin[own]),
+         np.array_equal(runner.sim.fhf[own], ref_fhf[own]))
+ok = all(parts)
+if not ok:
+    kin, fh = runner.sim.kinematics, runner.sim.fhf
+    bad_k = np.flatnonzero(own & (kin != ref_kin).any(axis=1)); bad_f = np.flatnonzero(own & (fh != ref_fhf).any(axis=1))
+    bad_rows = np.flatnonzero((got[x0:x1_] != ref_f[x0:x1_]).any(axis=(1, 2))) + x0
+    print(f"[rank {rank}] rows [{x0}, {x1_}): f / kinematics / fhf equal: {parts}; grains with other kinematics {bad_k[:8]} "
+          f"(xc {np.round(ref_kin[bad_k[:8], 0] / runner.sim.cfg.dx, 1)}), other fhf {bad_f[:8]}, rows with other f {bad_rows[:8]} .. "
+          f"{bad_rows[-3:]} ({len(bad_rows)})", flush=True)
 flag = torch.tensor([1 if ok else 0], device=ctl); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 if rank == 0:
     print("MULTI-GPU-OK" if int(flag) == 1 else "MULTI-GPU-MISMATCH", world, mode, flush=True)
