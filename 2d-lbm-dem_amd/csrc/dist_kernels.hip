@@ -21,10 +21,31 @@ namespace {
 constexpr int ERR_LIST_OVERFLOW = 4;   // more grains near a cut than the message capacity
 constexpr int ERR_MERGE_CLASH = 8;     // two ranks produced the same link sum
 
+struct Buf2 { real* p[2]; };
+struct CBuf2 { const real* p[2]; };
+
+// one side's kinematics message from its send list: {count; count x {id, x1 x2 x3 v1 v2 v3 a1 a2 a3}}
+__device__ __forceinline__ void pack_kin_side(const int* __restrict__ list, int cnt, const Kin& K, real* __restrict__ buf,
+                                              int first, int stride) {
+  if (first == 0) buf[0] = (real)cnt;
+  for (int k = first; k < cnt; k += stride) {
+    const int i = list[k];
+    real* o = buf + 1 + (long)k * 10;
+    o[0] = (real)i;
+    o[1] = K.x1[i]; o[2] = K.x2[i]; o[3] = K.x3[i]; o[4] = K.v1[i]; o[5] = K.v2[i]; o[6] = K.v3[i];
+    o[7] = K.a1[i]; o[8] = K.a2[i]; o[9] = K.a3[i];
+  }
+}
+
+// `KB` (C transport): the two kinematics messages are packed by the workgroup that finishes the classification LAST
+// (ticket counter [7]; device-scope release by every workgroup before it takes its ticket, acquire by the last one) -- the
+// lists are a few hundred grains, one workgroup packs them in the time a dependent launch would need to start.
 __global__ __launch_bounds__(1024) void k_dist_classify(DistDevice D, DistGeom Gm, int n, const real* __restrict__ x1,
                                                        const real* __restrict__ r, const real* __restrict__ rLB,
-                                                       unsigned char* __restrict__ owner, int* __restrict__ error) {
+                                                       unsigned char* __restrict__ owner, int* __restrict__ error,
+                                                       Kin K, Buf2 KB) {
   __shared__ int sCnt[5], sBase[5];
+  __shared__ int sLast;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   // the other set of counters (the period before used it; every reader is earlier in the stream) is zeroed for the next period
   if (blockIdx.x == 0 && threadIdx.x < 8) D.counters_alt[threadIdx.x] = 0;
@@ -65,41 +86,42 @@ __global__ __launch_bounds__(1024) void k_dist_classify(DistDevice D, DistGeom G
     const int k = sBase[w] + pos[w];
     if (k < cap) list[k] = i; else atomicOr(error, ERR_LIST_OVERFLOW);
   }
+  if (!KB.p[0] && !KB.p[1]) return;
+  __threadfence();                       // this workgroup's list entries and counts are visible device-wide ...
+  __syncthreads();
+  if (threadIdx.x == 0)
+    sLast = __hip_atomic_fetch_add(&D.counters[7], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!sLast) return;
+  __threadfence();                       // ... and the last one sees everybody's
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    if (!KB.p[side]) continue;
+    int cnt = __hip_atomic_load(&D.counters[side], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cnt > D.cap_g) cnt = D.cap_g;    // an overflow was flagged above
+    pack_kin_side(D.send_list[side], cnt, K, KB.p[side], (int)threadIdx.x, (int)blockDim.x);
+  }
 }
 
 // The per-side kernels below take both sides in one launch: blockIdx.y = side (0 low, 1 high); a null buffer
 // skips the side.
-struct Buf2 { real* p[2]; };
-struct CBuf2 { const real* p[2]; };
-
 __global__ void k_pack_kin(DistDevice D, Kin K, Buf2 B) {
   const int side = blockIdx.y;
-  real* __restrict__ buf = B.p[side];
-  if (!buf) return;
-  const int* __restrict__ list = D.send_list[side];
+  if (!B.p[side]) return;
   const int cnt = D.counters[side] < D.cap_g ? D.counters[side] : D.cap_g;   // an overflow is flagged by k_dist_classify
-  if (blockIdx.x == 0 && threadIdx.x == 0) buf[0] = (real)cnt;
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) {
-    const int i = list[k];
-    real* o = buf + 1 + (long)k * 10;
-    o[0] = (real)i;
-    o[1] = K.x1[i]; o[2] = K.x2[i]; o[3] = K.x3[i]; o[4] = K.v1[i]; o[5] = K.v2[i]; o[6] = K.v3[i];
-    o[7] = K.a1[i]; o[8] = K.a2[i]; o[9] = K.a3[i];
-  }
+  pack_kin_side(D.send_list[side], cnt, K, B.p[side], blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
-__global__ void k_unpack_kin(DistDevice D, CBuf2 B, Kin K, int n, int* __restrict__ error) {
-  const int side = blockIdx.y;
-  const real* __restrict__ buf = B.p[side];
-  if (!buf) return;
+__device__ __forceinline__ void unpack_kin_side(const DistDevice& D, int side, const real* __restrict__ buf, const Kin& K,
+                                                int n, int* __restrict__ error, int first, int stride) {
   const int cap = D.cap_g;
   unsigned char* __restrict__ active = D.active;
   int* __restrict__ recv_ids = D.recv_ids[side];
   int* __restrict__ recv_count = D.counters + 4 + side;
   int cnt = (int)buf[0];
-  if (cnt < 0 || cnt > cap) { cnt = 0; if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(error, ERR_LIST_OVERFLOW); }
-  if (blockIdx.x == 0 && threadIdx.x == 0) *recv_count = cnt;
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) {
+  if (cnt < 0 || cnt > cap) { cnt = 0; if (first == 0) atomicOr(error, ERR_LIST_OVERFLOW); }
+  if (first == 0) *recv_count = cnt;
+  for (int k = first; k < cnt; k += stride) {
     const real* o = buf + 1 + (long)k * 10;
     const int i = (int)o[0];
     if (i < 0 || i >= n) continue;
@@ -108,6 +130,12 @@ __global__ void k_unpack_kin(DistDevice D, CBuf2 B, Kin K, int n, int* __restric
     K.a1[i] = o[7]; K.a2[i] = o[8]; K.a3[i] = o[9];
     active[i] = 1;
   }
+}
+
+__global__ void k_unpack_kin(DistDevice D, CBuf2 B, Kin K, int n, int* __restrict__ error) {
+  const int side = blockIdx.y;
+  if (!B.p[side]) return;
+  unpack_kin_side(D, side, B.p[side], K, n, error, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 __global__ void k_pack_fhf(DistDevice D, const real* __restrict__ fhf, int n, Buf2 B) {
@@ -135,16 +163,14 @@ __global__ void k_unpack_fhf(DistDevice D, real* __restrict__ fhf, int n, CBuf2 
 }
 
 // the neighbour's part of the link-sum tables of grains this rank owns: slot by slot into the local table
-__global__ void k_merge_tables(ForceSlots S, CBuf2 B, int cap) {
-  const real* __restrict__ buf = B.p[blockIdx.y];
-  if (!buf) return;
+// (wave = this wavefront's index among the nwaves that share the side)
+__device__ __forceinline__ void merge_tables_side(const ForceSlots& S, const real* __restrict__ buf, int cap, int wave,
+                                                  int nwaves, int lane) {
   int cnt = (int)buf[0];
-  if (cnt < 0 || cnt > cap) { cnt = 0; if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(S.error, ERR_LIST_OVERFLOW); }
+  if (cnt < 0 || cnt > cap) { cnt = 0; if (wave == 0 && lane == 0) atomicOr(S.error, ERR_LIST_OVERFLOW); }
   const int nslot = 8 * S.spd;
   const unsigned long long* b = reinterpret_cast<const unsigned long long*>(buf);
   unsigned long long* tab = reinterpret_cast<unsigned long long*>(S.tab);
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   for (int e = wave; e < cnt; e += nwaves) {
     const unsigned long long* ent = b + 1 + (long)e * (1 + nslot);
     const int i = (int)reinterpret_cast<const real*>(ent)[0];
@@ -156,6 +182,30 @@ __global__ void k_merge_tables(ForceSlots S, CBuf2 B, int cap) {
       if (*t != LBMDEM_SLOT_EMPTY) atomicOr(S.error, ERR_MERGE_CLASH);
       *t = v;
     }
+  }
+}
+
+__global__ void k_merge_tables(ForceSlots S, CBuf2 B, int cap) {
+  if (!B.p[blockIdx.y]) return;
+  merge_tables_side(S, B.p[blockIdx.y], cap, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, (gridDim.x * blockDim.x) >> 6,
+                    threadIdx.x & 63);
+}
+
+// C transport: everything that follows the arrival of the TABLES message in ONE launch -- the neighbours' table parts
+// merged (workgroups [0, 2 MB)), their kinematics messages unpacked ([2 MB, 4 MB): they arrived during the fluid kernels),
+// and the obstacle map the fused kernel has just finished with reset for the next rasterisation (the rest; main.c:997-999).
+constexpr int UNPACK_MB = 16;   // workgroups per side and message
+__global__ __launch_bounds__(256) void k_unpack_tables_kin_fill(ForceSlots S, CBuf2 TB, int cap_t, DistDevice D, CBuf2 KB,
+                                                                Kin K, int n, int* __restrict__ dead_obst, LatticeView L) {
+  const int b = blockIdx.x;
+  if (b < 2 * UNPACK_MB) {
+    const int side = b / UNPACK_MB, wb = b % UNPACK_MB;
+    if (TB.p[side]) merge_tables_side(S, TB.p[side], cap_t, (wb * 256 + (int)threadIdx.x) >> 6, UNPACK_MB * 4, threadIdx.x & 63);
+  } else if (b < 4 * UNPACK_MB) {
+    const int side = (b - 2 * UNPACK_MB) / UNPACK_MB, wb = b % UNPACK_MB;
+    if (KB.p[side]) unpack_kin_side(D, side, KB.p[side], K, n, S.error, wb * 256 + (int)threadIdx.x, UNPACK_MB * 256);
+  } else if (dead_obst) {
+    obst_fill_range(dead_obst, L, (long)(b - 4 * UNPACK_MB) * 256 + threadIdx.x, (long)(gridDim.x - 4 * UNPACK_MB) * 256);
   }
 }
 
@@ -202,7 +252,25 @@ void launch_dist_classify(const DistDevice& D, const DistGeom& Gm, int n, const 
                           const real* rLB, unsigned char* owner, int* error, hipStream_t st) {
   // D.counters is all zero here: the classification of the period before cleared it (the received counts [4], [5] are
   // SET by the next unpack). The counts may exceed the capacities (flagged): every reader clamps.
-  hipLaunchKernelGGL(k_dist_classify, dim3((n + 1023) / 1024), dim3(1024), 0, st, D, Gm, n, x1, r, rLB, owner, error);
+  hipLaunchKernelGGL(k_dist_classify, dim3((n + 1023) / 1024), dim3(1024), 0, st, D, Gm, n, x1, r, rLB, owner, error,
+                     Kin{}, Buf2{{nullptr, nullptr}});
+}
+
+void launch_dist_classify_pack_kin(const DistDevice& D, const DistGeom& Gm, int n, const real* x1, const real* r,
+                                   const real* rLB, unsigned char* owner, int* error, const Kin& K, real* kin_lo,
+                                   real* kin_hi, hipStream_t st) {
+  hipLaunchKernelGGL(k_dist_classify, dim3((n + 1023) / 1024), dim3(1024), 0, st, D, Gm, n, x1, r, rLB, owner, error, K,
+                     Buf2{{kin_lo, kin_hi}});
+}
+
+void launch_dist_unpack_tables_kin_fill(const ForceSlots& S, const real* tab_lo, const real* tab_hi, int cap_t,
+                                        const DistDevice& D, const real* kin_lo, const real* kin_hi, const Kin& K, int n,
+                                        int* dead_obst, const LatticeView& L, hipStream_t st) {
+  const long fill4 = dead_obst ? (long)L.nxl * L.sy / 4 : 0;
+  long fb = (fill4 + 256 * 8 - 1) / (256 * 8);      // eight 16-byte stores per thread
+  if (fb > 1024) fb = 1024;
+  hipLaunchKernelGGL(k_unpack_tables_kin_fill, dim3(4 * UNPACK_MB + (unsigned)fb), dim3(256), 0, st, S, CBuf2{{tab_lo, tab_hi}},
+                     cap_t, D, CBuf2{{kin_lo, kin_hi}}, K, n, dead_obst, L);
 }
 
 void launch_dist_pack_kin(const DistDevice& D, const Kin& K, real* lo, real* hi, hipStream_t st) {

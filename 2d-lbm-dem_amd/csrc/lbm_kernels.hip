@@ -220,23 +220,9 @@ __device__ __forceinline__ real link_delta(int x, int y, real xc, real yc, real 
 // small kernels
 // ---------------------------------------------------------------------------------------------
 
-// obst = -1 in the interior, nbgrains on the four lattice edges (main.c:669-683, 997-999); 16-byte stores
-// (the row pitch is a multiple of 16 elements)
+// obst = -1 in the interior, nbgrains on the four lattice edges (main.c:669-683, 997-999): obst_fill_range (lbmdem_internal.h)
 __global__ void k_obst_fill(int* __restrict__ obst, LatticeView L) {
-  const long total4 = (long)L.nxl * L.sy / 4;
-  int4* o4 = reinterpret_cast<int4*>(obst);
-  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < total4; k += (long)gridDim.x * blockDim.x) {
-    const long e = k * 4;
-    const int xl = (int)(e / L.sy), y0 = (int)(e % L.sy);
-    const int gx = L.gx0 + xl;
-    const bool xedge = (gx == 0 || gx == L.lx - 1);
-    int4 v;
-    v.x = (xedge || y0 == 0 || y0 >= L.ly - 1) ? L.n : -1;
-    v.y = (xedge || y0 + 1 >= L.ly - 1) ? L.n : -1;
-    v.z = (xedge || y0 + 2 >= L.ly - 1) ? L.n : -1;
-    v.w = (xedge || y0 + 3 >= L.ly - 1) ? L.n : -1;
-    o4[k] = v;
-  }
+  obst_fill_range(obst, L, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 // Rasterise the reduced discs (main.c:1016-1032). One wavefront per grain: every lane derives the grain's lattice

@@ -145,7 +145,8 @@ static int paint_into(lbmdem_handle* h, int* obst) {
       h->paint_epoch = 1;
     }
   }
-  launch_obst_fill(obst, h->L, h->stream);
+  if (!(h->obst_prefilled && obst == h->obst[1 - h->ocur])) launch_obst_fill(obst, h->L, h->stream);
+  h->obst_prefilled = false;
   launch_obst_paint(obst, h->L, h->n, K.x1, K.x2, h->r, h->rLB, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0, h->pk,
                     h->fs.touched, h->dist ? h->dd.fluidmask : nullptr, h->mincov, h->paint_epoch,
                     h->dist ? h->dd.local_list : nullptr, h->dist ? h->dd.counters + 6 : nullptr, h->dist ? h->dd.cap_l : 0,
@@ -455,7 +456,25 @@ int lbmdem_collide_stream(lbmdem_handle* h) try {
   return fail(LBMDEM_EINVAL, "unexpected C++ exception");
 }
 
-int lbmdem_collide_stream_part(lbmdem_handle* h, int part) try {
+// what a split collide_stream does on the handle's stream BEFORE its first kernel: start of the profiling interval, the
+// slot table the kernels fill (emptied here if it still holds unconsumed sums)
+int lbmdem_collide_stream_prepare(lbmdem_handle* h) {
+  hipEvent_t e1 = nullptr;  // the interval of this step's fused kernels ends in INTERIOR
+  int rc = prof_begin(h, &e1);
+  if (rc != LBMDEM_OK) return rc;
+  h->cs_slots = slots_for_launch(h);
+  return LBMDEM_OK;
+}
+
+int lbmdem_collide_stream_part(lbmdem_handle* h, int part) {
+  if (!h) return fail(LBMDEM_EINVAL, "null handle");
+  return lbmdem_collide_stream_part_on(h, part, h->stream);
+}
+
+// `st`: the stream the part's kernel goes to. EDGES prepares the launch (slot table emptied if need be, profiling start)
+// on the handle's stream and, when st is another stream, expects the caller to have made st wait for that point; the two
+// parts write disjoint rows from the same old lattice, so they may run concurrently.
+int lbmdem_collide_stream_part_on(lbmdem_handle* h, int part, hipStream_t st) try {
   CHECK_H(h);
   PhaseRange range_("lbmdem:collide_stream_part");
   const LatticeView& L = h->L;
@@ -471,12 +490,12 @@ int lbmdem_collide_stream_part(lbmdem_handle* h, int part) try {
     h->cs_ob_old = h->obst[h->ocur];
     h->cs_ob_new = h->obst_pending ? h->obst[1 - h->ocur] : h->obst[h->ocur];
     h->cs_lo_end = lo_end; h->cs_hi_begin = hi_begin;
-    hipEvent_t e1 = nullptr;  // the interval of this step's fused kernels ends in INTERIOR
-    int rc = prof_begin(h, &e1);
-    if (rc != LBMDEM_OK) return rc;
-    h->cs_slots = slots_for_launch(h);
+    if (st == h->stream) {   // (another stream: the caller has called lbmdem_collide_stream_prepare before its hand-over)
+      int rc = lbmdem_collide_stream_prepare(h);
+      if (rc != LBMDEM_OK) return rc;
+    }
     launch_collide_stream_edges(h->cs_fin, h->f[1 - h->fcur], h->cs_ob_old, h->cs_ob_new, L, gview(h), h->cs_slots, L.xo0,
-                                lo_end, hi_begin, L.xo1, h->stream);
+                                lo_end, hi_begin, L.xo1, st);
     HIP_TRY(hipGetLastError());
     h->fcur = 1 - h->fcur;
     if (h->obst_pending) { h->ocur = 1 - h->ocur; h->obst_pending = false; }
@@ -489,7 +508,7 @@ int lbmdem_collide_stream_part(lbmdem_handle* h, int part) try {
       LatticeView Ls = L;
       Ls.xo0 = h->cs_lo_end; Ls.xo1 = h->cs_hi_begin;
       // the grain records are those of EDGES: nothing moves the grains between the two parts
-      launch_collide_stream(h->cs_fin, h->f[h->fcur], h->cs_ob_old, h->cs_ob_new, Ls, gview(h), h->cs_slots, h->stream);
+      launch_collide_stream(h->cs_fin, h->f[h->fcur], h->cs_ob_old, h->cs_ob_new, Ls, gview(h), h->cs_slots, st);
     }
     h->slots_valid = h->cs_slots.tab != nullptr;
     if (h->prof && h->ev_used > 0) HIP_TRY(hipEventRecord(h->ev1[h->ev_used - 1], h->stream));

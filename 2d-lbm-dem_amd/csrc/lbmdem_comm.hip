@@ -72,12 +72,18 @@ struct lbmdem_comm {
   hipEvent_t ready[LANE_COUNT] = {}, done[LANE_COUNT] = {};
   // device buffers for one handle: [kind or halo][side][send/recv]
   lbmdem_handle* bound = nullptr;
-  double* buf[4][2][2] = {};
-  size_t count[4] = {};   // doubles per message: KIN, FHF, TABLES, halo
+  double* buf[3][2][2] = {};
+  size_t count[3] = {};   // doubles per message: KIN, FHF, TABLES
   double* scratch = nullptr;
   float* vtk_dev = nullptr;   // staging of one strip's VTK fields (lbmdem_comm_write_vtk), kept between frames
   size_t vtk_floats = 0;
+  bool stale = false;         // experiment build only (lbmdem_comm_debug_stale): the step runs without its transfers
 };
+#ifdef LBMDEM_AB
+#define COMM_STALE(c) ((c)->stale)
+#else
+#define COMM_STALE(c) false
+#endif
 
 #pragma GCC visibility push(default)
 extern "C" {
@@ -143,14 +149,16 @@ static int comm_begin(lbmdem_comm* c, hipStream_t main, int lane, int kind, cons
   if (!has[0] && !has[1]) return LBMDEM_OK;
   HIP_TRY(hipEventRecord(c->ready[lane], main));
   HIP_TRY(hipStreamWaitEvent(c->side[lane], c->ready[lane], 0));
-  NCCL_TRY(g_rccl.GroupStart());
-  for (int s = 0; s < 2; ++s) {
-    if (!has[s]) continue;
-    const int peer = s == 0 ? c->rank - 1 : c->rank + 1;
-    NCCL_TRY(g_rccl.Send(c->buf[kind][s][0], c->count[kind], ncclDouble, peer, c->nccl[lane], c->side[lane]));
-    NCCL_TRY(g_rccl.Recv(c->buf[kind][s][1], c->count[kind], ncclDouble, peer, c->nccl[lane], c->side[lane]));
+  if (!COMM_STALE(c)) {
+    NCCL_TRY(g_rccl.GroupStart());
+    for (int s = 0; s < 2; ++s) {
+      if (!has[s]) continue;
+      const int peer = s == 0 ? c->rank - 1 : c->rank + 1;
+      NCCL_TRY(g_rccl.Send(c->buf[kind][s][0], c->count[kind], ncclDouble, peer, c->nccl[lane], c->side[lane]));
+      NCCL_TRY(g_rccl.Recv(c->buf[kind][s][1], c->count[kind], ncclDouble, peer, c->nccl[lane], c->side[lane]));
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
   }
-  NCCL_TRY(g_rccl.GroupEnd());
   HIP_TRY(hipEventRecord(c->done[lane], c->side[lane]));
   return LBMDEM_OK;
 }
@@ -159,6 +167,7 @@ static int comm_begin(lbmdem_comm* c, hipStream_t main, int lane, int kind, cons
 // more than the transfer itself (~10 us).
 static int comm_inline(lbmdem_comm* c, hipStream_t main, int lane, int kind, const bool has[2]) {
   if (!has[0] && !has[1]) return LBMDEM_OK;
+  if (COMM_STALE(c)) return LBMDEM_OK;
   NCCL_TRY(g_rccl.GroupStart());
   for (int s = 0; s < 2; ++s) {
     if (!has[s]) continue;
@@ -182,8 +191,7 @@ static int comm_bind(lbmdem_comm* c, lbmdem_handle* h) {
   c->count[LBMDEM_MSG_KIN] = (size_t)lbmdem_dist_message_doubles(h, LBMDEM_MSG_KIN);
   c->count[LBMDEM_MSG_FHF] = (size_t)lbmdem_dist_message_doubles(h, LBMDEM_MSG_FHF);
   c->count[LBMDEM_MSG_TABLES] = (size_t)lbmdem_dist_message_doubles(h, LBMDEM_MSG_TABLES);
-  c->count[3] = (size_t)lbmdem_halo_doubles(h);
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < 3; ++k)   // (the f halo rows travel straight between the lattices: halo_exchange)
     for (int s = 0; s < 2; ++s)
       for (int d = 0; d < 2; ++d) {
         HIP_TRY(hipMalloc((void**)&c->buf[k][s][d], sizeof(double) * (c->count[k] ? c->count[k] : 1)));
@@ -195,31 +203,72 @@ static int comm_bind(lbmdem_comm* c, lbmdem_handle* h) {
 }
 
 
+// The f halo travels straight out of and into the lattice: in the device layout f[xl][y / 16][q][y % 16] a lattice row is
+// one contiguous slab of 9 * sy reals, so the `halo` owned rows next to a cut ARE the message and the neighbour's halo rows
+// ARE the receive buffer -- no pack / unpack kernels, no staging copies.
+static int halo_exchange(lbmdem_handle* h, lbmdem_comm* c, hipStream_t st, const bool has[2]) {
+  const LatticeView& L = h->L;
+  const int H = h->cfg.halo;
+  if (H < 1 || L.xo1 - L.xo0 < H) return fail(LBMDEM_EINVAL, "strip narrower than its halo");
+  if (COMM_STALE(c)) return LBMDEM_OK;
+  real* f = h->f[h->fcur];                     // the lattice the edge rows have just been written to
+  const size_t row = (size_t)L.sy * 9, cnt = row * H;
+  NCCL_TRY(g_rccl.GroupStart());
+  if (has[0]) {
+    NCCL_TRY(g_rccl.Send(f + row * L.xo0, cnt, ncclDouble, c->rank - 1, c->nccl[LANE_HALO], st));
+    NCCL_TRY(g_rccl.Recv(f + row * (L.xo0 - H), cnt, ncclDouble, c->rank - 1, c->nccl[LANE_HALO], st));
+  }
+  if (has[1]) {
+    NCCL_TRY(g_rccl.Send(f + row * (L.xo1 - H), cnt, ncclDouble, c->rank + 1, c->nccl[LANE_HALO], st));
+    NCCL_TRY(g_rccl.Recv(f + row * L.xo1, cnt, ncclDouble, c->rank + 1, c->nccl[LANE_HALO], st));
+  }
+  NCCL_TRY(g_rccl.GroupEnd());
+  return LBMDEM_OK;
+}
+
+// One fluid step of a strip with its neighbours. Launches on the critical path (main stream), per period:
+//   classification + both kinematics messages (1) . rasteriser (1; the map was reset by the unpack launch of the period
+//   before) . interior rows of the fused kernel (1) . this rank's part of the neighbours' link-sum tables (1) . [TABLES
+//   exchange] . unpack: tables merged + kinematics unpacked + dead obstacle map reset (1) . force table + gather queue (2)
+//   . forces packed (1) . [FHF exchange] . forces unpacked (1) . npDEM sub-steps.
+// Off the critical path: the edge rows of the fused kernel run on the halo lane's stream NEXT TO the interior rows (both
+// read the old lattice and write disjoint rows of the new one), followed there by the halo exchange straight between the
+// lattices; the kinematics travel on their own lane under the whole fluid step.
 int lbmdem_comm_lbm_step(lbmdem_handle* h, lbmdem_comm* c) {
   CHECK_H(h);
   if (!c) return fail(LBMDEM_EINVAL, "null communicator");
   RC_TRY(comm_bind(c, h));
   const bool has[2] = {h->cfg.x_begin > 0, h->cfg.x_end < h->cfg.lx};
+  const bool cut = has[0] || has[1];
   hipStream_t main = h->stream;
-  RC_TRY(lbmdem_dist_begin_period(h));                       // ownership + message lists from the current positions
-  RC_TRY(lbmdem_dist_pack2(h, LBMDEM_MSG_KIN, has[0] ? c->buf[LBMDEM_MSG_KIN][0][0] : nullptr, has[1] ? c->buf[LBMDEM_MSG_KIN][1][0] : nullptr));
+  double* (*B)[2][2] = c->buf;
+  // ownership + message lists from the current positions, and the two kinematics messages, in one launch
+  RC_TRY(lbmdem_dist_begin_period_packed(h, has[0] ? B[LBMDEM_MSG_KIN][0][0] : nullptr, has[1] ? B[LBMDEM_MSG_KIN][1][0] : nullptr));
   RC_TRY(comm_begin(c, main, LANE_KIN, LBMDEM_MSG_KIN, has));      // margin refresh / migration, under the fluid step
   RC_TRY(lbmdem_obst_construction(h));
-  RC_TRY(lbmdem_collide_stream_part(h, LBMDEM_CS_EDGES));
-  RC_TRY(lbmdem_halo_pack2(h, has[0] ? c->buf[3][0][0] : nullptr, has[1] ? c->buf[3][1][0] : nullptr));
-  RC_TRY(comm_begin(c, main, LANE_HALO, 3, has));
-  RC_TRY(lbmdem_collide_stream_part(h, LBMDEM_CS_INTERIOR));  // ... while the bulk of the rows is computed
-  RC_TRY(comm_end(c, main, LANE_HALO, has));
-  RC_TRY(lbmdem_halo_unpack2(h, has[0] ? c->buf[3][0][1] : nullptr, has[1] ? c->buf[3][1][1] : nullptr));
-  RC_TRY(lbmdem_dist_pack2(h, LBMDEM_MSG_TABLES, has[0] ? c->buf[LBMDEM_MSG_TABLES][0][0] : nullptr, has[1] ? c->buf[LBMDEM_MSG_TABLES][1][0] : nullptr));
+  if (cut) {
+    RC_TRY(lbmdem_collide_stream_prepare(h));
+    hipStream_t side = c->side[LANE_HALO];
+    HIP_TRY(hipEventRecord(c->ready[LANE_HALO], main));
+    HIP_TRY(hipStreamWaitEvent(side, c->ready[LANE_HALO], 0));
+    RC_TRY(lbmdem_collide_stream_part_on(h, LBMDEM_CS_EDGES, side));      // the rows the neighbours wait for ...
+    RC_TRY(halo_exchange(h, c, side, has));
+    HIP_TRY(hipEventRecord(c->done[LANE_HALO], side));
+    RC_TRY(lbmdem_collide_stream_part_on(h, LBMDEM_CS_INTERIOR, main));   // ... next to the bulk of the rows
+    HIP_TRY(hipStreamWaitEvent(main, c->done[LANE_HALO], 0));
+  } else {
+    RC_TRY(lbmdem_collide_stream(h));
+  }
+  RC_TRY(lbmdem_dist_pack2(h, LBMDEM_MSG_TABLES, has[0] ? B[LBMDEM_MSG_TABLES][0][0] : nullptr, has[1] ? B[LBMDEM_MSG_TABLES][1][0] : nullptr));
   RC_TRY(comm_inline(c, main, LANE_TAB, LBMDEM_MSG_TABLES, has));  // link sums of the grains the neighbours own
-  RC_TRY(lbmdem_dist_unpack2(h, LBMDEM_MSG_TABLES, has[0] ? c->buf[LBMDEM_MSG_TABLES][0][1] : nullptr, has[1] ? c->buf[LBMDEM_MSG_TABLES][1][1] : nullptr));
+  RC_TRY(comm_end(c, main, LANE_KIN, has));                        // (arrived long ago)
+  if (cut)
+    RC_TRY(lbmdem_dist_unpack_tables_kin_fill(h, has[0] ? B[LBMDEM_MSG_TABLES][0][1] : nullptr, has[1] ? B[LBMDEM_MSG_TABLES][1][1] : nullptr,
+                                              has[0] ? B[LBMDEM_MSG_KIN][0][1] : nullptr, has[1] ? B[LBMDEM_MSG_KIN][1][1] : nullptr));
   RC_TRY(lbmdem_forces_fluid(h));
-  RC_TRY(comm_end(c, main, LANE_KIN, has));
-  RC_TRY(lbmdem_dist_unpack2(h, LBMDEM_MSG_KIN, has[0] ? c->buf[LBMDEM_MSG_KIN][0][1] : nullptr, has[1] ? c->buf[LBMDEM_MSG_KIN][1][1] : nullptr));
-  RC_TRY(lbmdem_dist_pack2(h, LBMDEM_MSG_FHF, has[0] ? c->buf[LBMDEM_MSG_FHF][0][0] : nullptr, has[1] ? c->buf[LBMDEM_MSG_FHF][1][0] : nullptr));
+  RC_TRY(lbmdem_dist_pack2(h, LBMDEM_MSG_FHF, has[0] ? B[LBMDEM_MSG_FHF][0][0] : nullptr, has[1] ? B[LBMDEM_MSG_FHF][1][0] : nullptr));
   RC_TRY(comm_inline(c, main, LANE_FHF, LBMDEM_MSG_FHF, has));    // forces of the margin grains, from their owners
-  RC_TRY(lbmdem_dist_unpack2(h, LBMDEM_MSG_FHF, has[0] ? c->buf[LBMDEM_MSG_FHF][0][1] : nullptr, has[1] ? c->buf[LBMDEM_MSG_FHF][1][1] : nullptr));
+  RC_TRY(lbmdem_dist_unpack2(h, LBMDEM_MSG_FHF, has[0] ? B[LBMDEM_MSG_FHF][0][1] : nullptr, has[1] ? B[LBMDEM_MSG_FHF][1][1] : nullptr));
   return LBMDEM_OK;
 }
 
@@ -448,6 +497,15 @@ int lbmdem_comm_selftest(lbmdem_comm* c, int doubles) {
 }
 
 #ifdef LBMDEM_AB
+/* Measurement helper, only in the experiment build (not declared in include/lbmdem_hip.h; scripts/strip_proxy_c.py): from
+ * here on the fluid step of this rank runs WITHOUT its transfers -- the message buffers and halo rows keep what arrived
+ * last (same sizes, same work) -- so that one rank of a decomposition can be stepped and timed alone on a one-GPU box. */
+int lbmdem_comm_debug_stale(lbmdem_comm* c, int on) {
+  if (!c) return fail(LBMDEM_EINVAL, "null communicator");
+  c->stale = on != 0;
+  return LBMDEM_OK;
+}
+
 /* Measurement helper, only in the experiment build (make AB=1 -> liblbmdem_hip_ab.so; bound by scripts/exchange_probe.py,
  * not declared in include/lbmdem_hip.h): what one exchange on the step's critical path costs on this stack. `iters` times
  * { small kernel on a main stream; ready event -> side stream; grouped send + receive of `doubles` values to this rank

@@ -44,6 +44,8 @@ struct lbmdem_handle {
   int* obst[2] = {nullptr, nullptr};
   int ocur = 0;           // map the current f was produced with ("old" for the next collide_stream)
   bool obst_pending = false;  // obst[1 - ocur] holds a newer map not yet consumed by collide_stream
+  bool obst_prefilled = false;  // obst[1 - ocur] has already been reset to "no grains" (C transport: by the launch that
+                                // unpacks the neighbours' messages); the next obst_construction only paints
   // collide_stream in two parts (lbmdem_collide_stream_part): after EDGES the interior rows of f[fcur] are
   // still missing; the operands of the launch are kept for INTERIOR
   bool cs_interior_pending = false;
@@ -170,5 +172,11 @@ static inline DemParams dem_params(const lbmdem_handle* h) {
 #define LBMDEM_INTERNAL extern "C" __attribute__((visibility("hidden")))
 LBMDEM_INTERNAL int lbmdem_write_vtk_file(const char* path, int nx, int ny, const char* name, int dim, const float* data);
 LBMDEM_INTERNAL int lbmdem_verlet_build_lists(lbmdem_handle* h);
+// pieces of the fluid step for the C transport (lbmdem_comm.hip), which runs the edge rows on its halo lane's stream:
+LBMDEM_INTERNAL int lbmdem_collide_stream_prepare(lbmdem_handle* h);
+LBMDEM_INTERNAL int lbmdem_collide_stream_part_on(lbmdem_handle* h, int part, hipStream_t st);   // part on stream `st`
+LBMDEM_INTERNAL int lbmdem_dist_begin_period_packed(lbmdem_handle* h, void* kin_lo, void* kin_hi);
+LBMDEM_INTERNAL int lbmdem_dist_unpack_tables_kin_fill(lbmdem_handle* h, const void* tab_lo, const void* tab_hi,
+                                                       const void* kin_lo, const void* kin_hi);
 LBMDEM_INTERNAL int lbmdem_vtk_place_block(float* fields11, int lx, int ly, int x0, int nx, const float* block11);
 LBMDEM_INTERNAL int lbmdem_dist_enable_caps(lbmdem_handle* h, int M, long cap_g, long cap_t, long cap_l);

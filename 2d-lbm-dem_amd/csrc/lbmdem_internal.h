@@ -55,6 +55,25 @@ struct LatticeView {
   real wc_diag, wc_axis;   // w_q / c for the diagonal and the axis directions (main.c:1174,1184)
 };
 
+// obst = -1 in the interior, nbgrains on the four lattice edges (main.c:669-683, 997-999); 16-byte stores (the row pitch
+// is a multiple of 16 elements). Thread `first` of `stride` threads.
+__device__ __forceinline__ void obst_fill_range(int* __restrict__ obst, const LatticeView& L, long first, long stride) {
+  const long total4 = (long)L.nxl * L.sy / 4;
+  int4* o4 = reinterpret_cast<int4*>(obst);
+  for (long k = first; k < total4; k += stride) {
+    const long e = k * 4;
+    const int xl = (int)(e / L.sy), y0 = (int)(e % L.sy);
+    const int gx = L.gx0 + xl;
+    const bool xedge = (gx == 0 || gx == L.lx - 1);
+    int4 v;
+    v.x = (xedge || y0 == 0 || y0 >= L.ly - 1) ? L.n : -1;
+    v.y = (xedge || y0 + 1 >= L.ly - 1) ? L.n : -1;
+    v.z = (xedge || y0 + 2 >= L.ly - 1) ? L.n : -1;
+    v.w = (xedge || y0 + 3 >= L.ly - 1) ? L.n : -1;
+    o4[k] = v;
+  }
+}
+
 // Grain state used by the fluid kernels. xc, yc, r2, rbl0 are the lattice-unit centre, squared
 // reduced radius and unreduced radius (main.c:1009-1013), refreshed by every obst_construction.
 struct GrainFluidView {
@@ -167,6 +186,14 @@ void dist_free(DistDevice& D);
 // ownership, masks and the send / straddler lists from the current positions of the grains that were active
 void launch_dist_classify(const DistDevice& D, const DistGeom& Gm, int n, const real* x1, const real* r,
                           const real* rLB, unsigned char* owner, int* error, hipStream_t st);
+// the same + the two kinematics messages packed by the launch's last workgroup (C transport: one launch instead of two)
+void launch_dist_classify_pack_kin(const DistDevice& D, const DistGeom& Gm, int n, const real* x1, const real* r,
+                                   const real* rLB, unsigned char* owner, int* error, const Kin& K, real* kin_lo,
+                                   real* kin_hi, hipStream_t st);
+// C transport, one launch: merge the neighbours' TABLES messages, unpack their KIN messages, reset `dead_obst` (null: not)
+void launch_dist_unpack_tables_kin_fill(const ForceSlots& S, const real* tab_lo, const real* tab_hi, int cap_t,
+                                        const DistDevice& D, const real* kin_lo, const real* kin_hi, const Kin& K, int n,
+                                        int* dead_obst, const LatticeView& L, hipStream_t st);
 // messages: {count; count x {id, x1 x2 x3 v1 v2 v3 a1 a2 a3}} / {count x {fhf1 fhf2 fhf3}} in the order of that list
 // (both sides in one launch: `lo` / `hi` = the low / high neighbour's buffer, null to skip)
 void launch_dist_pack_kin(const DistDevice& D, const Kin& K, real* lo, real* hi, hipStream_t st);

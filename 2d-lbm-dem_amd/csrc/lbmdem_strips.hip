@@ -184,7 +184,10 @@ long lbmdem_dist_message_doubles(lbmdem_handle* h, int kind) {
   return -1;
 }
 
-int lbmdem_dist_begin_period(lbmdem_handle* h) {
+int lbmdem_dist_begin_period(lbmdem_handle* h) { return lbmdem_dist_begin_period_packed(h, nullptr, nullptr); }
+
+// kin_lo / kin_hi (C transport): the two kinematics messages are packed by the same launch (null: not)
+int lbmdem_dist_begin_period_packed(lbmdem_handle* h, void* kin_lo, void* kin_hi) {
   CHECK_H(h);
   CHECK_NOT_SPLIT(h);
   if (!h->dist) return fail(LBMDEM_EINVAL, "lbmdem_dist_enable first");
@@ -203,7 +206,11 @@ int lbmdem_dist_begin_period(lbmdem_handle* h) {
   Gm.gx0 = h->L.gx0; Gm.nxl = h->L.nxl;
   { int* t = h->dd.counters; h->dd.counters = h->dd.counters_alt; h->dd.counters_alt = t; }   // the set cleared last period
   h->fs.local_count = h->dd.counters + 6;
-  launch_dist_classify(h->dd, Gm, h->n, h->kin[h->kcur].x1, h->r, h->rLB, h->owner, h->fs.error, h->stream);
+  if (kin_lo || kin_hi)
+    launch_dist_classify_pack_kin(h->dd, Gm, h->n, h->kin[h->kcur].x1, h->r, h->rLB, h->owner, h->fs.error, h->kin[h->kcur],
+                                  (real*)kin_lo, (real*)kin_hi, h->stream);
+  else
+    launch_dist_classify(h->dd, Gm, h->n, h->kin[h->kcur].x1, h->r, h->rLB, h->owner, h->fs.error, h->stream);
   HIP_TRY(hipGetLastError());
   h->dist_period_open = true;
   return LBMDEM_OK;
@@ -241,6 +248,21 @@ int lbmdem_dist_unpack2(lbmdem_handle* h, int kind, const void* buf_lo, const vo
     launch_dist_merge_tables(h->fs, (const real*)buf_lo, (const real*)buf_hi, h->dd.cap_t, h->stream);
   else return fail(LBMDEM_EINVAL, "unknown message kind");
   HIP_TRY(hipGetLastError());
+  return LBMDEM_OK;
+}
+
+// C transport: the neighbours' TABLES messages merged, their KIN messages unpacked, and the obstacle map the fused
+// kernel has finished with (obst[1 - ocur] after collide_stream) reset for the next rasterisation -- one launch
+int lbmdem_dist_unpack_tables_kin_fill(lbmdem_handle* h, const void* tab_lo, const void* tab_hi, const void* kin_lo,
+                                       const void* kin_hi) {
+  CHECK_H(h);
+  CHECK_NOT_SPLIT(h);
+  if (!h->dist) return fail(LBMDEM_EINVAL, "lbmdem_dist_enable first");
+  if (h->obst_pending) return fail(LBMDEM_EINVAL, "between obst_construction and collide_stream");
+  launch_dist_unpack_tables_kin_fill(h->fs, (const real*)tab_lo, (const real*)tab_hi, h->dd.cap_t, h->dd, (const real*)kin_lo,
+                                     (const real*)kin_hi, h->kin[h->kcur], h->n, h->obst[1 - h->ocur], h->L, h->stream);
+  HIP_TRY(hipGetLastError());
+  h->obst_prefilled = true;
   return LBMDEM_OK;
 }
 

@@ -40,7 +40,7 @@
 
 namespace {
 
-constexpr size_t CHUNK = 1u << 20;        // bytes per channel slot
+constexpr size_t CHUNK = 128u << 10;      // bytes per channel slot (8 ranks x 4 communicators stay below 40 MB of /dev/shm)
 constexpr int MAX_RANKS = 8;
 
 struct alignas(128) Word { volatile uint32_t v; };

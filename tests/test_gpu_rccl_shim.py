@@ -73,7 +73,7 @@ def test_transport_selftest_with_several_ranks_on_one_gpu(world, tmp_path):
     the host all-reduce behind check_density / the merged outputs."""
     code = PRELUDE + '''
 comm.selftest(4096)
-comm.selftest(300000)        # 2.4 MB per message: several rounds through the stand-in's 1 MB slots
+comm.selftest(300000)        # 2.4 MB per message: several rounds through the stand-in's 128 KB slots
 s = comm.allreduce_sum(np.array([rank + 1.0, 10.0 * (rank + 1)]))
 assert s[0] == world * (world + 1) / 2 and s[1] == 10 * s[0], s
 print("SELFTEST-OK")
