@@ -24,31 +24,30 @@ constexpr int ERR_MERGE_CLASH = 8;     // two ranks produced the same link sum
 struct Buf2 { real* p[2]; };
 struct CBuf2 { const real* p[2]; };
 
-// one side's kinematics message from its send list: {count; count x {id, x1 x2 x3 v1 v2 v3 a1 a2 a3}}
+// kinematics message: {count; count x {id, x1 x2 x3 v1 v2 v3 a1 a2 a3}} in the order of the side's send list
+__device__ __forceinline__ void pack_kin_entry(const Kin& K, int i, real* __restrict__ o) {
+  o[0] = (real)i;
+  o[1] = K.x1[i]; o[2] = K.x2[i]; o[3] = K.x3[i]; o[4] = K.v1[i]; o[5] = K.v2[i]; o[6] = K.v3[i];
+  o[7] = K.a1[i]; o[8] = K.a2[i]; o[9] = K.a3[i];
+}
 __device__ __forceinline__ void pack_kin_side(const int* __restrict__ list, int cnt, const Kin& K, real* __restrict__ buf,
                                               int first, int stride) {
   if (first == 0) buf[0] = (real)cnt;
-  for (int k = first; k < cnt; k += stride) {
-    const int i = list[k];
-    real* o = buf + 1 + (long)k * 10;
-    o[0] = (real)i;
-    o[1] = K.x1[i]; o[2] = K.x2[i]; o[3] = K.x3[i]; o[4] = K.v1[i]; o[5] = K.v2[i]; o[6] = K.v3[i];
-    o[7] = K.a1[i]; o[8] = K.a2[i]; o[9] = K.a3[i];
-  }
+  for (int k = first; k < cnt; k += stride) pack_kin_entry(K, list[k], buf + 1 + (long)k * 10);
 }
 
-// `KB` (C transport): the two kinematics messages are packed by the workgroup that finishes the classification LAST
-// (ticket counter [7]; device-scope release by every workgroup before it takes its ticket, acquire by the last one) -- the
-// lists are a few hundred grains, one workgroup packs them in the time a dependent launch would need to start.
+// `KB` (C transport): the same launch also writes the two kinematics messages.
 __global__ __launch_bounds__(1024) void k_dist_classify(DistDevice D, DistGeom Gm, int n, const real* __restrict__ x1,
                                                        const real* __restrict__ r, const real* __restrict__ rLB,
                                                        unsigned char* __restrict__ owner, int* __restrict__ error,
-                                                       Kin K, Buf2 KB) {
+                                                       int* __restrict__ error_mirror, Kin K, Buf2 KB) {
   __shared__ int sCnt[5], sBase[5];
-  __shared__ int sLast;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   // the other set of counters (the period before used it; every reader is earlier in the stream) is zeroed for the next period
   if (blockIdx.x == 0 && threadIdx.x < 8) D.counters_alt[threadIdx.x] = 0;
+  // the error flag of the periods before, as it stands now, to its mirror in pinned host memory (the host looks at it when
+  // it opens the NEXT period): a store from here instead of a copy command of its own in the stream
+  if (error_mirror && blockIdx.x == 0 && threadIdx.x == 8) *error_mirror = *error;
   const bool in = i < n;
   const bool act = in && D.active[i] != 0;   // integrated during the last period: exact wherever it matters below
   const real xc = in ? (x1[i] - Gm.Mgx) / Gm.dx : 0.0;   // the rasteriser's lattice coordinate of the centre (main.c:1009)
@@ -85,21 +84,20 @@ __global__ __launch_bounds__(1024) void k_dist_classify(DistDevice D, DistGeom G
     const int cap = w == 4 ? D.cap_l : (w < 2 ? D.cap_g : D.cap_t);
     const int k = sBase[w] + pos[w];
     if (k < cap) list[k] = i; else atomicOr(error, ERR_LIST_OVERFLOW);
+    // C transport: the grain's entry of the kinematics message goes out with its list slot (same index)
+    if (w < 2 && k < cap && KB.p[w]) pack_kin_entry(K, i, KB.p[w] + 1 + (long)k * 10);
   }
   if (!KB.p[0] && !KB.p[1]) return;
-  __threadfence();                       // this workgroup's list entries and counts are visible device-wide ...
+  // ... and the workgroup that finishes last writes the two message headers (the final counts). Only atomics cross
+  // workgroups here -- this workgroup's additions to the counters have returned (sBase) before it takes its ticket -- so
+  // no device-wide fence is needed (a fence means a write-back of the whole L2 on this GPU: ~40 us in this launch, measured).
   __syncthreads();
-  if (threadIdx.x == 0)
-    sLast = __hip_atomic_fetch_add(&D.counters[7], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
-  __syncthreads();
-  if (!sLast) return;
-  __threadfence();                       // ... and the last one sees everybody's
-#pragma unroll
-  for (int side = 0; side < 2; ++side) {
-    if (!KB.p[side]) continue;
-    int cnt = __hip_atomic_load(&D.counters[side], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cnt > D.cap_g) cnt = D.cap_g;    // an overflow was flagged above
-    pack_kin_side(D.send_list[side], cnt, K, KB.p[side], (int)threadIdx.x, (int)blockDim.x);
+  if (threadIdx.x == 0 && atomicAdd(&D.counters[7], 1) == (int)gridDim.x - 1) {
+    for (int side = 0; side < 2; ++side) {
+      if (!KB.p[side]) continue;
+      const int cnt = atomicAdd(&D.counters[side], 0);
+      KB.p[side][0] = (real)(cnt < D.cap_g ? cnt : D.cap_g);   // an overflow was flagged above
+    }
   }
 }
 
@@ -249,18 +247,18 @@ void dist_free(DistDevice& D) {
 }
 
 void launch_dist_classify(const DistDevice& D, const DistGeom& Gm, int n, const real* x1, const real* r,
-                          const real* rLB, unsigned char* owner, int* error, hipStream_t st) {
+                          const real* rLB, unsigned char* owner, int* error, int* error_mirror, hipStream_t st) {
   // D.counters is all zero here: the classification of the period before cleared it (the received counts [4], [5] are
   // SET by the next unpack). The counts may exceed the capacities (flagged): every reader clamps.
   hipLaunchKernelGGL(k_dist_classify, dim3((n + 1023) / 1024), dim3(1024), 0, st, D, Gm, n, x1, r, rLB, owner, error,
-                     Kin{}, Buf2{{nullptr, nullptr}});
+                     error_mirror, Kin{}, Buf2{{nullptr, nullptr}});
 }
 
 void launch_dist_classify_pack_kin(const DistDevice& D, const DistGeom& Gm, int n, const real* x1, const real* r,
-                                   const real* rLB, unsigned char* owner, int* error, const Kin& K, real* kin_lo,
-                                   real* kin_hi, hipStream_t st) {
-  hipLaunchKernelGGL(k_dist_classify, dim3((n + 1023) / 1024), dim3(1024), 0, st, D, Gm, n, x1, r, rLB, owner, error, K,
-                     Buf2{{kin_lo, kin_hi}});
+                                   const real* rLB, unsigned char* owner, int* error, int* error_mirror, const Kin& K,
+                                   real* kin_lo, real* kin_hi, hipStream_t st) {
+  hipLaunchKernelGGL(k_dist_classify, dim3((n + 1023) / 1024), dim3(1024), 0, st, D, Gm, n, x1, r, rLB, owner, error,
+                     error_mirror, K, Buf2{{kin_lo, kin_hi}});
 }
 
 void launch_dist_unpack_tables_kin_fill(const ForceSlots& S, const real* tab_lo, const real* tab_hi, int cap_t,

@@ -347,6 +347,7 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
   *h->ovf_host = 0;
   CREATE_TRY(hipHostMalloc((void**)&h->ferr_host, sizeof(int), hipHostMallocDefault));
   *h->ferr_host = 0;
+  CREATE_TRY(hipHostGetDevicePointer((void**)&h->ferr_mirror, (void*)h->ferr_host, 0));
   // init_density (main.c:716-724) and init_obst (main.c:663-711)
   launch_fill_equilibrium(h->f[0], L, h->stream);
   launch_fill_equilibrium(h->f[1], L, h->stream);
@@ -463,6 +464,7 @@ int lbmdem_collide_stream_prepare(lbmdem_handle* h) {
   int rc = prof_begin(h, &e1);
   if (rc != LBMDEM_OK) return rc;
   h->cs_slots = slots_for_launch(h);
+  h->cs_prepared = true;
   return LBMDEM_OK;
 }
 
@@ -490,10 +492,12 @@ int lbmdem_collide_stream_part_on(lbmdem_handle* h, int part, hipStream_t st) tr
     h->cs_ob_old = h->obst[h->ocur];
     h->cs_ob_new = h->obst_pending ? h->obst[1 - h->ocur] : h->obst[h->ocur];
     h->cs_lo_end = lo_end; h->cs_hi_begin = hi_begin;
-    if (st == h->stream) {   // (another stream: the caller has called lbmdem_collide_stream_prepare before its hand-over)
+    if (!h->cs_prepared) {   // (a caller that hands the part to another stream has prepared before its hand-over)
+      if (st != h->stream) return fail(LBMDEM_EINVAL, "lbmdem_collide_stream_prepare comes before a part on another stream");
       int rc = lbmdem_collide_stream_prepare(h);
       if (rc != LBMDEM_OK) return rc;
     }
+    h->cs_prepared = false;
     launch_collide_stream_edges(h->cs_fin, h->f[1 - h->fcur], h->cs_ob_old, h->cs_ob_new, L, gview(h), h->cs_slots, L.xo0,
                                 lo_end, hi_begin, L.xo1, st);
     HIP_TRY(hipGetLastError());

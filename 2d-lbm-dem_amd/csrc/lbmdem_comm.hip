@@ -249,9 +249,15 @@ int lbmdem_comm_lbm_step(lbmdem_handle* h, lbmdem_comm* c) {
   if (cut) {
     RC_TRY(lbmdem_collide_stream_prepare(h));
     hipStream_t side = c->side[LANE_HALO];
+#ifdef LBMDEM_AB   /* A/B: the edge rows through the main stream, only the exchange on the lane's stream */
+    static const bool edges_main = getenv("LBMDEM_COMM_EDGES_MAIN") != nullptr;
+    if (edges_main) RC_TRY(lbmdem_collide_stream_part_on(h, LBMDEM_CS_EDGES, main));
+#else
+    const bool edges_main = false;
+#endif
     HIP_TRY(hipEventRecord(c->ready[LANE_HALO], main));
     HIP_TRY(hipStreamWaitEvent(side, c->ready[LANE_HALO], 0));
-    RC_TRY(lbmdem_collide_stream_part_on(h, LBMDEM_CS_EDGES, side));      // the rows the neighbours wait for ...
+    if (!edges_main) RC_TRY(lbmdem_collide_stream_part_on(h, LBMDEM_CS_EDGES, side));      // the rows the neighbours wait for ...
     RC_TRY(halo_exchange(h, c, side, has));
     HIP_TRY(hipEventRecord(c->done[LANE_HALO], side));
     RC_TRY(lbmdem_collide_stream_part_on(h, LBMDEM_CS_INTERIOR, main));   // ... next to the bulk of the rows

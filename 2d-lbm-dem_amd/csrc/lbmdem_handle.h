@@ -49,6 +49,7 @@ struct lbmdem_handle {
   // collide_stream in two parts (lbmdem_collide_stream_part): after EDGES the interior rows of f[fcur] are
   // still missing; the operands of the launch are kept for INTERIOR
   bool cs_interior_pending = false;
+  bool cs_prepared = false;   // lbmdem_collide_stream_prepare has run for the coming EDGES part
   const real* cs_fin = nullptr;
   const int *cs_ob_old = nullptr, *cs_ob_new = nullptr;
   int cs_lo_end = 0, cs_hi_begin = 0;  // interior = local rows [cs_lo_end, cs_hi_begin)
@@ -90,7 +91,8 @@ struct lbmdem_handle {
   bool verlet_ok = false;
   bool verlet_tracks_positions = false;  // the positions have only moved by DEM sub-steps since the list was built (no upload)
   volatile int* ovf_host = nullptr;  // pinned mirror of V.overflow, refreshed (asynchronously) after every rebuild
-  volatile int* ferr_host = nullptr; // pinned mirror of fs.error (strip decomposition), refreshed after every period's forces
+  volatile int* ferr_host = nullptr; // pinned mirror of fs.error (strip decomposition), refreshed by every period's classification launch
+  int* ferr_mirror = nullptr;        // ... its device address
   long nbsteps = 0;
   int force_mode = 0;
   // derived scalars

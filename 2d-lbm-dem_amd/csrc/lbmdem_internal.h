@@ -184,12 +184,13 @@ struct DistGeom { real lo, hi, margin, dx, Mgx; int has_lo, has_hi, first, last,
 int dist_alloc(DistDevice& D, int n, int cap_g, int cap_t, int cap_l);
 void dist_free(DistDevice& D);
 // ownership, masks and the send / straddler lists from the current positions of the grains that were active
+// (error_mirror: device address of the pinned host word that follows *error, written by the launch; may be null)
 void launch_dist_classify(const DistDevice& D, const DistGeom& Gm, int n, const real* x1, const real* r,
-                          const real* rLB, unsigned char* owner, int* error, hipStream_t st);
+                          const real* rLB, unsigned char* owner, int* error, int* error_mirror, hipStream_t st);
 // the same + the two kinematics messages packed by the launch's last workgroup (C transport: one launch instead of two)
 void launch_dist_classify_pack_kin(const DistDevice& D, const DistGeom& Gm, int n, const real* x1, const real* r,
-                                   const real* rLB, unsigned char* owner, int* error, const Kin& K, real* kin_lo,
-                                   real* kin_hi, hipStream_t st);
+                                   const real* rLB, unsigned char* owner, int* error, int* error_mirror, const Kin& K,
+                                   real* kin_lo, real* kin_hi, hipStream_t st);
 // C transport, one launch: merge the neighbours' TABLES messages, unpack their KIN messages, reset `dead_obst` (null: not)
 void launch_dist_unpack_tables_kin_fill(const ForceSlots& S, const real* tab_lo, const real* tab_hi, int cap_t,
                                         const DistDevice& D, const real* kin_lo, const real* kin_hi, const Kin& K, int n,

@@ -194,11 +194,14 @@ int lbmdem_dist_begin_period_packed(lbmdem_handle* h, void* kin_lo, void* kin_hi
   // errors of earlier periods (a truncated message list, overlapping discs across a cut, a clash while merging tables)
   // are flagged on the device; the flag follows every period to pinned host memory and stops the run HERE, at the next
   // period, instead of letting it continue on truncated messages until somebody calls lbmdem_sync
+#ifdef LBMDEM_AB   /* experiment build: a rank stepped alone on stale neighbour messages (scripts/strip_proxy*.py) raises the flag by design */
+  static const bool ignore_flag = getenv("LBMDEM_IGNORE_DIST_ERRORS") != nullptr;
+  if (ignore_flag) *h->ferr_host = 0;
+#endif
   if (*h->ferr_host)
     return fail(LBMDEM_EINVAL, "strip decomposition: device error flag %d in an earlier fluid step (4: more grains near a cut "
                                "than the message capacity, 8: two ranks produced the same link sum, others: the force of a "
                                "grain on a cut could not be formed)", (int)*h->ferr_host);
-  HIP_TRY(hipMemcpyAsync((void*)h->ferr_host, h->fs.error, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   const lbmdem_config& c = h->cfg;
   DistGeom Gm;
   Gm.lo = (double)c.x_begin; Gm.hi = (double)c.x_end; Gm.margin = (double)h->dist_margin; Gm.dx = c.dx; Gm.Mgx = c.Mgx;
@@ -207,10 +210,10 @@ int lbmdem_dist_begin_period_packed(lbmdem_handle* h, void* kin_lo, void* kin_hi
   { int* t = h->dd.counters; h->dd.counters = h->dd.counters_alt; h->dd.counters_alt = t; }   // the set cleared last period
   h->fs.local_count = h->dd.counters + 6;
   if (kin_lo || kin_hi)
-    launch_dist_classify_pack_kin(h->dd, Gm, h->n, h->kin[h->kcur].x1, h->r, h->rLB, h->owner, h->fs.error, h->kin[h->kcur],
-                                  (real*)kin_lo, (real*)kin_hi, h->stream);
+    launch_dist_classify_pack_kin(h->dd, Gm, h->n, h->kin[h->kcur].x1, h->r, h->rLB, h->owner, h->fs.error, h->ferr_mirror,
+                                  h->kin[h->kcur], (real*)kin_lo, (real*)kin_hi, h->stream);
   else
-    launch_dist_classify(h->dd, Gm, h->n, h->kin[h->kcur].x1, h->r, h->rLB, h->owner, h->fs.error, h->stream);
+    launch_dist_classify(h->dd, Gm, h->n, h->kin[h->kcur].x1, h->r, h->rLB, h->owner, h->fs.error, h->ferr_mirror, h->stream);
   HIP_TRY(hipGetLastError());
   h->dist_period_open = true;
   return LBMDEM_OK;

@@ -10,6 +10,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "scripts")]
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+os.environ.setdefault("LBMDEM_HIP_LIBRARY", os.path.join(ROOT, "2d-lbm-dem_amd", "liblbmdem_hip_ab.so"))   # exchange probe, error-flag switch
+os.environ["LBMDEM_IGNORE_DIST_ERRORS"] = "1"   # stale neighbour messages raise the strip error flag by design
 import torch
 import __graft_entry__ as ge, samples
 from strip_backends import LoopbackComm, lockstep_render_dist
