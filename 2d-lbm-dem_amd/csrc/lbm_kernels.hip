@@ -52,9 +52,14 @@ __host__ __device__ constexpr real Wq(int q) {   // real _w[Q] = {4. / 9, 1. / 3
 __device__ __forceinline__ long fbase(long node) {
   return (node / LBMDEM_TILE_Y) * (9 * LBMDEM_TILE_Y) + (node % LBMDEM_TILE_Y);
 }
+// the same from the local row and the column (sy is a multiple of the tile)
+__device__ __forceinline__ long fbase_xy(const LatticeView& L, int xl, int y) {
+  return (long)xl * L.sy * 9 + (y / LBMDEM_TILE_Y) * (9 * LBMDEM_TILE_Y) + (y % LBMDEM_TILE_Y);
+}
 #define F_QSTRIDE(L) ((long)LBMDEM_TILE_Y)
 #else
 __device__ __forceinline__ long fbase(long node) { return node; }
+__device__ __forceinline__ long fbase_xy(const LatticeView& L, int xl, int y) { return (long)xl * L.sy + y; }
 #define F_QSTRIDE(L) ((L).plane)
 #endif
 #define fidx(q, node) (fbase(node) + (q) * F_QSTRIDE(L))   // needs the LatticeView `L` in scope
@@ -847,9 +852,8 @@ __device__ __forceinline__ void classify_store_all(const RegCtx3& C, const Latti
 // that link's NN is interior / is a solid node whose own update precedes S's (q <= 4).
 template <bool EDGE, class Ctx>
 __device__ __forceinline__ void classify_store_row(const Ctx& C, const LatticeView& L, int gx, int y,
-                                                   real* __restrict__ fout, long node, unsigned& ibb,
+                                                   real* __restrict__ fout, long fb, unsigned& ibb,
                                                    unsigned& nnm, unsigned& hzm) {
-  const long fb = fbase(node);
   fout[fb] = C.own(0);
 #define LBM_CLASSIFY(Q)                                                   \
   {                                                                       \
@@ -879,8 +883,7 @@ __device__ __forceinline__ void classify_store_row(const Ctx& C, const LatticeVi
 // kernel (A/B on one GPU, four interleaved pairs).
 template <class Ctx>
 __device__ __forceinline__ void classify_store_row_deep(const Ctx& C, const LatticeView& L, real* __restrict__ fout,
-                                                        long node, unsigned& ibb, unsigned& nnm, unsigned& hzm) {
-  const long fb = fbase(node);
+                                                        long fb, unsigned& ibb, unsigned& nnm, unsigned& hzm) {
   fout[fb] = C.own(0);
   const bool own_solid = C.o_own() != -1;
 #define LBM_CLASSIFY_DEEP(Q)                                                        \
@@ -1026,7 +1029,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
   // off-lattice positions load a clamped neighbour's values; they are never used (pull_one tests the
   // bounds of the source node before touching its populations)
   auto load_raw = [&](int xl, real (&raw)[9]) {
-    const long fb = fbase(node_of(xl));
+    const long fb = fbase_xy(L, xl < 0 ? 0 : (xl >= L.nxl ? L.nxl - 1 : xl), ycl);
 #pragma unroll
     for (int q = 0; q < 9; ++q) raw[q] = fin[fb + q * F_QSTRIDE(L)];
   };
@@ -1133,18 +1136,18 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
             (((pk_up >> 2) & 1u) << 7) | (((pk_up >> 1) & 1u) << 8);
     {
       const int gx = L.gx0 + x;
-      const long node = (long)x * L.sy + y;
+      const long fb_row = fbase_xy(L, x, y);   // (only used by the producing lanes: y is on the lattice there)
       // wave-uniform: is every producing lane of this row at least two nodes away from all edges?
       const bool deep = deep_y && gx >= 2 && gx <= L.lx - 3;
       // (a) everything but the interpolated bounce-back links: computed and stored
       unsigned ibb = 0, nnm = 0, hzm = 0;
       if (writer && x < xe) {
 #ifndef MARCH_BRANCHY
-        if (deep) classify_store_row_deep(C, L, fout, node, ibb, nnm, hzm);
+        if (deep) classify_store_row_deep(C, L, fout, fb_row, ibb, nnm, hzm);
 #else
-        if (deep) classify_store_row<false>(C, L, gx, y, fout, node, ibb, nnm, hzm);
+        if (deep) classify_store_row<false>(C, L, gx, y, fout, fb_row, ibb, nnm, hzm);
 #endif
-        else classify_store_row<true>(C, L, gx, y, fout, node, ibb, nnm, hzm);
+        else classify_store_row<true>(C, L, gx, y, fout, fb_row, ibb, nnm, hzm);
       }
       MT(4)
       // (b) the bounce-back links of the whole row (typically ~20, spread over all eight directions
@@ -1187,7 +1190,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
           // the result goes straight to the population it belongs to: node of lane `src`, plane q
           const real out =
               ibb_eval_rt(L, k, wc_diag, wc_axis, [&](int dx, int dy) { return ring.get(x + dx, src + dy); });
-          fout[fidx(k.q, node - lane + src)] = out;
+          fout[fbase_xy(L, x, k.gy) + k.q * F_QSTRIDE(L)] = out;
           // ... and the link's momentum-exchange sum f_new[S][opp q] + f_new[P][q] (main.c:1313-1316; the first
           // is f*[P][opp q], streamed unchanged into the solid node) to the owning grain's slot table
           if (S.tab != nullptr) {
