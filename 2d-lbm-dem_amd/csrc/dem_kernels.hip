@@ -279,11 +279,16 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const real
                                                      const unsigned char* __restrict__ wallflags,
                                                      real* __restrict__ pout, DemParams P,
                                                      const unsigned char* __restrict__ active, CarryTrack T,
-                                                     long long stamp, const unsigned char* __restrict__ owner) {
+                                                     long long stamp, const unsigned char* __restrict__ owner,
+                                                     ObstFillJob fill, int tiles) {
   __shared__ real sF1[DEM_ENTRIES], sF2[DEM_ENTRIES], sF3[DEM_ENTRIES], sFn[DEM_ENTRIES];
   __shared__ unsigned char sTouched[DEM_ENTRIES];
   __shared__ int sLast;   // highest list entry of this tile that is a touching contact in the reference's frame
   const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= tiles) {   // the workgroups behind the grain tiles reset a slice of the next obstacle map
+    obst_fill_range(fill.map, fill.L, (long)(blockIdx.x - tiles) * 256 + tid, (long)(gridDim.x - tiles) * 256, fill.row0, fill.row1);
+    return;
+  }
   if (T.stamp) {   // before anything is in flight: the barrier costs nothing here
     if (tid == 0) sLast = -1;
     __syncthreads();
@@ -859,7 +864,8 @@ void launch_fill_own(const VerletDevice& V, int n, hipStream_t st) {
 void launch_dem_substep(const Kin& in, const Kin& out, const real* r, const real* m,
                         const real* It, const real* fhf, const VerletDevice& V, real* pout,
                         const DemParams& P, int film, real* diag, const DiagExtra* X, const unsigned char* active,
-                        const CarryTrack* track, long long stamp, const unsigned char* owner, hipStream_t st) {
+                        const CarryTrack* track, long long stamp, const unsigned char* owner, const ObstFillJob& fill,
+                        hipStream_t st) {
   const int n = P.n;
   const CarryTrack T = track ? *track : CarryTrack{};
 #ifdef LBMDEM_AB
@@ -869,14 +875,21 @@ void launch_dem_substep(const Kin& in, const Kin& out, const real* r, const real
 #endif
   if (!diag && variant == 1) {  // one lane per list entry
     const int nbe = (n + DEM_GRAINS - 1) / DEM_GRAINS;
+    int extra = 0;
+    if (fill.map && fill.row1 > fill.row0) {   // ~8 16-byte stores per thread, at most one workgroup per CU
+      const long v4 = (long)(fill.row1 - fill.row0) * fill.L.sy / 4;
+      extra = (int)((v4 + 256 * 8 - 1) / (256 * 8));
+      if (extra > 256) extra = 256;
+    }
     if (film)
-      hipLaunchKernelGGL(k_dem_entries<true>, dim3(nbe), dim3(256), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
-                         V.own, V.wallflags, pout, P, active, T, stamp, owner);
+      hipLaunchKernelGGL(k_dem_entries<true>, dim3(nbe + extra), dim3(256), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
+                         V.own, V.wallflags, pout, P, active, T, stamp, owner, fill, nbe);
     else
-      hipLaunchKernelGGL(k_dem_entries<false>, dim3(nbe), dim3(256), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
-                         V.own, V.wallflags, pout, P, active, T, stamp, owner);
+      hipLaunchKernelGGL(k_dem_entries<false>, dim3(nbe + extra), dim3(256), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
+                         V.own, V.wallflags, pout, P, active, T, stamp, owner, fill, nbe);
     return;
   }
+  if (fill.map && fill.row1 > fill.row0) launch_obst_fill_rows(fill.map, fill.L, fill.row0, fill.row1, st);   // (the diagnostic sub-step has its own kernel)
   const int nb = (P.n + 127) / 128;
   DiagOut D{};
   if (diag) {  // [8][n] doubles then [2][n] ints

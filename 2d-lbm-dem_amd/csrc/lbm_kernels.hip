@@ -226,8 +226,8 @@ __device__ __forceinline__ real link_delta(int x, int y, real xc, real yc, real 
 // ---------------------------------------------------------------------------------------------
 
 // obst = -1 in the interior, nbgrains on the four lattice edges (main.c:669-683, 997-999): obst_fill_range (lbmdem_internal.h)
-__global__ void k_obst_fill(int* __restrict__ obst, LatticeView L) {
-  obst_fill_range(obst, L, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+__global__ void k_obst_fill(int* __restrict__ obst, LatticeView L, int row0, int row1) {
+  obst_fill_range(obst, L, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x, row0, row1);
 }
 
 // Rasterise the reduced discs (main.c:1016-1032). One wavefront per grain: every lane derives the grain's lattice
@@ -2676,8 +2676,11 @@ inline int grid_for(long total, int block = 256, int cap = 256 * 8) {
 // launchers
 // ---------------------------------------------------------------------------------------------
 
-void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st) {
-  hipLaunchKernelGGL(k_obst_fill, dim3(grid_for((long)L.nxl * L.sy / 4)), dim3(256), 0, st, obst, L);
+void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st) { launch_obst_fill_rows(obst, L, 0, L.nxl, st); }
+
+void launch_obst_fill_rows(int* obst, const LatticeView& L, int row0, int row1, hipStream_t st) {
+  if (row1 <= row0) return;
+  hipLaunchKernelGGL(k_obst_fill, dim3(grid_for((long)(row1 - row0) * L.sy / 4)), dim3(256), 0, st, obst, L, row0, row1);
 }
 
 void launch_obst_paint(int* obst, const LatticeView& L, int n, const real* x1, const real* x2, const real* r,

@@ -145,8 +145,8 @@ static int paint_into(lbmdem_handle* h, int* obst) {
       h->paint_epoch = 1;
     }
   }
-  if (!(h->obst_prefilled && obst == h->obst[1 - h->ocur])) launch_obst_fill(obst, h->L, h->stream);
-  h->obst_prefilled = false;
+  launch_obst_fill_rows(obst, h->L, obst == h->obst[1 - h->ocur] ? h->obst_reset_rows : 0, h->L.nxl, h->stream);
+  h->obst_reset_rows = 0;
   launch_obst_paint(obst, h->L, h->n, K.x1, K.x2, h->r, h->rLB, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0, h->pk,
                     h->fs.touched, h->dist ? h->dd.fluidmask : nullptr, h->mincov, h->paint_epoch,
                     h->dist ? h->dd.local_list : nullptr, h->dist ? h->dd.counters + 6 : nullptr, h->dist ? h->dd.cap_l : 0,
@@ -449,7 +449,7 @@ int lbmdem_collide_stream(lbmdem_handle* h) try {
   h->slots_valid = h->fs.tab != nullptr;
   HIP_TRY(hipGetLastError());
   h->fcur = 1 - h->fcur;
-  if (h->obst_pending) { h->ocur = 1 - h->ocur; h->obst_pending = false; }
+  if (h->obst_pending) { h->ocur = 1 - h->ocur; h->obst_pending = false; h->obst_reset_rows = 0; }
   return LBMDEM_OK;
 } catch (const std::bad_alloc&) {
   return fail(LBMDEM_ENOMEM, "host memory allocation failed");
@@ -502,7 +502,7 @@ int lbmdem_collide_stream_part_on(lbmdem_handle* h, int part, hipStream_t st) tr
                                 lo_end, hi_begin, L.xo1, st);
     HIP_TRY(hipGetLastError());
     h->fcur = 1 - h->fcur;
-    if (h->obst_pending) { h->ocur = 1 - h->ocur; h->obst_pending = false; }
+    if (h->obst_pending) { h->ocur = 1 - h->ocur; h->obst_pending = false; h->obst_reset_rows = 0; }
     h->cs_interior_pending = true;
     return LBMDEM_OK;
   }
@@ -662,9 +662,18 @@ int lbmdem_dem_substep(lbmdem_handle* h) {
   track = nullptr;
 #endif
   const DemParams P = dem_params(h);
+  // a slice of the next rasterisation's canvas is reset under this sub-step (npDEM slices between two fluid steps)
+  ObstFillJob fill{nullptr, h->L, 0, 0};
+  if (!h->obst_pending && !h->cs_interior_pending && h->obst_reset_rows < h->L.nxl) {
+    const int slice = (h->L.nxl + h->cfg.npDEM - 1) / h->cfg.npDEM;
+    fill.map = h->obst[1 - h->ocur];
+    fill.row0 = h->obst_reset_rows;
+    fill.row1 = fill.row0 + slice < h->L.nxl ? fill.row0 + slice : h->L.nxl;
+    h->obst_reset_rows = fill.row1;
+  }
   launch_dem_substep(h->kin[h->kcur], h->kin[1 - h->kcur], h->r, h->m, h->It, h->fhf, h->V, h->gp,
                      P, film, want_diag ? h->diag : nullptr, want_diag ? &h->dx : nullptr,
-                     h->dist ? h->dd.active : nullptr, track, h->substep_seq, h->dist ? h->owner : nullptr,
+                     h->dist ? h->dd.active : nullptr, track, h->substep_seq, h->dist ? h->owner : nullptr, fill,
                      h->stream);
   if (h->dist && h->dist_poison) launch_dist_poison(h->dd, h->kin[0], h->kin[1], h->n, h->stream);
   if (want_diag) {

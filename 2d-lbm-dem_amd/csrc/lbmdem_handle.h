@@ -44,8 +44,10 @@ struct lbmdem_handle {
   int* obst[2] = {nullptr, nullptr};
   int ocur = 0;           // map the current f was produced with ("old" for the next collide_stream)
   bool obst_pending = false;  // obst[1 - ocur] holds a newer map not yet consumed by collide_stream
-  bool obst_prefilled = false;  // obst[1 - ocur] has already been reset to "no grains" (C transport: by the launch that
-                                // unpacks the neighbours' messages); the next obst_construction only paints
+  // obst[1 - ocur] -- the map the fused kernel has finished with, the next rasterisation's canvas -- is reset to "no
+  // grains" in slices by the DEM sub-step launches (single domain) or all at once by the launch that unpacks the
+  // neighbours' messages (C transport): local rows [0, obst_reset_rows) are done; obst_construction does the rest
+  int obst_reset_rows = 0;
   // collide_stream in two parts (lbmdem_collide_stream_part): after EDGES the interior rows of f[fcur] are
   // still missing; the operands of the launch are kept for INTERIOR
   bool cs_interior_pending = false;

@@ -57,10 +57,11 @@ struct LatticeView {
 
 // obst = -1 in the interior, nbgrains on the four lattice edges (main.c:669-683, 997-999); 16-byte stores (the row pitch
 // is a multiple of 16 elements). Thread `first` of `stride` threads.
-__device__ __forceinline__ void obst_fill_range(int* __restrict__ obst, const LatticeView& L, long first, long stride) {
-  const long total4 = (long)L.nxl * L.sy / 4;
+__device__ __forceinline__ void obst_fill_range(int* __restrict__ obst, const LatticeView& L, long first, long stride,
+                                                int row0 = 0, int row1 = -1) {   // local rows [row0, row1); -1: to the end
+  const long total4 = (long)(row1 < 0 ? L.nxl : row1) * L.sy / 4;
   int4* o4 = reinterpret_cast<int4*>(obst);
-  for (long k = first; k < total4; k += stride) {
+  for (long k = (long)row0 * L.sy / 4 + first; k < total4; k += stride) {
     const long e = k * 4;
     const int xl = (int)(e / L.sy), y0 = (int)(e % L.sy);
     const int gx = L.gx0 + xl;
@@ -301,7 +302,13 @@ void diag_extra_free(DiagExtra& X);
 void launch_diag_extra(const DiagExtra& X, const Kin& in, const real* r, const VerletDevice& V,
                        const DemParams& P, int film, hipStream_t st);
 void launch_fill_own(const VerletDevice& V, int n, hipStream_t st);
+// A slice of the obstacle map that the next rasterisation starts from (obst = -1 / wall codes, main.c:997-999), reset by
+// extra workgroups of a DEM sub-step launch: the sub-step kernel is a latency chain that leaves the GPU idle, the reset is
+// 67 MB of stores per fluid step -- in npDEM slices they disappear under the sub-steps. map == nullptr: nothing to do.
+struct ObstFillJob { int* map; LatticeView L; int row0, row1; };
 void launch_dem_substep(const Kin& in, const Kin& out, const real* r, const real* m,
                         const real* It, const real* fhf, const VerletDevice& V, real* pout,
                         const DemParams& P, int film, real* diag, const DiagExtra* X, const unsigned char* active,
-                        const CarryTrack* track, long long stamp, const unsigned char* owner, hipStream_t st);
+                        const CarryTrack* track, long long stamp, const unsigned char* owner, const ObstFillJob& fill,
+                        hipStream_t st);
+void launch_obst_fill_rows(int* obst, const LatticeView& L, int row0, int row1, hipStream_t st);

@@ -265,7 +265,7 @@ int lbmdem_dist_unpack_tables_kin_fill(lbmdem_handle* h, const void* tab_lo, con
   launch_dist_unpack_tables_kin_fill(h->fs, (const real*)tab_lo, (const real*)tab_hi, h->dd.cap_t, h->dd, (const real*)kin_lo,
                                      (const real*)kin_hi, h->kin[h->kcur], h->n, h->obst[1 - h->ocur], h->L, h->stream);
   HIP_TRY(hipGetLastError());
-  h->obst_prefilled = true;
+  h->obst_reset_rows = h->L.nxl;
   return LBMDEM_OK;
 }
 
@@ -355,7 +355,7 @@ int lbmdem_dist_table_substep(lbmdem_handle* h, const double* state12_full, cons
   const int film = (h->nbsteps % h->cfg.phys.stepFilm == 0) ? 1 : 0;
   const DemParams P = dem_params(h);
   launch_dem_substep(h->kin[h->kcur], h->kin[1 - h->kcur], h->r, h->m, h->It, h->fhf, h->V, h->gp, P, film, h->diag,
-                     &h->dx, nullptr, nullptr, h->substep_seq, nullptr, h->stream);
+                     &h->dx, nullptr, nullptr, h->substep_seq, nullptr, ObstFillJob{nullptr, h->L, 0, 0}, h->stream);
   launch_diag_extra(h->dx, h->kin[h->kcur], h->r, h->V, P, film, h->stream);
   h->carry_from = h->substep_seq + 1;
   h->substep_seq++;
