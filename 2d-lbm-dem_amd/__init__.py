@@ -331,6 +331,11 @@ class LbmDem:
         """n x (Verlet rebuild when due; DEM sub-step) -- renderScene without its fluid step."""
         _chk(self._L.lbmdem_run_dem(self._h, int(n)))
 
+    def renderScene_dry(self, n=1):
+        """n x renderScene() of the reference compiled without `#define _FLUIDE_` (main.c:16, 1709-1719): DEM only -- no
+        fluid step, the hydrodynamic forces keep their values (0 from the start)."""
+        self.run_dem(n)
+
     def lbm_step(self):
         """reinit_obst_density + obst_construction + collision_streaming + forces_fluid (main.c:1711-1717)."""
         _chk(self._L.lbmdem_lbm_step(self._h))

@@ -8,6 +8,8 @@
  * `#define duration 1.5`, main.c:27-32,47); here the same defaults apply and can be overridden at
  * run time: --lx N --ly N --scale S --duration SECONDS --steps N_DEM_STEPS --device K, and (absent in
  * the reference, which cannot resume) --checkpoint FILE (written at the end) / --restart FILE.
+ * --dry: the reference compiled without `#define _FLUIDE_` (main.c:16) -- DEM only: no fluid step and no check_density
+ * line (main.c:1709-1719), no VTK frames although nFile still advances (main.c:1767-1772), hydrodynamic forces 0.
  * --gpus N: one process per GPU, rank k on device K + k; --devices a,b,c names the device of every rank instead (the
  * same device may appear twice: that is how the tests run several ranks on a one-GPU box, see tests/rccl_shim).
  */
@@ -27,7 +29,7 @@
 /* --gpus N: one process per GPU (forked before anything touches the HIP runtime), x-strips with the grains
  * distributed, neighbour messages over RCCL (lbmdem_comm_*). Rank 0 creates the RCCL id and hands it to the others
  * through a file in a private temporary directory. Rank 0 prints and writes the VTK frames and DEM tables (merged over the ranks); checkpoints are single-GPU. */
-static int g_rank = 0, g_world = 1, g_use_comm = 0;
+static int g_rank = 0, g_world = 1, g_use_comm = 0, g_dry = 0;
 static char g_iddir[256] = "";
 static int g_devices[64], g_ndevices = 0;   /* --devices */
 
@@ -65,7 +67,7 @@ static int check_decomposition(int argc, char** argv, int gpus) {
     if (!strcmp(argv[a], "--lx") && a + 1 < argc) lx = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--ly") && a + 1 < argc) ly = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--scale") && a + 1 < argc) scale = atof(argv[++a]);
-    else if (argv[a][0] == '-' && argv[a][1] == '-' && strcmp(argv[a], "--comm") && a + 1 < argc) ++a;
+    else if (argv[a][0] == '-' && argv[a][1] == '-' && strcmp(argv[a], "--comm") && strcmp(argv[a], "--dry") && a + 1 < argc) ++a;
     else if (argv[a][0] != '-' && !sample) sample = argv[a];
   }
   if (!sample) return 0;   /* run() prints the usage line */
@@ -99,6 +101,7 @@ int main(int argc, char** argv) {
   for (int a = 1; a < argc; ++a) {
     if (!strcmp(argv[a], "--gpus") && a + 1 < argc) gpus = atoi(argv[a + 1]);
     if (!strcmp(argv[a], "--comm")) g_use_comm = 1;   /* the RCCL path with a single rank */
+    if (!strcmp(argv[a], "--dry")) g_dry = 1;
     if (!strcmp(argv[a], "--devices") && a + 1 < argc) {
       for (const char* p = argv[a + 1]; *p && g_ndevices < 64;) {
         char* end = NULL;
@@ -111,6 +114,7 @@ int main(int argc, char** argv) {
     }
   }
   if (g_ndevices > 0 && g_ndevices < gpus) { fprintf(stderr, "--devices names %d devices for %d ranks\n", g_ndevices, gpus); return EXIT_FAILURE; }
+  if (g_dry && (gpus > 1 || g_use_comm)) { fprintf(stderr, "--dry is a single-GPU mode (the strips exist for the fluid)\n"); return EXIT_FAILURE; }
   if (gpus <= 1) return run(argc, argv);
   g_world = gpus; g_use_comm = 1;
   { /* every strip must be at least one margin wide (lbmdem_dist_enable would refuse on the ranks whose strip is one
@@ -189,11 +193,12 @@ static int run(int argc, char** argv) {
     else if (!strcmp(argv[a], "--gpus") && a + 1 < argc) ++a;
     else if (!strcmp(argv[a], "--devices") && a + 1 < argc) ++a;
     else if (!strcmp(argv[a], "--comm")) {}
+    else if (!strcmp(argv[a], "--dry")) {}
     else if (argv[a][0] != '-' && !sample) sample = argv[a];
     else { sample = NULL; break; }
   }
   if (!sample) {
-    SAY("usage: usage %s <filename> [--lx N --ly N --scale S --duration T --steps N --device K --gpus N --devices a,b,..]\n", argv[0]);
+    SAY("usage: usage %s <filename> [--lx N --ly N --scale S --duration T --steps N --device K --gpus N --devices a,b,.. --dry]\n", argv[0]);
     exit(EXIT_FAILURE);
   }
   SAY("Opening file : %s\n", sample);
@@ -286,7 +291,9 @@ static int run(int argc, char** argv) {
     /* check_density cadence (main.c:1715): printed right after the fluid step of such a DEM step */
     for (long k = 0; k < todo; ++k) {
       int lbm_now = (nbsteps % cfg.npDEM == 0), console_now = (nbsteps % stepConsole == 0);
-      if (lbm_now && console_now) {
+      if (g_dry) {   /* renderScene without its `#ifdef _FLUIDE_` block (main.c:1709-1719) */
+        DIE(lbmdem_run_dem(h, 1), "run_dem");
+      } else if (lbm_now && console_now) {
         if (comm) DIE(lbmdem_comm_lbm_step(h, comm), "comm_lbm_step"); else DIE(lbmdem_lbm_step(h), "lbm_step");
         double sum = serial_density(h, comm);
         SAY("Iteration Number %ld, Total density in the system %f\n", nbsteps, sum);
@@ -301,7 +308,8 @@ static int run(int argc, char** argv) {
       /* output cadence of renderScene (main.c:1767-1772): write_vtk every stepFilm DEM steps. With several strips
        * the columns are merged over the ranks and rank 0 writes the same five files */
       if (nbsteps % cfg.phys.stepFilm == 0) {
-        if (comm) DIE(lbmdem_comm_write_vtk(h, comm, ".", nFile), "comm_write_vtk");
+        if (g_dry) {}   /* write_vtk sits inside `#ifdef _FLUIDE_` (main.c:1768-1770); nFile++ does not */
+        else if (comm) DIE(lbmdem_comm_write_vtk(h, comm, ".", nFile), "comm_write_vtk");
         else DIE(lbmdem_write_vtk(h, ".", nFile), "write_vtk");
         nFile++;
       }
@@ -334,7 +342,7 @@ static int run(int argc, char** argv) {
     DIE(lbmdem_comm_allreduce_sum(comm, tmax, g_world), "allreduce");
     for (int r = 0; r < g_world; ++r) if (tmax[r] > secs) secs = tmax[r];
   }
-  long lbm_steps = (nbsteps + cfg.npDEM - 1) / cfg.npDEM;
+  long lbm_steps = g_dry ? 0 : (nbsteps + cfg.npDEM - 1) / cfg.npDEM;
   if (g_rank == 0) {
     fprintf(stderr, "final_density: %f\n", sum);
     fprintf(stderr, "time: %e\n", secs);

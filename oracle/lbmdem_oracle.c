@@ -872,6 +872,15 @@ ORA_API void ora_steps(ora_sim* s, long n) {
   for (long k = 0; k < n; ++k) ora_render_scene(s);
 }
 
+/* renderScene with _FLUIDE_ undefined (main.c:16, 1709-1719): no fluid step, the hydrodynamic forces stay what they
+ * are (0 from the start), everything else as above */
+ORA_API void ora_steps_dry(ora_sim* s, long n) {
+  for (long k = 0; k < n; ++k) {
+    if (s->nbsteps % s->updateVerlet == 0) ora_verlet_rebuild(s);
+    ora_dem_substep(s);
+  }
+}
+
 /* ------------------------------------------------------------------ access */
 
 ORA_API void ora_set_threads(ora_sim* s, int nthreads) { s->threads = nthreads > 1; }

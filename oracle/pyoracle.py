@@ -41,18 +41,19 @@ def reference_available() -> bool:
     return os.path.isfile(os.path.join(REF_ROOT, "src", "main.c"))
 
 
-def ref_lib_path(lx: int, ly: int, fast: bool = False, sp: bool = False) -> str:
-    return os.path.join(HERE, "_ref", f"libref_{'fast_' if fast else ''}{'sp_' if sp else ''}{lx}x{ly}.so")
+def ref_lib_path(lx: int, ly: int, fast: bool = False, sp: bool = False, dry: bool = False) -> str:
+    return os.path.join(HERE, "_ref", f"libref_{'fast_' if fast else ''}{'sp_' if sp else ''}{'dry_' if dry else ''}{lx}x{ly}.so")
 
 
-def build_ref(lx: int, ly: int, fast: bool = False, sp: bool = False) -> str | None:
-    """Compile the reference TU for one lattice size (only where /root/reference exists). sp: -DSINGLE_PRECISION."""
-    path = ref_lib_path(lx, ly, fast, sp)
+def build_ref(lx: int, ly: int, fast: bool = False, sp: bool = False, dry: bool = False) -> str | None:
+    """Compile the reference TU for one lattice size (only where /root/reference exists). sp: -DSINGLE_PRECISION;
+    dry: with its `#define _FLUIDE_` (main.c:16) taken out -- the reference's DEM-only mode."""
+    path = ref_lib_path(lx, ly, fast, sp, dry)
     if os.path.exists(path):
         return path
     if not reference_available():
         return None
-    subprocess.run(["make", "-s", "-C", HERE, "ref_sp" if sp else ("ref_fast" if fast else "ref"), f"LX={lx}", f"LY={ly}"],
+    subprocess.run(["make", "-s", "-C", HERE, "ref_dry" if dry else ("ref_sp" if sp else ("ref_fast" if fast else "ref")), f"LX={lx}", f"LY={ly}"],
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return path if os.path.exists(path) else None
 
@@ -105,6 +106,7 @@ class Oracle:
 
     # stepping
     def steps(self, n): self._call("ora_steps", C.c_long(n))
+    def steps_dry(self, n): self._call("ora_steps_dry", C.c_long(n))   # the reference without _FLUIDE_ (main.c:16)
     def lbm_steps(self, n): self._call("ora_lbm_steps", C.c_int(n))
     def reinit(self): self._call("ora_reinit_obst_density")
     def obst_construction(self): self._call("ora_obst_construction")
@@ -209,8 +211,8 @@ class Reference:
     """The unmodified reference TU, compiled for one (lx, ly). One instance per process:
     the reference keeps its state in globals."""
 
-    def __init__(self, lx, ly, sample_path, fast=False, sp=False):
-        path = build_ref(lx, ly, fast, sp)
+    def __init__(self, lx, ly, sample_path, fast=False, sp=False, dry=False):
+        path = build_ref(lx, ly, fast, sp, dry)
         if path is None:
             raise FileNotFoundError("reference build not available")
         self.L = C.CDLL(path)

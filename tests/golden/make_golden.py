@@ -200,7 +200,14 @@ def make_vtk_fixture():
     assert R.L.ref_write_vtk(os.fsencode(out), 3) == 0
 
 
-def make_dem_output_fixture():
+def make_dry_output_fixture():
+    """tests/golden/dem_dry_G6_4000steps/: the same files from the reference compiled WITHOUT `_FLUIDE_` (main.c:16 taken out:
+    oracle/Makefile ref_dry) -- its DEM-only mode: no fluid step, no VTK frames, hydrodynamic forces 0 (main.c:1709-1719,
+    1768-1772)."""
+    make_dem_output_fixture(dry=True)
+
+
+def make_dem_output_fixture(dry=False):
     """tests/golden/dem_G6_4000steps/{DEM000000.dat, stats.data}: what the reference's write_DEM
     (main.c:340-438) writes for case G6 at step 4000, plus the grain table at that moment."""
     import ctypes
@@ -209,9 +216,9 @@ def make_dem_output_fixture():
     tmp = tempfile.NamedTemporaryFile("w", suffix=".data", delete=False)
     tmp.close()
     po.write_sample(tmp.name, c["r_mm"], c["x_mm"], c["y_mm"])
-    R = po.Reference(c["lx"], c["ly"], tmp.name)
+    R = po.Reference(c["lx"], c["ly"], tmp.name, dry=dry)
     os.unlink(tmp.name)
-    out = os.path.join(HERE, "dem_G6_4000steps")
+    out = os.path.join(HERE, "dem_dry_G6_4000steps" if dry else "dem_G6_4000steps")
     os.makedirs(out, exist_ok=True)
     for f in os.listdir(out):
         os.unlink(os.path.join(out, f))
@@ -328,6 +335,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--f32":
         make_f32_fixtures()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--dry":
+        make_dry_output_fixture()
+        return
     if len(sys.argv) > 1:      # python make_golden.py real_50000_8192x4096 ...: only these real-sample fixtures
         make_real_fixtures(sys.argv[1:])
         return
@@ -342,7 +352,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **pack(name, case, res))
         print("wrote", name, {k: getattr(v, "shape", None) for k, v in pack(name, case, res).items()})
     make_real_fixtures()
-    for target in (make_vtk_fixture, make_dem_output_fixture):
+    for target in (make_vtk_fixture, make_dem_output_fixture, make_dry_output_fixture):
         p = mp.Process(target=target)
         p.start()
         p.join()
