@@ -1,0 +1,562 @@
+// lbm_fused.hip -- the fused fluid kernels of the MI355X LBM-DEM stepper (gfx950, wave64): the PRODUCT kernels only.
+// (The experiment build adds k_cs_march3 and the per-phase timers from lbm_fused_ab.hip / lbm_march_timing.h.)
+//
+// What the reference does in five in-place sweeps of an AoS lattice per fluid step
+// (reinit_obst_density main.c:966-986, then collision_streaming main.c:1071-1243: collide,
+// edge bounce-back copies, grain interpolated bounce-back, swap, stream) is done here in ONE
+// two-lattice pass over SoA planes:
+//
+//   k_collide_stream: a workgroup stages the post-collision state of a (TX+2)x(TY+2) tile in LDS
+//   (solid nodes hold their re-initialised equilibrium instead), then every node of the inner
+//   TXxTY tile PULLS its nine populations from the staged neighbours, evaluating the lattice-edge
+//   bounce-back and the grain interpolated bounce-back (Bouzidi, moving wall) on the fly. The wall
+//   distance delta (main.c:1054-1058) and the `act` flag (main.c:1039-1052) are recomputed from the
+//   obstacle map and the grain centres instead of being stored (the reference spends most of
+//   obst_construction clearing a 9-real-per-node delta array).
+//
+// Bit parity with the reference's serial loops is a design constraint: expression association is
+// kept, the file is compiled with -ffp-contract=off, and the one order-dependent read of the
+// reference's in-place IBB loop (a node two links out that the x-outer/y-inner scan has already
+// rewritten) is reproduced by recomputing that node's new value (see pull_one()).
+//
+// The equivalence swap+stream == pull, f_new[P][q] = f*[P - e_q][q] (or f*[P][opp q] when P - e_q is
+// off the array), is derived in SURVEY.md "Notes" and verified by tests against the oracle.
+
+
+#include "lbm_march.h"
+#if defined(LBMDEM_AB) && defined(MARCH_TIMING)
+#include "lbm_march_timing.h"
+#else
+#define MT_DECL
+#define MT(i)
+#define MT_FLUSH
+#endif
+
+#ifdef LBMDEM_AB
+void launch_march3_ab(int which, int lx_template, const real* fin, real* fout, const int* obst_old, const int* obst_new,
+                      const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, int nstrips, int nwork, int remap,
+                      int seg_rows, int seg_stride, int grid, hipStream_t st);   // lbm_fused_ab.hip
+#endif
+
+namespace {
+
+// context over the LDS tile
+template <int TX, int TY>
+struct TileCtx {
+  const Tile<TX, TY>& T;
+  const LatticeView& L;
+  const GrainFluidView& G;
+  int px, py, gx, gy;
+  __device__ __forceinline__ real own(int q) const { return T.F(q, px, py); }
+  __device__ __forceinline__ real in(int d) const { return T.F(OPPq(d), px + EXq(d), py + EYq(d)); }
+  __device__ __forceinline__ int o_own() const { return T.O(px, py); }
+  __device__ __forceinline__ int o_nb(int d) const { return T.O(px + EXq(d), py + EYq(d)); }
+  __device__ __forceinline__ bool act_nb(int d) const {
+    return T.active(L, G, px + EXq(d), py + EYq(d), gx + EXq(d), gy + EYq(d));
+  }
+  __device__ __forceinline__ GP gp_nb(int d) const { return load_gp(G, o_nb(d)); }
+};
+
+template <int TX, int TY>
+__global__ __launch_bounds__(256) void k_collide_stream(const real* __restrict__ fin,
+                                                        real* __restrict__ fout,
+                                                        const int* __restrict__ ob_old,
+                                                        const int* __restrict__ ob_new, LatticeView L,
+                                                        GrainFluidView G, int tiles_y, int ntiles,
+                                                        int xcd_remap) {
+  using TT = Tile<TX, TY>;
+  __shared__ real sF[9 * TT::RX * TT::RY];
+  __shared__ int sO[TT::OX * TT::OY];
+  TT T{sF, sO};
+  const int tid = threadIdx.x;
+  // Tile index. Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), each
+  // with a private L2. With the remap, XCD k walks the k-th contiguous eighth of the tile sequence
+  // (y fastest), so tiles that share halo rows/columns run on the same XCD close in time and the
+  // halo re-reads hit that L2. Placement only affects speed.
+  int t = blockIdx.x;
+  if (xcd_remap) {
+    const int per = gridDim.x >> 3;
+    t = (t & 7) * per + (t >> 3);
+  }
+  if (t >= ntiles) return;
+  const int ty0 = (t % tiles_y) * TY;           // global y of the tile origin
+  const int txl0 = L.xo0 + (t / tiles_y) * TX;  // local row of the tile origin
+
+  // obstacle ids, halo 2; positions off the lattice read as "wall" so they never look fluid
+  for (int k = tid; k < TT::OX * TT::OY; k += 256) {
+    const int ox = k / TT::OY, oy = k % TT::OY;
+    const int xl = txl0 - 2 + ox, y = ty0 - 2 + oy;
+    int v = L.n;
+    if (xl >= 0 && xl < L.nxl && y >= 0 && y < L.ly) v = ob_new[(long)xl * L.sy + y];
+    sO[k] = v;
+  }
+  __syncthreads();
+
+  // phase 1: stage f* (before IBB) for the tile + halo 1
+  for (int k = tid; k < TT::RX * TT::RY; k += 256) {
+    const int rx = k / TT::RY, ry = k % TT::RY;
+    const int xl = txl0 - 1 + rx, y = ty0 - 1 + ry;
+    if (xl < 0 || xl >= L.nxl || y < 0 || y >= L.ly) continue;  // never read in phase 2
+    const int gx = L.gx0 + xl;
+    const long node = (long)xl * L.sy + y;
+    const bool interior = gx >= 1 && gx <= L.lx - 2 && y >= 1 && y <= L.ly - 2;
+    real f[9];
+    // reinit_obst_density (main.c:966-986) acts on the PREVIOUS obstacle map with the current grain
+    // state: nodes that were solid restart from the grain's equilibrium
+    const int oo = interior ? ob_old[node] : -1;
+    if (oo != -1) {
+      grain_equilibrium(L, load_gp(G, oo), gx, y, f);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) f[q] = fin[fidx(q, node)];
+    }
+    if (interior && sO[(rx + 1) * TT::OY + (ry + 1)] == -1) mrt_collide(L, f);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) sF[(q * TT::RX + rx) * TT::RY + ry] = f[q];
+  }
+  __syncthreads();
+
+  // phase 2: pull
+  for (int k = tid; k < TX * TY; k += 256) {
+    const int px = k / TY, py = k % TY;
+    const int xl = txl0 + px, gy = ty0 + py;
+    if (xl >= L.xo1 || gy >= L.ly) continue;
+    const int gx = L.gx0 + xl;
+    const long node = (long)xl * L.sy + gy;
+    const TileCtx<TX, TY> C{T, L, G, px, py, gx, gy};
+    fout[fidx(0, node)] = T.F(0, px, py);
+    fout[fidx(1, node)] = pull_one<1>(C, L, G, gx, gy);
+    fout[fidx(2, node)] = pull_one<2>(C, L, G, gx, gy);
+    fout[fidx(3, node)] = pull_one<3>(C, L, G, gx, gy);
+    fout[fidx(4, node)] = pull_one<4>(C, L, G, gx, gy);
+    fout[fidx(5, node)] = pull_one<5>(C, L, G, gx, gy);
+    fout[fidx(6, node)] = pull_one<6>(C, L, G, gx, gy);
+    fout[fidx(7, node)] = pull_one<7>(C, L, G, gx, gy);
+    fout[fidx(8, node)] = pull_one<8>(C, L, G, gx, gy);
+  }
+}
+
+template <int LX, int MINW, int WW>
+__global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__ fin, real* __restrict__ fout,
+                                                  const int* __restrict__ ob_old,
+                                                  const int* __restrict__ ob_new, LatticeView L,
+                                                  GrainFluidView G, ForceSlots S, int nstrips, int nwork,
+                                                  int xcd_remap, int seg_rows, int seg_stride) {
+  const int lane = threadIdx.x & 63;
+  int blk = blockIdx.x;
+  if (xcd_remap) {  // XCD k (blocks b % 8 == k) walks the k-th contiguous eighth of the work list
+    const int per = gridDim.x >> 3;
+    blk = (blk & 7) * per + (blk >> 3);
+  }
+  const int w = blk * 4 + (threadIdx.x >> 6);
+  if (w >= nwork) return;  // whole wave
+  const int strip = w % nstrips, seg = w / nstrips;
+  // WW producing lanes in the middle of the window, (64 - WW) / 2 feeding lanes on either side
+  constexpr int OFF = (64 - WW) / 2;
+  const int y = strip * WW - OFF + lane;
+  const bool yin = y >= 0 && y < L.ly;
+  const bool writer = lane >= OFF && lane < OFF + WW && yin;
+  const bool deep_y = strip * WW >= 2 && strip * WW + WW - 1 <= L.ly - 3;  // the producing lanes
+  // rows per wave: the template value, or (LX == 0) a run-time value chosen so that one round of resident
+  // waves covers the lattice
+  const int rows_per_wave = LX > 0 ? LX : seg_rows;
+  // segment k starts seg_stride rows after segment k-1: = rows_per_wave for a contiguous row range; larger when one
+  // launch covers the two edge-row ranges of a strip
+  const int xs = L.xo0 + seg * seg_stride;
+  const int xe = xs + rows_per_wave < L.xo1 ? xs + rows_per_wave : L.xo1;
+
+  // Software pipeline. In iteration x (producing row x) the wave issues, in this order,
+  //   (1) small gathers: new ids of row x+4, previous-map id of row x+4, the record of the grain that
+  //       owned (x+2, y) before (reinit of row x+2), the record of the grain that owns (x+3, y) now
+  //   (2) the nine populations of row x+3 into the row buffer it has just consumed (two buffers,
+  //       ping-pong, loop unrolled by two: no register copies, so the loads stay in flight for two
+  //       iterations)
+  //   (3) the nine stores of row x.
+  // gfx9 retires vector-memory operations in issue order (one vmcnt counter), so data must be consumed
+  // in the order it was requested; no other global load exists inside the loop.
+  __shared__ real2 sRec[4 * REC_RING * 4 * 64];
+  const RecRing ring{sRec + (threadIdx.x >> 6) * (REC_RING * 4 * 64)};
+  // wave-private scratch for the compacted bounce-back evaluation: 64 link slots
+  // (Round 3 measured a spare 65th slot that lanes without a link write to, instead of sitting out the writes under an
+  // exec mask: eight mask round trips per row less, but 12 B of scratch and twice the scalar spill reloads: +1.7 %.)
+  constexpr int LINK_SLOTS = 64;
+  __shared__ real sPay[4 * LINK_SLOTS * 4];
+  __shared__ int sDesc[4 * LINK_SLOTS];
+  real* const pay = sPay + (threadIdx.x >> 6) * (LINK_SLOTS * 4);
+  int* const desc = sDesc + (threadIdx.x >> 6) * LINK_SLOTS;
+  const real wc_diag = L.wc_diag, wc_axis = L.wc_axis;  // kernel arguments: scalar registers
+  auto row_ok = [&](int xl) { return yin && xl >= 0 && xl < L.nxl; };
+  const int ycl = y < 0 ? 0 : (y >= L.ly ? L.ly - 1 : y);
+  auto node_of = [&](int xl) {  // clamped: always a valid address
+    const int xc = xl < 0 ? 0 : (xl >= L.nxl ? L.nxl - 1 : xl);
+    return (long)xc * L.sy + ycl;
+  };
+  // unconditional (clamped address): every use is guarded by interior(xl), and grain_rec clamps the
+  // id. (A `row_ok ? v : -1` select here makes the compiler sink the load into a branch followed by
+  // s_waitcnt vmcnt(0), which drains the whole prefetch pipeline once per iteration.)
+  auto load_old = [&](int xl) { return ob_old[node_of(xl)]; };
+  // off-lattice positions load a clamped neighbour's values; they are never used (pull_one tests the
+  // bounds of the source node before touching its populations)
+  auto load_raw = [&](int xl, real (&raw)[9]) {
+    const long fb = fbase_xy(L, xl < 0 ? 0 : (xl >= L.nxl ? L.nxl - 1 : xl), ycl);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) raw[q] = fin[fb + q * F_QSTRIDE(L)];
+  };
+  auto interior = [&](int xl) {
+    const int gx = L.gx0 + xl;
+    return row_ok(xl) && gx >= 1 && gx <= L.lx - 2 && y >= 1 && y <= L.ly - 2;
+  };
+  // f* of one node: reinit (previous map) + collide (current map)
+  auto make_fstar = [&](int xl, real (&f)[9], int oo, const GP& g, int on) {
+    const bool in = interior(xl);
+    if (in && oo != -1) grain_equilibrium(L, g, L.gx0 + xl, y, f);
+    if (in && on == -1) mrt_collide(L, f);
+  };
+  auto grain_rec = [&](int id) { return load_gp(G, (id < 0 || id >= L.n) ? 0 : id); };
+
+  real Fm[9], F0[9], Fp[9], bufA[9], bufB[9];
+
+  Ids3 iA = load_ids(ob_new, L, xs - 2, y);  // row x-2 (only needed for act of row x-1)
+  Ids3 iB = load_ids(ob_new, L, xs - 1, y);  // row x-1
+  Ids3 iC = load_ids(ob_new, L, xs, y);      // row x
+  Ids3 iD = load_ids(ob_new, L, xs + 1, y);  // row x+1
+  Ids3 iE = load_ids(ob_new, L, xs + 2, y);  // row x+2
+  {
+    int oo = load_old(xs - 1);
+    load_raw(xs - 1, Fm);
+    make_fstar(xs - 1, Fm, oo, grain_rec(oo), iB.c);
+    oo = load_old(xs);
+    load_raw(xs, F0);
+    make_fstar(xs, F0, oo, grain_rec(oo), iC.c);
+  }
+  // records of the current owners of rows x-1 .. x+2 into the ring
+  ring.put(xs - 1, lane, grain_rec(iB.c));
+  ring.put(xs, lane, grain_rec(iC.c));
+  ring.put(xs + 1, lane, grain_rec(iD.c));
+  ring.put(xs + 2, lane, grain_rec(iE.c));
+  int oo1 = load_old(xs + 1);   // previous-map ids of rows x+1, x+2, x+3
+  int oo2 = load_old(xs + 2);
+  int oo3 = load_old(xs + 3);
+  Ids3 inext = load_ids(ob_new, L, xs + 3, y);
+  GP gre = grain_rec(oo1);      // reinit record for row x+1
+  GP rec_next = grain_rec(inext.c);  // owner record of row x+3, goes into the ring next iteration
+  load_raw(xs + 1, bufA);
+  load_raw(xs + 2, bufB);
+  bool actm = iB.c != -1 && node_active(L, G, iA, iB, iC, L.gx0 + xs - 1, y, [&] { return ring.get(xs - 1, lane); });
+  bool act0 = iC.c != -1 && node_active(L, G, iB, iC, iD, L.gx0 + xs, y, [&] { return ring.get(xs, lane); });
+
+  MT_DECL
+  // one iteration; `buf` holds row x+1 on entry and is refilled with row x+3
+  auto iterate = [&](int x, real (&buf)[9]) {
+    MT(7)   // loop head
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Fp[q] = buf[q];
+#ifdef MARCH_TIMING   /* phase 0 = the wait for the row's populations alone */
+#pragma unroll
+    for (int q = 0; q < 9; ++q) asm volatile("" ::"v"(Fp[q]));
+    MT(0)
+#endif
+    make_fstar(x + 1, Fp, oo1, gre, iD.c);
+    MT(1)
+    const Ids3 iF = inext;  // row x+3
+    // ---- (1) small gathers
+    oo1 = oo2;
+    oo2 = oo3;
+    gre = grain_rec(oo1);                      // reinit record of row x+2
+    inext = load_ids(ob_new, L, x + 4, y);
+    oo3 = load_old(x + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- (2) the big loads: populations of row x+3
+    load_raw(x + 3, buf);
+    __builtin_amdgcn_sched_barrier(0);
+    MT(2)
+    // (the column re-declared opaque: otherwise (double)(y - 1), (double)y, (double)(y + 1) of node_active's rare path are
+    // hoisted out of the loop into six registers the kernel does not have, and one pair ends up in scratch -- whose reload
+    // drains the row prefetch)
+    int y_act = y;
+    asm volatile("" : "+v"(y_act));
+    const bool actp = iD.c != -1 && node_active(L, G, iC, iD, iE, L.gx0 + x + 1, y_act, [&] { return ring.get(x + 1, lane); });
+    MT(3)
+
+    RegCtx C;
+    C.ring = ring;
+    C.row = x;
+    C.lane = lane;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) C.Fo[q] = F0[q];
+    C.In[0] = 0.0;
+    C.In[2] = Fm[6];            // (-1, 0): same lane, row x-1, slot opp(2) = 6
+    C.In[6] = Fp[2];            // ( 1, 0)
+    C.In[1] = shfl_dn1(Fm[5]);  // (-1, 1): lane+1, row x-1, slot 5
+    C.In[8] = shfl_dn1(F0[4]);  // ( 0, 1)
+    C.In[7] = shfl_dn1(Fp[3]);  // ( 1, 1)
+    C.In[3] = shfl_up1(Fm[7]);  // (-1,-1): lane-1
+    C.In[4] = shfl_up1(F0[8]);  // ( 0,-1)
+    C.In[5] = shfl_up1(Fp[1]);  // ( 1,-1)
+    C.o0 = iC.c;
+    C.onb[0] = 0;
+    C.onb[1] = iB.p; C.onb[2] = iB.c; C.onb[3] = iB.m; C.onb[4] = iC.m;
+    C.onb[5] = iD.m; C.onb[6] = iD.c; C.onb[7] = iD.p; C.onb[8] = iC.p;
+    const int pack = (actm ? 1 : 0) | (act0 ? 2 : 0) | (actp ? 4 : 0);  // rows x-1, x, x+1 of this lane
+    const int pk_up = shfl_dn1(pack);                                  // lane+1 (y+1)
+    const int pk_dn = shfl_up1(pack);                                  // lane-1 (y-1)
+    C.act = (((pk_up >> 0) & 1u) << 1) | (((pack >> 0) & 1u) << 2) | (((pk_dn >> 0) & 1u) << 3) |
+            (((pk_dn >> 1) & 1u) << 4) | (((pk_dn >> 2) & 1u) << 5) | (((pack >> 2) & 1u) << 6) |
+            (((pk_up >> 2) & 1u) << 7) | (((pk_up >> 1) & 1u) << 8);
+    {
+      const int gx = L.gx0 + x;
+      const long fb_row = fbase_xy(L, x, y);   // (only used by the producing lanes: y is on the lattice there)
+      // wave-uniform: is every producing lane of this row at least two nodes away from all edges?
+      const bool deep = deep_y && gx >= 2 && gx <= L.lx - 3;
+      // (a) everything but the interpolated bounce-back links: computed and stored
+      unsigned ibb = 0, nnm = 0, hzm = 0;
+      if (writer && x < xe) {
+        if (deep) classify_store_row_deep(C, L, fout, fb_row, ibb, nnm, hzm);
+        else classify_store_row<true>(C, L, gx, y, fout, fb_row, ibb, nnm, hzm);
+      }
+      MT(4)
+      // (b) the bounce-back links of the whole row (typically ~20, spread over all eight directions
+      // and a few lanes) are compacted into dense lanes through LDS and evaluated in ONE pass with the
+      // direction as data, instead of ~3.5 direction-specific divergent passes of ~130 instructions.
+      // slot of link (lane, q) = number of links in directions < q + number in direction q on lower lanes
+      int T = 0;
+#pragma unroll
+      for (int q = 1; q < 9; ++q) T += __popcll(__ballot((ibb >> q) & 1u));
+      for (int base = 0; base < T; base += 64) {  // wave-uniform; a second round only if > 64 links
+        int before = 0;
+#pragma unroll
+        for (int q = 1; q < 9; ++q) {
+          const unsigned long long b = __ballot((ibb >> q) & 1u);
+          const int t = before + (int)mbcnt(b) - base;
+          before += __popcll(b);
+          if (((ibb >> q) & 1u) && t >= 0 && t < 64) {
+            // bits 14..31: the grain that owns S = P - e_q (the slot table is only used with < 2^18 grains)
+            desc[t] = lane | (q << 8) | (((nnm >> q) & 1u) << 12) | (((hzm >> q) & 1u) << 13) | (C.onb[OPPq(q)] << 14);
+            pay[t * 4 + 0] = C.Fo[OPPq(q)];
+            pay[t * 4 + 1] = C.Fo[q];
+            pay[t * 4 + 2] = C.In[q];
+            pay[t * 4 + 3] = C.In[OPPq(q)];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();  // LDS operations of one wave execute in order
+        if (base + lane < T) {
+          const int d = desc[lane];
+          const int src = d & 63;
+          RtLink k;
+          k.q = (d >> 8) & 15;
+          k.gx = gx;
+          k.gy = y - lane + src;
+          k.own_qo = pay[lane * 4 + 0];
+          k.own_q = pay[lane * 4 + 1];
+          k.in_q = pay[lane * 4 + 2];
+          k.in_qo = pay[lane * 4 + 3];
+          k.nn_int = (d >> 12) & 1;
+          k.hazard = (d >> 13) & 1;
+          // the result goes straight to the population it belongs to: node of lane `src`, plane q
+          const real out =
+              ibb_eval_rt(L, k, wc_diag, wc_axis, [&](int dx, int dy) { return ring.get(x + dx, src + dy); });
+          fout[fbase_xy(L, x, k.gy) + k.q * F_QSTRIDE(L)] = out;
+          // ... and the link's momentum-exchange sum f_new[S][opp q] + f_new[P][q] (main.c:1313-1316; the first
+          // is f*[P][opp q], streamed unchanged into the solid node) to the owning grain's slot table
+          if (S.tab != nullptr) {
+            const int ex = (k.q >= 1 && k.q <= 3) ? -1 : ((k.q >= 5 && k.q <= 7) ? 1 : 0);
+            const int ey = (k.q == 1 || k.q >= 7) ? 1 : ((k.q >= 3 && k.q <= 5) ? -1 : 0);
+            real cx, cy;
+            ring.get_centre(x - ex, src - ey, cx, cy);
+            const int rel = slot_line(k.gx - ex, k.gy - ey, ex, ey, cx, cy) + S.half;
+            if ((unsigned)rel < (unsigned)S.spd)
+              S.tab[((long)((unsigned)d >> 14) * 8 + (k.q - 1)) * S.spd + rel] = k.own_qo + out;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      MT(5)
+    }
+    // row x-1 is no longer needed: its ring slot takes the owner records of row x+3; then request
+    // those of row x+4 (consumed at this point of the next iteration)
+    ring.put(x + 3, lane, rec_next);
+    rec_next = grain_rec(inext.c);
+    // rotate
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { Fm[q] = F0[q]; F0[q] = Fp[q]; }
+    iB = iC; iC = iD; iD = iE; iE = iF;
+    actm = act0; act0 = actp;
+    MT(6)
+  };
+
+  // Both halves run unconditionally (a row >= xe stores nothing): with `if (x + 1 < xe)` around the second one the
+  // compiler cannot count its loads as younger than the first half's when it places s_waitcnt at the loop head, and
+  // waits for more of the pipeline than the data it needs (vmcnt(4) instead of vmcnt(9); 1.5-2 % of the kernel).
+  for (int x = xs; x < xe; x += 2) {
+    iterate(x, bufA);
+    iterate(x + 1, bufB);
+  }
+  MT_FLUSH
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+
+template <int TX, int TY>
+static void launch_cs(const real* fin, real* fout, const int* obst_old, const int* obst_new,
+                      const LatticeView& L, const GrainFluidView& G, int remap, hipStream_t st) {
+  const int rows = L.xo1 - L.xo0;
+  const int tiles_y = (L.ly + TY - 1) / TY, tiles_x = (rows + TX - 1) / TX;
+  const int ntiles = tiles_y * tiles_x;
+  const int grid = remap ? ((ntiles + 7) / 8) * 8 : ntiles;
+  hipLaunchKernelGGL((k_collide_stream<TX, TY>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new,
+                     L, G, tiles_y, ntiles, remap);
+}
+
+#ifdef LBMDEM_AB
+// A/B builds only (make AB=1): LBMDEM_CS_VARIANT = kernel shape + 8 * xcd_remap
+static int cs_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("LBMDEM_CS_VARIANT");
+    v = e ? atoi(e) : 25;
+  }
+  return v;
+}
+#endif
+
+// rows per wave of the marching kernel: 32 (the measured optimum on a full lattice) unless that leaves fewer than two
+// rounds of resident waves; then the largest even count (the kernel works through its rows in pairs) that still gives
+// two full rounds, as short as 8. Measured on 508 rows x 66 windows (the interior of a 512-row strip), fused kernel
+// in us for 4 / 6 / 8 / 10 / 12 / 14 / 16 / 18 / 20 rows: 146 / 144 / 138 / 150 / 157 / 169 / 145 / 144 / 156 -- a
+// little more than a whole number of rounds is good, a little less than the next one is bad.
+static int march_segment_rows(int rows, int nstrips) {
+  const int resident = 256 * 2 * 4;
+  int nseg = (2 * resident + nstrips - 1) / nstrips;
+  if (nseg < 1) nseg = 1;
+  int seg_rows = rows / nseg;
+  seg_rows &= ~1;
+  if (seg_rows < 8) seg_rows = 8;
+  if (seg_rows > 32) seg_rows = 32;
+  return seg_rows;
+}
+
+// which marching kernel: 2 = k_cs_march (two waves per SIMD), 3 = k_cs_march3 (three)
+#ifndef LBMDEM_MARCH_DEFAULT
+#define LBMDEM_MARCH_DEFAULT 2
+#endif
+__attribute__((unused)) static int march_kernel() {
+#ifdef LBMDEM_AB
+  static const int v = getenv("LBMDEM_MARCH") ? atoi(getenv("LBMDEM_MARCH")) : LBMDEM_MARCH_DEFAULT;
+  return v;
+#else
+  return LBMDEM_MARCH_DEFAULT;
+#endif
+}
+
+template <int LX, int MINW, int WW = 62>
+static void launch_march(const real* fin, real* fout, const int* obst_old, const int* obst_new,
+                         const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, int remap,
+                         hipStream_t st) {
+  const int rows = L.xo1 - L.xo0;
+  const int nstrips = (L.ly + WW - 1) / WW;
+  int seg_rows = LX;
+  if (LX == 0) {
+    // run-time segment length for SHORT row ranges (a strip of a multi-GPU decomposition, the rows next to a cut):
+    // 256 CUs x 2 workgroups x 4 waves are resident (VGPR- and LDS-limited) and a wave takes about as long for 32
+    // rows as the whole lattice takes per round, so fewer rows than two full rounds are cut into shorter segments
+    seg_rows = march_segment_rows(rows, nstrips);
+#ifdef LBMDEM_AB
+    static const int env_rows = getenv("LBMDEM_CS_ROWS") ? atoi(getenv("LBMDEM_CS_ROWS")) : 0;
+    if (env_rows > 0) seg_rows = env_rows;
+#endif
+  }
+  const int nseg = (rows + seg_rows - 1) / seg_rows;
+  const int nwork = nstrips * nseg;
+  int grid = (nwork + 3) / 4;
+  if (remap) grid = ((grid + 7) / 8) * 8;
+#ifdef LBMDEM_AB   // k_cs_march3 (lbm_fused_ab.hip) only exists in the experiment build
+  if constexpr (WW == 62) {
+    const int mk = march_kernel();
+    if (mk == 3 || mk == 21 || mk == 22) {
+      launch_march3_ab(mk, LX, fin, fout, obst_old, obst_new, L, G, S, nstrips, nwork, remap, seg_rows, seg_rows, grid, st);
+      return;
+    }
+  }
+#endif
+  unsigned dyn_lds = 0;
+#ifdef LBMDEM_AB   // occupancy experiment: extra (unused) dynamic LDS so that only ONE workgroup fits a CU
+  static const int env_lds = getenv("LBMDEM_MARCH_DYNLDS") ? atoi(getenv("LBMDEM_MARCH_DYNLDS")) : 0;
+  dyn_lds = (unsigned)env_lds;
+#endif
+  hipLaunchKernelGGL((k_cs_march<LX, MINW, WW>), dim3(grid), dim3(256), dyn_lds, st, fin, fout, obst_old, obst_new, L, G,
+                     S, nstrips, nwork, remap, seg_rows, seg_rows);
+}
+
+// Two row ranges of equal width w <= 32 (the rows next to the two cuts of a strip) in ONE launch: two segments of w rows,
+// the second `stride` rows after the first.
+static void launch_march_two_ranges(const real* fin, real* fout, const int* obst_old, const int* obst_new,
+                                    const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, int lo0, int w,
+                                    int hi0, hipStream_t st) {
+  constexpr int WW = 62;
+  LatticeView Ls = L;
+  Ls.xo0 = lo0; Ls.xo1 = hi0 + w;
+  const int nstrips = (L.ly + WW - 1) / WW;
+  const int nwork = nstrips * 2;
+  const int grid = (nwork + 3) / 4;
+#ifdef LBMDEM_AB
+  if (march_kernel() == 3) {
+    launch_march3_ab(3, 0, fin, fout, obst_old, obst_new, Ls, G, S, nstrips, nwork, 0, w, hi0 - lo0, grid, st);
+    return;
+  }
+#endif
+  hipLaunchKernelGGL((k_cs_march<0, 2, WW>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, Ls, G, S, nstrips,
+                     nwork, 0, w, hi0 - lo0);
+}
+
+// The marching kernel assumes reductionR < 1 (always true in the reference); other configurations run the
+// LDS-tile kernel, which does not fill the slot table.
+bool collide_stream_fills_slots(const LatticeView& L) { return L.reduced_lt1 != 0; }
+
+void launch_collide_stream(const real* fin, real* fout, const int* obst_old, const int* obst_new,
+                           const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, hipStream_t st) {
+#ifdef LBMDEM_AB
+  if (getenv("LBMDEM_CS_VARIANT")) {   // experiments with other kernel shapes; without the variable: the product's choice
+    int v = cs_variant();
+    const int remap = (v >> 3) & 1;
+    if (!L.reduced_lt1 && (v & ~8) >= 16) v = 1;
+    switch (v & ~8) {
+      case 0: launch_cs<8, 64>(fin, fout, obst_old, obst_new, L, G, remap, st); return;
+      case 1: launch_cs<4, 64>(fin, fout, obst_old, obst_new, L, G, remap, st); return;
+      case 2: launch_cs<4, 128>(fin, fout, obst_old, obst_new, L, G, remap, st); return;
+      case 16: launch_march<16, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;
+      case 19: launch_march<64, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;
+      case 20: launch_march<0, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;  // one balanced round
+      case 21: launch_march<32, 2, 56>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;  // 64-byte aligned stores
+      default: launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;
+    }
+  }
+#endif
+  if (L.reduced_lt1) {
+    if (march_segment_rows(L.xo1 - L.xo0, (L.ly + 61) / 62) >= 32)
+      launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, S, /*xcd remap*/ 1, st);
+    else
+      launch_march<0, 2>(fin, fout, obst_old, obst_new, L, G, S, /*xcd remap*/ 1, st);
+  }
+  else launch_cs<4, 64>(fin, fout, obst_old, obst_new, L, G, 0, st);
+}
+
+void launch_collide_stream_edges(const real* fin, real* fout, const int* obst_old, const int* obst_new,
+                                 const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, int lo0, int lo1,
+                                 int hi0, int hi1, hipStream_t st) {
+  bool one_launch = lo1 > lo0 && hi1 > hi0 && lo1 - lo0 == hi1 - hi0 && lo1 - lo0 <= 32 && lo1 <= hi0 && L.reduced_lt1;
+#ifdef LBMDEM_AB
+  if (getenv("LBMDEM_CS_VARIANT")) one_launch = false;   // an experiment with another fused kernel
+#endif
+  if (one_launch) {
+    launch_march_two_ranges(fin, fout, obst_old, obst_new, L, G, S, lo0, lo1 - lo0, hi0, st);
+    return;
+  }
+  LatticeView Ls = L;
+  if (lo1 > lo0) { Ls.xo0 = lo0; Ls.xo1 = lo1; launch_collide_stream(fin, fout, obst_old, obst_new, Ls, G, S, st); }
+  if (hi1 > hi0) { Ls.xo0 = hi0; Ls.xo1 = hi1; launch_collide_stream(fin, fout, obst_old, obst_new, Ls, G, S, st); }
+}
+

@@ -1,0 +1,159 @@
+// lbm_obst.hip -- the obstacle map (obst_construction, main.c:991-1065): reset and rasterisation of the reduced discs.
+// `act` and `delta` are not stored: the fused kernel recomputes them from the map and the grain centres.
+
+#include "lbm_device.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------------------------
+
+// obst = -1 in the interior, nbgrains on the four lattice edges (main.c:669-683, 997-999): obst_fill_range (lbmdem_internal.h)
+__global__ void k_obst_fill(int* __restrict__ obst, LatticeView L, int row0, int row1) {
+  obst_fill_range(obst, L, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x, row0, row1);
+}
+
+// Rasterise the reduced discs (main.c:1016-1032). One wavefront per grain: every lane derives the grain's lattice
+// geometry (main.c:1009-1013: centre, squared reduced radius, unreduced radius in nodes), lane 0 stores it -- also as
+// one packed 64-byte record {x1, x2, v1, v2, v3, xc, yc, r2} for the fluid kernels -- and the lanes sweep the bounding
+// box two rows at a time, y fastest (coalesced, no integer divisions). Overlaps resolve to the highest grain index,
+// which is what the reference's ascending serial paint produces (main.c:1028) -> atomicMax; the value it returns
+// tells a painter that the node lies under several discs: both grains are flagged as overlapping (the force kernel
+// derives the footprint of unflagged grains from the disc test alone) and the lowest index covering the node is
+// recorded in `mincov` (every painter records itself and the owner it found, so the lowest cover ends up there
+// whatever the order of the painters).
+// (Measured alternative: plain stores, then a second launch that re-reads the nodes and settles overlaps with atomics
+// only where they occur -- 37 + 30 us against 52 us: the kernel is bound by its 50 000 short waves, not by atomics.)
+__global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const real* __restrict__ x1,
+                             const real* __restrict__ x2, const real* __restrict__ r,
+                             const real* __restrict__ rLB, const real* __restrict__ v1,
+                             const real* __restrict__ v2, const real* __restrict__ v3,
+                             real* __restrict__ oxc, real* __restrict__ oyc, real* __restrict__ or2,
+                             real* __restrict__ orbl0, real* __restrict__ pk,
+                             unsigned char* __restrict__ touched, const unsigned char* __restrict__ mask,
+                             unsigned* __restrict__ mincov, unsigned epoch, const int* __restrict__ list,
+                             const int* __restrict__ list_count, int list_cap, const int* __restrict__ voff,
+                             const int* __restrict__ vnbr) {
+  const int lane = threadIdx.x & 63;
+  int i = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (list) {                    // strip decomposition: only the grains that can reach this rank's rows
+    if (i >= *list_count || i >= list_cap) return;   // (an overflowing list is flagged by its producer)
+    i = list[i];
+  }
+  if (i >= n) return;
+  if (mask && !mask[i]) return;
+  const real gx1 = x1[i], gx2 = x2[i];
+  const real xc = (gx1 - L.Mgx) / L.dx, yc = (gx2 - L.Mby) / L.dx, r2 = rLB[i] * rLB[i], rbl0 = r[i] / L.dx;
+  if (lane == 0) {
+    oxc[i] = xc; oyc[i] = yc; or2[i] = r2; orbl0[i] = rbl0;
+    real* o = pk + (long)i * 8;
+    o[0] = gx1; o[1] = gx2; o[2] = v1[i]; o[3] = v2[i]; o[4] = v3[i]; o[5] = xc; o[6] = yc; o[7] = r2;
+  }
+  const real R2 = rbl0 * rbl0;
+  int xi = (int)(xc - rbl0), xf = (int)(xc + rbl0);
+  if (xi < 1) xi = 1;
+  if (xf >= L.lx - 1) xf = L.lx - 2;
+  int yi = (int)(yc - rbl0), yf = (int)(yc + rbl0);
+  if (yi < 1) yi = 1;
+  if (yf >= L.ly - 1) yf = L.ly - 2;
+  // restrict to the local slab
+  if (xi < L.gx0) xi = L.gx0;
+  if (xf > L.gx0 + L.nxl - 1) xf = L.gx0 + L.nxl - 1;
+  if (xi > xf || yi > yf) return;
+  const int ny = yf - yi + 1;
+  auto in_disc = [&](int x, int y) {
+    const real d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc);
+    return d2 <= R2 && d2 <= r2;
+  };
+  // Round 3: reduced discs of a physical packing do not overlap, so nearly all of the ~10 M returning atomicMax per
+  // step had nobody to arbitrate with (they were what set this kernel's time: profiles/r02_l_sq_counters.txt). A disc that
+  // is at least 1.5 nodes clear of every partner in the grain's Verlet list (symmetric: every pair within distVerlet of
+  // touching at the last rebuild, which is far more than reduced discs need to meet) shares no node with another disc:
+  // plain stores, no flags. Everything else -- and every grain while there is no list (voff == null: before the first
+  // rebuild, strips with distributed grains) -- keeps the atomic path.
+  bool alone = false;
+  if (voff) {
+    const int k0 = voff[i], k1 = voff[i + 1];
+    bool near = false;
+    const real ri = rLB[i];
+    for (int k = k0 + lane; k < k1; k += 64) {
+      const int j = vnbr[k];
+      const real ddx = (x1[j] - gx1) / L.dx, ddy = (x2[j] - gx2) / L.dx, rr = ri + rLB[j] + 1.5;
+      near |= !(ddx * ddx + ddy * ddy >= rr * rr);   // also true for a NaN
+    }
+    alone = !__any(near);
+  }
+  if (alone) {
+    if (ny <= 32) {
+      const int y = yi + (lane & 31);
+      if ((lane & 31) < ny)
+        for (int x = xi + (lane >> 5); x <= xf; x += 2)
+          if (in_disc(x, y)) obst[(long)(x - L.gx0) * L.sy + y] = i;
+    } else {
+      const int total = (xf - xi + 1) * ny;
+      for (int k = lane; k < total; k += 64) {
+        const int x = xi + k / ny, y = yi + k % ny;
+        if (in_disc(x, y)) obst[(long)(x - L.gx0) * L.sy + y] = i;
+      }
+    }
+    return;
+  }
+  auto overlap = [&](long node, int old) {   // the node was somebody else's: rare
+    if (old >= 0 && old < n && old != i) {
+      touched[i] = 1; touched[old] = 1;
+      if (mincov) {
+        atomicMax(&mincov[node], (epoch & 0xFFFu) << 20 | (0xFFFFFu - (unsigned)i));
+        atomicMax(&mincov[node], (epoch & 0xFFFu) << 20 | (0xFFFFFu - (unsigned)old));
+      }
+    }
+  };
+  constexpr int SWEEPS = 12;   // two rows of the box per sweep, y fastest: no integer divisions
+  if (ny <= 32 && xf - xi + 1 <= 2 * SWEEPS) {
+    // all atomics of the wave are issued before the first returned value is looked at: one round trip, not twelve
+    const int y = yi + (lane & 31);
+    const bool col = (lane & 31) < ny;
+    int old[SWEEPS];
+#pragma unroll
+    for (int s_ = 0; s_ < SWEEPS; ++s_) {
+      const int x = xi + 2 * s_ + (lane >> 5);
+      old[s_] = -1;
+      if (col && x <= xf && in_disc(x, y)) old[s_] = atomicMax(&obst[(long)(x - L.gx0) * L.sy + y], i);
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < SWEEPS; ++s_) {
+      const int x = xi + 2 * s_ + (lane >> 5);
+      if (old[s_] >= 0) overlap((long)(x - L.gx0) * L.sy + y, old[s_]);
+    }
+  } else {
+    const int total = (xf - xi + 1) * ny;
+    for (int k = lane; k < total; k += 64) {
+      const int x = xi + k / ny, y = yi + k % ny;
+      if (in_disc(x, y)) {
+        const long node = (long)(x - L.gx0) * L.sy + y;
+        overlap(node, atomicMax(&obst[node], i));
+      }
+    }
+  }
+}
+
+}  // namespace
+
+void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st) { launch_obst_fill_rows(obst, L, 0, L.nxl, st); }
+
+void launch_obst_fill_rows(int* obst, const LatticeView& L, int row0, int row1, hipStream_t st) {
+  if (row1 <= row0) return;
+  hipLaunchKernelGGL(k_obst_fill, dim3(grid_for((long)(row1 - row0) * L.sy / 4)), dim3(256), 0, st, obst, L, row0, row1);
+}
+
+void launch_obst_paint(int* obst, const LatticeView& L, int n, const real* x1, const real* x2, const real* r,
+                       const real* rLB, const real* v1, const real* v2, const real* v3, real* xc,
+                       real* yc, real* r2, real* rbl0, real* pk, unsigned char* touched,
+                       const unsigned char* mask, unsigned* mincov, unsigned epoch, const int* list,
+                       const int* list_count, int list_cap, const int* voff, const int* vnbr, hipStream_t st) {
+  const long threads = (long)(list ? list_cap : n) * 64;
+  hipLaunchKernelGGL(k_obst_paint, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, obst, L, n, x1, x2, r,
+                     rLB, v1, v2, v3, xc, yc, r2, rbl0, pk, touched, mask, mincov, epoch, list, list_count, list_cap, voff,
+                     vnbr);
+}
+

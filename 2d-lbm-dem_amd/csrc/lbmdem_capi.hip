@@ -1,6 +1,6 @@
 // lbmdem_capi.hip -- the C ABI of liblbmdem_hip.so (include/lbmdem_hip.h): handle, memory, the
 // step driver with the reference's cadences (renderScene, main.c:1697-1765) and state transfer in
-// the reference's host layout. All arithmetic of the hot path lives in lbm_kernels.hip and
+// the reference's host layout. All arithmetic of the hot path lives in lbm_fused.hip, lbm_forces.hip, lbm_obst.hip, lbm_lattice.hip and
 // dem_kernels.hip; the host-side arithmetic here is the one-off time-step derivation
 // (main.c:1836-1860) and per-grain constants (main.c:624-626,1859), kept bit-identical.
 

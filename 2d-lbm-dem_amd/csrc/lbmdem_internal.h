@@ -32,7 +32,7 @@ __host__ __device__ __forceinline__ real2 make_real2(real a, real b) { real2 v; 
 // ---------------------------------------------------------------------------------------------
 
 // Local lattice slab: global rows [gx0, gx0 + nxl), all ly columns. Device layout of the populations:
-// f[xl][y / 16][q][y % 16] (row pitch sy, a multiple of 16; see fbase() in lbm_kernels.hip) -- the reference's
+// f[xl][y / 16][q][y % 16] (row pitch sy, a multiple of 16; see fbase() in lbm_device.h) -- the reference's
 // fast axis (main.c:56) is kept as the fast axis so that an x-strip is one contiguous slab and halo rows
 // are contiguous. The obstacle map is plain obst[xl][y] with the same pitch.
 struct LatticeView {
@@ -46,7 +46,7 @@ struct LatticeView {
   real dx, c, Mgx, Mby;
   real s2, s3, s5, s7, s8, s9;
   int reduced_lt1;  // phys.reductionR < 1: reduced discs lie strictly inside the grains (always, in the reference)
-  // x / c and x / (c*c) as correctly rounded quotients from the reciprocals (exact_div in lbm_kernels.hip);
+  // x / c and x / (c*c) as correctly rounded quotients from the reciprocals (round-1 form of the quotients, no longer used);
   // recip_ok = 0 when a divisor's significand is all ones (the one case the construction does not cover)
   real rc, rcc;
   int recip_ok;
@@ -140,7 +140,7 @@ struct Kin {
 // Launchers (host functions defined in the .hip files)
 // ---------------------------------------------------------------------------------------------
 
-// lbm_kernels.hip
+// lbm_fused.hip, lbm_forces.hip, lbm_obst.hip, lbm_lattice.hip
 void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st);
 // fills xc, yc, r2, rbl0, pk (per-grain lattice geometry, main.c:1009-1013) and paints the reduced discs
 void launch_obst_paint(int* obst, const LatticeView& L, int n, const real* x1, const real* x2, const real* r,
