@@ -1,32 +1,37 @@
-"""x-strip decomposition of the coupled LBM-DEM step across the GPUs of one node.
+"""x-strip decomposition of the coupled LBM-DEM step across the GPUs of one node, one process per GPU.
 
-The reference has nothing distributed (one address space). This module is the
-multi-GPU design of BASELINE.json's north_star, one process per GPU:
+The reference has nothing distributed (one address space). The protocol itself lives in the C ABI
+(include/lbmdem_hip.h: lbmdem_dist_*, lbmdem_halo_*, lbmdem_comm_*); this module holds the Python drivers over it.
 
-* **Fluid**: the lattice is cut along x (the reference's slow axis, which this framework keeps as the
-  slow device axis -- a strip is one contiguous slab per population plane and a halo row is
-  contiguous). Rank k owns rows [x_k, x_{k+1}); it keeps `halo` extra rows on each interior side.
-  The fused collide+stream kernel first produces the `halo` owned rows next to each cut; they travel
-  to the neighbour's halo (one send + one receive per neighbour per fluid step, point to point over
-  xGMI: RCCL through torch.distributed's batched isend/irecv, issued on a side stream) WHILE the
-  kernel produces the interior rows -- the exchange is off the critical path. halo = 2 + the largest
-  grain radius in nodes, so that (a) the next collide+stream finds the f row and the two obstacle
-  rows it reads beyond the cut and (b) the owner of a grain sees every node of the grain's bounding
-  box and computes its hydrodynamic force in the reference's serial order -- results do not depend
-  on the number of GPUs.
-* **Grains**: 50 000 grains are 3.6 MB of state and one DEM sub-step is a ~10 us latency-bound
-  launch, npDEM (12) of them per fluid step. Exchanging ghosts every sub-step would cost more in
-  xGMI latency than the sub-step itself, so the DEM state is REPLICATED: every rank integrates all
-  grains with identical arithmetic, rasterises the grains that overlap its slab, and computes the
-  hydrodynamic force of the grains whose centre it owns. One all-reduce per fluid step (3 doubles
-  per grain, summed as int64 bit patterns: owner's bits + zeros = owner's bits, exact) hands every
-  rank every force. Grains that cross a cut simply change owner at the next fluid step -- no
-  migration messages.
+**What runs by default** (bench.py --gpus N, host/lbmdem --gpus N): grains DISTRIBUTED over the strips, neighbour messages
+only, no collective on the step path --
 
-`StripRunner` holds the orchestration only; it talks to a *backend* (the HIP library through
-`GpuStripBackend`, or the CPU oracle in tests) and a *comm* (`TorchComm` over RCCL/gloo, or an
-in-process loop-back in tests), so the same code path is what runs on 8 GPUs and what the
-world_size-2 gloo tests on CPU check.
+* Fluid: rank k owns lattice rows [x_k, x_{k+1}) (x is the reference's slow axis and the slow device axis: a strip is one
+  contiguous slab, a lattice row is contiguous) plus a halo of 2 rows on each interior side. The fused kernel produces
+  the 2 owned rows next to each cut first; they travel to the neighbour WHILE the interior rows are computed.
+* Grains: every rank keeps arrays for all n grains (global index = array index, so Verlet lists, summation order and all
+  formulas are those of one GPU) but integrates only the grains whose centre lies in its rows plus a margin of
+  `default_margin()` rows on either side -- deep enough that an error at the margin's outer edge cannot reach an owned
+  grain within the npDEM sub-steps between two fluid steps. Per fluid step and neighbour four point-to-point messages:
+  KIN (kinematics of the owned grains inside the neighbour's margin; a grain that crossed the cut changes owner here --
+  this IS the migration), the f halo rows, TABLES (this rank's part of the link-sum tables of grains the neighbour owns)
+  and FHF (hydrodynamic forces of the KIN grains). Results are bit-identical for any number of strips.
+
+Drivers of that protocol:
+
+* `CCommRunner` -- what bench.py measures: the whole period in C (`lbmdem_comm_run`, the library's own RCCL transport:
+  edge rows + halo exchange on a side stream next to the interior rows, halo rows sent straight out of / into the lattice,
+  24 launches per period); torch.distributed only hands out the RCCL ids. No Python on the step path.
+* `DistStripRunner` -- the same period written as a Python generator that yields its communication points, driven by
+  `TorchComm` (RCCL / gloo through torch.distributed) or, in the single-process tests, by a lock-step driver that copies
+  the buffers by hand. ~30 library calls per period from Python: the reference implementation of the protocol and the
+  fallback bench.py measures when the C transport's trial run fails.
+* `StripRunner` -- the round-1 scheme, kept for strips NARROWER than the margin (where a margin grain could belong to a
+  rank that is not a neighbour): grains replicated on every rank, halo of 2 + the largest grain radius rows, one bit-exact
+  all-reduce of the hydrodynamic forces per fluid step (owner's bits + zeros, summed as int64).
+
+Backends: `GpuStripBackend` (the HIP library restricted to a strip + torch device tensors as message buffers); the CPU
+oracle backends of the tests (tests/strip_backends.py) stand in for it in the world_size-2/3 gloo tests.
 """
 from __future__ import annotations
 
