@@ -195,11 +195,11 @@ def test_c_driver_restart_of_two_ranks(po, tmp_path):
     assert fd(full) == fd(second)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_python_ccomm_runner_on_one_gpu_equals_the_oracle(world):
     """strips.CCommRunner (what bench.py --gpus N measures) with `world` ranks on one GPU against the CPU oracle, across a
-    Verlet rebuild; control plane over gloo."""
-    env = shim_env(SHARED_GPU="1", MODE="ccomm", NSTEPS="113")
+    Verlet rebuild; control plane over gloo. 8 = the rank count of the node the scaling curve is taken on."""
+    env = shim_env(SHARED_GPU="1", MODE="ccomm", NSTEPS="113" if world < 8 else "41", RCCL_SHIM_TIMEOUT_S="90")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29670 + world), os.path.join(ROOT, "tests", "multi_gpu_check.py")]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
