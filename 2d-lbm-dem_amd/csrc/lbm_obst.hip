@@ -14,7 +14,7 @@ __global__ void k_obst_fill(int* __restrict__ obst, LatticeView L, int row0, int
   obst_fill_range(obst, L, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x, row0, row1);
 }
 
-// Rasterise the reduced discs (main.c:1016-1032). One wavefront per grain: every lane derives the grain's lattice
+// Rasterise the reduced discs (main.c:1016-1032). One half-wavefront per grain (round 4; a wavefront before): every lane derives the grain's lattice
 // geometry (main.c:1009-1013: centre, squared reduced radius, unreduced radius in nodes), lane 0 stores it -- also as
 // one packed 64-byte record {x1, x2, v1, v2, v3, xc, yc, r2} for the fluid kernels -- and the lanes sweep the bounding
 // box two rows at a time, y fastest (coalesced, no integer divisions). Overlaps resolve to the highest grain index,
@@ -35,8 +35,10 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
                              unsigned* __restrict__ mincov, unsigned epoch, const int* __restrict__ list,
                              const int* __restrict__ list_count, int list_cap, const int* __restrict__ voff,
                              const int* __restrict__ vnbr) {
-  const int lane = threadIdx.x & 63;
-  int i = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  // TWO grains per wavefront, 32 lanes each (a reduced disc is at most ~20 nodes across): the per-grain set-up -- geometry,
+  // three divisions, the partner test -- is paid once per pair, and the kernel was bound by its 50 000 short waves
+  const int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
+  int i = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5);
   if (list) {                    // strip decomposition: only the grains that can reach this rank's rows
     if (i >= *list_count || i >= list_cap) return;   // (an overflowing list is flagged by its producer)
     i = list[i];
@@ -45,7 +47,7 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
   if (mask && !mask[i]) return;
   const real gx1 = x1[i], gx2 = x2[i];
   const real xc = (gx1 - L.Mgx) / L.dx, yc = (gx2 - L.Mby) / L.dx, r2 = rLB[i] * rLB[i], rbl0 = r[i] / L.dx;
-  if (lane == 0) {
+  if (hl == 0) {
     oxc[i] = xc; oyc[i] = yc; or2[i] = r2; orbl0[i] = rbl0;
     real* o = pk + (long)i * 8;
     o[0] = gx1; o[1] = gx2; o[2] = v1[i]; o[3] = v2[i]; o[4] = v3[i]; o[5] = xc; o[6] = yc; o[7] = r2;
@@ -77,22 +79,22 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
     const int k0 = voff[i], k1 = voff[i + 1];
     bool near = false;
     const real ri = rLB[i];
-    for (int k = k0 + lane; k < k1; k += 64) {
+    for (int k = k0 + hl; k < k1; k += 32) {
       const int j = vnbr[k];
       const real ddx = (x1[j] - gx1) / L.dx, ddy = (x2[j] - gx2) / L.dx, rr = ri + rLB[j] + 1.5;
       near |= !(ddx * ddx + ddy * ddy >= rr * rr);   // also true for a NaN
     }
-    alone = !__any(near);
+    alone = ((__ballot(near) >> (32 * half)) & 0xFFFFFFFFull) == 0;   // this half's lanes
   }
   if (alone) {
     if (ny <= 32) {
-      const int y = yi + (lane & 31);
-      if ((lane & 31) < ny)
-        for (int x = xi + (lane >> 5); x <= xf; x += 2)
+      const int y = yi + hl;
+      if (hl < ny)
+        for (int x = xi; x <= xf; ++x)
           if (in_disc(x, y)) obst[(long)(x - L.gx0) * L.sy + y] = i;
     } else {
       const int total = (xf - xi + 1) * ny;
-      for (int k = lane; k < total; k += 64) {
+      for (int k = hl; k < total; k += 32) {
         const int x = xi + k / ny, y = yi + k % ny;
         if (in_disc(x, y)) obst[(long)(x - L.gx0) * L.sy + y] = i;
       }
@@ -108,26 +110,26 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
       }
     }
   };
-  constexpr int SWEEPS = 12;   // two rows of the box per sweep, y fastest: no integer divisions
-  if (ny <= 32 && xf - xi + 1 <= 2 * SWEEPS) {
-    // all atomics of the wave are issued before the first returned value is looked at: one round trip, not twelve
-    const int y = yi + (lane & 31);
-    const bool col = (lane & 31) < ny;
+  constexpr int SWEEPS = 24;   // one row of the box per sweep, y fastest: no integer divisions
+  if (ny <= 32 && xf - xi + 1 <= SWEEPS) {
+    // all atomics of the half-wave are issued before the first returned value is looked at: one round trip
+    const int y = yi + hl;
+    const bool col = hl < ny;
     int old[SWEEPS];
 #pragma unroll
     for (int s_ = 0; s_ < SWEEPS; ++s_) {
-      const int x = xi + 2 * s_ + (lane >> 5);
+      const int x = xi + s_;
       old[s_] = -1;
       if (col && x <= xf && in_disc(x, y)) old[s_] = atomicMax(&obst[(long)(x - L.gx0) * L.sy + y], i);
     }
 #pragma unroll
     for (int s_ = 0; s_ < SWEEPS; ++s_) {
-      const int x = xi + 2 * s_ + (lane >> 5);
+      const int x = xi + s_;
       if (old[s_] >= 0) overlap((long)(x - L.gx0) * L.sy + y, old[s_]);
     }
   } else {
     const int total = (xf - xi + 1) * ny;
-    for (int k = lane; k < total; k += 64) {
+    for (int k = hl; k < total; k += 32) {
       const int x = xi + k / ny, y = yi + k % ny;
       if (in_disc(x, y)) {
         const long node = (long)(x - L.gx0) * L.sy + y;
@@ -151,7 +153,7 @@ void launch_obst_paint(int* obst, const LatticeView& L, int n, const real* x1, c
                        real* yc, real* r2, real* rbl0, real* pk, unsigned char* touched,
                        const unsigned char* mask, unsigned* mincov, unsigned epoch, const int* list,
                        const int* list_count, int list_cap, const int* voff, const int* vnbr, hipStream_t st) {
-  const long threads = (long)(list ? list_cap : n) * 64;
+  const long threads = (long)(list ? list_cap : n) * 32;   // half a wavefront per grain
   hipLaunchKernelGGL(k_obst_paint, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, obst, L, n, x1, x2, r,
                      rLB, v1, v2, v3, xc, yc, r2, rbl0, pk, touched, mask, mincov, epoch, list, list_count, list_cap, voff,
                      vnbr);
