@@ -267,6 +267,7 @@ __global__ void k_dem_substep(Kin in, Kin out, const real* __restrict__ r, const
 // x - y == x + (-y) in IEEE arithmetic, so `a1 + (i < j ? f1 : -f1)` is bit for bit the reference's
 // `a1 + f1` / `a1 - f1`.
 constexpr int DEM_GRAINS = DEM_TILE;  // grains per workgroup
+#define DEM_GRID(nbe) ((((nbe) + 7) / 8) * 8)   /* tile slots: a multiple of the 8 XCDs, see the kernel */
 constexpr int DEM_ENTRIES = 512;  // list entries staged per round (8 per grain; denser lists take more rounds)
 
 template <bool FILM>
@@ -285,15 +286,21 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const real
   __shared__ unsigned char sTouched[DEM_ENTRIES];
   __shared__ int sLast;   // highest list entry of this tile that is a touching contact in the reference's frame
   const int tid = threadIdx.x;
-  if ((int)blockIdx.x >= tiles) {   // the workgroups behind the grain tiles reset a slice of the next obstacle map
-    obst_fill_range(fill.map, fill.L, (long)(blockIdx.x - tiles) * 256 + tid, (long)(gridDim.x - tiles) * 256, fill.row0, fill.row1);
+  // Workgroups are handed out round-robin over the 8 XCDs (b % 8), each with a private L2. XCD k takes the k-th CONTIGUOUS
+  // eighth of the tiles: a tile's partners sit in the neighbouring tiles (grains are numbered along the packing's rows),
+  // and every sub-step finds the state its own XCD wrote in the sub-step before: 9.5 -> 8.5 us per sub-step (A/B, round 4).
+  const int tslots = ((tiles + 7) / 8) * 8;
+  if ((int)blockIdx.x >= tslots) {   // the workgroups behind the grain tiles reset a slice of the next obstacle map
+    obst_fill_range(fill.map, fill.L, (long)(blockIdx.x - tslots) * 256 + tid, (long)(gridDim.x - tslots) * 256, fill.row0, fill.row1);
     return;
   }
+  const int tile = ((int)blockIdx.x & 7) * (tslots >> 3) + ((int)blockIdx.x >> 3);
+  if (tile >= tiles) return;
   if (T.stamp) {   // before anything is in flight: the barrier costs nothing here
     if (tid == 0) sLast = -1;
     __syncthreads();
   }
-  const int g0 = blockIdx.x * DEM_GRAINS;
+  const int g0 = tile * DEM_GRAINS;
   const int g1 = g0 + DEM_GRAINS < P.n ? g0 + DEM_GRAINS : P.n;
   // phase-2 lanes: everything that does not depend on the partners is requested now
   const int i = g0 + tid;
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const real
   }
   if (T.stamp) {  // the tile's last grain contact, for the carries (every round of the loop above ends with a barrier)
     if (last_e >= 0 && last_e == sLast) {
-      const long rec = (long)blockIdx.x * 4 + CARRY_GRAIN;
+      const long rec = (long)tile * 4 + CARRY_GRAIN;
       T.stamp[rec] = stamp; T.val[2 * rec] = last_ft; T.val[2 * rec + 1] = last_f3; T.who[rec] = last_who;
     }
   }
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const real
       const unsigned bit = kind == CARRY_BOTTOM ? 1u : (kind == CARRY_LEFT ? 4u : 8u);
       const unsigned long long hit = __ballot((wh.mask & bit) != 0 && (!owner || (mine && owner[i])));
       if (hit != 0 && tid == 63 - __builtin_clzll(hit)) {
-        const long rec = (long)blockIdx.x * 4 + kind;
+        const long rec = (long)tile * 4 + kind;
         T.stamp[rec] = stamp;
         T.who[rec] = (long long)i << 32;
         T.val[2 * rec] = kind == CARRY_BOTTOM ? wh.ftB : (kind == CARRY_LEFT ? wh.ftL : wh.ftR);
@@ -882,10 +889,10 @@ void launch_dem_substep(const Kin& in, const Kin& out, const real* r, const real
       if (extra > 256) extra = 256;
     }
     if (film)
-      hipLaunchKernelGGL(k_dem_entries<true>, dim3(nbe + extra), dim3(256), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
+      hipLaunchKernelGGL(k_dem_entries<true>, dim3(DEM_GRID(nbe) + extra), dim3(256), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
                          V.own, V.wallflags, pout, P, active, T, stamp, owner, fill, nbe);
     else
-      hipLaunchKernelGGL(k_dem_entries<false>, dim3(nbe + extra), dim3(256), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
+      hipLaunchKernelGGL(k_dem_entries<false>, dim3(DEM_GRID(nbe) + extra), dim3(256), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
                          V.own, V.wallflags, pout, P, active, T, stamp, owner, fill, nbe);
     return;
   }
