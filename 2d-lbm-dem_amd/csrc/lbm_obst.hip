@@ -38,7 +38,11 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
   // TWO grains per wavefront, 32 lanes each (a reduced disc is at most ~20 nodes across): the per-grain set-up -- geometry,
   // three divisions, the partner test -- is paid once per pair, and the kernel was bound by its 50 000 short waves
   const int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
-  int i = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5);
+  // XCD k (workgroups b % 8 == k) takes the k-th contiguous eighth of the grains, as the DEM sub-step does: the positions
+  // and the partner lists a grain's half-wave reads were written through that XCD's L2 (36 -> 32.5 us, A/B)
+  const int bslots = (int)gridDim.x >> 3;
+  const int blk = ((int)blockIdx.x & 7) * bslots + ((int)blockIdx.x >> 3);
+  int i = (int)(((long)blk * blockDim.x + threadIdx.x) >> 5);
   if (list) {                    // strip decomposition: only the grains that can reach this rank's rows
     if (i >= *list_count || i >= list_cap) return;   // (an overflowing list is flagged by its producer)
     i = list[i];
@@ -154,7 +158,8 @@ void launch_obst_paint(int* obst, const LatticeView& L, int n, const real* x1, c
                        const unsigned char* mask, unsigned* mincov, unsigned epoch, const int* list,
                        const int* list_count, int list_cap, const int* voff, const int* vnbr, hipStream_t st) {
   const long threads = (long)(list ? list_cap : n) * 32;   // half a wavefront per grain
-  hipLaunchKernelGGL(k_obst_paint, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, obst, L, n, x1, x2, r,
+  const unsigned pgrid = (unsigned)(((threads + 255) / 256 + 7) / 8 * 8);   // a multiple of the 8 XCDs (see the kernel)
+  hipLaunchKernelGGL(k_obst_paint, dim3(pgrid), dim3(256), 0, st, obst, L, n, x1, x2, r,
                      rLB, v1, v2, v3, xc, yc, r2, rbl0, pk, touched, mask, mincov, epoch, list, list_count, list_cap, voff,
                      vnbr);
 }
