@@ -39,3 +39,12 @@ def test_launcher_path_one_rank():
     assert out.returncode == 0, out.stderr[-800:]
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 1 and d["value"] > 1000
+
+
+def test_plain_python_strips_form_one_rank():
+    """`python bench.py --gpus 1 --strips` without any launcher: the strip driver (C transport, one rank) in a plain process"""
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--strips", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-800:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 1 and d["value"] > 1000 and d["config"]["driver"].startswith("C (lbmdem_comm_run")
