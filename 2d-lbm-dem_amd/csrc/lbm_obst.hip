@@ -14,7 +14,7 @@ __global__ void k_obst_fill(int* __restrict__ obst, LatticeView L, int row0, int
   obst_fill_range(obst, L, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x, row0, row1);
 }
 
-// Rasterise the reduced discs (main.c:1016-1032). One half-wavefront per grain (round 4; a wavefront before): every lane derives the grain's lattice
+// Rasterise the reduced discs (main.c:1016-1032). A quarter of a wavefront per grain (round 4; a wavefront before): every lane derives the grain's lattice
 // geometry (main.c:1009-1013: centre, squared reduced radius, unreduced radius in nodes), lane 0 stores it -- also as
 // one packed 64-byte record {x1, x2, v1, v2, v3, xc, yc, r2} for the fluid kernels -- and the lanes sweep the bounding
 // box two rows at a time, y fastest (coalesced, no integer divisions). Overlaps resolve to the highest grain index,
@@ -25,6 +25,7 @@ __global__ void k_obst_fill(int* __restrict__ obst, LatticeView L, int row0, int
 // whatever the order of the painters).
 // (Measured alternative: plain stores, then a second launch that re-reads the nodes and settles overlaps with atomics
 // only where they occur -- 37 + 30 us against 52 us: the kernel is bound by its 50 000 short waves, not by atomics.)
+constexpr int PAINT_LANES = 16;   // lanes per grain in k_obst_paint
 __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const real* __restrict__ x1,
                              const real* __restrict__ x2, const real* __restrict__ r,
                              const real* __restrict__ rLB, const real* __restrict__ v1,
@@ -35,14 +36,17 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
                              unsigned* __restrict__ mincov, unsigned epoch, const int* __restrict__ list,
                              const int* __restrict__ list_count, int list_cap, const int* __restrict__ voff,
                              const int* __restrict__ vnbr) {
-  // TWO grains per wavefront, 32 lanes each (a reduced disc is at most ~20 nodes across): the per-grain set-up -- geometry,
-  // three divisions, the partner test -- is paid once per pair, and the kernel was bound by its 50 000 short waves
-  const int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
+  // FOUR grains per wavefront, PAINT_LANES = 16 lanes each, sweeping their boxes (11 ... 19 columns) in chunks of 16 columns:
+  // the per-grain set-up -- geometry, three divisions, the partner test -- is paid once per four grains and the sweep's lanes
+  // are mostly busy. One wavefront per grain 46 us (the kernel was bound by its 50 000 short waves), 32 lanes per grain 32.5,
+  // 16: 27, 8: 29 us (A/B, round 4).
+  constexpr int GL = PAINT_LANES;
+  const int lane = threadIdx.x & 63, half = lane / GL, hl = lane % GL;
   // XCD k (workgroups b % 8 == k) takes the k-th contiguous eighth of the grains, as the DEM sub-step does: the positions
-  // and the partner lists a grain's half-wave reads were written through that XCD's L2 (36 -> 32.5 us, A/B)
+  // and the partner lists a grain's lanes read were written through that XCD's L2 (36 -> 32.5 us, A/B)
   const int bslots = (int)gridDim.x >> 3;
   const int blk = ((int)blockIdx.x & 7) * bslots + ((int)blockIdx.x >> 3);
-  int i = (int)(((long)blk * blockDim.x + threadIdx.x) >> 5);
+  int i = (int)(((long)blk * blockDim.x + threadIdx.x) / GL);
   if (list) {                    // strip decomposition: only the grains that can reach this rank's rows
     if (i >= *list_count || i >= list_cap) return;   // (an overflowing list is flagged by its producer)
     i = list[i];
@@ -83,26 +87,17 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
     const int k0 = voff[i], k1 = voff[i + 1];
     bool near = false;
     const real ri = rLB[i];
-    for (int k = k0 + hl; k < k1; k += 32) {
+    for (int k = k0 + hl; k < k1; k += GL) {
       const int j = vnbr[k];
       const real ddx = (x1[j] - gx1) / L.dx, ddy = (x2[j] - gx2) / L.dx, rr = ri + rLB[j] + 1.5;
       near |= !(ddx * ddx + ddy * ddy >= rr * rr);   // also true for a NaN
     }
-    alone = ((__ballot(near) >> (32 * half)) & 0xFFFFFFFFull) == 0;   // this half's lanes
+    alone = ((__ballot(near) >> (GL * half)) & ((1ull << GL) - 1)) == 0;   // this grain's lanes
   }
   if (alone) {
-    if (ny <= 32) {
-      const int y = yi + hl;
-      if (hl < ny)
-        for (int x = xi; x <= xf; ++x)
-          if (in_disc(x, y)) obst[(long)(x - L.gx0) * L.sy + y] = i;
-    } else {
-      const int total = (xf - xi + 1) * ny;
-      for (int k = hl; k < total; k += 32) {
-        const int x = xi + k / ny, y = yi + k % ny;
+    for (int y = yi + hl; y <= yf; y += GL)          // the box in chunks of GL columns, y fastest: no integer divisions
+      for (int x = xi; x <= xf; ++x)
         if (in_disc(x, y)) obst[(long)(x - L.gx0) * L.sy + y] = i;
-      }
-    }
     return;
   }
   auto overlap = [&](long node, int old) {   // the node was somebody else's: rare
@@ -115,8 +110,8 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
     }
   };
   constexpr int SWEEPS = 24;   // one row of the box per sweep, y fastest: no integer divisions
-  if (ny <= 32 && xf - xi + 1 <= SWEEPS) {
-    // all atomics of the half-wave are issued before the first returned value is looked at: one round trip
+  if (ny <= GL && xf - xi + 1 <= SWEEPS) {
+    // all atomics of the grain's lanes are issued before the first returned value is looked at: one round trip
     const int y = yi + hl;
     const bool col = hl < ny;
     int old[SWEEPS];
@@ -133,7 +128,7 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
     }
   } else {
     const int total = (xf - xi + 1) * ny;
-    for (int k = hl; k < total; k += 32) {
+    for (int k = hl; k < total; k += GL) {
       const int x = xi + k / ny, y = yi + k % ny;
       if (in_disc(x, y)) {
         const long node = (long)(x - L.gx0) * L.sy + y;
@@ -157,7 +152,7 @@ void launch_obst_paint(int* obst, const LatticeView& L, int n, const real* x1, c
                        real* yc, real* r2, real* rbl0, real* pk, unsigned char* touched,
                        const unsigned char* mask, unsigned* mincov, unsigned epoch, const int* list,
                        const int* list_count, int list_cap, const int* voff, const int* vnbr, hipStream_t st) {
-  const long threads = (long)(list ? list_cap : n) * 32;   // half a wavefront per grain
+  const long threads = (long)(list ? list_cap : n) * PAINT_LANES;
   const unsigned pgrid = (unsigned)(((threads + 255) / 256 + 7) / 8 * 8);   // a multiple of the 8 XCDs (see the kernel)
   hipLaunchKernelGGL(k_obst_paint, dim3(pgrid), dim3(256), 0, st, obst, L, n, x1, x2, r,
                      rLB, v1, v2, v3, xc, yc, r2, rbl0, pk, touched, mask, mincov, epoch, list, list_count, list_cap, voff,

@@ -57,11 +57,11 @@ def test_checkpoint_and_restart_from_the_command_line(po, tmp_path, comm):
     sample = tmp_path / "packing.data"
     po.write_sample(str(sample), c["r_mm"], c["x_mm"], c["y_mm"])
     base = [EXE, str(sample), "--lx", "256", "--ly", "200"] + comm
-    full = subprocess.run(base + ["--steps", "150"], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    full = subprocess.run(base + ["--steps", "150"], capture_output=True, text=True, cwd=tmp_path, timeout=900)
     a = subprocess.run(base + ["--steps", "67", "--checkpoint", "half.ckpt"], capture_output=True, text=True,
-                       cwd=tmp_path, timeout=300)
+                       cwd=tmp_path, timeout=900)
     b = subprocess.run(base + ["--steps", "150", "--restart", "half.ckpt"], capture_output=True, text=True,
-                       cwd=tmp_path, timeout=300)
+                       cwd=tmp_path, timeout=900)
     assert full.returncode == 0 and a.returncode == 0 and b.returncode == 0, (a.stderr[-300:], b.stderr[-300:])
     assert ("Restarted from half.ckpt.rank0 at step 67" if comm else "Restarted from half.ckpt at step 67") in b.stdout
     assert os.path.exists(tmp_path / ("half.ckpt.rank0" if comm else "half.ckpt"))
@@ -82,7 +82,7 @@ def test_duration_stops_after_the_same_step_as_the_reference(po, tmp_path):
     want_steps = 237
     duration = (want_steps - 0.5) * dt          # 236 * dt <= duration < 237 * dt
     out = subprocess.run([EXE, str(sample), "--lx", "256", "--ly", "200", "--duration", repr(float(duration))],
-                         capture_output=True, text=True, cwd=tmp_path, timeout=300)
+                         capture_output=True, text=True, cwd=tmp_path, timeout=900)
     assert out.returncode == 0, out.stderr[-500:]
     assert int(re.search(r"dem_steps: (\d+)", out.stderr).group(1)) == want_steps
     assert re.search(r"steps 200 steps", out.stdout) and not re.search(r"steps 300 steps", out.stdout)
@@ -100,7 +100,7 @@ def test_rccl_path_of_the_c_driver_with_one_rank(po, tmp_path):
     po.write_sample(str(sample), c["r_mm"], c["x_mm"], c["y_mm"])
     nsteps = 130
     out = subprocess.run([EXE, str(sample), "--lx", "256", "--ly", "200", "--steps", str(nsteps), "--comm"],
-                         capture_output=True, text=True, cwd=tmp_path, timeout=300)
+                         capture_output=True, text=True, cwd=tmp_path, timeout=900)
     assert out.returncode == 0, (out.stdout[-300:], out.stderr[-600:])
     assert int(re.search(r"dem_steps: (\d+)", out.stderr).group(1)) == nsteps
     fd_text = re.search(r"final_density: ([0-9.]+)", out.stderr).group(1)
@@ -138,7 +138,7 @@ print("TRANSPORT-OK")
         env.pop("LBMDEM_HIP_LIBRARY", None)
         if lib:
             env["LBMDEM_HIP_LIBRARY"] = lib
-        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "TRANSPORT-OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
         assert (lib is None) or "PROBE" in out.stdout
 
