@@ -25,7 +25,11 @@ __global__ void k_obst_fill(int* __restrict__ obst, LatticeView L, int row0, int
 // whatever the order of the painters).
 // (Measured alternative: plain stores, then a second launch that re-reads the nodes and settles overlaps with atomics
 // only where they occur -- 37 + 30 us against 52 us: the kernel is bound by its 50 000 short waves, not by atomics.)
-constexpr int PAINT_LANES = 16;   // lanes per grain in k_obst_paint
+// GL = lanes per grain: 16 (four grains per wavefront) when the pair list tells which discs are alone -- nearly all, and
+// they take the plain-store sweep --, 64 (one grain per wavefront, the round-3 form) when every grain takes the atomic path
+// (no list: strips with distributed grains, the first step): its batched atomics want the whole box in one sweep.
+constexpr int PAINT_LANES = 16;
+template <int GL>
 __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const real* __restrict__ x1,
                              const real* __restrict__ x2, const real* __restrict__ r,
                              const real* __restrict__ rLB, const real* __restrict__ v1,
@@ -40,12 +44,12 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
   // the per-grain set-up -- geometry, three divisions, the partner test -- is paid once per four grains and the sweep's lanes
   // are mostly busy. One wavefront per grain 46 us (the kernel was bound by its 50 000 short waves), 32 lanes per grain 32.5,
   // 16: 27, 8: 29 us (A/B, round 4).
-  constexpr int GL = PAINT_LANES;
   const int lane = threadIdx.x & 63, half = lane / GL, hl = lane % GL;
   // XCD k (workgroups b % 8 == k) takes the k-th contiguous eighth of the grains, as the DEM sub-step does: the positions
   // and the partner lists a grain's lanes read were written through that XCD's L2 (36 -> 32.5 us, A/B)
+  // (not with a list: its entries fill only the head of the launch's positions, which would all land on the first XCDs)
   const int bslots = (int)gridDim.x >> 3;
-  const int blk = ((int)blockIdx.x & 7) * bslots + ((int)blockIdx.x >> 3);
+  const int blk = list ? (int)blockIdx.x : ((int)blockIdx.x & 7) * bslots + ((int)blockIdx.x >> 3);
   int i = (int)(((long)blk * blockDim.x + threadIdx.x) / GL);
   if (list) {                    // strip decomposition: only the grains that can reach this rank's rows
     if (i >= *list_count || i >= list_cap) return;   // (an overflowing list is flagged by its producer)
@@ -92,7 +96,7 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
       const real ddx = (x1[j] - gx1) / L.dx, ddy = (x2[j] - gx2) / L.dx, rr = ri + rLB[j] + 1.5;
       near |= !(ddx * ddx + ddy * ddy >= rr * rr);   // also true for a NaN
     }
-    alone = ((__ballot(near) >> (GL * half)) & ((1ull << GL) - 1)) == 0;   // this grain's lanes
+    alone = ((__ballot(near) >> ((GL * half) & 63)) & (GL >= 64 ? ~0ull : (1ull << (GL & 63)) - 1)) == 0;   // this grain's lanes
   }
   if (alone) {
     for (int y = yi + hl; y <= yf; y += GL)          // the box in chunks of GL columns, y fastest: no integer divisions
@@ -109,21 +113,22 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
       }
     }
   };
-  constexpr int SWEEPS = 24;   // one row of the box per sweep, y fastest: no integer divisions
-  if (ny <= GL && xf - xi + 1 <= SWEEPS) {
-    // all atomics of the grain's lanes are issued before the first returned value is looked at: one round trip
-    const int y = yi + hl;
-    const bool col = hl < ny;
+  // the box in one sweep: XR rows at a time, y fastest (no integer divisions); all atomics of the grain's lanes are issued
+  // before the first returned value is looked at: one round trip, not SWEEPS
+  constexpr int XR = GL >= 64 ? 2 : 1, YL = GL / XR, SWEEPS = GL >= 64 ? 12 : 24;
+  if (ny <= YL && xf - xi + 1 <= XR * SWEEPS) {
+    const int y = yi + hl % YL, xsub = hl / YL;
+    const bool col = hl % YL < ny;
     int old[SWEEPS];
 #pragma unroll
     for (int s_ = 0; s_ < SWEEPS; ++s_) {
-      const int x = xi + s_;
+      const int x = xi + XR * s_ + xsub;
       old[s_] = -1;
       if (col && x <= xf && in_disc(x, y)) old[s_] = atomicMax(&obst[(long)(x - L.gx0) * L.sy + y], i);
     }
 #pragma unroll
     for (int s_ = 0; s_ < SWEEPS; ++s_) {
-      const int x = xi + s_;
+      const int x = xi + XR * s_ + xsub;
       if (old[s_] >= 0) overlap((long)(x - L.gx0) * L.sy + y, old[s_]);
     }
   } else {
@@ -152,10 +157,14 @@ void launch_obst_paint(int* obst, const LatticeView& L, int n, const real* x1, c
                        real* yc, real* r2, real* rbl0, real* pk, unsigned char* touched,
                        const unsigned char* mask, unsigned* mincov, unsigned epoch, const int* list,
                        const int* list_count, int list_cap, const int* voff, const int* vnbr, hipStream_t st) {
-  const long threads = (long)(list ? list_cap : n) * PAINT_LANES;
+  const int gl = voff ? PAINT_LANES : 64;
+  const long threads = (long)(list ? list_cap : n) * gl;
   const unsigned pgrid = (unsigned)(((threads + 255) / 256 + 7) / 8 * 8);   // a multiple of the 8 XCDs (see the kernel)
-  hipLaunchKernelGGL(k_obst_paint, dim3(pgrid), dim3(256), 0, st, obst, L, n, x1, x2, r,
-                     rLB, v1, v2, v3, xc, yc, r2, rbl0, pk, touched, mask, mincov, epoch, list, list_count, list_cap, voff,
-                     vnbr);
+  if (voff)
+    hipLaunchKernelGGL(k_obst_paint<PAINT_LANES>, dim3(pgrid), dim3(256), 0, st, obst, L, n, x1, x2, r, rLB, v1, v2, v3, xc, yc, r2,
+                       rbl0, pk, touched, mask, mincov, epoch, list, list_count, list_cap, voff, vnbr);
+  else
+    hipLaunchKernelGGL(k_obst_paint<64>, dim3(pgrid), dim3(256), 0, st, obst, L, n, x1, x2, r, rLB, v1, v2, v3, xc, yc, r2, rbl0, pk,
+                       touched, mask, mincov, epoch, list, list_count, list_cap, voff, vnbr);
 }
 
