@@ -24,7 +24,7 @@
 
 
 #include "lbm_march.h"
-#if defined(LBMDEM_AB) && defined(MARCH_TIMING)
+#if defined(LBMDEM_AB) && (defined(MARCH_TIMING) || defined(MARCH_TRACE))
 #include "lbm_march_timing.h"
 #else
 #define MT_DECL
@@ -136,33 +136,68 @@ __global__ __launch_bounds__(256) void k_collide_stream(const real* __restrict__
   }
 }
 
+// How the rows [xo0, xo1) of one launch are cut into work items (a window of WW columns x a segment of rows, one per
+// wavefront). nlev == 0: uniform segments (seg_rows / seg_stride arguments of the kernel). nlev > 0: the rows are split into
+// eight bands of band_rows rows, one per XCD (workgroup b runs on XCD b % 8), and every band is cut into rows[0] rows in
+// segments of seg[0] rows, then rows[1] rows in segments of seg[1] rows, ...: LONG SEGMENTS FIRST, SHORT ONES LAST. The
+// launch is bound by the memory system while all wave slots are busy (scripts/march_trace.py: ~390 row-equivalents per us with
+// 1 800 or with 2 040 of the 2 048 slots busy), so what a schedule can lose is its tail: with uniform 32-row segments a slot
+// idles for the last 125 us of 920 on average (14 % of the slot time); with the last rows of each band in 16- and 8-row
+// segments 4.5 %.
+// The band of XCD k is not one contiguous row range but the chunks k, k + 8, k + 16, ... of `chunk` rows each (a multiple of
+// every segment length), so that a packing that fills only part of the lattice's length loads all eight XCDs alike.
+struct MarchPlan {
+  int nlev, band_rows, chunk;
+  int seg[4];     // rows per segment of level l
+  int off[4];     // first row of level l within the band
+  int first[5];   // first item of level l within the band's item list; first[nlev] = items per band
+};
+
 template <int LX, int MINW, int WW>
 __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__ fin, real* __restrict__ fout,
                                                   const int* __restrict__ ob_old,
                                                   const int* __restrict__ ob_new, LatticeView L,
                                                   GrainFluidView G, ForceSlots S, int nstrips, int nwork,
-                                                  int xcd_remap, int seg_rows, int seg_stride) {
+                                                  int xcd_remap, int seg_rows, int seg_stride, MarchPlan P) {
   const int lane = threadIdx.x & 63;
   int blk = blockIdx.x;
-  if (xcd_remap) {  // XCD k (blocks b % 8 == k) walks the k-th contiguous eighth of the work list
-    const int per = gridDim.x >> 3;
-    blk = (blk & 7) * per + (blk >> 3);
+  int w, strip, xs, rows_per_wave;
+  if (LX == 0 && P.nlev > 0) {
+    const int band = blk & 7, local = (blk >> 3) * 4 + (threadIdx.x >> 6);
+    if (local >= P.first[P.nlev]) return;  // whole wave
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (k < P.nlev && local >= P.first[k]) l = k;
+    const int j = local - P.first[l], sg = j / nstrips;
+    strip = j - sg * nstrips;
+    rows_per_wave = P.seg[l];
+    const int v = P.off[l] + sg * rows_per_wave, c = v / P.chunk;   // row within the band -> chunk c of this XCD
+    xs = L.xo0 + (c * 8 + band) * P.chunk + (v - c * P.chunk);
+    if (xs >= L.xo1) return;               // a band that ends beyond the row range (row counts that are no multiple of 8 bands)
+    w = band * P.first[P.nlev] + local;
+  } else {
+    if (xcd_remap) {  // XCD k (blocks b % 8 == k) walks the k-th contiguous eighth of the work list
+      const int per = gridDim.x >> 3;
+      blk = (blk & 7) * per + (blk >> 3);
+    }
+    w = blk * 4 + (threadIdx.x >> 6);
+    if (w >= nwork) return;  // whole wave
+    const int seg = w / nstrips;
+    strip = w - seg * nstrips;
+    // rows per wave: the template value, or (LX == 0) a run-time value
+    rows_per_wave = LX > 0 ? LX : seg_rows;
+    // segment k starts seg_stride rows after segment k-1: = rows_per_wave for a contiguous row range; larger when one
+    // launch covers the two edge-row ranges of a strip
+    xs = L.xo0 + seg * seg_stride;
   }
-  const int w = blk * 4 + (threadIdx.x >> 6);
-  if (w >= nwork) return;  // whole wave
-  const int strip = w % nstrips, seg = w / nstrips;
+  (void)w;   // (the experiment build's row trace indexes its buffer with it)
   // WW producing lanes in the middle of the window, (64 - WW) / 2 feeding lanes on either side
   constexpr int OFF = (64 - WW) / 2;
   const int y = strip * WW - OFF + lane;
   const bool yin = y >= 0 && y < L.ly;
   const bool writer = lane >= OFF && lane < OFF + WW && yin;
   const bool deep_y = strip * WW >= 2 && strip * WW + WW - 1 <= L.ly - 3;  // the producing lanes
-  // rows per wave: the template value, or (LX == 0) a run-time value chosen so that one round of resident
-  // waves covers the lattice
-  const int rows_per_wave = LX > 0 ? LX : seg_rows;
-  // segment k starts seg_stride rows after segment k-1: = rows_per_wave for a contiguous row range; larger when one
-  // launch covers the two edge-row ranges of a strip
-  const int xs = L.xo0 + seg * seg_stride;
   const int xe = xs + rows_per_wave < L.xo1 ? xs + rows_per_wave : L.xo1;
 
   // Software pipeline. In iteration x (producing row x) the wave issues, in this order,
@@ -439,6 +474,45 @@ static int march_segment_rows(int rows, int nstrips) {
   return seg_rows;
 }
 
+// The tapered schedule of a LARGE row range (MarchPlan above): eight XCD bands, each cut into 32-row segments followed by
+// `tail` levels of shorter ones. Returns a plan with nlev == 0 when the range is too small for it (short ranges run uniform
+// short segments: march_segment_rows).
+static MarchPlan march_plan(int rows, int nstrips, int main_seg, const int (*tail)[2], int ntail, int chunk) {
+  MarchPlan P{};
+  if (rows < 8 * (main_seg + 64)) return P;
+  if (chunk <= 0) chunk = 1 << 30;                         // one contiguous band per XCD
+  int band_rows = (((rows + 7) / 8) + 7) & ~7;             // a multiple of 8: every level below is cut into whole segments
+  if (chunk < band_rows) band_rows = (band_rows + chunk - 1) / chunk * chunk;
+  else chunk = band_rows;
+  P.chunk = chunk;
+  int tail_rows = 0;
+  for (int k = 0; k < ntail; ++k) tail_rows += tail[k][1];
+  if (band_rows - tail_rows < main_seg) return P;
+  const int main_rows = (band_rows - tail_rows) / main_seg * main_seg;
+  int rem = band_rows - tail_rows - main_rows;            // < main_seg, a multiple of 8: joins the tail levels it fits into
+  P.band_rows = band_rows;
+  int off = 0, first = 0, lev = 0;
+  bool fits = true;   // every segment inside one chunk
+  auto add = [&](int seg, int r) {
+    if (r <= 0) return;
+    if (chunk % seg != 0 || off % seg != 0) fits = false;
+    P.seg[lev] = seg; P.off[lev] = off; P.first[lev] = first;
+    off += r; first += r / seg * nstrips; ++lev;
+  };
+  add(main_seg, main_rows);
+  for (int k = 0; k < ntail; ++k) {
+    int r = tail[k][1];
+    const int seg = tail[k][0];
+    const int take = k + 1 < ntail ? rem / seg * seg : rem;   // the last (shortest) level takes what is left
+    r += take; rem -= take;
+    add(seg, r);
+  }
+  if (rem != 0 || !fits) return MarchPlan{};   // (no tail level to take the remainder, ...: uniform segments instead)
+  P.nlev = lev;
+  P.first[lev] = first;
+  return P;
+}
+
 // which marching kernel: 2 = k_cs_march (two waves per SIMD), 3 = k_cs_march3 (three)
 #ifndef LBMDEM_MARCH_DEFAULT
 #define LBMDEM_MARCH_DEFAULT 2
@@ -470,9 +544,32 @@ static void launch_march(const real* fin, real* fout, const int* obst_old, const
 #endif
   }
   const int nseg = (rows + seg_rows - 1) / seg_rows;
-  const int nwork = nstrips * nseg;
+  int nwork = nstrips * nseg;
   int grid = (nwork + 3) / 4;
   if (remap) grid = ((grid + 7) / 8) * 8;
+  MarchPlan P{};
+  if (LX == 0 && remap && seg_rows >= 32) {   // a large row range: the tapered schedule
+    int main_seg = 32, ntail = 2;
+    int tail[3][2] = {{16, 64}, {8, 64}, {0, 0}};   // {rows per segment, rows of every band cut that way}
+#ifdef LBMDEM_AB   // LBMDEM_PLAN="seg:rows,seg:rows[,seg:rows]" (tail levels), LBMDEM_CS_ROWS = the main segment length
+    if (getenv("LBMDEM_CS_ROWS")) main_seg = atoi(getenv("LBMDEM_CS_ROWS"));
+    if (const char* e = getenv("LBMDEM_PLAN")) {
+      ntail = sscanf(e, "%d:%d,%d:%d,%d:%d", &tail[0][0], &tail[0][1], &tail[1][0], &tail[1][1], &tail[2][0], &tail[2][1]) / 2;
+    }
+#endif
+    bool ok = main_seg >= 8 && main_seg % 8 == 0;
+    for (int k = 0; k < ntail; ++k) ok = ok && tail[k][0] >= 8 && tail[k][0] % 8 == 0 && tail[k][1] % tail[k][0] == 0;
+    int chunk = 64;
+#ifdef LBMDEM_AB
+    if (getenv("LBMDEM_CHUNK")) chunk = atoi(getenv("LBMDEM_CHUNK"));
+#endif
+    if (chunk > 0 && chunk % main_seg != 0) chunk = 0;
+    if (ok) P = march_plan(rows, nstrips, main_seg, tail, ntail, chunk);
+    if (P.nlev > 0) {
+      nwork = 8 * P.first[P.nlev];
+      grid = 8 * ((P.first[P.nlev] + 3) / 4);
+    }
+  }
 #ifdef LBMDEM_AB   // k_cs_march3 (lbm_fused_ab.hip) only exists in the experiment build
   if constexpr (WW == 62) {
     const int mk = march_kernel();
@@ -488,7 +585,7 @@ static void launch_march(const real* fin, real* fout, const int* obst_old, const
   dyn_lds = (unsigned)env_lds;
 #endif
   hipLaunchKernelGGL((k_cs_march<LX, MINW, WW>), dim3(grid), dim3(256), dyn_lds, st, fin, fout, obst_old, obst_new, L, G,
-                     S, nstrips, nwork, remap, seg_rows, seg_rows);
+                     S, nstrips, nwork, remap, seg_rows, seg_rows, P);
 }
 
 // Two row ranges of equal width w <= 32 (the rows next to the two cuts of a strip) in ONE launch: two segments of w rows,
@@ -509,7 +606,7 @@ static void launch_march_two_ranges(const real* fin, real* fout, const int* obst
   }
 #endif
   hipLaunchKernelGGL((k_cs_march<0, 2, WW>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, Ls, G, S, nstrips,
-                     nwork, 0, w, hi0 - lo0);
+                     nwork, 0, w, hi0 - lo0, MarchPlan{});
 }
 
 // The marching kernel assumes reductionR < 1 (always true in the reference); other configurations run the
@@ -536,10 +633,7 @@ void launch_collide_stream(const real* fin, real* fout, const int* obst_old, con
   }
 #endif
   if (L.reduced_lt1) {
-    if (march_segment_rows(L.xo1 - L.xo0, (L.ly + 61) / 62) >= 32)
-      launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, S, /*xcd remap*/ 1, st);
-    else
-      launch_march<0, 2>(fin, fout, obst_old, obst_new, L, G, S, /*xcd remap*/ 1, st);
+    launch_march<0, 2>(fin, fout, obst_old, obst_new, L, G, S, /*xcd remap*/ 1, st);
   }
   else launch_cs<4, 64>(fin, fout, obst_old, obst_new, L, G, 0, st);
 }

@@ -409,6 +409,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
+    # the state the timed run left behind must be a lattice (checked here, before the informative legs below: those step the
+    # DEM and the fluid SEPARATELY -- 100 periods of sub-steps without a fluid step in between -- which leaves a physically
+    # inconsistent state by design, and with the reference's own geometry falling under gravity sometimes a non-finite one)
+    mass = sim.final_density()
+    if world > 1 or args.strips:   # every rank holds the mass of its own rows
+        import torch.distributed as dist
+        tm = torch.tensor([mass], dtype=torch.float64, device=reduce_dev)
+        dist.all_reduce(tm, op=dist.ReduceOp.SUM)
+        mass = float(tm[0])
+    if not np.isfinite(mass):
+        raise SystemExit("non-finite lattice mass after the timed run")
     # informative: the DEM side alone (sub-steps incl. the Verlet rebuilds that fall inside), after the timed region
     dem_only = lbm_only_ms = None
     if world == 1 and not args.strips:
@@ -433,6 +444,8 @@ def main():
         sim.set_force_mode(1); sim.forces_fluid(); ff = sim.fhf.copy()
         scale_f = np.abs(fp).max(axis=0)
         drift = float((np.abs(ff - fp).max(axis=0) / np.where(scale_f > 0, scale_f, 1.0)).max())
+        if not np.isfinite(drift):   # (the separately stepped state above can be non-finite: see the mass check)
+            drift = None
         nf = max(10, min(50, args.steps))
         run_steps(2); sync()
         t0 = time.perf_counter(); run_steps(nf); sync(); t1 = time.perf_counter()
@@ -441,14 +454,6 @@ def main():
                 "steps": nf, "max_rel_drift_vs_parity": drift,
                 "note": "force_mode=1: the table's link sums reduced across lanes instead of replayed in reference order (last-bit differences); not the headline"}
 
-    mass = sim.final_density()
-    if world > 1 or args.strips:   # every rank holds the mass of its own rows
-        import torch.distributed as dist
-        tm = torch.tensor([mass], dtype=torch.float64, device=reduce_dev)
-        dist.all_reduce(tm, op=dist.ReduceOp.SUM)
-        mass = float(tm[0])
-    if not np.isfinite(mass):
-        raise SystemExit("non-finite lattice mass after the timed run")
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
