@@ -302,7 +302,10 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
     oo3 = load_old(x + 4);
     __builtin_amdgcn_sched_barrier(0);
     // ---- (2) the big loads: populations of row x+3
-    load_raw(x + 3, buf);
+    // (rows beyond xe are never consumed: the last two prefetches of a segment re-request row xe, which the wave loaded
+    // one or two iterations ago, instead of two new rows -- 2 of the 36 rows a 32-row segment would read, 2 of 12 for 8 rows;
+    // the loads stay unconditional so that the in-order vmcnt bookkeeping of the pipeline does not change)
+    load_raw(x + 3 < xe ? x + 3 : xe, buf);
     __builtin_amdgcn_sched_barrier(0);
     MT(2)
     // (the column re-declared opaque: otherwise (double)(y - 1), (double)y, (double)(y + 1) of node_active's rare path are
