@@ -107,6 +107,7 @@ def _open_library(LIB_PATH):
                  "download_kinematics", "download_fhf", "set_stream"):
         getattr(L, "lbmdem_" + name).argtypes = [C.c_void_p, C.c_void_p]
     L.lbmdem_path_info.argtypes = [C.c_void_p, C.c_void_p]
+    L.lbmdem_fused_work_order.argtypes = [C.c_void_p, C.c_void_p]
     L.lbmdem_dist_export_carries.argtypes = [C.c_void_p] * 4
     L.lbmdem_dist_set_carries.argtypes = [C.c_void_p, C.c_void_p]
     L.lbmdem_dist_export_owned.argtypes = [C.c_void_p] * 5
@@ -584,6 +585,15 @@ class LbmDem:
         v = (C.c_int * 4)()
         _chk(self._L.lbmdem_path_info(self._h, v))
         return dict(table=bool(v[0]), slots_per_direction=int(v[1]), mincov=bool(v[2]), marching=bool(v[3]))
+
+    def fused_work_order(self):
+        """how the fused kernel's launch is cut into work items: dict(levels, band_rows, chunk_rows, segment_rows [per level],
+        level_rows [band rows cut at each level], items); levels == 0: uniform segments of segment_rows[0] rows"""
+        v = (C.c_int * 12)()
+        _chk(self._L.lbmdem_fused_work_order(self._h, v))
+        nl = max(int(v[0]), 1)
+        return dict(levels=int(v[0]), band_rows=int(v[1]), chunk_rows=int(v[2]), segment_rows=[int(v[3 + k]) for k in range(nl)],
+                    level_rows=[int(v[7 + k]) for k in range(nl)], items=int(v[11]))
 
     def dist_export_owned(self):
         """-> (state12 [n][12], owned [n] uint8, carry_keys [3][2] int64, carry_vals [3]): what this rank contributes

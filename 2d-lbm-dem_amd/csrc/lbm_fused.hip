@@ -516,6 +516,32 @@ static MarchPlan march_plan(int rows, int nstrips, int main_seg, const int (*tai
   return P;
 }
 
+// The work order the product uses for `rows` rows of `nstrips` windows: tapered for a large range (uniform segments would be
+// 32 rows long), else none (nlev == 0: uniform segments of seg_rows rows).
+static MarchPlan product_plan(int rows, int nstrips, int seg_rows) {
+  MarchPlan P{};
+  if (seg_rows < 32) return P;
+  {
+    int main_seg = 32, ntail = 2;
+    int tail[3][2] = {{16, 64}, {8, 64}, {0, 0}};   // {rows per segment, rows of every band cut that way}
+#ifdef LBMDEM_AB   // LBMDEM_PLAN="seg:rows,seg:rows[,seg:rows]" (tail levels), LBMDEM_CS_ROWS = the main segment length
+    if (getenv("LBMDEM_CS_ROWS")) main_seg = atoi(getenv("LBMDEM_CS_ROWS"));
+    if (const char* e = getenv("LBMDEM_PLAN")) {
+      ntail = sscanf(e, "%d:%d,%d:%d,%d:%d", &tail[0][0], &tail[0][1], &tail[1][0], &tail[1][1], &tail[2][0], &tail[2][1]) / 2;
+    }
+#endif
+    bool ok = main_seg >= 8 && main_seg % 8 == 0;
+    for (int k = 0; k < ntail; ++k) ok = ok && tail[k][0] >= 8 && tail[k][0] % 8 == 0 && tail[k][1] % tail[k][0] == 0;
+    int chunk = 64;
+#ifdef LBMDEM_AB
+    if (getenv("LBMDEM_CHUNK")) chunk = atoi(getenv("LBMDEM_CHUNK"));
+#endif
+    if (chunk > 0 && chunk % main_seg != 0) chunk = 0;
+    if (ok) P = march_plan(rows, nstrips, main_seg, tail, ntail, chunk);
+  }
+  return P;
+}
+
 // which marching kernel: 2 = k_cs_march (two waves per SIMD), 3 = k_cs_march3 (three)
 #ifndef LBMDEM_MARCH_DEFAULT
 #define LBMDEM_MARCH_DEFAULT 2
@@ -551,27 +577,10 @@ static void launch_march(const real* fin, real* fout, const int* obst_old, const
   int grid = (nwork + 3) / 4;
   if (remap) grid = ((grid + 7) / 8) * 8;
   MarchPlan P{};
-  if (LX == 0 && remap && seg_rows >= 32) {   // a large row range: the tapered schedule
-    int main_seg = 32, ntail = 2;
-    int tail[3][2] = {{16, 64}, {8, 64}, {0, 0}};   // {rows per segment, rows of every band cut that way}
-#ifdef LBMDEM_AB   // LBMDEM_PLAN="seg:rows,seg:rows[,seg:rows]" (tail levels), LBMDEM_CS_ROWS = the main segment length
-    if (getenv("LBMDEM_CS_ROWS")) main_seg = atoi(getenv("LBMDEM_CS_ROWS"));
-    if (const char* e = getenv("LBMDEM_PLAN")) {
-      ntail = sscanf(e, "%d:%d,%d:%d,%d:%d", &tail[0][0], &tail[0][1], &tail[1][0], &tail[1][1], &tail[2][0], &tail[2][1]) / 2;
-    }
-#endif
-    bool ok = main_seg >= 8 && main_seg % 8 == 0;
-    for (int k = 0; k < ntail; ++k) ok = ok && tail[k][0] >= 8 && tail[k][0] % 8 == 0 && tail[k][1] % tail[k][0] == 0;
-    int chunk = 64;
-#ifdef LBMDEM_AB
-    if (getenv("LBMDEM_CHUNK")) chunk = atoi(getenv("LBMDEM_CHUNK"));
-#endif
-    if (chunk > 0 && chunk % main_seg != 0) chunk = 0;
-    if (ok) P = march_plan(rows, nstrips, main_seg, tail, ntail, chunk);
-    if (P.nlev > 0) {
-      nwork = 8 * P.first[P.nlev];
-      grid = 8 * ((P.first[P.nlev] + 3) / 4);
-    }
+  if (LX == 0 && remap) P = product_plan(rows, nstrips, seg_rows);   // a large row range: the tapered work order
+  if (P.nlev > 0) {
+    nwork = 8 * P.first[P.nlev];
+    grid = 8 * ((P.first[P.nlev] + 3) / 4);
   }
 #ifdef LBMDEM_AB   // k_cs_march3 (lbm_fused_ab.hip) only exists in the experiment build
   if constexpr (WW == 62) {
@@ -615,6 +624,27 @@ static void launch_march_two_ranges(const real* fin, real* fout, const int* obst
 // The marching kernel assumes reductionR < 1 (always true in the reference); other configurations run the
 // LDS-tile kernel, which does not fill the slot table.
 bool collide_stream_fills_slots(const LatticeView& L) { return L.reduced_lt1 != 0; }
+
+void collide_stream_work_order(const LatticeView& L, int* info) {
+  for (int k = 0; k < 12; ++k) info[k] = 0;
+  if (!L.reduced_lt1) return;   // the LDS-tile kernel: no marching work items
+  const int rows = L.xo1 - L.xo0, nstrips = (L.ly + 61) / 62;
+  const int seg_rows = march_segment_rows(rows, nstrips);
+  const MarchPlan P = product_plan(rows, nstrips, seg_rows);
+  info[0] = P.nlev;
+  if (P.nlev == 0) {
+    info[3] = seg_rows;
+    info[7] = rows;
+    info[11] = nstrips * ((rows + seg_rows - 1) / seg_rows);
+    return;
+  }
+  info[1] = P.band_rows; info[2] = P.chunk;
+  for (int l = 0; l < P.nlev; ++l) {
+    info[3 + l] = P.seg[l];
+    info[7 + l] = (l + 1 < P.nlev ? P.off[l + 1] : P.band_rows) - P.off[l];
+  }
+  info[11] = 8 * P.first[P.nlev];
+}
 
 void launch_collide_stream(const real* fin, real* fout, const int* obst_old, const int* obst_new,
                            const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, hipStream_t st) {

@@ -584,6 +584,12 @@ int lbmdem_path_info(lbmdem_handle* h, int* info4) {
   return LBMDEM_OK;
 }
 
+int lbmdem_fused_work_order(lbmdem_handle* h, int* info12) {
+  if (!h || !info12) return fail(LBMDEM_EINVAL, "null argument");
+  collide_stream_work_order(h->L, info12);
+  return LBMDEM_OK;
+}
+
 #ifdef LBMDEM_AB
 int lbmdem_debug_gather_queue(lbmdem_handle* h, int* out, int cap) {   // experiment builds only
   CHECK_H(h);

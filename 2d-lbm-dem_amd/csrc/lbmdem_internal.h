@@ -158,6 +158,7 @@ void launch_collide_stream_edges(const real* fin, real* fout, const int* obst_ol
                                  int hi0, int hi1, hipStream_t st);
 // true when launch_collide_stream(..., S) with S.tab != nullptr fills the table (the marching kernel does)
 bool collide_stream_fills_slots(const LatticeView& L);
+void collide_stream_work_order(const LatticeView& L, int* info12);   // the launch's work items (lbmdem_fused_work_order)
 void launch_slots_clear(const ForceSlots& S, int n, hipStream_t st);
 // parity forces from the slot table (resets it to empty); grains whose table is incomplete gather from f
 void launch_forces_slots(const real* f, const int* obst, const LatticeView& L, const GrainFluidView& G,

@@ -116,6 +116,11 @@ int lbmdem_force_stats(lbmdem_handle* h, int* from_table, int* gathered);
  * < ~20 nodes, reductionR < 1), info4[1] its slots per direction, info4[2] the lowest-cover record that keeps `act` exact
  * where three or more reduced discs overlap (< 2^20 grains; else the two-disc rule), info4[3] the marching fused kernel. */
 int lbmdem_path_info(lbmdem_handle* h, int* info4);
+/* How the fused kernel's launch over this handle's rows is cut into work items (windows of 62 columns x segments of rows):
+ * info12 = {levels, rows per XCD band, rows per interleaved chunk, segment rows of level 0..3, band rows cut at level 0..3,
+ * work items in all}. levels == 0: uniform segments of info12[3] rows (short row ranges: strips, small lattices); else the
+ * tapered order (long segments first, short ones last) of DESIGN.md section 4. Host-side arithmetic only. */
+int lbmdem_fused_work_order(lbmdem_handle* h, int* info12);
 
 /* initVerlet + VerletWall, main.c:1519-1594 (same pair set; uniform grid + radix sort instead of
  * the O(N^2) scan). Also moves the right/top DEM walls as VerletWall does (main.c:1555-1561). */

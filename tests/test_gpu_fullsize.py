@@ -22,6 +22,7 @@ def test_c3_2048_7000_grains_two_fluid_steps_exact(pkg, po):
     lx = ly = 2048
     r, x1, x2 = packing(lx, ly, 7000, seed=99)
     sim = pkg.LbmDem(lx, ly, r, x1, x2)
+    assert sim.fused_work_order()["levels"] == 0          # too few rows for the taper: uniform short segments
     ora = po.Oracle(lx, ly, r, x1, x2)
     n = sim.cfg.npDEM + 1   # fluid steps at nbsteps 0 and npDEM
     sim.renderScene(n); ora.steps(n)
@@ -35,11 +36,33 @@ def test_c3_2048_7000_grains_two_fluid_steps_exact(pkg, po):
     assert np.array_equal(cg, co) and np.array_equal(ng, no[:len(ng)])
 
 
+@pytest.mark.parametrize("lx,ly,n", [(4000, 2046, 12000), (3000, 2790, 12000)])
+def test_tapered_work_order_on_row_counts_that_are_no_multiple_of_its_bands(pkg, po, lx, ly, n):
+    """Large row ranges run the fused kernel with the tapered work order (eight XCD bands of interleaved 64-row chunks, 32-row
+    segments first, 16- and 8-row segments last: lbm_fused.hip march_plan). With lx = 4000 / 3000 the bands (8 x 512 / 8 x 384
+    rows) reach beyond the lattice: items that start past the last row must do nothing, the item that straddles it must stop
+    there. Two fluid steps and the sub-steps between them, every array against the CPU oracle."""
+    r, x1, x2 = packing(lx, ly, n, seed=7)
+    sim = pkg.LbmDem(lx, ly, r, x1, x2)
+    wo = sim.fused_work_order()
+    assert wo["levels"] == 3 and wo["segment_rows"] == [32, 16, 8] and wo["chunk_rows"] == 64
+    assert 8 * wo["band_rows"] > lx and sum(wo["level_rows"]) == wo["band_rows"]     # the bands overshoot the lattice
+    ora = po.Oracle(lx, ly, r, x1, x2)
+    k = sim.cfg.npDEM + 1   # fluid steps at nbsteps 0 and npDEM
+    sim.renderScene(k); ora.steps(k)
+    assert ora.act_anomalies() == 0
+    assert np.array_equal(sim.obst, ora.get_obst())
+    assert np.array_equal(sim.f, ora.get_f())
+    assert np.array_equal(sim.fhf, ora.get_fhf())
+    assert np.array_equal(sim.kinematics, ora.get_grains()[:, :9])
+
+
 def test_c4_4096_50k_first_step_exact_then_properties(pkg, po):
     lx = ly = 4096
     r, x1, x2 = packing(lx, ly, 50000)
     assert len(r) == 50000
     sim = pkg.LbmDem(lx, ly, r, x1, x2)
+    assert sim.fused_work_order()["levels"] == 3          # the headline lattice runs the tapered work order
     ora = po.Oracle(lx, ly, r, x1, x2)
     # one renderScene: fluid step + O(N^2) Verlet build + DEM sub-step on the CPU (~10 s)
     sim.renderScene(1); ora.steps(1)
