@@ -235,7 +235,11 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
   auto load_raw = [&](int xl, real (&raw)[9]) {
     const long fb = fbase_xy(L, xl < 0 ? 0 : (xl >= L.nxl ? L.nxl - 1 : xl), ycl);
 #pragma unroll
+#if defined(LBMDEM_AB) && defined(MARCH_NT_LOADS)   /* experiment: stream the populations past the L2's retention */
+    for (int q = 0; q < 9; ++q) raw[q] = __builtin_nontemporal_load(&fin[fb + q * F_QSTRIDE(L)]);
+#else
     for (int q = 0; q < 9; ++q) raw[q] = fin[fb + q * F_QSTRIDE(L)];
+#endif
   };
   auto interior = [&](int xl) {
     const int gx = L.gx0 + xl;

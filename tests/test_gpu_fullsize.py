@@ -128,6 +128,43 @@ def test_strips_equal_single_domain_at_1024(pkg):
         assert np.array_equal(R.b.sim.fhf, single.fhf)
 
 
+def test_two_strips_of_the_headline_lattice_equal_one_domain(pkg):
+    """bench.py --gpus 2 cuts 4096^2 into two strips of 2048 rows: their interior rows (2044, starting at local row 4) are a
+    LARGE row range and run the fused kernel's tapered work order with a row offset and bands that overshoot the range. Two
+    strips with distributed grains on this GPU (loop-back messages) against one domain, bit for bit, over three periods."""
+    import torch
+    from strip_backends import LoopbackComm, lockstep_render_dist
+    strips = pkg.strips_module()
+    lx = ly = 4096
+    r, x1, x2 = packing(lx, ly, 50000)
+    cfg = pkg.derive(lx, ly, r)
+    parts = strips.partition(lx, 2)
+    margin = strips.default_margin(cfg.npDEM, float(r.max()), cfg.phys.distVerlet, cfg.dx)
+    runners = []
+    for rank, strip in enumerate(parts):
+        be = strips.GpuStripBackend(pkg, torch, lx, ly, r, x1, x2, strip, 2, 0, distributed=True, margin=margin, poison=True)
+        runners.append(strips.DistStripRunner(be, LoopbackComm(), rank, 2))
+    assert runners[0].b.sim.fused_work_order()["levels"] == 3      # (whole strip; its interior rows take the same order)
+    n = 3 * cfg.npDEM + 1
+    lockstep_render_dist(runners, n)
+    for R in runners:
+        R.b.sim.sync()
+    single = pkg.LbmDem(lx, ly, r, x1, x2)
+    single.renderScene(n)
+    got = np.full((lx, ly, 9), np.nan)
+    for R in runners:
+        R.b.sim.download_f_into(got)
+    fs = single.f
+    assert np.array_equal(got, fs)
+    del got, fs
+    ks = single.kinematics
+    xc = ks[:, 0] / cfg.dx
+    for R, (a, b) in zip(runners, parts):
+        own = ((a == 0) | (xc >= a)) & ((b == lx) | (xc < b))
+        assert np.array_equal(R.b.sim.kinematics[own], ks[own])
+        assert np.array_equal(R.b.sim.fhf[own], single.fhf[own])
+
+
 def test_c2_1024_fluid_only_rho_u(pkg, po):
     """BASELINE config 2 shape: 1024 x 1024, fluid only. The reference cannot run with 0 grains
     (main.c:220 reads g[0]) and has no lid (its lid terms are commented out, main.c:1125-1130), so the
