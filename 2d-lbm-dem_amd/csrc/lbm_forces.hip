@@ -265,6 +265,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const real* __re
                                                                 PackSides sides,
                                                                 const unsigned char* __restrict__ mask, int list_cap) {
   extern __shared__ real sDyn[];
+  __shared__ __attribute__((aligned(16))) real sZero[8];   // phase B: what a lane adds once its own list has ended
   real* __restrict__ packbuf = nullptr;
   if (mode == FT_PACK) {
     packbuf = sides.buf[blockIdx.y];
@@ -574,6 +575,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const real* __re
     if (blockIdx.x == 0 && threadIdx.x == 0) packbuf[0] = (real)ntodo;
     return;
   }
+  if (threadIdx.x < 8) sZero[threadIdx.x] = 0.0;
   __syncthreads();
   if (wave != 0) return;
   // ---- phase B, first wave only: lane 3g + a replays accumulator a of grain g of the workgroup (the serial part
@@ -600,15 +602,39 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const real* __re
     }
     const real* tl = sDyn + (size_t)(g < NG ? g : 0) * per_grain + (a == 0 ? 0 : (a == 1 ? cap1 : 2 * cap1));
     real h = 0.0;
-    for (int t = 0; t < longest; t += 8) {  // wave-uniform trip count
-      if (t < mine) {
-        real2 v[4];
+    // The additions are one dependent chain per lane; what can be hidden is the LDS latency of the addends. Two-stage
+    // software pipeline: the block of 8 addends after the one being added is already in flight. No exec masks in the loop:
+    // a lane whose list has ended reads a block of zeros instead (h + 0.0 == h: an accumulator is never -0.0, see above).
+    // (Before: load 8, wait, add 8 under `if (t < mine)` -- every block paid the full LDS round trip plus a mask round trip,
+    // ~2.5 us for the ~300 addends of a torque; the kernel ran 84 us against 61 us with the cross-lane reduction.)
+    longest = __builtin_amdgcn_readfirstlane(longest);
+    auto block_at = [&](int t) { return reinterpret_cast<const real2*>(t < mine ? tl + t : sZero); };
+    auto fetch = [&](real2 (&v)[4], int t) {
+      const real2* p = block_at(t);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const real2*>(tl + t)[u];  // issued ahead of the chain
+      for (int u = 0; u < 4; ++u) v[u] = p[u];
+    };
+    auto chain = [&](const real2 (&v)[4]) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { h = h + v[u].x; h = h + v[u].y; }
-      }
+      for (int u = 0; u < 4; ++u) { h = h + v[u].x; h = h + v[u].y; }
+    };
+    real2 va[4], vb[4];
+    // (the empty asm statements keep the compiler from merging the two fetches of `va` into one load at the loop head --
+    // load(phi) for phi(load, load) -- which puts the LDS round trip back in front of the chain)
+#define FT_STAGE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    fetch(va, 0);
+    FT_STAGE();
+    for (int t = 0; t < longest; t += 16) {  // wave-uniform trip count
+      fetch(vb, t + 8);
+      FT_STAGE();
+      chain(va);
+      FT_STAGE();
+      fetch(va, t + 16);
+      FT_STAGE();
+      chain(vb);
+      FT_STAGE();
     }
+#undef FT_STAGE
     if (g < NG && gi >= 0 && replayed) fhf[a * L.n + gi] = mine_own ? h * (a == 2 ? scale3 : scale12) : 0.0;
   }
 }
