@@ -559,7 +559,14 @@ __attribute__((unused)) static int march_kernel() {
 #endif
 }
 
-template <int LX, int MINW, int WW = 62>
+// Producing lanes per 64-lane window. 60: a window's stores start at y = 60 k, i.e. on a 32-byte sector boundary of the
+// [y/16][q][y%16] tile rows, and cover 15 whole sectors -- with 62 (rounds 1-4) the two sectors at every window seam were
+// written half by one wavefront and half by its neighbour, at different times (partial-line writes). Interleaved A/B on one
+// GPU, product work order: 62: 0.7197 / 0.7209 ms, 60: 0.7128 / 0.7113, 56 (64-byte aligned): 0.7172 / 0.7176 (the wider
+// halo costs more waves than the alignment saves).
+constexpr int MARCH_WW = 60;
+
+template <int LX, int MINW, int WW = MARCH_WW>
 static void launch_march(const real* fin, real* fout, const int* obst_old, const int* obst_new,
                          const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, int remap,
                          hipStream_t st) {
@@ -609,15 +616,16 @@ static void launch_march(const real* fin, real* fout, const int* obst_old, const
 static void launch_march_two_ranges(const real* fin, real* fout, const int* obst_old, const int* obst_new,
                                     const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, int lo0, int w,
                                     int hi0, hipStream_t st) {
-  constexpr int WW = 62;
+  constexpr int WW = MARCH_WW;
   LatticeView Ls = L;
   Ls.xo0 = lo0; Ls.xo1 = hi0 + w;
   const int nstrips = (L.ly + WW - 1) / WW;
   const int nwork = nstrips * 2;
   const int grid = (nwork + 3) / 4;
 #ifdef LBMDEM_AB
-  if (march_kernel() == 3) {
-    launch_march3_ab(3, 0, fin, fout, obst_old, obst_new, Ls, G, S, nstrips, nwork, 0, w, hi0 - lo0, grid, st);
+  if (march_kernel() == 3) {   // (k_cs_march3 is laid out for 62-column windows)
+    const int ns3 = (L.ly + 61) / 62, nw3 = ns3 * 2;
+    launch_march3_ab(3, 0, fin, fout, obst_old, obst_new, Ls, G, S, ns3, nw3, 0, w, hi0 - lo0, (nw3 + 3) / 4, st);
     return;
   }
 #endif
@@ -632,7 +640,7 @@ bool collide_stream_fills_slots(const LatticeView& L) { return L.reduced_lt1 != 
 void collide_stream_work_order(const LatticeView& L, int* info) {
   for (int k = 0; k < 12; ++k) info[k] = 0;
   if (!L.reduced_lt1) return;   // the LDS-tile kernel: no marching work items
-  const int rows = L.xo1 - L.xo0, nstrips = (L.ly + 61) / 62;
+  const int rows = L.xo1 - L.xo0, nstrips = (L.ly + MARCH_WW - 1) / MARCH_WW;
   const int seg_rows = march_segment_rows(rows, nstrips);
   const MarchPlan P = product_plan(rows, nstrips, seg_rows);
   info[0] = P.nlev;
@@ -665,11 +673,19 @@ void launch_collide_stream(const real* fin, real* fout, const int* obst_old, con
       case 19: launch_march<64, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;
       case 20: launch_march<0, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;  // one balanced round
       case 21: launch_march<32, 2, 56>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;  // 64-byte aligned stores
+      case 22: launch_march<0, 2, 62>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;   // rounds 1-4: 62 producing lanes, product work order
+      case 23: launch_march<0, 2, 56>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;   // 64-byte aligned stores, product work order
       default: launch_march<32, 2>(fin, fout, obst_old, obst_new, L, G, S, remap, st); return;
     }
   }
 #endif
   if (L.reduced_lt1) {
+#ifdef LBMDEM_AB
+    if (march_kernel() != 2) {   // k_cs_march3 (62-column windows only)
+      launch_march<0, 2, 62>(fin, fout, obst_old, obst_new, L, G, S, /*xcd remap*/ 1, st);
+      return;
+    }
+#endif
     launch_march<0, 2>(fin, fout, obst_old, obst_new, L, G, S, /*xcd remap*/ 1, st);
   }
   else launch_cs<4, 64>(fin, fout, obst_old, obst_new, L, G, 0, st);

@@ -26,7 +26,7 @@ L = pkg.load_library()
 fn = L.lbmdem_ab_march_trace
 fn.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
 rows = int(os.environ.get("LBMDEM_CS_ROWS", "32"))
-nstrips = (w["ly"] + 61) // 62
+nstrips = (w["ly"] + 59) // 60   # MARCH_WW of lbm_fused.hip
 cap = nstrips * (w["lx"] // 8 + 8)              # room for any mix of segments of >= 8 rows
 stride = rows + 8
 buf = torch.zeros(cap * stride, dtype=torch.int32, device="cuda")
