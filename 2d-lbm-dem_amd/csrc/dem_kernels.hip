@@ -269,9 +269,12 @@ __global__ void k_dem_substep(Kin in, Kin out, const real* __restrict__ r, const
 constexpr int DEM_GRAINS = DEM_TILE;  // grains per workgroup
 #define DEM_GRID(nbe) ((((nbe) + 7) / 8) * 8)   /* tile slots: a multiple of the 8 XCDs, see the kernel */
 constexpr int DEM_ENTRIES = 512;  // list entries staged per round (8 per grain; denser lists take more rounds)
+#ifndef DEM_THREADS
+#define DEM_THREADS 256           /* lanes per workgroup of k_dem_entries (phase 1: one list entry per lane and pass) */
+#endif
 
 template <bool FILM>
-__global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const real* __restrict__ r,
+__global__ __launch_bounds__(DEM_THREADS) void k_dem_entries(Kin in, Kin out, const real* __restrict__ r,
                                                      const real* __restrict__ m,
                                                      const real* __restrict__ It,
                                                      const real* __restrict__ fhf,
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const real
   // and every sub-step finds the state its own XCD wrote in the sub-step before: 9.5 -> 8.5 us per sub-step (A/B, round 4).
   const int tslots = ((tiles + 7) / 8) * 8;
   if ((int)blockIdx.x >= tslots) {   // the workgroups behind the grain tiles reset a slice of the next obstacle map
-    obst_fill_range(fill.map, fill.L, (long)(blockIdx.x - tslots) * 256 + tid, (long)(gridDim.x - tslots) * 256, fill.row0, fill.row1);
+    obst_fill_range(fill.map, fill.L, (long)(blockIdx.x - tslots) * DEM_THREADS + tid, (long)(gridDim.x - tslots) * DEM_THREADS, fill.row0, fill.row1);
     return;
   }
   const int tile = ((int)blockIdx.x & 7) * (tslots >> 3) + ((int)blockIdx.x >> 3);
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(256) void k_dem_entries(Kin in, Kin out, const real
   // contact is evaluated in the frame of its lower grain, so exactly one rank records it
   for (int base = e0; base < e1; base += DEM_ENTRIES) {
     const int lim = base + DEM_ENTRIES < e1 ? base + DEM_ENTRIES : e1;
-    for (int e = base + tid; e < lim; e += 256) {
+    for (int e = base + tid; e < lim; e += DEM_THREADS) {
       const int gi = own[e], gj = nbr[e];
       if (active && !active[gi]) continue;   // nobody adds this entry up
       const GrainState a = advance(in, r, gi, P), b = advance(in, r, gj, P);
@@ -610,22 +613,30 @@ __device__ __forceinline__ int cell_coord(real x, real o, real cs, int nc) {
   return c < 0 ? 0 : (c >= nc ? nc - 1 : c);
 }
 
-__global__ void k_cell_keys(int n, const real* __restrict__ x1, const real* __restrict__ x2, real ox,
-                            real oy, real cs, int ncx, int ncy, unsigned int* __restrict__ keys,
-                            int* __restrict__ vals) {
+// Grains by cell, as a counting sort (round 4; before: hipCUB radix sort of (cell, grain) pairs = 7 launches at this size,
+// two memsets and a bounds kernel): k_cell_count leaves every grain's cell and its arrival rank within the cell,
+// an exclusive scan of the per-cell counts gives cell_start[0 .. ncell] (cell c = [cell_start[c], cell_start[c + 1])), and
+// k_cell_scatter writes the grain to its place and returns the count to zero for the next rebuild. The order of the grains
+// WITHIN a cell is whatever order the atomics arrived in -- k_verlet_scan<1> sorts every grain's partners anyway, so the
+// list does not depend on it.
+__global__ void k_cell_count(int n, const real* __restrict__ x1, const real* __restrict__ x2, real ox,
+                             real oy, real cs, int ncx, int ncy, unsigned int* __restrict__ keys,
+                             int* __restrict__ rank, int* __restrict__ cell_cnt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  keys[i] = (unsigned)(cell_coord(x2[i], oy, cs, ncy) * ncx + cell_coord(x1[i], ox, cs, ncx));
-  vals[i] = i;
+  const unsigned c = (unsigned)(cell_coord(x2[i], oy, cs, ncy) * ncx + cell_coord(x1[i], ox, cs, ncx));
+  keys[i] = c;
+  rank[i] = atomicAdd(&cell_cnt[c], 1);
 }
 
-__global__ void k_cell_bounds(int n, const unsigned int* __restrict__ keys, int* __restrict__ cell_start,
-                              int* __restrict__ cell_end) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  const unsigned c = keys[k];
-  if (k == 0 || keys[k - 1] != c) cell_start[c] = k;
-  if (k == n - 1 || keys[k + 1] != c) cell_end[c] = k + 1;
+__global__ void k_cell_scatter(int n, const unsigned int* __restrict__ keys, const int* __restrict__ rank,
+                               const int* __restrict__ cell_start, int* __restrict__ cell_cnt,
+                               int* __restrict__ sorted) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned c = keys[i];
+  sorted[cell_start[c] + rank[i]] = i;
+  cell_cnt[c] = 0;   // (every occupied cell is visited by its grains; nobody reads the counts in this launch)
 }
 
 // the reference's candidate test (main.c:1527-1532), lo < hi
@@ -639,26 +650,50 @@ __device__ __forceinline__ bool verlet_pair(real x1l, real x2l, real rl, real x1
   return false;
 }
 
-// MODE 0: count partners; MODE 1: write them (then sort ascending) -- one thread per grain
+// wall candidate lists as per-grain flags: main.c:1563-1593
+__device__ __forceinline__ unsigned char wall_flags_of(real x1, real x2, real r, const DemParams& P) {
+  unsigned f = 0;
+  if (x2 - r - P.Mby < P.distVerlet) f |= 1u;
+  if (-x2 - r + P.Mhy < P.distVerlet) f |= 2u;
+  if (x1 - r - P.Mgx < P.distVerlet) f |= 4u;
+  if (-x1 - r + P.Mdx < P.distVerlet) f |= 8u;
+  return (unsigned char)f;
+}
+
+// MODE 0: count partners; MODE 1: write them (then sort ascending), clamp the offsets, wall flags -- one thread per grain
 template <int MODE>
 __global__ void k_verlet_scan(int n, const real* __restrict__ x1, const real* __restrict__ x2,
                               const real* __restrict__ r, real ox, real oy, real cs, int ncx, int ncy,
-                              const int* __restrict__ cell_start, const int* __restrict__ cell_end,
+                              const int* __restrict__ cell_start,
                               const int* __restrict__ sorted, real dV, int* __restrict__ counts,
-                              const int* __restrict__ offsets, int* __restrict__ nbr, int* __restrict__ own,
-                              long cap, int* __restrict__ overflow) {
+                              int* __restrict__ offsets, int* __restrict__ nbr, int* __restrict__ own,
+                              long cap, int* __restrict__ overflow, DemParams P, unsigned char* __restrict__ wallflags) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const real xi = x1[i], yi = x2[i], ri = r[i];
   const int cx = cell_coord(xi, ox, cs, ncx), cy = cell_coord(yi, oy, cs, ncy);
   int cnt = 0;
-  const int base = MODE ? offsets[i] : 0;
+  int base = 0;
+  if (MODE) {
+    // offsets[] arrives as the plain exclusive sum of the counts. A list longer than the allocation is truncated (and
+    // flagged): no kernel may index nbr[] / own[] past `cap`, so every grain clamps its own offset, and the last grain
+    // writes the total (before: two more launches, k_set_last_offset and k_clamp_offsets)
+    const long raw = offsets[i];
+    if (i == n - 1) {
+      const long total = raw + counts[i];
+      if (total > cap) *overflow = 1;
+      offsets[n] = (int)(total > cap ? cap : total);
+    }
+    if (raw > cap) { offsets[i] = (int)cap; *overflow = 1; }
+    base = (int)(raw > cap ? cap : raw);
+    wallflags[i] = wall_flags_of(xi, yi, ri, P);   // VerletWall's four candidate lists (main.c:1563-1593)
+  }
   for (int yy = cy - 1; yy <= cy + 1; ++yy) {
     if (yy < 0 || yy >= ncy) continue;
     for (int xx = cx - 1; xx <= cx + 1; ++xx) {
       if (xx < 0 || xx >= ncx) continue;
       const int c = yy * ncx + xx;
-      const int s = cell_start[c], e = cell_end[c];
+      const int s = cell_start[c], e = cell_start[c + 1];
       for (int k = s; k < e; ++k) {
         const int j = sorted[k];
         if (j == i) continue;
@@ -686,44 +721,11 @@ __global__ void k_verlet_scan(int n, const real* __restrict__ x1, const real* __
   }
 }
 
-// wall candidate lists as per-grain flags: main.c:1563-1593
-__global__ void k_wall_flags(int n, const real* __restrict__ x1, const real* __restrict__ x2,
-                             const real* __restrict__ r, DemParams P, unsigned char* __restrict__ flags) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  unsigned f = 0;
-  if (x2[i] - r[i] - P.Mby < P.distVerlet) f |= 1u;
-  if (-x2[i] - r[i] + P.Mhy < P.distVerlet) f |= 2u;
-  if (x1[i] - r[i] - P.Mgx < P.distVerlet) f |= 4u;
-  if (-x1[i] - r[i] + P.Mdx < P.distVerlet) f |= 8u;
-  flags[i] = (unsigned char)f;
-}
-
 // owner of every list entry, from the offsets (after a checkpoint load; k_verlet_scan<1> writes it directly)
 __global__ void k_fill_own(int n, const int* __restrict__ offsets, int* __restrict__ own) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   for (int k = offsets[i]; k < offsets[i + 1]; ++k) own[k] = i;
-}
-
-__global__ void k_set_last_offset(int n, const int* __restrict__ counts, int* __restrict__ offsets) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n] = offsets[n - 1] + counts[n - 1];
-}
-
-// A list longer than the allocation is truncated (and flagged): no kernel may index nbr[] / own[] past `cap`.
-__global__ void k_clamp_offsets(int n, int* __restrict__ offsets, long cap, int* __restrict__ overflow) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i > n) return;
-  if ((long)offsets[i] > cap) {
-    offsets[i] = (int)cap;
-    *overflow = 1;
-  }
-}
-
-inline int key_bits(int ncells) {
-  int b = 1;
-  while ((1L << b) < ncells) ++b;
-  return b;
 }
 
 }  // namespace
@@ -768,20 +770,22 @@ int verlet_alloc(VerletDevice& V, int n, real cs, real ox, real oy, real wx, rea
   V.cap = (long)n * 32;
   hipError_t e = hipSuccess;
   auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 16); };
-  A((void**)&V.keys_in, sizeof(unsigned) * n); A((void**)&V.keys_out, sizeof(unsigned) * n);
-  A((void**)&V.vals_in, sizeof(int) * n); A((void**)&V.vals_out, sizeof(int) * n);
-  A((void**)&V.cell_start, sizeof(int) * ncell); A((void**)&V.cell_end, sizeof(int) * ncell);
+  A((void**)&V.keys_in, sizeof(unsigned) * n);                                  // cell of grain i
+  A((void**)&V.vals_in, sizeof(int) * n); A((void**)&V.vals_out, sizeof(int) * n);   // rank within its cell; grains by cell
+  // cell_start[0 .. ncell] (exclusive scan of the counts), cell_end[0 .. ncell] = the per-cell counts (zero between rebuilds)
+  A((void**)&V.cell_start, sizeof(int) * (ncell + 1)); A((void**)&V.cell_end, sizeof(int) * (ncell + 1));
   A((void**)&V.counts, sizeof(int) * n); A((void**)&V.offsets, sizeof(int) * (n + 1));
   A((void**)&V.nbr, sizeof(int) * V.cap); A((void**)&V.own, sizeof(int) * V.cap); A((void**)&V.wallflags, n);
   A((void**)&V.overflow, sizeof(int));
   if (e != hipSuccess) return -1;
-  V.sort_tmp_bytes = 0;
-  if (hipcub::DeviceRadixSort::SortPairs(nullptr, V.sort_tmp_bytes, V.keys_in, V.keys_out, V.vals_in, V.vals_out, n, 0,
-                                         key_bits((int)ncell)) != hipSuccess) return -1;
   V.scan_tmp_bytes = 0;
+  size_t cells_tmp = 0;
   if (hipcub::DeviceScan::ExclusiveSum(nullptr, V.scan_tmp_bytes, V.counts, V.offsets, n) != hipSuccess) return -1;
-  A(&V.sort_tmp, V.sort_tmp_bytes); A(&V.scan_tmp, V.scan_tmp_bytes);
+  if (hipcub::DeviceScan::ExclusiveSum(nullptr, cells_tmp, V.cell_end, V.cell_start, (int)(ncell + 1)) != hipSuccess) return -1;
+  if (cells_tmp > V.scan_tmp_bytes) V.scan_tmp_bytes = cells_tmp;
+  A(&V.scan_tmp, V.scan_tmp_bytes);
   if (e != hipSuccess) return -1;
+  if (hipMemset(V.cell_end, 0, sizeof(int) * (ncell + 1)) != hipSuccess) return -1;
   if (hipMemset(V.offsets, 0, sizeof(int) * (n + 1)) != hipSuccess) return -1;
   if (hipMemset(V.wallflags, 0, n) != hipSuccess) return -1;
   if (hipMemset(V.overflow, 0, sizeof(int)) != hipSuccess) return -1;
@@ -791,7 +795,7 @@ int verlet_alloc(VerletDevice& V, int n, real cs, real ox, real oy, real wx, rea
 }
 
 void verlet_free(VerletDevice& V) {
-  void* ps[] = {V.keys_in, V.keys_out, V.vals_in, V.vals_out, V.cell_start, V.cell_end, V.sort_tmp,
+  void* ps[] = {V.keys_in, V.vals_in, V.vals_out, V.cell_start, V.cell_end,
                 V.scan_tmp, V.counts, V.offsets, V.nbr, V.own, V.wallflags, V.overflow};
   for (void* p : ps) if (p) (void)hipFree(p);
   V = VerletDevice{};
@@ -803,25 +807,22 @@ int launch_verlet_rebuild(VerletDevice& V, const Kin& K, const real* r, const De
   const int n = P.n;
   const int nb = (n + 255) / 256;
   const size_t ncell = (size_t)V.ncx * V.ncy;
-  hipLaunchKernelGGL(k_cell_keys, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, V.ox, V.oy, V.cs, V.ncx, V.ncy,
-                     V.keys_in, V.vals_in);
-  e = hipcub::DeviceRadixSort::SortPairs(V.sort_tmp, V.sort_tmp_bytes, V.keys_in, V.keys_out, V.vals_in, V.vals_out, n, 0,
-                                         key_bits((int)ncell), st);
-  if (e == hipSuccess) e = hipMemsetAsync(V.cell_start, 0, sizeof(int) * ncell, st);
-  if (e == hipSuccess) e = hipMemsetAsync(V.cell_end, 0, sizeof(int) * ncell, st);
+  // 9 dependent launches (20 before the counting sort and the folded offset / wall-flag kernels: a rebuild is launch
+  // latency, 130 us per 100 DEM steps for a few us of work)
+  hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, V.ox, V.oy, V.cs, V.ncx, V.ncy,
+                     V.keys_in, V.vals_in, V.cell_end);
+  e = hipcub::DeviceScan::ExclusiveSum(V.scan_tmp, V.scan_tmp_bytes, V.cell_end, V.cell_start, (int)(ncell + 1), st);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(k_cell_bounds, dim3(nb), dim3(256), 0, st, n, V.keys_out, V.cell_start, V.cell_end);
+  hipLaunchKernelGGL(k_cell_scatter, dim3(nb), dim3(256), 0, st, n, V.keys_in, V.vals_in, V.cell_start, V.cell_end,
+                     V.vals_out);
   hipLaunchKernelGGL(k_verlet_scan<0>, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, r, V.ox, V.oy, V.cs, V.ncx,
-                     V.ncy, V.cell_start, V.cell_end, V.vals_out, P.distVerlet, V.counts, V.offsets, V.nbr,
-                     V.own, V.cap, V.overflow);
+                     V.ncy, V.cell_start, V.vals_out, P.distVerlet, V.counts, V.offsets, V.nbr,
+                     V.own, V.cap, V.overflow, P, V.wallflags);
   e = hipcub::DeviceScan::ExclusiveSum(V.scan_tmp, V.scan_tmp_bytes, V.counts, V.offsets, n, st);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(k_set_last_offset, dim3(1), dim3(1), 0, st, n, V.counts, V.offsets);
-  hipLaunchKernelGGL(k_clamp_offsets, dim3(n / 256 + 1), dim3(256), 0, st, n, V.offsets, V.cap, V.overflow);
   hipLaunchKernelGGL(k_verlet_scan<1>, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, r, V.ox, V.oy, V.cs, V.ncx,
-                     V.ncy, V.cell_start, V.cell_end, V.vals_out, P.distVerlet, V.counts, V.offsets, V.nbr,
-                     V.own, V.cap, V.overflow);
-  hipLaunchKernelGGL(k_wall_flags, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, r, P, V.wallflags);
+                     V.ncy, V.cell_start, V.vals_out, P.distVerlet, V.counts, V.offsets, V.nbr,
+                     V.own, V.cap, V.overflow, P, V.wallflags);
   return (int)hipGetLastError();
 }
 
@@ -885,14 +886,14 @@ void launch_dem_substep(const Kin& in, const Kin& out, const real* r, const real
     int extra = 0;
     if (fill.map && fill.row1 > fill.row0) {   // ~8 16-byte stores per thread, at most one workgroup per CU
       const long v4 = (long)(fill.row1 - fill.row0) * fill.L.sy / 4;
-      extra = (int)((v4 + 256 * 8 - 1) / (256 * 8));
+      extra = (int)((v4 + DEM_THREADS * 8 - 1) / (DEM_THREADS * 8));
       if (extra > 256) extra = 256;
     }
     if (film)
-      hipLaunchKernelGGL(k_dem_entries<true>, dim3(DEM_GRID(nbe) + extra), dim3(256), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
+      hipLaunchKernelGGL(k_dem_entries<true>, dim3(DEM_GRID(nbe) + extra), dim3(DEM_THREADS), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
                          V.own, V.wallflags, pout, P, active, T, stamp, owner, fill, nbe);
     else
-      hipLaunchKernelGGL(k_dem_entries<false>, dim3(DEM_GRID(nbe) + extra), dim3(256), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
+      hipLaunchKernelGGL(k_dem_entries<false>, dim3(DEM_GRID(nbe) + extra), dim3(DEM_THREADS), 0, st, in, out, r, m, It, fhf, V.offsets, V.nbr,
                          V.own, V.wallflags, pout, P, active, T, stamp, owner, fill, nbe);
     return;
   }

@@ -242,10 +242,9 @@ struct VerletDevice {
   // uniform grid
   int ncx, ncy;
   real ox, oy, cs;
-  unsigned int* keys_in; unsigned int* keys_out;
-  int* vals_in; int* vals_out;
-  int* cell_start; int* cell_end;
-  void* sort_tmp; size_t sort_tmp_bytes;
+  unsigned int* keys_in;          // [n] cell of grain i
+  int* vals_in; int* vals_out;    // [n] arrival rank within the cell; [n] the grains ordered by cell
+  int* cell_start; int* cell_end; // [ncell + 1] first grain of cell c in vals_out (.. [ncell] = n); per-cell counts (0 between rebuilds)
   void* scan_tmp; size_t scan_tmp_bytes;
   // symmetric CSR neighbour list, partners ascending
   int* counts;   // n
