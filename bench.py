@@ -19,6 +19,11 @@ send/recv inside the library, no Python on the step path) after a watchdogged tr
 that this transport works on this node and reproduces the single-domain bits; otherwise the torch.distributed strip
 driver is measured instead -- `config.driver` says which one ran.
 
+Before the W warm-up steps the same run advances `--settle` (default 40) further untimed steps, reported as
+`config.settle_steps`: a load that starts on an idle GPU sees the chip's power management dip a few milliseconds in (all
+kernels ~10 % slower during roughly steps 4-10 of a run, profiles/r04_g_step_trace.jsonl), which a short warm-up would end
+in the middle of. The timed region is exactly K steps either way; `--settle 0` switches it off.
+
 Output: one JSON line on rank 0. `value` = lattice-node updates of the whole job per second / 1e6
 with all state resident in HBM. `roofline` prices the dominant kernel (k_collide_stream) from HIP
 events recorded on its own stream; `cpu_baseline` times the reference's serial C path (prebuilt
@@ -270,6 +275,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)     # >= 200 timed steps after 20 warm-up
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle", type=int, default=40,
+                    help="untimed coupled steps of the same run BEFORE the --warmup steps (reported as config.settle_steps): "
+                         "under a load that starts from idle the GPU's power management first dips -- every kernel, fused or "
+                         "tiny, runs ~10 %% slower during roughly the 4th to 10th millisecond (profiles/r04_g_step_trace.jsonl) "
+                         "-- and a 5-step warm-up ends in the middle of that; 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-mode", type=int, default=0, help="0 = parity hydro-force kernel, 1 = fast")
     ap.add_argument("--workload", choices=["metric", "configs4", "real50k"], default="metric",
@@ -392,6 +402,9 @@ def main():
         barrier = dist.barrier
         reduce_dev = ctl
 
+    if args.settle > 0:
+        run_steps(args.settle)   # clocks settle (see --settle); the run simply starts its timed steps later
+        sync()
     run_steps(args.warmup)
     sync()
     sim.profile_enable(True)
@@ -481,6 +494,7 @@ def main():
             "config": {"workload": w["name"], "lx": lx, "ly": ly, "grains": int(len(r)), "npDEM": int(npdem),
                        "step": "1 fluid step + npDEM DEM sub-steps (+ Verlet rebuild every 100 DEM steps)",
                        "force_kernel": "parity" if args.force_mode == 0 else "fast",
+                       "settle_steps": args.settle,   # untimed steps of this run before the warm-up (GPU clocks; see --settle)
                        "driver": None if runner is None else ("C (lbmdem_comm_run, RCCL send/recv inside the library)" if
                                                                 isinstance(runner, strips.CCommRunner) else "torch.distributed (strips.py)"),
                        "driver_trial": None if runner is None else driver_note,
