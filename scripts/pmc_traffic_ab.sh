@@ -1,5 +1,7 @@
 # HBM traffic of the fused kernel for several env settings of the experiment build (calibration as pmc_traffic.sh)
 # usage: bash scripts/pmc_traffic_ab.sh "<env1>" "<env2>" ...
+# (the calibration binary is git-ignored: built where it is missing)
+[ -x $GRAFT_REPO_ROOT/scripts/micro/stream_pattern ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $GRAFT_REPO_ROOT/scripts/micro/stream_pattern $GRAFT_REPO_ROOT/scripts/micro/stream_pattern.hip
 cd /tmp && export TMPDIR=/tmp
 export LBMDEM_HIP_LIBRARY=${LBMDEM_HIP_LIBRARY:-$GRAFT_REPO_ROOT/2d-lbm-dem_amd/liblbmdem_hip_ab.so}
 O=$GRAFT_REPO_ROOT/gpurun_out/traffic_ab; rm -rf $O; mkdir -p $O
