@@ -11,7 +11,9 @@
 //    is exactly the order in which the reference's serial loop accumulates into a grain.
 //
 //  * Verlet list (main.c:1519-1594): the reference tests all N^2/2 pairs. Here grains are binned on
-//    a uniform grid (cell = 2 r_max + distVerlet), sorted by cell with a radix sort (hipCUB), and each
+//    a uniform grid (cell = 2 r_max + distVerlet), sorted by cell with a one-digit radix sort of our own (the cell index
+//    is the digit: histogram with arrival ranks, hipCUB exclusive scan, scatter -- 4 launches; hipCUB's pair sort took 7
+//    at 50 000 keys and a rebuild is launch latency), and each
 //    grain scans its 3x3 cells with the reference's three predicates (main.c:1529-1532) evaluated
 //    in the (i < j) frame -> the same pair set. The list is kept symmetric (CSR, partners ascending).
 //
@@ -613,7 +615,7 @@ __device__ __forceinline__ int cell_coord(real x, real o, real cs, int nc) {
   return c < 0 ? 0 : (c >= nc ? nc - 1 : c);
 }
 
-// Grains by cell, as a counting sort (round 4; before: hipCUB radix sort of (cell, grain) pairs = 7 launches at this size,
+// Grains by cell, as a counting sort = a radix sort with the whole cell index as its one digit (round 4; before: hipCUB radix sort of (cell, grain) pairs = 7 launches at this size,
 // two memsets and a bounds kernel): k_cell_count leaves every grain's cell and its arrival rank within the cell,
 // an exclusive scan of the per-cell counts gives cell_start[0 .. ncell] (cell c = [cell_start[c], cell_start[c + 1])), and
 // k_cell_scatter writes the grain to its place and returns the count to zero for the next rebuild. The order of the grains

@@ -249,7 +249,10 @@ constexpr unsigned long long M_DIAG = 0x5555555555555555ull;  // bits of q = 1, 
 constexpr unsigned long long M_XDIR = 0x2222222222222222ull;  // q = 2, 6 (ey = 0)
 constexpr unsigned long long M_YDIR = 0x8888888888888888ull;  // q = 4, 8 (ex = 0)
 
-constexpr int FT_WAVES = 4;  // waves per workgroup of k_forces_table
+#ifndef LBMDEM_FT_WAVES
+#define LBMDEM_FT_WAVES 4
+#endif
+constexpr int FT_WAVES = LBMDEM_FT_WAVES;  // waves per workgroup of k_forces_table
 
 // FT_PACK takes both neighbours in one launch: blockIdx.y = side (0 low, 1 high); a null buffer skips the side
 struct PackSides { const int* list[2]; const int* count[2]; real* buf[2]; };

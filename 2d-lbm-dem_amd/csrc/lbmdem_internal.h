@@ -257,7 +257,7 @@ struct VerletDevice {
 };
 int verlet_alloc(VerletDevice& V, int n, real cs, real ox, real oy, real wx, real wy);
 void verlet_free(VerletDevice& V);
-// returns 0 or the hipError_t of the failing call (hipCUB sort / scan, memset, launch)
+// returns 0 or the hipError_t of the failing call (hipCUB scan, launch)
 int launch_verlet_rebuild(VerletDevice& V, const Kin& K, const real* r, const DemParams& P,
                           hipStream_t st);
 // Buffers of the order-dependent contact diagnostics fr, ice, slip, rw (main.c:782-789, 840-843, 851, 893,
