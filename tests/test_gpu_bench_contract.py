@@ -29,6 +29,16 @@ def test_single_process_line():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["warmup"] == 1 and d["config"]["settle_steps"] == 40      # the untimed steps before the warm-up are reported
+
+
+def test_settle_steps_can_be_switched_off():
+    """--settle 0: no untimed steps before the W warm-up steps (the timed region is K steps either way)"""
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--settle", "0", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-500:]
+    d = _last_json(out.stdout)
+    assert d["steps"] == 3 and d["config"]["settle_steps"] == 0 and d["value"] > 1000
 
 
 def test_launcher_path_one_rank():
