@@ -1,6 +1,7 @@
 # usage: bash scripts/pmc_kernel.sh <tag> <kernel-substring> "<counters>"
 tag=$1; pat=$2; ctrs=$3
 cd /tmp && export TMPDIR=/tmp
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmck_$tag   # (a pass whose counters do not exist must not read the previous pass's file)
 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmck_$tag -o $tag -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python - <<PY
 import csv,glob,collections
