@@ -5,7 +5,7 @@ import csv, sys, json
 
 def short(n):
     for k in ("k_cs_march", "k_forces_table", "k_forces_gather_queue", "k_obst_paint", "k_obst_fill", "k_dem_entries",
-              "k_verlet_scan", "k_cell_keys", "k_wall_flags"):
+              "k_verlet_scan", "k_cell_count", "k_cell_scatter"):
         if k in n:
             return k
     return "other"
@@ -36,7 +36,7 @@ for i, st in enumerate(steps[:-1]):
                 "table": round(sum(d.get("k_forces_table", [0])), 1), "queue": round(sum(d.get("k_forces_gather_queue", [0])), 1),
                 "dem_sum": round(sum(dem), 1), "dem_n": len(dem), "dem_min": round(min(dem), 1) if dem else 0,
                 "dem_max": round(max(dem), 1) if dem else 0, "n_launch": len(st["k"]),
-                "other": round(sum(sum(v) for k, v in d.items() if k in ("other", "k_verlet_scan", "k_cell_keys", "k_wall_flags", "k_obst_fill")), 1)})
+                "other": round(sum(sum(v) for k, v in d.items() if k in ("other", "k_verlet_scan", "k_cell_count", "k_cell_scatter", "k_obst_fill")), 1)})
 lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (0, len(out))
 for o in out[lo:hi]:
     print(json.dumps(o))
