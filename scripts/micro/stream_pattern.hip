@@ -101,6 +101,14 @@ int main() {
   MARCHL(32, 1, 76800, "march LX32 62/64 16-node tiles     2 workgroups/CU");
   MARCHL(16, 0, 76800, "march LX16 62/64 planes            2 workgroups/CU");
   MARCHL(16, 1, 76800, "march LX16 62/64 16-node tiles     2 workgroups/CU");
+  // producing lanes per window, tile layout, the real kernel's occupancy: 62 (round 1-4), 60 (stores on 32-byte sector boundaries), 56 (64-byte)
+#define MARCHU(LX, USE, OFF, SHM, NAME) { const int ns = (ly + USE - 1) / USE, nseg = (lx + LX - 1) / LX, nw = ns * nseg; int g = ((nw + 3) / 4 + 7) / 8 * 8; \
+    rep(NAME, timeit([&] { hipLaunchKernelGGL((k_march<LX, USE, OFF, 0, 1, 1>), dim3(g), dim3(256), SHM, 0, a, b, lx, ly, plane, ns, nw, 1); })); }
+  MARCHU(32, 62, 1, 76800, "march LX32 62/64 off-1 tiles       2 workgroups/CU");
+  MARCHU(32, 60, 2, 76800, "march LX32 60/64 off-2 tiles       2 workgroups/CU");
+  MARCHU(32, 56, 4, 76800, "march LX32 56/64 off-4 tiles       2 workgroups/CU");
+  MARCHU(32, 62, 1, 76800, "march LX32 62/64 off-1 tiles       2 workgroups/CU (again)");
+  MARCHU(32, 60, 2, 76800, "march LX32 60/64 off-2 tiles       2 workgroups/CU (again)");
   // aligned 64-lane windows (idea: seam columns through LDS), with and without a workgroup barrier per row
 #define MARCHS(LX, SYNC, SHM, NAME) { const int ns = ly / 64, nseg = (lx + LX - 1) / LX, nw = ns * nseg; int g = ((nw + 3) / 4 + 7) / 8 * 8; \
     rep(NAME, timeit([&] { hipLaunchKernelGGL((k_march<LX, 64, 0, 0, 1, 1, SYNC>), dim3(g), dim3(256), SHM, 0, a, b, lx, ly, plane, ns, nw, 1); })); }
