@@ -128,6 +128,8 @@ def _open_library(LIB_PATH):
     L.lbmdem_checkpoint_save.argtypes = [C.c_void_p, C.c_char_p]
     L.lbmdem_checkpoint_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     L.lbmdem_set_force_mode.argtypes = [C.c_void_p, C.c_int]
+    L.lbmdem_set_dem_chain.argtypes = [C.c_void_p, C.c_int]
+    L.lbmdem_dem_chain_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lbmdem_set_lid.argtypes = [C.c_void_p, C.c_double]
     L.lbmdem_force_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lbmdem_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -501,6 +503,16 @@ class LbmDem:
 
     def set_force_mode(self, mode):
         _chk(self._L.lbmdem_set_force_mode(self._h, int(mode)))
+
+    def set_dem_chain(self, max_substeps):
+        """Longest run of ordinary sub-steps renderScene hands to ONE launch (< 2: one launch per sub-step)."""
+        _chk(self._L.lbmdem_set_dem_chain(self._h, int(max_substeps)))
+
+    def dem_chain_stats(self):
+        """(launches, sub-steps covered, tile slots a launch needs resident, slots the census found; -1 = not taken)"""
+        a, b, c, d = C.c_long(0), C.c_long(0), C.c_int(0), C.c_int(0)
+        _chk(self._L.lbmdem_dem_chain_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
 
     def force_stats(self):
         """(grains summed from the fused kernel's link table, grains gathered from the lattice) of the last

@@ -400,6 +400,447 @@ __global__ __launch_bounds__(DEM_THREADS) void k_dem_entries(Kin in, Kin out, co
 }
 
 // ---------------------------------------------------------------------------------------------
+// Several sub-steps in ONE launch
+// ---------------------------------------------------------------------------------------------
+//
+// A sub-step of k_dem_entries costs ~8 us of which ~2 are arithmetic: the rest is the dependent launch and three
+// dependent rounds of memory loads, and npDEM (12) of them sit between two fluid steps. k_dem_chain runs a whole run of
+// ordinary sub-steps (regular contact law, no diagnostics, no list rebuild in between) in one launch:
+//   * a workgroup owns the same tile of 64 consecutive grains for the whole launch; the first wavefront keeps their
+//     kinematics in registers from sub-step to sub-step;
+//   * what a sub-step needs of OTHER tiles -- the drifted state (x1, x2, v1, v2, v3: main.c:1748-1753) of the tile's
+//     "halo" grains, the distinct partners outside the tile that k_tile_halo listed after the last list rebuild -- travels
+//     through `pub`: per grain and parity of the sub-step one 128-byte line of five 16-byte slots {lo, tag, hi, tag}, tag =
+//     the sub-step's sequence number. Stores are write-through (sc1), loads bypass the L1 (sc1): the per-XCD L2s are not
+//     coherent with each other and an L1 never sees another CU's stores. Each 8-byte half carries its own tag, so the
+//     data is its own flag: a reader re-reads a slot until both tags match -- no flag round trip, no fence, no grid
+//     barrier; a tile only ever waits for the tiles of its own partners.
+//   * TWO copies of every line. 782 tiles polling ~135 lines each through the fabric cost 17 us per sub-step (first
+//     version, profiles/r05_dem_chain_ab.txt). Tiles are laid out in contiguous eighths per XCD (block b runs on XCD
+//     b % 8 -- observed, not promised), so nearly all partners of a tile run on its own XCD, whose L2 IS coherent for
+//     them: the LOCAL copy is written with plain stores (they stay in that L2) and read with L1-bypassing loads (L2 hits),
+//     the REMOTE copy is written through to memory (sc1) for the readers on other XCDs. A reader picks the copy by the
+//     XCD the partner's tile is expected on, and switches an item to the remote copy when the local one stays stale
+//     (a workgroup that did not land where expected). The tags make a wrong guess slow, never wrong.
+//   * two parities suffice: a tile overwrites its sub-step s-1 line in sub-step s+1, i.e. after it has read the sub-step s
+//     state of every halo grain, which their tiles published after they had finished reading for sub-step s-1 (the list
+//     is symmetric: whoever reads this tile is read by it).
+//   * the drifted state is computed ONCE, by the owner, with the arithmetic every partner used to repeat (advance()):
+//     same bits. Phase 1 / phase 2 are those of k_dem_entries, fed from LDS.
+// Every spin is bounded; a tile that gives up poisons its lines so that its partners give up at once, and raises the
+// handle's error flag. All workgroups of the tile slots must be resident together (checked once per handle by a census
+// launch of the same kernel, dem_chain_census).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CH_SLOTS = DEM_TILE + DEM_CHAIN_HALO;   // grains staged in LDS: the tile's own, then its halo
+constexpr int CH_ENTRIES = 384;                       // list entries staged per round (k_dem_entries: DEM_ENTRIES)
+constexpr int CH_META = 768;                          // list entries whose emeta word is kept in LDS
+constexpr int CH_ITEMS = 3;                          // 16-byte slots a lane has in flight per pass of the halo fetch (153 grains)
+constexpr unsigned CH_SPINS = 1u << 18;
+constexpr unsigned CH_LOCAL_SPINS = 1u << 11;        // polls of a local copy before the item turns to the remote one
+constexpr unsigned CH_POISON = 0xFFFFFFFEu;
+constexpr unsigned CH_SKIP = 0xFFFFFFFFu;             // emeta of an entry nobody adds up (its grain is not integrated here)
+
+__host__ __device__ __forceinline__ unsigned chain_tag(long long seq) {   // 1 .. 2^31 - 3, consecutive sub-steps differ (| 2^31: a launch's static tag, never CH_POISON)
+  return (unsigned)((unsigned long long)seq % 0x7FFFFFFDull) + 1u;
+}
+
+struct ChainRead { real x1, x2, v1, v2, v3; };
+
+// one 16-byte slot straight from memory (a partner beyond the staged halo; rare): bounded spin
+__device__ __forceinline__ bool chain_read_slot(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, unsigned stag, real& out) {
+  unsigned spins = 0;
+#pragma nounroll
+  for (;;) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+    if (v.y == CH_POISON || v.w == CH_POISON || ++spins > CH_SPINS) return false;
+    if ((v.y == tag || v.y == stag) && (v.w == tag || v.w == stag)) {
+      out = __longlong_as_double((long long)(((unsigned long long)v.z << 32) | v.x));
+      return true;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+__device__ __forceinline__ bool chain_read_direct(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, unsigned stag,
+                                                  ChainRead& R) {
+  return chain_read_slot(rs, off, tag, stag, R.x1) && chain_read_slot(rs, off + 16u, tag, stag, R.x2) &&
+         chain_read_slot(rs, off + 32u, tag, stag, R.v1) && chain_read_slot(rs, off + 48u, tag, stag, R.v2) &&
+         chain_read_slot(rs, off + 64u, tag, stag, R.v3);
+}
+
+template <int AUX>   // 0: plain store (stays in the XCD's L2), 16 = sc1: written through to memory
+__device__ __forceinline__ void chain_publish(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, real x1, real x2,
+                                              real v1, real v2, real v3) {
+  const real val[5] = {x1, x2, v1, v2, v3};
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong((double)val[k]);
+    u32x4 v; v.x = (unsigned)b; v.y = tag; v.z = (unsigned)(b >> 32); v.w = tag;
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, off + 16u * k, 0, AUX);
+  }
+}
+
+__global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, const real* __restrict__ r,
+                                                           const real* __restrict__ m, const real* __restrict__ It,
+                                                           const real* __restrict__ fhf, const int* __restrict__ offsets,
+                                                           const int* __restrict__ nbr, const unsigned* __restrict__ emeta,
+                                                           const int* __restrict__ halo_ids,
+                                                           const int* __restrict__ halo_cnt,
+                                                           const unsigned char* __restrict__ wallflags,
+                                                           real* __restrict__ pout, DemParams P,
+                                                           const unsigned char* __restrict__ active, CarryTrack T,
+                                                           long long stamp0, const unsigned char* __restrict__ owner,
+                                                           ObstFillJob fill, int tiles, int nsteps, void* pub,
+                                                           unsigned pub_bytes, int* __restrict__ err, int* census,
+                                                           long long* dbg, int one_xcd) {
+  __shared__ real sF1[CH_ENTRIES], sF2[CH_ENTRIES], sF3[CH_ENTRIES], sFn[CH_ENTRIES];
+  __shared__ unsigned char sTouched[CH_ENTRIES];
+  __shared__ real sS[5 * CH_SLOTS];     // drifted x1, x2, v1, v2, v3 of the staged grains, one array per field
+  __shared__ real sR[CH_SLOTS];
+  __shared__ unsigned sMeta[CH_META];
+  __shared__ unsigned char sFlag[DEM_TILE];   // bit 0: integrated here, bit 1: owned (records its contacts)
+  __shared__ unsigned sHoff[DEM_CHAIN_HALO];  // the halo grains' lines in `pub` (byte offset within a parity)
+  // per grain of the tile, kept out of the registers: the angle (no contact needs it), the hydrodynamic force, 1 / the
+  // inertia terms' divisors and the gravity terms
+  __shared__ real sX3[DEM_TILE], sFh[3 * DEM_TILE], sMI[2 * DEM_TILE], sG[2 * DEM_TILE];
+  __shared__ int sLast, sFail;
+  const int tid = threadIdx.x;
+  // one_xcd: every eighth block is a tile (they all land on one XCD, whose L2 then carries every hand-off), the others idle
+  const int tslots = one_xcd ? tiles * 8 : ((tiles + 7) / 8) * 8;
+  if ((int)blockIdx.x >= tslots) {   // the workgroups behind the tile slots reset a slice of the next obstacle map
+    obst_fill_range(fill.map, fill.L, (long)(blockIdx.x - tslots) * DEM_THREADS + tid, (long)(gridDim.x - tslots) * DEM_THREADS, fill.row0, fill.row1);
+    return;
+  }
+  if (nsteps < 0) {   // census: do all tile slots run at the same time?
+    if (tid == 0) {
+      __hip_atomic_fetch_add(census, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      while (__hip_atomic_load(census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tslots) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 15)) { *err = 1; break; }
+      }
+    }
+    return;
+  }
+  if (one_xcd && ((int)blockIdx.x & 7) != 0) return;
+  const int tile = one_xcd ? (int)blockIdx.x >> 3 : ((int)blockIdx.x & 7) * (tslots >> 3) + ((int)blockIdx.x >> 3);   // as in k_dem_entries
+  if (tile >= tiles) return;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pub, 0, (int)pub_bytes, 0x00020000);
+  const unsigned line_par = (unsigned)P.n * 128u;   // bytes between the two parities
+  const unsigned remote = 2u * line_par;            // ... and between the local and the remote copy
+  // Workgroups go to the XCDs round-robin, CONTINUING where the launch before stopped (measured: block b on XCD
+  // (b + k) % 8 with k fixed per launch), so two blocks share an XCD iff their indices agree mod 8 -- the tiles of one
+  // contiguous eighth. Nothing promises it: a local copy that stays stale is given up for the remote one.
+  const int tiles_per_xcd = tslots >> 3;
+#ifdef LBMDEM_AB
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const bool placed = true;
+#endif
+  const int g0 = tile * DEM_GRAINS;
+  const int g1 = g0 + DEM_GRAINS < P.n ? g0 + DEM_GRAINS : P.n;
+  const int i = g0 + tid;
+  const bool have = tid < DEM_GRAINS && i < P.n;
+  const bool mine = have && (!active || active[i]);
+  const unsigned tag0 = chain_tag(stamp0), stag = 0x80000000u | tag0;
+  // the grains of this tile, as the previous sub-step left them
+  real x1 = 0., x2 = 0., v1 = 0., v2 = 0., v3 = 0., a1 = 0., a2 = 0., a3 = 0.;
+  if (have) {
+    sX3[tid] = in.x3[i];
+    x1 = in.x1[i]; x2 = in.x2[i]; v1 = in.v1[i]; v2 = in.v2[i]; v3 = in.v3[i];
+    a1 = in.a1[i]; a2 = in.a2[i]; a3 = in.a3[i];
+  }
+  if (active && !__syncthreads_or(mine ? 1 : 0)) {
+    // nobody here is integrated by this rank: the state stands for the whole launch (both parities, the launch's static
+    // tag), and follows the ping-pong of the buffers
+    if (have) {
+      for (unsigned par = 0; par < 2; ++par) {
+        chain_publish<0>(rs, par * line_par + (unsigned)i * 128u, stag, x1, x2, v1, v2, v3);
+        chain_publish<16>(rs, remote + par * line_par + (unsigned)i * 128u, stag, x1, x2, v1, v2, v3);
+      }
+      out.x1[i] = x1; out.x2[i] = x2; out.x3[i] = sX3[tid]; out.v1[i] = v1; out.v2[i] = v2; out.v3[i] = v3;
+      out.a1[i] = a1; out.a2[i] = a2; out.a3[i] = a3;
+    }
+    return;
+  }
+  const int e0 = offsets[g0], e1 = offsets[g1];
+  const int hcnt = halo_cnt[tile];
+  const int nitems = hcnt * 5;
+  for (int h = tid; h < hcnt; h += DEM_THREADS) {
+    const int g = halo_ids[(long)tile * DEM_CHAIN_HALO + h];
+    // bit 0: read the remote copy (the grain's tile is expected on another XCD)
+    sHoff[h] = (unsigned)g * 128u | ((!one_xcd && (g / DEM_TILE) / tiles_per_xcd != tile / tiles_per_xcd) ? 1u : 0u);
+    sR[DEM_TILE + h] = r[g];
+  }
+  for (int k = tid; k < CH_META && e0 + k < e1; k += DEM_THREADS) {
+    unsigned w = emeta[e0 + k];
+    if (active && !active[g0 + (int)(w & 63u)]) w = CH_SKIP;
+    sMeta[k] = w;
+  }
+  real pr = 0.0;
+  int k0 = 0, k1 = 0;
+  unsigned wf = 0;
+  if (tid < DEM_GRAINS) {
+    sR[tid] = have ? r[i] : (real)0.;
+    sFlag[tid] = (unsigned char)((mine ? 1 : 0) | ((mine && (!owner || owner[i])) ? 2 : 0));
+  }
+  if (mine) {
+    sFh[tid] = fhf[i]; sFh[DEM_TILE + tid] = fhf[P.n + i]; sFh[2 * DEM_TILE + tid] = fhf[2 * P.n + i];   // main.c:1429-1431: constant between two fluid steps
+    k0 = offsets[i]; k1 = offsets[i + 1];
+    wf = wallflags[i];
+    const real mi = m[i], mw = 0.0;
+    sMI[tid] = mi; sMI[DEM_TILE + tid] = It[i];
+    // main.c:1511-1512: the gravity term of a grain's acceleration does not change from sub-step to sub-step
+    sG[tid] = ((mi - mw) / mi) * P.xG; sG[DEM_TILE + tid] = ((mi - mw) / mi) * P.yG;
+  }
+  if (tid == 0) sFail = 0;
+  __syncthreads();
+
+#ifdef LBMDEM_AB   /* experiment build: where a tile's time goes (100 MHz clock), dbg[tile][16] */
+  long long t_wait = 0, t_work = 0, n_spins = 0, t_begin = wall_clock64();
+  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm = t_begin;
+#define CH_MARK(k) do { const long long now_ = wall_clock64(); ph[k] += now_ - tm; tm = now_; } while (0)
+#else
+#define CH_MARK(k) do { } while (0)
+#endif
+  // only a tile that reads some grain through the fabric is read through it (the list is symmetric)
+  bool any_far = false;
+  for (int h = 0; h < hcnt; ++h) any_far = any_far || (sHoff[h] & 1u);
+  GrainState me{};
+  me.r = tid < DEM_GRAINS ? sR[tid] : (real)0.;
+  // drift + first half kick (main.c:1748-1753) of the sub-step with sequence number `stamp`, published to the partners'
+  // tiles and to this tile's LDS
+  auto drift_publish = [&](long long stamp) {
+    if (tid < DEM_GRAINS) {
+      const unsigned pb = (stamp & 1) ? line_par : 0u;
+      if (mine) {
+        x1 = x1 + P.dt * v1 + P.dt2 * a1 / 2.;
+        x2 = x2 + P.dt * v2 + P.dt2 * a2 / 2.;
+        sX3[tid] = sX3[tid] + P.dt * v3 + P.dt2 * a3 / 2.;
+        v1 = v1 + P.dt * a1 / 2.;
+        v2 = v2 + P.dt * a2 / 2.;
+        v3 = v3 + P.dt * a3 / 2.;
+      }
+      if (have) {
+        chain_publish<0>(rs, pb + (unsigned)i * 128u, chain_tag(stamp), x1, x2, v1, v2, v3);
+        if (any_far) chain_publish<16>(rs, remote + pb + (unsigned)i * 128u, chain_tag(stamp), x1, x2, v1, v2, v3);
+      }
+      sS[tid] = x1; sS[CH_SLOTS + tid] = x2; sS[2 * CH_SLOTS + tid] = v1; sS[3 * CH_SLOTS + tid] = v2; sS[4 * CH_SLOTS + tid] = v3;
+      me.x1 = x1; me.x2 = x2; me.v1 = v1; me.v2 = v2; me.v3 = v3;
+      if (tid == 0) sLast = -1;
+    }
+  };
+  drift_publish(stamp0);
+  for (int s = 0; s < nsteps; ++s) {
+#ifdef LBMDEM_AB
+    const long long t_a = wall_clock64();
+    tm = t_a;
+#endif
+    const long long stamp = stamp0 + s;
+    const unsigned tag = chain_tag(stamp);
+    const unsigned pbase = (stamp & 1) ? line_par : 0u;
+    // (the other wavefronts park here while the first one finishes the sub-step before: polling from its start, they
+    // flood the L2 with reads that cannot succeed yet and take issue slots from the wavefronts that work)
+    __syncthreads();
+    CH_MARK(1);   // barrier A
+    // ---- the halo grains' state of this sub-step: re-read until both tags of a slot match
+    for (int first = 0; first < nitems; first += CH_ITEMS * DEM_THREADS) {
+      u32x4 v[CH_ITEMS];
+      unsigned off[CH_ITEMS];
+#pragma unroll
+      for (int it = 0; it < CH_ITEMS; ++it) {
+        const int idx = first + tid + it * DEM_THREADS;
+        if (idx < nitems) {
+          const unsigned ho = sHoff[idx / 5];
+          off[it] = ((ho & 1u) ? remote : 0u) + pbase + (ho & ~1u) + 16u * (unsigned)(idx % 5);
+          v[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[it], 0, 16);   // sc1: past the L1, served by the L2
+        }
+      }
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true, bad = false, waitfar = false;
+#pragma unroll
+        for (int it = 0; it < CH_ITEMS; ++it)
+          if (first + tid + it * DEM_THREADS < nitems) {
+            const bool g = (v[it].y == tag || v[it].y == stag) && (v[it].w == tag || v[it].w == stag);
+            bad = bad || v[it].y == CH_POISON || v[it].w == CH_POISON;
+            if (!g) {
+              // a local copy that stays stale: its writer did not land on this XCD -- the remote copy always arrives
+              // (a writer without far readers publishes no remote copy: then this is the end of the launch)
+              if (spins == CH_LOCAL_SPINS && off[it] < remote) off[it] += remote;
+              waitfar = waitfar || off[it] >= remote;
+              v[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[it], 0, 16);
+            }
+            ok = ok && g;
+          }
+        if (__any(bad) || ++spins > CH_SPINS) { sFail = 1; break; }
+#ifdef LBMDEM_AB
+        ++n_spins;
+#endif
+        if (__all(ok)) break;
+        if (__any(waitfar)) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(1);   // polls through the fabric: fewer
+      }
+#pragma unroll
+      for (int it = 0; it < CH_ITEMS; ++it) {
+        const int idx = first + tid + it * DEM_THREADS;
+        if (idx < nitems)
+          sS[(idx % 5) * CH_SLOTS + DEM_TILE + idx / 5] =
+              __longlong_as_double((long long)(((unsigned long long)v[it].z << 32) | v[it].x));
+      }
+    }
+    CH_MARK(2);   // halo landed (this wavefront's part)
+    __syncthreads();
+    CH_MARK(3);   // barrier B
+#ifdef LBMDEM_AB
+    const long long t_b = wall_clock64();
+    t_wait += t_b - t_a;
+#endif
+    if (sFail) break;
+    // ---- contacts: phase 1 (one lane per list entry) and phase 2 (one lane per grain, list order) of k_dem_entries
+    real c1 = 0., c2 = 0., c3 = 0.;
+    if (mine) { c1 = sFh[tid]; c2 = sFh[DEM_TILE + tid]; c3 = sFh[2 * DEM_TILE + tid]; }
+    pr = 0.0;
+    int last_e = -1, slast = -1;
+    real last_ft = 0., last_f3 = 0.;
+    bool lost = false;
+    for (int base = e0; base < e1; base += CH_ENTRIES) {
+      const int lim = base + CH_ENTRIES < e1 ? base + CH_ENTRIES : e1;
+      for (int e = base + tid; e < lim; e += DEM_THREADS) {
+        unsigned w;
+        if (e - e0 < CH_META) w = sMeta[e - e0];
+        else { w = emeta[e]; if (active && !active[g0 + (int)(w & 63u)]) w = CH_SKIP; }
+        if (w == CH_SKIP) continue;
+        const int li = (int)(w & 63u);
+        const bool lower = (w & 64u) != 0;
+        const unsigned slot = w >> 8;
+        GrainState a, b;
+        a.x1 = sS[li]; a.x2 = sS[CH_SLOTS + li]; a.v1 = sS[2 * CH_SLOTS + li]; a.v2 = sS[3 * CH_SLOTS + li];
+        a.v3 = sS[4 * CH_SLOTS + li]; a.r = sR[li];
+        if (slot != DEM_CHAIN_DIRECT) {
+          b.x1 = sS[slot]; b.x2 = sS[CH_SLOTS + slot]; b.v1 = sS[2 * CH_SLOTS + slot]; b.v2 = sS[3 * CH_SLOTS + slot];
+          b.v3 = sS[4 * CH_SLOTS + slot]; b.r = sR[slot];
+        } else {
+          const int gj = nbr[e];
+          ChainRead R{};
+          if (!chain_read_direct(rs, remote + pbase + (unsigned)gj * 128u, tag, stag, R)) lost = true;
+          b.x1 = R.x1; b.x2 = R.x2; b.v1 = R.v1; b.v2 = R.v2; b.v3 = R.v3; b.r = r[gj];
+        }
+        bool touched;
+        const Force3 F = contact<false>(lower ? a : b, lower ? b : a, P, touched);  // main.c:1443-1448
+        if (touched && lower && (sFlag[li] & 2)) {
+          last_e = e; last_ft = F.ft; last_f3 = F.f3;
+          if (T.stamp) atomicMax(&sLast, e);
+        }
+        const int q = e - base;
+        sF1[q] = lower ? F.f1 : -F.f1;
+        sF2[q] = lower ? F.f2 : -F.f2;
+        sF3[q] = F.f3;
+        sFn[q] = touched ? F.fn : (real)0.;
+        sTouched[q] = touched ? 1 : 0;
+      }
+      if (lost) sFail = 1;
+      CH_MARK(4);   // phase 1
+      __syncthreads();
+      CH_MARK(5);   // its barrier
+      slast = sLast;   // (between the round's two barriers: the first wavefront resets it after the second one)
+      if (mine) {
+        // the entries of this grain in list order; four at a time are fetched from LDS at once and added one after the
+        // other (an entry past the end is loaded from a clamped index and NOT added: x + 0 is not x for x = -0)
+        const int lo = k0 > base ? k0 : base, hi = k1 < lim ? k1 : lim;
+        for (int kb = lo; kb < hi; kb += 4) {
+          real u1[4], u2[4], u3[4], un[4];
+          unsigned char ut[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int q = (kb + j < hi ? kb + j : hi - 1) - base;
+            u1[j] = sF1[q]; u2[j] = sF2[q]; u3[j] = sF3[q]; un[j] = sFn[q]; ut[j] = sTouched[q];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (kb + j < hi) {
+              c1 = c1 + u1[j]; c2 = c2 + u2[j]; c3 = c3 + u3[j];
+              if (ut[j]) pr += un[j];
+            }
+        }
+      }
+      __syncthreads();
+      CH_MARK(6);   // phase 2 + barrier
+    }
+    if (sFail) break;
+    WallHits wh;
+    if (tid < DEM_GRAINS && mine) {   // the first wavefront holds the tile's grains
+      real ds = 0., df1 = 0., dM11 = 0., dM12 = 0., dM21 = 0., dM22 = 0.;
+      int dz = 0;
+      walls<false>(me, wf, P, c1, c2, c3, pr, ds, df1, dz, dM11, dM12, dM21, dM22, wh);
+      // main.c:1511-1515, then the second half kick main.c:1760-1762
+      const real mi = sMI[tid], Iti = sMI[DEM_TILE + tid];
+      a1 = c1 / mi + sG[tid];
+      a2 = (c2 / mi) + sG[DEM_TILE + tid];
+      a3 = c3 / Iti;
+      v1 = v1 + P.dt * a1 / 2.;
+      v2 = v2 + P.dt * a2 / 2.;
+      v3 = v3 + P.dt * a3 / 2.;
+    }
+    CH_MARK(7);   // walls, accelerations, second half kick
+    // the next sub-step's state goes out before this one's book-keeping: the partners' tiles are waiting for it
+    const int last_own = last_e >= 0 && last_e == slast ? last_e : -1;
+    if (s + 1 < nsteps) drift_publish(stamp + 1);
+    CH_MARK(0);   // drift + publish
+    if (T.stamp && last_own >= 0) {   // the tile's last grain contact, for the carries
+      const long rec = (long)tile * 4 + CARRY_GRAIN;
+      T.stamp[rec] = stamp; T.val[2 * rec] = last_ft; T.val[2 * rec + 1] = last_f3;
+      T.who[rec] = ((long long)(g0 + (int)(((last_own - e0 < CH_META) ? sMeta[last_own - e0] : emeta[last_own]) & 63u)) << 32) | (unsigned)nbr[last_own];
+    }
+    if (T.stamp && tid < DEM_GRAINS) {   // per wall, the highest grain of the tile that touched it
+#pragma unroll
+      for (int kind = CARRY_BOTTOM; kind <= CARRY_RIGHT; ++kind) {
+        const unsigned bit = kind == CARRY_BOTTOM ? 1u : (kind == CARRY_LEFT ? 4u : 8u);
+        const unsigned long long hit = __ballot((wh.mask & bit) != 0 && (sFlag[tid] & 2));
+        if (hit != 0 && tid == 63 - __builtin_clzll(hit)) {
+          const long rec = (long)tile * 4 + kind;
+          T.stamp[rec] = stamp;
+          T.who[rec] = (long long)i << 32;
+          T.val[2 * rec] = kind == CARRY_BOTTOM ? wh.ftB : (kind == CARRY_LEFT ? wh.ftL : wh.ftR);
+          T.val[2 * rec + 1] = wh.f3B;
+        }
+      }
+    }
+#ifdef LBMDEM_AB
+    t_work += wall_clock64() - t_b;
+#endif
+  }
+#ifdef LBMDEM_AB
+  if (dbg && tid == 0) {
+    long long* d = dbg + (long)tile * 16;
+    for (int k = 0; k < 8; ++k) d[8 + k] = ph[k];
+    d[0] = t_wait; d[1] = t_work; d[2] = n_spins; d[3] = placed ? 1 : 0; d[4] = hcnt; d[5] = e1 - e0;
+    d[6] = t_begin; d[7] = wall_clock64();
+    int nfar = 0;
+    for (int h = 0; h < hcnt; ++h) nfar += (int)(sHoff[h] & 1u);
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    d[3] |= (long long)nfar << 8 | (long long)(xcc & 0xFu) << 32 | (long long)hwid << 36;
+  }
+#endif
+  if (sFail) {   // (uniform: read after a barrier) -- let the partners know, and the host
+    if (have) {
+      for (unsigned par = 0; par < 2; ++par) {
+        chain_publish<0>(rs, par * line_par + (unsigned)i * 128u, CH_POISON, 0., 0., 0., 0., 0.);
+        chain_publish<16>(rs, remote + par * line_par + (unsigned)i * 128u, CH_POISON, 0., 0., 0., 0., 0.);
+      }
+    }
+    if (tid == 0) *err = 1;
+    return;
+  }
+  if (have) {   // grains this rank does not integrate keep their state, in the buffer that is current from now on
+    out.x1[i] = x1; out.x2[i] = x2; out.x3[i] = sX3[tid];
+    out.v1[i] = v1; out.v2[i] = v2; out.v3[i] = v3;
+    out.a1[i] = a1; out.a2[i] = a2; out.a3[i] = a3;
+    if (mine) pout[i] = pr;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Order-dependent contact diagnostics: fr, ice, slip, rw
 // ---------------------------------------------------------------------------------------------
 //
@@ -730,6 +1171,74 @@ __global__ void k_fill_own(int n, const int* __restrict__ offsets, int* __restri
   for (int k = offsets[i]; k < offsets[i + 1]; ++k) own[k] = i;
 }
 
+// What k_dem_chain needs of a freshly built list, one workgroup per tile: the distinct partners outside the tile (an LDS
+// hash set, then numbered by a scan over the table) and every entry's emeta word. Which halo slot a grain gets depends on
+// the order the atomics arrive in -- only the LDS placement, never a result.
+__global__ __launch_bounds__(256) void k_tile_halo(int n, const int* __restrict__ offsets, const int* __restrict__ nbr,
+                                                   const int* __restrict__ own, int* __restrict__ halo_ids,
+                                                   int* __restrict__ halo_cnt, unsigned* __restrict__ emeta) {
+  constexpr int CELLS = 1024;
+  __shared__ int table[CELLS], cidx[CELLS];
+  __shared__ int wsum[4];
+  const int tile = blockIdx.x, tid = threadIdx.x;
+  const int g0 = tile * DEM_TILE;
+  const int g1 = g0 + DEM_TILE < n ? g0 + DEM_TILE : n;
+  const int e0 = offsets[g0], e1 = offsets[g1];
+  for (int c = tid; c < CELLS; c += 256) table[c] = -1;
+  __syncthreads();
+  for (int e = e0 + tid; e < e1; e += 256) {
+    const int gj = nbr[e];
+    if (gj >= g0 && gj < g1) continue;
+    unsigned hsh = ((unsigned)gj * 2654435761u) >> 22;   // 10 bits
+    for (int probe = 0; probe < CELLS; ++probe) {
+      const int old = atomicCAS(&table[hsh], -1, gj);
+      if (old == -1 || old == gj) break;
+      hsh = (hsh + 1) & (CELLS - 1);
+    }
+  }
+  __syncthreads();
+  // number the occupied cells: four consecutive cells per thread, wave scan, wave totals
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) cnt += table[4 * tid + k] >= 0 ? 1 : 0;
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d);
+    if ((tid & 63) >= d) incl += up;
+  }
+  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  int basei = incl - cnt;
+  for (int w = 0; w < (tid >> 6); ++w) basei += wsum[w];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = 4 * tid + k;
+    if (table[c] >= 0) {
+      cidx[c] = basei;
+      if (basei < DEM_CHAIN_HALO) halo_ids[(long)tile * DEM_CHAIN_HALO + basei] = table[c];
+      ++basei;
+    }
+  }
+  if (tid == 255) halo_cnt[tile] = basei < DEM_CHAIN_HALO ? basei : DEM_CHAIN_HALO;
+  __syncthreads();
+  for (int e = e0 + tid; e < e1; e += 256) {
+    const int gi = own[e], gj = nbr[e];
+    unsigned slot = DEM_CHAIN_DIRECT;
+    if (gj >= g0 && gj < g1) slot = (unsigned)(gj - g0);
+    else {
+      unsigned hsh = ((unsigned)gj * 2654435761u) >> 22;
+      for (int probe = 0; probe < CELLS; ++probe) {
+        const int t = table[hsh];
+        if (t == gj) { if (cidx[hsh] < DEM_CHAIN_HALO) slot = (unsigned)(DEM_TILE + cidx[hsh]); break; }
+        if (t == -1) break;
+        hsh = (hsh + 1) & (CELLS - 1);
+      }
+    }
+    emeta[e] = (unsigned)(gi - g0) | (gi < gj ? 64u : 0u) | (slot << 8);
+  }
+}
+
 }  // namespace
 
 int carry_track_alloc(CarryTrack& T, int n) {
@@ -779,6 +1288,11 @@ int verlet_alloc(VerletDevice& V, int n, real cs, real ox, real oy, real wx, rea
   A((void**)&V.counts, sizeof(int) * n); A((void**)&V.offsets, sizeof(int) * (n + 1));
   A((void**)&V.nbr, sizeof(int) * V.cap); A((void**)&V.own, sizeof(int) * V.cap); A((void**)&V.wallflags, n);
   A((void**)&V.overflow, sizeof(int));
+  {
+    const size_t tiles = ((size_t)n + DEM_TILE - 1) / DEM_TILE;
+    A((void**)&V.halo_ids, sizeof(int) * tiles * DEM_CHAIN_HALO); A((void**)&V.halo_cnt, sizeof(int) * tiles);
+    A((void**)&V.emeta, sizeof(unsigned) * V.cap);
+  }
   if (e != hipSuccess) return -1;
   V.scan_tmp_bytes = 0;
   size_t cells_tmp = 0;
@@ -798,7 +1312,7 @@ int verlet_alloc(VerletDevice& V, int n, real cs, real ox, real oy, real wx, rea
 
 void verlet_free(VerletDevice& V) {
   void* ps[] = {V.keys_in, V.vals_in, V.vals_out, V.cell_start, V.cell_end,
-                V.scan_tmp, V.counts, V.offsets, V.nbr, V.own, V.wallflags, V.overflow};
+                V.scan_tmp, V.counts, V.offsets, V.nbr, V.own, V.wallflags, V.overflow, V.halo_ids, V.halo_cnt, V.emeta};
   for (void* p : ps) if (p) (void)hipFree(p);
   V = VerletDevice{};
 }
@@ -825,6 +1339,7 @@ int launch_verlet_rebuild(VerletDevice& V, const Kin& K, const real* r, const De
   hipLaunchKernelGGL(k_verlet_scan<1>, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, r, V.ox, V.oy, V.cs, V.ncx,
                      V.ncy, V.cell_start, V.vals_out, P.distVerlet, V.counts, V.offsets, V.nbr,
                      V.own, V.cap, V.overflow, P, V.wallflags);
+  launch_tile_halo(V, n, st);
   return (int)hipGetLastError();
 }
 
@@ -916,3 +1431,79 @@ void launch_dem_substep(const Kin& in, const Kin& out, const real* r, const real
 #undef LBM_DEM_LAUNCH
 }
 
+
+void launch_tile_halo(const VerletDevice& V, int n, hipStream_t st) {
+  const int tiles = (n + DEM_TILE - 1) / DEM_TILE;
+  hipLaunchKernelGGL(k_tile_halo, dim3(tiles), dim3(256), 0, st, n, V.offsets, V.nbr, V.own, V.halo_ids, V.halo_cnt, V.emeta);
+}
+
+int dem_chain_tslots(int n) { return DEM_GRID((n + DEM_GRAINS - 1) / DEM_GRAINS); }
+
+int dem_chain_alloc(DemChain& C, int n) {
+  C = DemChain{};
+  const size_t bytes = (size_t)4 * n * 128;   // two parities x (local copy, remote copy)
+  if (bytes >= ((size_t)1 << 31)) return 0;   // 32-bit buffer offsets: the chain stays off (capacity 0)
+  if (hipMalloc(&C.pub, bytes ? bytes : 128) != hipSuccess) return -1;
+  C.pub_bytes = bytes;
+  if (hipMalloc((void**)&C.census, sizeof(int)) != hipSuccess) { dem_chain_free(C); return -1; }
+  if (hipHostMalloc((void**)&C.err_host, sizeof(int), hipHostMallocDefault) != hipSuccess) { dem_chain_free(C); return -1; }
+  *C.err_host = 0;
+  if (hipHostGetDevicePointer((void**)&C.err, (void*)C.err_host, 0) != hipSuccess) { dem_chain_free(C); return -1; }
+  if (hipMemset(C.pub, 0, bytes ? bytes : 128) != hipSuccess || hipMemset(C.census, 0, sizeof(int)) != hipSuccess ||
+      hipDeviceSynchronize() != hipSuccess) { dem_chain_free(C); return -1; }
+  return 0;
+}
+
+void dem_chain_free(DemChain& C) {
+  if (C.pub) (void)hipFree(C.pub);
+  if (C.census) (void)hipFree(C.census);
+  if (C.err_host) (void)hipHostFree((void*)C.err_host);
+  C = DemChain{};
+}
+
+// All workgroups of the tile slots have to run at the same time (a tile waits for the tiles of its partners). The
+// occupancy query bounds it; a census launch of the SAME kernel (same registers, same LDS) with exactly that many
+// workgroups, each waiting until all have checked in, proves it on this GPU. Synchronises the stream; once per handle.
+int dem_chain_census(DemChain& C, int tslots, hipStream_t st) {
+  C.capacity = 0;
+  if (!C.pub) return 0;
+  int per_cu = 0, dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dem_chain, DEM_THREADS, 0) != hipSuccess) return 0;
+  if ((long)per_cu * prop.multiProcessorCount < tslots) return 0;
+  if (hipMemsetAsync(C.census, 0, sizeof(int), st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 0;
+  *C.err_host = 0;
+  hipLaunchKernelGGL(k_dem_chain, dim3(tslots), dim3(DEM_THREADS), 0, st, Kin{}, Kin{}, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, DemParams{}, nullptr, CarryTrack{}, 0ll,
+                     nullptr, ObstFillJob{}, tslots, -1, C.pub, (unsigned)C.pub_bytes, C.err, C.census, nullptr, 0);
+  int seen = 0;
+  if (hipMemcpyAsync(&seen, C.census, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return 0;
+  if (hipStreamSynchronize(st) != hipSuccess) return 0;
+  if (*C.err_host == 0 && seen == tslots) C.capacity = tslots;
+  *C.err_host = 0;
+  return C.capacity;
+}
+
+void launch_dem_chain(const Kin& in, const Kin& out, const real* r, const real* m, const real* It, const real* fhf,
+                      const VerletDevice& V, real* pout, const DemParams& P, const unsigned char* active,
+                      const CarryTrack* track, long long stamp0, const unsigned char* owner, const ObstFillJob& fill,
+                      const DemChain& C, int nsteps, hipStream_t st) {
+  const int n = P.n;
+  const CarryTrack T = track ? *track : CarryTrack{};
+  const int nbe = (n + DEM_GRAINS - 1) / DEM_GRAINS;
+  int extra = 0;
+  if (fill.map && fill.row1 > fill.row0) {
+    const long v4 = (long)(fill.row1 - fill.row0) * fill.L.sy / 4;
+    extra = (int)((v4 + DEM_THREADS * 8 - 1) / (DEM_THREADS * 8));
+    if (extra > 128) extra = 128;   // next to a latency chain: few workgroups, many stores each
+  }
+  int one_xcd = 0;
+#ifdef LBMDEM_AB
+  static const bool want_one = getenv("LBMDEM_CHAIN_ONE_XCD") != nullptr;
+  one_xcd = want_one && nbe <= 128 ? 1 : 0;
+#endif
+  hipLaunchKernelGGL(k_dem_chain, dim3((one_xcd ? nbe * 8 : DEM_GRID(nbe)) + extra), dim3(DEM_THREADS), 0, st, in, out, r, m, It, fhf, V.offsets,
+                     V.nbr, V.emeta, V.halo_ids, V.halo_cnt, V.wallflags, pout, P, active, T, stamp0, owner, fill, nbe, nsteps,
+                     C.pub, (unsigned)C.pub_bytes, C.err, C.census, C.dbg, one_xcd);
+}

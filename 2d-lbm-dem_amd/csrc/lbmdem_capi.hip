@@ -343,6 +343,11 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
       return rc;
     }
   }
+  if (dem_chain_alloc(h->chain, n) != 0) {
+    int rc = fail(LBMDEM_ENOMEM, "sub-step hand-over lines: hipMalloc failed");
+    lbmdem_destroy(h);
+    return rc;
+  }
   CREATE_TRY(hipHostMalloc((void**)&h->ovf_host, sizeof(int), hipHostMallocDefault));
   *h->ovf_host = 0;
   CREATE_TRY(hipHostMalloc((void**)&h->ferr_host, sizeof(int), hipHostMallocDefault));
@@ -383,6 +388,7 @@ int lbmdem_destroy(lbmdem_handle* h) {
   if (h->fs.error) (void)hipFree(h->fs.error);
   if (h->dpartial) (void)hipFree(h->dpartial);
   verlet_free(h->V);
+  dem_chain_free(h->chain);
   dist_free(h->dd);
   if (h->ovf_host) (void)hipHostFree((void*)h->ovf_host);
   if (h->ferr_host) (void)hipHostFree((void*)h->ferr_host);
@@ -591,6 +597,21 @@ int lbmdem_fused_work_order(lbmdem_handle* h, int* info12) {
 }
 
 #ifdef LBMDEM_AB
+// experiment builds only: per tile of the last k_dem_chain launch {clocks waiting for the halo, clocks working, poll rounds,
+// placed | far items << 8, halo grains, list entries, first clock, last clock} (100 MHz)
+int lbmdem_debug_chain_times(lbmdem_handle* h, long long* out, int tiles_cap) {
+  CHECK_H(h);
+  const int tiles = (h->n + DEM_TILE - 1) / DEM_TILE;
+  if (!h->chain.dbg) {
+    HIP_TRY(hipMalloc((void**)&h->chain.dbg, sizeof(long long) * 16 * (size_t)tiles));
+    HIP_TRY(hipMemset(h->chain.dbg, 0, sizeof(long long) * 16 * (size_t)tiles));
+    return 0;
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int nt = tiles < tiles_cap ? tiles : tiles_cap;
+  HIP_TRY(hipMemcpy(out, h->chain.dbg, sizeof(long long) * 16 * (size_t)nt, hipMemcpyDeviceToHost));
+  return nt;
+}
 int lbmdem_debug_gather_queue(lbmdem_handle* h, int* out, int cap) {   // experiment builds only
   CHECK_H(h);
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -645,6 +666,7 @@ int lbmdem_dem_substep(lbmdem_handle* h) {
   CHECK_NOT_SPLIT(h);
   if (!h->verlet_ok) return fail(LBMDEM_EINVAL, "lbmdem_dem_substep before the first lbmdem_verlet_rebuild");
   if (*h->ovf_host) return fail(LBMDEM_ENOMEM, "Verlet list overflow (more than %ld symmetric entries)", h->V.cap);
+  if (CHAIN_FAILED(h)) return fail(LBMDEM_EHIP, CHAIN_FAIL_MSG);
   const int film = (h->nbsteps % h->cfg.phys.stepFilm == 0) ? 1 : 0;  // main.c:1342
   // contact diagnostics are only needed by write_DEM, which renderScene calls when the step counter
   // reaches a multiple of stepStrob = 4000 (main.c:142,1773): produce them in exactly that sub-step
@@ -697,13 +719,80 @@ int lbmdem_dem_substep(lbmdem_handle* h) {
   return LBMDEM_OK;
 }
 
+long lbmdem_dem_chain_length(lbmdem_handle* h, long remaining, int fluid) {
+  if (h->chain_max < 2 || remaining < 2 || h->diag_always || !h->chain.pub) return 0;
+  const lbmdem_config& c = h->cfg;
+  const long cap = remaining < h->chain_max ? remaining : h->chain_max;
+  long k = 0;
+  for (; k < cap; ++k) {
+    const long t = h->nbsteps + k;
+    if (k > 0 && ((fluid && t % c.npDEM == 0) || t % c.phys.updateVerlet == 0)) break;   // main.c:1710, 1721
+    if (t % c.phys.stepFilm == 0) break;                                                  // film law, main.c:1342
+    if ((t + 1) % 4000 == 0) break;                                                       // feeds write_DEM, main.c:1773
+  }
+  if (k < 2) return 0;
+  if (!h->chain_checked) {   // once per handle: do all tiles of this packing run at the same time on this GPU?
+    h->chain_checked = true;
+    (void)dem_chain_census(h->chain, dem_chain_tslots(h->n), h->stream);
+  }
+  return h->chain.capacity >= dem_chain_tslots(h->n) ? k : 0;
+}
+
+// k ordinary sub-steps (lbmdem_dem_chain_length said so) in one launch
+int lbmdem_dem_chain(lbmdem_handle* h, long k) {
+  CHECK_H(h);
+  PhaseRange range_("lbmdem:dem_chain");
+  CHECK_NOT_SPLIT(h);
+  if (!h->verlet_ok) return fail(LBMDEM_EINVAL, "lbmdem_dem_substep before the first lbmdem_verlet_rebuild");
+  if (*h->ovf_host) return fail(LBMDEM_ENOMEM, "Verlet list overflow (more than %ld symmetric entries)", h->V.cap);
+  if (CHAIN_FAILED(h)) return fail(LBMDEM_EHIP, CHAIN_FAIL_MSG);
+  const DemParams P = dem_params(h);
+  ObstFillJob fill{nullptr, h->L, 0, 0};   // k slices of the next rasterisation's canvas (lbmdem_dem_substep: one each)
+  if (!h->obst_pending && !h->cs_interior_pending && h->obst_reset_rows < h->L.nxl) {
+    const long slice = (h->L.nxl + h->cfg.npDEM - 1) / h->cfg.npDEM;
+    fill.map = h->obst[1 - h->ocur];
+    fill.row0 = h->obst_reset_rows;
+    fill.row1 = fill.row0 + slice * k < h->L.nxl ? (int)(fill.row0 + slice * k) : h->L.nxl;
+    h->obst_reset_rows = fill.row1;
+  }
+  launch_dem_chain(h->kin[h->kcur], h->kin[1 - h->kcur], h->r, h->m, h->It, h->fhf, h->V, h->gp, P,
+                   h->dist ? h->dd.active : nullptr, &h->ct, h->substep_seq, h->dist ? h->owner : nullptr, fill, h->chain,
+                   (int)k, h->stream);
+  if (h->dist && h->dist_poison) launch_dist_poison(h->dd, h->kin[0], h->kin[1], h->n, h->stream);
+  h->substep_seq += k;
+  h->chain_launches++; h->chain_substeps += k;
+  h->diag_valid = false;
+  HIP_TRY(hipGetLastError());
+  h->kcur = 1 - h->kcur;
+  h->nbsteps += k;
+  return LBMDEM_OK;
+}
+
+int lbmdem_set_dem_chain(lbmdem_handle* h, int max_substeps) {
+  if (!h) return fail(LBMDEM_EINVAL, "null handle");
+  h->chain_max = max_substeps;
+  return LBMDEM_OK;
+}
+
+int lbmdem_dem_chain_stats(lbmdem_handle* h, long* launches, long* substeps, int* tile_slots, int* resident) {
+  if (!h) return fail(LBMDEM_EINVAL, "null handle");
+  if (launches) *launches = h->chain_launches;
+  if (substeps) *substeps = h->chain_substeps;
+  if (tile_slots) *tile_slots = dem_chain_tslots(h->n);
+  if (resident) *resident = h->chain_checked ? h->chain.capacity : -1;
+  return LBMDEM_OK;
+}
+
 int lbmdem_run(lbmdem_handle* h, long n_dem_steps) {
   CHECK_H(h);
-  for (long k = 0; k < n_dem_steps; ++k) {
+  for (long k = 0; k < n_dem_steps;) {
     int rc = LBMDEM_OK;
     if (h->nbsteps % h->cfg.npDEM == 0) rc = lbmdem_lbm_step(h);                                  // main.c:1710-1718
     if (rc == LBMDEM_OK && h->nbsteps % h->cfg.phys.updateVerlet == 0) rc = lbmdem_verlet_rebuild(h);  // main.c:1721-1724
-    if (rc == LBMDEM_OK) rc = lbmdem_dem_substep(h);                                              // main.c:1733-1764
+    if (rc != LBMDEM_OK) return rc;
+    const long run = lbmdem_dem_chain_length(h, n_dem_steps - k, 1);
+    if (run) { rc = lbmdem_dem_chain(h, run); k += run; }
+    else { rc = lbmdem_dem_substep(h); ++k; }                                                     // main.c:1733-1764
     if (rc != LBMDEM_OK) return rc;
   }
   return LBMDEM_OK;
@@ -711,10 +800,13 @@ int lbmdem_run(lbmdem_handle* h, long n_dem_steps) {
 
 int lbmdem_run_dem(lbmdem_handle* h, long n_dem_steps) {
   CHECK_H(h);
-  for (long k = 0; k < n_dem_steps; ++k) {
+  for (long k = 0; k < n_dem_steps;) {
     int rc = LBMDEM_OK;
     if (h->nbsteps % h->cfg.phys.updateVerlet == 0) rc = lbmdem_verlet_rebuild(h);  // main.c:1721-1724
-    if (rc == LBMDEM_OK) rc = lbmdem_dem_substep(h);                                // main.c:1733-1764
+    if (rc != LBMDEM_OK) return rc;
+    const long run = lbmdem_dem_chain_length(h, n_dem_steps - k, 0);
+    if (run) { rc = lbmdem_dem_chain(h, run); k += run; }
+    else { rc = lbmdem_dem_substep(h); ++k; }                                       // main.c:1733-1764
     if (rc != LBMDEM_OK) return rc;
   }
   return LBMDEM_OK;
@@ -1027,6 +1119,7 @@ int lbmdem_sync(lbmdem_handle* h) {
   int ovf = 0;
   HIP_TRY(hipMemcpy(&ovf, h->V.overflow, sizeof(int), hipMemcpyDeviceToHost));
   if (ovf) return fail(LBMDEM_ENOMEM, "Verlet list overflow (more than %ld symmetric entries)", h->V.cap);
+  if (CHAIN_FAILED(h)) return fail(LBMDEM_EHIP, CHAIN_FAIL_MSG);
   int ferr = 0;
   HIP_TRY(hipMemcpy(&ferr, h->fs.error, sizeof(int), hipMemcpyDeviceToHost));
   if (ferr) return fail(LBMDEM_EINVAL, "hydrodynamic force of a grain cut by a strip boundary could not be formed (code %d: "

@@ -160,6 +160,7 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
   h->verlet_tracks_positions = h->verlet_ok;
   if (h->verlet_ok) {  // the entry -> grain map is derived from the offsets
     launch_fill_own(h->V, n, h->stream);
+    launch_tile_halo(h->V, n, h->stream);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { lbmdem_destroy(h); return fail(LBMDEM_EHIP, "k_fill_own failed"); }
   }
   *out = h;

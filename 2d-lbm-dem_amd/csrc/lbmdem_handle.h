@@ -95,6 +95,11 @@ struct lbmdem_handle {
   volatile int* ovf_host = nullptr;  // pinned mirror of V.overflow, refreshed (asynchronously) after every rebuild
   volatile int* ferr_host = nullptr; // pinned mirror of fs.error (strip decomposition), refreshed by every period's classification launch
   int* ferr_mirror = nullptr;        // ... its device address
+  // runs of ordinary sub-steps in one launch (k_dem_chain, dem_kernels.hip)
+  DemChain chain{};
+  int chain_max = 128;         // longest run handed to one launch; < 2: one launch per sub-step (lbmdem_set_dem_chain)
+  bool chain_checked = false;  // the residency census has run (chain.capacity says what it found)
+  long chain_launches = 0, chain_substeps = 0;   // lbmdem_dem_chain_stats
   long nbsteps = 0;
   int force_mode = 0;
   // derived scalars
@@ -108,6 +113,9 @@ struct lbmdem_handle {
 
 #define CHECK_H(h) do { if (!(h)) return fail(LBMDEM_EINVAL, "null handle"); HIP_TRY(hipSetDevice((h)->cfg.device)); } while (0)
 #define CHECK_NOT_SPLIT(h) do { if ((h)->cs_interior_pending) return fail(LBMDEM_EINVAL, "lbmdem_collide_stream_part(LBMDEM_CS_INTERIOR) has not been called after LBMDEM_CS_EDGES"); } while (0)
+
+#define CHAIN_FAILED(h) ((h)->chain.err_host && *(h)->chain.err_host)
+#define CHAIN_FAIL_MSG "a tile of the multi-sub-step DEM kernel gave up waiting for its partners' state (workgroups not co-resident?); the grain state is undefined"
 
 // Named ranges for rocprofv3 --marker-trace around the phases of a step (LBMDEM_ROCTX=1; lbmdem_capi.hip)
 struct PhaseRange {
@@ -176,6 +184,10 @@ static inline DemParams dem_params(const lbmdem_handle* h) {
 #define LBMDEM_INTERNAL extern "C" __attribute__((visibility("hidden")))
 LBMDEM_INTERNAL int lbmdem_write_vtk_file(const char* path, int nx, int ny, const char* name, int dim, const float* data);
 LBMDEM_INTERNAL int lbmdem_verlet_build_lists(lbmdem_handle* h);
+// the coming ordinary sub-steps that nothing separates (fluid step when `fluid`, list rebuild, film law, table sub-step), at
+// most `remaining`; 0 when the run is shorter than 2 or the multi-sub-step kernel cannot be used -- and that many sub-steps
+LBMDEM_INTERNAL long lbmdem_dem_chain_length(lbmdem_handle* h, long remaining, int fluid);
+LBMDEM_INTERNAL int lbmdem_dem_chain(lbmdem_handle* h, long k);
 // pieces of the fluid step for the C transport (lbmdem_comm.hip), which runs the edge rows on its halo lane's stream:
 LBMDEM_INTERNAL int lbmdem_collide_stream_prepare(lbmdem_handle* h);
 LBMDEM_INTERNAL int lbmdem_collide_stream_part_on(lbmdem_handle* h, int part, hipStream_t st);   // part on stream `st`

@@ -254,7 +254,15 @@ struct VerletDevice {
   long cap;
   unsigned char* wallflags;  // n
   int* overflow;             // device flag
+  // what the multi-sub-step kernel (k_dem_chain) needs of the list, per tile of DEM_TILE consecutive grains; refreshed
+  // by every rebuild: the distinct partners outside the tile ("halo" grains, staged in LDS every sub-step) and, per list
+  // entry, where its two grains sit in that staging
+  int* halo_ids;             // [tiles][DEM_CHAIN_HALO]
+  int* halo_cnt;             // [tiles]
+  unsigned* emeta;           // [cap] own grain's index in its tile | (own < partner) << 6 | partner's staging slot << 8
 };
+constexpr int DEM_CHAIN_HALO = 320;          // halo grains staged per tile; partners beyond that are read from memory per entry
+constexpr unsigned DEM_CHAIN_DIRECT = 0xFFFFu;   // emeta slot value of such a partner
 int verlet_alloc(VerletDevice& V, int n, real cs, real ox, real oy, real wx, real wy);
 void verlet_free(VerletDevice& V);
 // returns 0 or the hipError_t of the failing call (hipCUB scan, launch)
@@ -302,6 +310,7 @@ void diag_extra_free(DiagExtra& X);
 void launch_diag_extra(const DiagExtra& X, const Kin& in, const real* r, const VerletDevice& V,
                        const DemParams& P, int film, hipStream_t st);
 void launch_fill_own(const VerletDevice& V, int n, hipStream_t st);
+void launch_tile_halo(const VerletDevice& V, int n, hipStream_t st);   // halo_ids / halo_cnt / emeta from offsets, nbr, own
 // A slice of the obstacle map that the next rasterisation starts from (obst = -1 / wall codes, main.c:997-999), reset by
 // extra workgroups of a DEM sub-step launch: the sub-step kernel is a latency chain that leaves the GPU idle, the reset is
 // 67 MB of stores per fluid step -- in npDEM slices they disappear under the sub-steps. map == nullptr: nothing to do.
@@ -312,3 +321,27 @@ void launch_dem_substep(const Kin& in, const Kin& out, const real* r, const real
                         const CarryTrack* track, long long stamp, const unsigned char* owner, const ObstFillJob& fill,
                         hipStream_t st);
 void launch_obst_fill_rows(int* obst, const LatticeView& L, int row0, int row1, hipStream_t st);
+
+// Several consecutive ordinary sub-steps (no film law, no diagnostics, no list rebuild in between) in ONE launch: every
+// tile keeps its grains in registers and hands the drifted state of each sub-step to the tiles of its partners through
+// `pub` -- per grain and parity of the sub-step one 128-byte line of five tagged 16-byte slots {lo, tag, hi, tag}, written
+// and read with sc1 (write-through / L1-bypassing) accesses: the data is its own flag, there is no grid barrier.
+struct DemChain {
+  void* pub;            // [local copy, remote copy][2 parities][n] lines of 128 bytes
+  size_t pub_bytes;
+  volatile int* err_host;  // pinned host word: a tile gave up waiting for a partner (every spin is bounded) ...
+  int* err;             // ... and its device address
+  int* census;          // device counter of the residency check
+  int capacity;         // tile slots the launch may use (all its workgroups must be resident at once); 0: not usable
+  long long* dbg;       // experiment build only: [tiles][8] clocks of the last launch (lbmdem_debug_chain_times)
+};
+int dem_chain_alloc(DemChain& C, int n);
+void dem_chain_free(DemChain& C);
+// how many workgroups of k_dem_chain this GPU keeps resident at once (occupancy x CUs), verified by a census launch of
+// `tslots` workgroups that all have to see each other; 0 when they do not fit
+int dem_chain_census(DemChain& C, int tslots, hipStream_t st);
+int dem_chain_tslots(int n);
+void launch_dem_chain(const Kin& in, const Kin& out, const real* r, const real* m, const real* It, const real* fhf,
+                      const VerletDevice& V, real* pout, const DemParams& P, const unsigned char* active,
+                      const CarryTrack* track, long long stamp0, const unsigned char* owner, const ObstFillJob& fill,
+                      const DemChain& C, int nsteps, hipStream_t st);

@@ -295,6 +295,9 @@ def main():
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64",
                     help="f64 = the reference's `real` (the headline); f32 = the float build of the library, the reference's "
                          "-DSINGLE_PRECISION mode (one GPU, its own line: dtype f32, 76 B/LUP; never the headline)")
+    ap.add_argument("--dem-chain", type=int, default=None,
+                    help="longest run of DEM sub-steps handed to one launch (lbmdem_set_dem_chain; default: the library's, "
+                         "128); 0 = one launch per sub-step (A/B)")
     ap.add_argument("--strips", action="store_true",
                     help="use the strip-decomposition driver (torch.distributed) even with one rank")
     args = ap.parse_args()
@@ -330,6 +333,8 @@ def main():
             raise SystemExit("--precision f32 is a one-GPU, single-domain mode")
         sim = pkg.LbmDem(lx, ly, r, x1, x2, device=local_rank, precision=args.precision)
         sim.set_force_mode(args.force_mode)
+        if args.dem_chain is not None:
+            sim.set_dem_chain(args.dem_chain)
         npdem = sim.cfg.npDEM
 
         def run_steps(k):
@@ -391,6 +396,8 @@ def main():
             runner = strips.make_gpu_runner(pkg, dist, rank, world, local_rank, lx, ly, r, x1, x2,
                                             force_mode=args.force_mode)
         sim = runner.sim
+        if args.dem_chain is not None:
+            sim.set_dem_chain(args.dem_chain)
         npdem = sim.cfg.npDEM
         dist_mode = isinstance(runner, (strips.DistStripRunner, strips.CCommRunner))
 
@@ -494,6 +501,7 @@ def main():
             "config": {"workload": w["name"], "lx": lx, "ly": ly, "grains": int(len(r)), "npDEM": int(npdem),
                        "step": "1 fluid step + npDEM DEM sub-steps (+ Verlet rebuild every 100 DEM steps)",
                        "force_kernel": "parity" if args.force_mode == 0 else "fast",
+                       "dem_chain": dict(zip(("launches", "substeps", "tile_slots", "resident"), sim.dem_chain_stats())),
                        "settle_steps": args.settle,   # untimed steps of this run before the warm-up (GPU clocks; see --settle)
                        "driver": None if runner is None else ("C (lbmdem_comm_run, RCCL send/recv inside the library)" if
                                                                 isinstance(runner, strips.CCommRunner) else "torch.distributed (strips.py)"),

@@ -149,6 +149,17 @@ int lbmdem_set_lid(lbmdem_handle* h, double uw_h);
  * kept for callers that do not need the reference's bits). Default 0. */
 int lbmdem_set_force_mode(lbmdem_handle* h, int mode);
 
+/* lbmdem_run / lbmdem_run_dem / lbmdem_comm_run hand every run of ordinary sub-steps (renderScene calls between which
+ * nothing else happens: no fluid step main.c:1710, no list rebuild main.c:1721, regular contact law main.c:1427-1451, no
+ * write_DEM diagnostics main.c:1773) to ONE kernel launch of at most `max_substeps` sub-steps: the tiles of grains hand
+ * their drifted state (main.c:1748-1753) to their partners' tiles through tagged cache-line records instead of kernel
+ * boundaries. Same bits as lbmdem_dem_substep called that many times. < 2: one launch per sub-step. Default 128. The
+ * library falls back to one launch per sub-step by itself where the tiles of a packing cannot all be resident at once. */
+int lbmdem_set_dem_chain(lbmdem_handle* h, int max_substeps);
+/* what that path has done so far: launches, sub-steps they covered, the workgroups ("tile slots": 64 grains each) one
+ * launch needs resident at once, and how many the census found resident (-1: not taken yet, 0: they do not fit) */
+int lbmdem_dem_chain_stats(lbmdem_handle* h, long* launches, long* substeps, int* tile_slots, int* resident);
+
 /* ---- state in / out (host layout) ------------------------------------------------------------ */
 
 int lbmdem_upload_f(lbmdem_handle* h, const double* f_aos);   /* [lx][ly][9]; rows of the local strip+halo are read */

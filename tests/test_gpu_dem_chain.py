@@ -1,0 +1,89 @@
+"""Runs of ordinary DEM sub-steps in ONE launch (k_dem_chain, lbmdem_set_dem_chain) against one launch per sub-step
+and against the CPU oracle: the tiles of grains hand their drifted state (main.c:1748-1753) to each other through
+tagged cache-line records inside the launch, so every bit has to be the one the per-sub-step kernels produce.
+
+Cases: several tiles with halos staged in LDS; grain indices shuffled so that a tile's partners are spread over the
+whole packing (halos larger than the staging: the per-entry reads from memory); the runs cut by fluid steps, list
+rebuilds (every 100), the film-law sub-step (8000) and the write_DEM sub-step (4000); the last-contact records the
+write_DEM diagnostics start from."""
+import numpy as np
+import pytest
+
+import samples
+
+pytestmark = pytest.mark.gpu
+
+
+def packing(lx, ly, n, seed, shuffle=False):
+    r, x, y = samples.row_packing(lx, ly, n, seed=seed)
+    r, x1, x2 = samples.to_metres(r, x, y)
+    if shuffle:
+        p = np.random.default_rng(seed).permutation(len(r))
+        r, x1, x2 = r[p], x1[p], x2[p]
+    return r, x1, x2
+
+
+def kick(sim_list, n, seed, scale=(0.05, 0.05, 30.0)):
+    rng = np.random.default_rng(seed)
+    k = sim_list[0].kinematics
+    k[:, 3:6] = rng.normal(0, 1, (n, 3)) * scale
+    for s in sim_list:
+        s.kinematics = k
+    return k
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_chain_equals_one_launch_per_substep(pkg, shuffle):
+    lx, ly = 1024, 640
+    r, x1, x2 = packing(lx, ly, 2500, 5, shuffle)
+    a = pkg.LbmDem(lx, ly, r, x1, x2)
+    b = pkg.LbmDem(lx, ly, r, x1, x2)
+    b.set_dem_chain(0)
+    kick([a, b], len(r), 17)
+    for n in (37, 1, 12, 200, 95):     # runs of every length, across fluid steps and list rebuilds
+        a.renderScene(n); b.renderScene(n)
+        assert a.nbsteps == b.nbsteps
+        assert np.array_equal(a.kinematics, b.kinematics), (shuffle, a.nbsteps)
+        assert np.array_equal(a.grain_pressure, b.grain_pressure), (shuffle, a.nbsteps)
+        assert np.array_equal(a.fhf, b.fhf), (shuffle, a.nbsteps)
+    assert np.array_equal(a.f, b.f)
+    assert np.array_equal(a.obst, b.obst)
+    la, sa, slots, resident = a.dem_chain_stats()
+    assert resident == slots and la >= 30 and sa >= 300, (la, sa, slots, resident)   # the chain did run
+    assert b.dem_chain_stats()[:2] == (0, 0)
+    a.close(); b.close()
+
+
+def test_chain_dem_only_long_runs_match_oracle(pkg, po):
+    """run_dem (the reference without _FLUIDE_): runs of 100 sub-steps between list rebuilds, shuffled indices."""
+    lx, ly = 512, 384
+    r, x1, x2 = packing(lx, ly, 900, 9, shuffle=True)
+    sim = pkg.LbmDem(lx, ly, r, x1, x2)
+    ora = po.Oracle(lx, ly, r, x1, x2)
+    k = kick([sim], len(r), 3)
+    ora.set_kinematics(k)
+    for n in (250, 333):
+        sim.run_dem(n); ora.steps_dry(n)
+        assert np.array_equal(sim.kinematics, ora.get_grains()[:, :9]), sim.nbsteps
+    assert sim.dem_chain_stats()[1] >= 570      # all but a handful of the 583 sub-steps went through the chain
+    sim.close()
+
+
+def test_chain_across_film_and_table_substeps_matches_oracle(pkg, po):
+    """sub-steps 3999 (feeds write_DEM: diagnostics, carries resolved from the chain's last-contact records) and 8000
+    (film law) cut the runs; the 30-column grain table after 4000 and 8000 sub-steps equals the oracle's."""
+    import golden_util as gu
+    r, x1, x2 = gu.inputs_m("G4_coupled_256x200")
+    sim = pkg.LbmDem(256, 200, r, x1, x2)
+    ora = po.Oracle(256, 200, r, x1, x2)
+    cols = [po.COL[c] for c in "x1 x2 x3 v1 v2 v3 a1 a2 a3 r m It p s f1 f2 ifm M11 M12 M21 M22 z zz "
+                               "fr ice slip rw".split()]
+    for n in (4000, 4000, 13):
+        sim.renderScene(n); ora.steps(n)
+        assert np.array_equal(sim.kinematics, ora.get_grains()[:, :9]), sim.nbsteps
+        if sim.nbsteps % 4000 == 0:
+            tg, to = sim.grain_table(), ora.get_grains()
+            for c in cols:
+                assert np.array_equal(tg[:, c], to[:, c]), (sim.nbsteps, c)
+    assert np.array_equal(sim.f, ora.get_f())
+    sim.close()
