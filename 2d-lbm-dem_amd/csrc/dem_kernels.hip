@@ -49,6 +49,14 @@ __device__ __forceinline__ GrainState advance(const Kin& K, const real* __restri
   return s;
 }
 
+// strip decomposition: a grain this rank does not integrate keeps its state, and BOTH ping-pong buffers carry it (a
+// run of sub-steps in one launch swaps the buffers once, single sub-steps once each: nothing may depend on the parity)
+__device__ __forceinline__ void carry_over(const Kin& in, const Kin& out, int i) {
+  out.x1[i] = in.x1[i]; out.x2[i] = in.x2[i]; out.x3[i] = in.x3[i];
+  out.v1[i] = in.v1[i]; out.v2[i] = in.v2[i]; out.v3[i] = in.v3[i];
+  out.a1[i] = in.a1[i]; out.a2[i] = in.a2[i]; out.a3[i] = in.a3[i];
+}
+
 // contact force on grain A (lower index) from grain B (higher index).
 // FILM = false: force_grains, main.c:739-774. FILM = true: the inline law of main.c:1365-1395.
 template <bool FILM>
@@ -187,7 +195,7 @@ __global__ void k_dem_substep(Kin in, Kin out, const real* __restrict__ r, const
                               DiagOut D, DemParams P, const unsigned char* __restrict__ active) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
-  if (active && !active[i]) return;  // strip decomposition: a grain another rank integrates
+  if (active && !active[i]) { carry_over(in, out, i); return; }  // strip decomposition: a grain another rank integrates
   const GrainState me = advance(in, r, i, P);
   const real x3 = in.x3[i] + P.dt * in.v3[i] + P.dt2 * in.a3[i] / 2.;
 
@@ -311,7 +319,11 @@ __global__ __launch_bounds__(DEM_THREADS) void k_dem_entries(Kin in, Kin out, co
   const int i = g0 + tid;
   // strip decomposition: only the grains this rank integrates (owned + margin); the others keep whatever they hold
   const bool mine = tid < DEM_GRAINS && i < P.n && (!active || active[i]);
-  if (active && !__syncthreads_or(mine ? 1 : 0)) return;
+  if (active && !__syncthreads_or(mine ? 1 : 0)) {
+    if (tid < DEM_GRAINS && i < P.n) carry_over(in, out, i);
+    return;
+  }
+  if (active && !mine && tid < DEM_GRAINS && i < P.n) carry_over(in, out, i);
   const int e0 = offsets[g0], e1 = offsets[g1];
   GrainState me{};
   real x3 = 0., a1 = 0., a2 = 0., a3 = 0., pr = 0.0, mi = 1., Iti = 1.;
@@ -437,7 +449,6 @@ constexpr int CH_ENTRIES = 384;                       // list entries staged per
 constexpr int CH_META = 768;                          // list entries whose emeta word is kept in LDS
 constexpr int CH_ITEMS = 3;                          // 16-byte slots a lane has in flight per pass of the halo fetch (153 grains)
 constexpr unsigned CH_SPINS = 1u << 18;
-constexpr unsigned CH_LOCAL_SPINS = 1u << 11;        // polls of a local copy before the item turns to the remote one
 constexpr unsigned CH_POISON = 0xFFFFFFFEu;
 constexpr unsigned CH_SKIP = 0xFFFFFFFFu;             // emeta of an entry nobody adds up (its grain is not integrated here)
 
@@ -486,13 +497,14 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
                                                            const int* __restrict__ nbr, const unsigned* __restrict__ emeta,
                                                            const int* __restrict__ halo_ids,
                                                            const int* __restrict__ halo_cnt,
+                                                           const unsigned char* __restrict__ tile_far,
                                                            const unsigned char* __restrict__ wallflags,
                                                            real* __restrict__ pout, DemParams P,
                                                            const unsigned char* __restrict__ active, CarryTrack T,
                                                            long long stamp0, const unsigned char* __restrict__ owner,
                                                            ObstFillJob fill, int tiles, int nsteps, void* pub,
                                                            unsigned pub_bytes, int* __restrict__ err, int* census,
-                                                           long long* dbg, int one_xcd) {
+                                                           long long* dbg, int flags) {
   __shared__ real sF1[CH_ENTRIES], sF2[CH_ENTRIES], sF3[CH_ENTRIES], sFn[CH_ENTRIES];
   __shared__ unsigned char sTouched[CH_ENTRIES];
   __shared__ real sS[5 * CH_SLOTS];     // drifted x1, x2, v1, v2, v3 of the staged grains, one array per field
@@ -505,14 +517,19 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
   __shared__ real sX3[DEM_TILE], sFh[3 * DEM_TILE], sMI[2 * DEM_TILE], sG[2 * DEM_TILE];
   __shared__ int sLast, sFail;
   const int tid = threadIdx.x;
+  const bool one_xcd = (flags & 1) != 0;
   // one_xcd: every eighth block is a tile (they all land on one XCD, whose L2 then carries every hand-off), the others idle
   const int tslots = one_xcd ? tiles * 8 : ((tiles + 7) / 8) * 8;
   if ((int)blockIdx.x >= tslots) {   // the workgroups behind the tile slots reset a slice of the next obstacle map
     obst_fill_range(fill.map, fill.L, (long)(blockIdx.x - tslots) * DEM_THREADS + tid, (long)(gridDim.x - tslots) * DEM_THREADS, fill.row0, fill.row1);
     return;
   }
-  if (nsteps < 0) {   // census: do all tile slots run at the same time?
+  if (nsteps < 0) {   // census: do all tile slots run at the same time, and do blocks that agree mod 8 share an XCD?
     if (tid == 0) {
+      unsigned xcc_id;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+      // bit (8 * (block mod 8) + XCD): a regular placement sets exactly one bit per byte, eight different ones
+      atomicOr(reinterpret_cast<unsigned long long*>(census + 2), 1ull << (8 * (blockIdx.x & 7) + (xcc_id & 7u)));
       __hip_atomic_fetch_add(census, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       unsigned spins = 0;
       while (__hip_atomic_load(census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tslots) {
@@ -528,9 +545,9 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pub, 0, (int)pub_bytes, 0x00020000);
   const unsigned line_par = (unsigned)P.n * 128u;   // bytes between the two parities
   const unsigned remote = 2u * line_par;            // ... and between the local and the remote copy
-  // Workgroups go to the XCDs round-robin, CONTINUING where the launch before stopped (measured: block b on XCD
-  // (b + k) % 8 with k fixed per launch), so two blocks share an XCD iff their indices agree mod 8 -- the tiles of one
-  // contiguous eighth. Nothing promises it: a local copy that stays stale is given up for the remote one.
+  // Workgroups go to the XCDs round-robin (measured: block b on the XCD with HW_REG_XCC_ID (b + 7) % 8, every launch), so
+  // two blocks share an XCD iff their indices agree mod 8 -- the tiles of one contiguous eighth. HIP does not promise it:
+  // the census launch checks it once per handle, and a reader whose local copy stays stale gives up (loudly).
   const int tiles_per_xcd = tslots >> 3;
 #ifdef LBMDEM_AB
   unsigned xcc;
@@ -603,9 +620,9 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
 #else
 #define CH_MARK(k) do { } while (0)
 #endif
-  // only a tile that reads some grain through the fabric is read through it (the list is symmetric)
-  bool any_far = false;
-  for (int h = 0; h < hcnt; ++h) any_far = any_far || (sHoff[h] & 1u);
+  // A tile with a partner on another XCD publishes both copies (only the remote one, for all its readers: measured slower,
+  // 137 k against 154 k sub-steps/s -- more tiles then wait for the fabric)
+  const bool any_far = !one_xcd && tile_far[tile];
   GrainState me{};
   me.r = tid < DEM_GRAINS ? sR[tid] : (real)0.;
   // drift + first half kick (main.c:1748-1753) of the sub-step with sequence number `stamp`, published to the partners'
@@ -639,8 +656,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
     const long long stamp = stamp0 + s;
     const unsigned tag = chain_tag(stamp);
     const unsigned pbase = (stamp & 1) ? line_par : 0u;
-    // (the other wavefronts park here while the first one finishes the sub-step before: polling from its start, they
-    // flood the L2 with reads that cannot succeed yet and take issue slots from the wavefronts that work)
+    // (the other wavefronts park here while the first one finishes the sub-step before)
     __syncthreads();
     CH_MARK(1);   // barrier A
     // ---- the halo grains' state of this sub-step: re-read until both tags of a slot match
@@ -665,9 +681,6 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
             const bool g = (v[it].y == tag || v[it].y == stag) && (v[it].w == tag || v[it].w == stag);
             bad = bad || v[it].y == CH_POISON || v[it].w == CH_POISON;
             if (!g) {
-              // a local copy that stays stale: its writer did not land on this XCD -- the remote copy always arrives
-              // (a writer without far readers publishes no remote copy: then this is the end of the launch)
-              if (spins == CH_LOCAL_SPINS && off[it] < remote) off[it] += remote;
               waitfar = waitfar || off[it] >= remote;
               v[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[it], 0, 16);
             }
@@ -1176,7 +1189,8 @@ __global__ void k_fill_own(int n, const int* __restrict__ offsets, int* __restri
 // the order the atomics arrive in -- only the LDS placement, never a result.
 __global__ __launch_bounds__(256) void k_tile_halo(int n, const int* __restrict__ offsets, const int* __restrict__ nbr,
                                                    const int* __restrict__ own, int* __restrict__ halo_ids,
-                                                   int* __restrict__ halo_cnt, unsigned* __restrict__ emeta) {
+                                                   int* __restrict__ halo_cnt, unsigned* __restrict__ emeta,
+                                                   unsigned char* __restrict__ tile_far, int tiles_per_xcd) {
   constexpr int CELLS = 1024;
   __shared__ int table[CELLS], cidx[CELLS];
   __shared__ int wsum[4];
@@ -1186,9 +1200,11 @@ __global__ __launch_bounds__(256) void k_tile_halo(int n, const int* __restrict_
   const int e0 = offsets[g0], e1 = offsets[g1];
   for (int c = tid; c < CELLS; c += 256) table[c] = -1;
   __syncthreads();
+  bool farp = false;
   for (int e = e0 + tid; e < e1; e += 256) {
     const int gj = nbr[e];
     if (gj >= g0 && gj < g1) continue;
+    farp = farp || (gj / DEM_TILE) / tiles_per_xcd != tile / tiles_per_xcd;
     unsigned hsh = ((unsigned)gj * 2654435761u) >> 22;   // 10 bits
     for (int probe = 0; probe < CELLS; ++probe) {
       const int old = atomicCAS(&table[hsh], -1, gj);
@@ -1221,7 +1237,9 @@ __global__ __launch_bounds__(256) void k_tile_halo(int n, const int* __restrict_
     }
   }
   if (tid == 255) halo_cnt[tile] = basei < DEM_CHAIN_HALO ? basei : DEM_CHAIN_HALO;
-  __syncthreads();
+  // does this tile have a partner in a tile of another XCD's eighth? (then it publishes through memory, for everybody)
+  const int anyfar = __syncthreads_or(farp ? 1 : 0);
+  if (tid == 0) tile_far[tile] = (unsigned char)(anyfar ? 1 : 0);
   for (int e = e0 + tid; e < e1; e += 256) {
     const int gi = own[e], gj = nbr[e];
     unsigned slot = DEM_CHAIN_DIRECT;
@@ -1292,6 +1310,7 @@ int verlet_alloc(VerletDevice& V, int n, real cs, real ox, real oy, real wx, rea
     const size_t tiles = ((size_t)n + DEM_TILE - 1) / DEM_TILE;
     A((void**)&V.halo_ids, sizeof(int) * tiles * DEM_CHAIN_HALO); A((void**)&V.halo_cnt, sizeof(int) * tiles);
     A((void**)&V.emeta, sizeof(unsigned) * V.cap);
+    A((void**)&V.tile_far, tiles);
   }
   if (e != hipSuccess) return -1;
   V.scan_tmp_bytes = 0;
@@ -1312,7 +1331,7 @@ int verlet_alloc(VerletDevice& V, int n, real cs, real ox, real oy, real wx, rea
 
 void verlet_free(VerletDevice& V) {
   void* ps[] = {V.keys_in, V.vals_in, V.vals_out, V.cell_start, V.cell_end,
-                V.scan_tmp, V.counts, V.offsets, V.nbr, V.own, V.wallflags, V.overflow, V.halo_ids, V.halo_cnt, V.emeta};
+                V.scan_tmp, V.counts, V.offsets, V.nbr, V.own, V.wallflags, V.overflow, V.halo_ids, V.halo_cnt, V.emeta, V.tile_far};
   for (void* p : ps) if (p) (void)hipFree(p);
   V = VerletDevice{};
 }
@@ -1434,7 +1453,8 @@ void launch_dem_substep(const Kin& in, const Kin& out, const real* r, const real
 
 void launch_tile_halo(const VerletDevice& V, int n, hipStream_t st) {
   const int tiles = (n + DEM_TILE - 1) / DEM_TILE;
-  hipLaunchKernelGGL(k_tile_halo, dim3(tiles), dim3(256), 0, st, n, V.offsets, V.nbr, V.own, V.halo_ids, V.halo_cnt, V.emeta);
+  hipLaunchKernelGGL(k_tile_halo, dim3(tiles), dim3(256), 0, st, n, V.offsets, V.nbr, V.own, V.halo_ids, V.halo_cnt, V.emeta,
+                     V.tile_far, dem_chain_tslots(n) >> 3);
 }
 
 int dem_chain_tslots(int n) { return DEM_GRID((n + DEM_GRAINS - 1) / DEM_GRAINS); }
@@ -1445,11 +1465,11 @@ int dem_chain_alloc(DemChain& C, int n) {
   if (bytes >= ((size_t)1 << 31)) return 0;   // 32-bit buffer offsets: the chain stays off (capacity 0)
   if (hipMalloc(&C.pub, bytes ? bytes : 128) != hipSuccess) return -1;
   C.pub_bytes = bytes;
-  if (hipMalloc((void**)&C.census, sizeof(int)) != hipSuccess) { dem_chain_free(C); return -1; }
+  if (hipMalloc((void**)&C.census, 4 * sizeof(int)) != hipSuccess) { dem_chain_free(C); return -1; }   // counter, pad, 64-bit placement map
   if (hipHostMalloc((void**)&C.err_host, sizeof(int), hipHostMallocDefault) != hipSuccess) { dem_chain_free(C); return -1; }
   *C.err_host = 0;
   if (hipHostGetDevicePointer((void**)&C.err, (void*)C.err_host, 0) != hipSuccess) { dem_chain_free(C); return -1; }
-  if (hipMemset(C.pub, 0, bytes ? bytes : 128) != hipSuccess || hipMemset(C.census, 0, sizeof(int)) != hipSuccess ||
+  if (hipMemset(C.pub, 0, bytes ? bytes : 128) != hipSuccess || hipMemset(C.census, 0, 4 * sizeof(int)) != hipSuccess ||
       hipDeviceSynchronize() != hipSuccess) { dem_chain_free(C); return -1; }
   return 0;
 }
@@ -1472,15 +1492,25 @@ int dem_chain_census(DemChain& C, int tslots, hipStream_t st) {
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dem_chain, DEM_THREADS, 0) != hipSuccess) return 0;
   if ((long)per_cu * prop.multiProcessorCount < tslots) return 0;
-  if (hipMemsetAsync(C.census, 0, sizeof(int), st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 0;
+  if (hipMemsetAsync(C.census, 0, 4 * sizeof(int), st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 0;
   *C.err_host = 0;
   hipLaunchKernelGGL(k_dem_chain, dim3(tslots), dim3(DEM_THREADS), 0, st, Kin{}, Kin{}, nullptr, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, DemParams{}, nullptr, CarryTrack{}, 0ll,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, DemParams{}, nullptr, CarryTrack{}, 0ll,
                      nullptr, ObstFillJob{}, tslots, -1, C.pub, (unsigned)C.pub_bytes, C.err, C.census, nullptr, 0);
-  int seen = 0;
-  if (hipMemcpyAsync(&seen, C.census, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return 0;
+  int seen[4] = {0, 0, 0, 0};
+  if (hipMemcpyAsync(seen, C.census, sizeof(seen), hipMemcpyDeviceToHost, st) != hipSuccess) return 0;
   if (hipStreamSynchronize(st) != hipSuccess) return 0;
-  if (*C.err_host == 0 && seen == tslots) C.capacity = tslots;
+  // placement: every residue class of the block index on exactly one XCD, the eight classes on eight different ones
+  unsigned long long map = 0;
+  memcpy(&map, seen + 2, sizeof(map));
+  unsigned used = 0;
+  bool regular = true;
+  for (int c = 0; c < 8; ++c) {
+    const unsigned byte = (unsigned)(map >> (8 * c)) & 0xFFu;
+    if (byte == 0 || (byte & (byte - 1)) != 0 || (used & byte)) regular = false;
+    used |= byte;
+  }
+  if (*C.err_host == 0 && seen[0] == tslots && regular) C.capacity = tslots;
   *C.err_host = 0;
   return C.capacity;
 }
@@ -1503,7 +1533,7 @@ void launch_dem_chain(const Kin& in, const Kin& out, const real* r, const real* 
   static const bool want_one = getenv("LBMDEM_CHAIN_ONE_XCD") != nullptr;
   one_xcd = want_one && nbe <= 128 ? 1 : 0;
 #endif
-  hipLaunchKernelGGL(k_dem_chain, dim3((one_xcd ? nbe * 8 : DEM_GRID(nbe)) + extra), dim3(DEM_THREADS), 0, st, in, out, r, m, It, fhf, V.offsets,
-                     V.nbr, V.emeta, V.halo_ids, V.halo_cnt, V.wallflags, pout, P, active, T, stamp0, owner, fill, nbe, nsteps,
+  hipLaunchKernelGGL(k_dem_chain, dim3(((one_xcd & 1) ? nbe * 8 : DEM_GRID(nbe)) + extra), dim3(DEM_THREADS), 0, st, in, out, r, m, It, fhf, V.offsets,
+                     V.nbr, V.emeta, V.halo_ids, V.halo_cnt, V.tile_far, V.wallflags, pout, P, active, T, stamp0, owner, fill, nbe, nsteps,
                      C.pub, (unsigned)C.pub_bytes, C.err, C.census, C.dbg, one_xcd);
 }

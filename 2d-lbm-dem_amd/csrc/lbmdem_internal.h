@@ -260,6 +260,7 @@ struct VerletDevice {
   int* halo_ids;             // [tiles][DEM_CHAIN_HALO]
   int* halo_cnt;             // [tiles]
   unsigned* emeta;           // [cap] own grain's index in its tile | (own < partner) << 6 | partner's staging slot << 8
+  unsigned char* tile_far;   // [tiles] the tile has a partner in a tile that is expected on another XCD
 };
 constexpr int DEM_CHAIN_HALO = 320;          // halo grains staged per tile; partners beyond that are read from memory per entry
 constexpr unsigned DEM_CHAIN_DIRECT = 0xFFFFu;   // emeta slot value of such a partner

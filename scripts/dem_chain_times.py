@@ -55,3 +55,10 @@ print("first wavefronts sharing a SIMD (count of (CU, SIMD) groups by size):", d
 
 names = ["drift+publish", "barrier A", "halo fetch", "barrier B", "phase 1", "barrier", "phase 2+barrier", "walls/acc/kick"]
 print("first wavefront's lane 0, us per sub-step (mean over tiles / max): " + "; ".join(f"{nm} {buf[:, 8 + k].mean() * 0.01 / nsub:.2f}/{buf[:, 8 + k].max() * 0.01 / nsub:.2f}" for k, nm in enumerate(names)))
+own = (buf[:, 8] + buf[:, 11] + buf[:, 12] + buf[:, 13] + buf[:, 14] + buf[:, 15]) * 0.01 / nsub   # all but the waits (barrier A = hint wait, halo fetch)
+waits = (buf[:, 9] + buf[:, 10]) * 0.01 / nsub
+print(f"per tile, us per sub-step: own time mean {own.mean():.2f} p90 {np.percentile(own, 90):.2f} p99 {np.percentile(own, 99):.2f} max {own.max():.2f}; waits mean {waits.mean():.2f} min {waits.min():.2f}; pace {(own + waits).mean():.2f}")
+top = np.argsort(-own)[:12]
+for t in top:
+    print(f"   tile {t:4d}: own {own[t]:.2f} waits {waits[t]:.2f}; tiles on its CU {per_cu[t]}; far {far[t]}; entries {buf[t,5]}; halo {buf[t,4]}; phases " +
+          " ".join(f"{buf[t, 8 + k] * 0.01 / nsub:.2f}" for k in range(8)))
