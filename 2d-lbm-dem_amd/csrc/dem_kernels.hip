@@ -549,7 +549,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
   // two blocks share an XCD iff their indices agree mod 8 -- the tiles of one contiguous eighth. HIP does not promise it:
   // the census launch checks it once per handle, and a reader whose local copy stays stale gives up (loudly).
   const int tiles_per_xcd = tslots >> 3;
-#ifdef LBMDEM_AB
+#ifdef LBMDEM_CHAIN_TIMING
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   const bool placed = true;
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
   if (tid == 0) sFail = 0;
   __syncthreads();
 
-#ifdef LBMDEM_AB   /* experiment build: where a tile's time goes (100 MHz clock), dbg[tile][16] */
+#ifdef LBMDEM_CHAIN_TIMING   /* experiment build: where a tile's time goes (100 MHz clock), dbg[tile][16] */
   long long t_wait = 0, t_work = 0, n_spins = 0, t_begin = wall_clock64();
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm = t_begin;
 #define CH_MARK(k) do { const long long now_ = wall_clock64(); ph[k] += now_ - tm; tm = now_; } while (0)
@@ -639,6 +639,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
         v3 = v3 + P.dt * a3 / 2.;
       }
       if (have) {
+        // (the remote copy first: measured 1.3 % slower)
         chain_publish<0>(rs, pb + (unsigned)i * 128u, chain_tag(stamp), x1, x2, v1, v2, v3);
         if (any_far) chain_publish<16>(rs, remote + pb + (unsigned)i * 128u, chain_tag(stamp), x1, x2, v1, v2, v3);
       }
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
   };
   drift_publish(stamp0);
   for (int s = 0; s < nsteps; ++s) {
-#ifdef LBMDEM_AB
+#ifdef LBMDEM_CHAIN_TIMING
     const long long t_a = wall_clock64();
     tm = t_a;
 #endif
@@ -687,11 +688,14 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
             ok = ok && g;
           }
         if (__any(bad) || ++spins > CH_SPINS) { sFail = 1; break; }
-#ifdef LBMDEM_AB
+#ifdef LBMDEM_CHAIN_TIMING
         ++n_spins;
 #endif
         if (__all(ok)) break;
         if (__any(waitfar)) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(1);   // polls through the fabric: fewer
+#ifdef LBMDEM_CHAIN_TIMING
+        for (int z = 0; z < ((flags >> 8) & 0xFF); ++z) __builtin_amdgcn_s_sleep(1);   // experiment: longer pauses between polls
+#endif
       }
 #pragma unroll
       for (int it = 0; it < CH_ITEMS; ++it) {
@@ -704,7 +708,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
     CH_MARK(2);   // halo landed (this wavefront's part)
     __syncthreads();
     CH_MARK(3);   // barrier B
-#ifdef LBMDEM_AB
+#ifdef LBMDEM_CHAIN_TIMING
     const long long t_b = wall_clock64();
     t_wait += t_b - t_a;
 #endif
@@ -818,11 +822,11 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
         }
       }
     }
-#ifdef LBMDEM_AB
+#ifdef LBMDEM_CHAIN_TIMING
     t_work += wall_clock64() - t_b;
 #endif
   }
-#ifdef LBMDEM_AB
+#ifdef LBMDEM_CHAIN_TIMING
   if (dbg && tid == 0) {
     long long* d = dbg + (long)tile * 16;
     for (int k = 0; k < 8; ++k) d[8 + k] = ph[k];
@@ -1532,6 +1536,8 @@ void launch_dem_chain(const Kin& in, const Kin& out, const real* r, const real* 
 #ifdef LBMDEM_AB
   static const bool want_one = getenv("LBMDEM_CHAIN_ONE_XCD") != nullptr;
   one_xcd = want_one && nbe <= 128 ? 1 : 0;
+  static const int extra_sleep = getenv("LBMDEM_CHAIN_SLEEP") ? atoi(getenv("LBMDEM_CHAIN_SLEEP")) : 0;
+  one_xcd |= (extra_sleep & 0xFF) << 8;
 #endif
   hipLaunchKernelGGL(k_dem_chain, dim3(((one_xcd & 1) ? nbe * 8 : DEM_GRID(nbe)) + extra), dim3(DEM_THREADS), 0, st, in, out, r, m, It, fhf, V.offsets,
                      V.nbr, V.emeta, V.halo_ids, V.halo_cnt, V.tile_far, V.wallflags, pout, P, active, T, stamp0, owner, fill, nbe, nsteps,

@@ -343,6 +343,9 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
       return rc;
     }
   }
+#ifdef LBMDEM_AB
+  if (const char* e = getenv("LBMDEM_DEM_CHAIN")) h->chain_max = atoi(e);   // A/B: 0 = one launch per sub-step
+#endif
   if (dem_chain_alloc(h->chain, n) != 0) {
     int rc = fail(LBMDEM_ENOMEM, "sub-step hand-over lines: hipMalloc failed");
     lbmdem_destroy(h);

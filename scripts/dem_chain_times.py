@@ -1,5 +1,6 @@
-"""Where a tile of k_dem_chain spends its time (experiment build: make -C 2d-lbm-dem_amd/csrc AB=1, run with
-LBMDEM_HIP_LIBRARY=2d-lbm-dem_amd/liblbmdem_hip_ab.so): per tile clocks waiting for the halo grains' state, clocks in the
+"""Where a tile of k_dem_chain spends its time (experiment build with the clock marks compiled in:
+make -C 2d-lbm-dem_amd/csrc AB=1 ABTAG=_ct ABFLAGS=-DLBMDEM_CHAIN_TIMING, run with LBMDEM_HIP_LIBRARY=2d-lbm-dem_amd/liblbmdem_hip_ab_ct.so;
+the marks cost ~0.5 us per sub-step): per tile clocks waiting for the halo grains' state, clocks in the
 contact phases, poll rounds, placement. DEM only (run_dem), the bench packing or a smaller one (argv[1] = grains)."""
 import ctypes as C, sys, os, time
 import numpy as np
