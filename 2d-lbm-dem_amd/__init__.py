@@ -129,6 +129,7 @@ def _open_library(LIB_PATH):
     L.lbmdem_checkpoint_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     L.lbmdem_set_force_mode.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_set_dem_chain.argtypes = [C.c_void_p, C.c_int]
+    L.lbmdem_measure_copy.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     L.lbmdem_dem_chain_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lbmdem_set_lid.argtypes = [C.c_void_p, C.c_double]
     L.lbmdem_force_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -507,6 +508,12 @@ class LbmDem:
     def set_dem_chain(self, max_substeps):
         """Longest run of ordinary sub-steps renderScene hands to ONE launch (< 2: one launch per sub-step)."""
         _chk(self._L.lbmdem_set_dem_chain(self._h, int(max_substeps)))
+
+    def measure_copy(self, nbytes=1200 * 1000 * 1000, reps=5):
+        """GB/s (read + written) of a plain copy of `nbytes` on this handle's device: the box's yardstick"""
+        g = C.c_double(0.0)
+        _chk(self._L.lbmdem_measure_copy(self._h, int(nbytes), int(reps), C.byref(g)))
+        return g.value
 
     def dem_chain_stats(self):
         """(launches, sub-steps covered, tile slots a launch needs resident, slots the census found; -1 = not taken)"""

@@ -1351,7 +1351,10 @@ int launch_verlet_rebuild(VerletDevice& V, const Kin& K, const real* r, const De
   hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, V.ox, V.oy, V.cs, V.ncx, V.ncy,
                      V.keys_in, V.vals_in, V.cell_end);
   e = hipcub::DeviceScan::ExclusiveSum(V.scan_tmp, V.scan_tmp_bytes, V.cell_end, V.cell_start, (int)(ncell + 1), st);
-  if (e != hipSuccess) return (int)e;
+  if (e != hipSuccess) {   // k_cell_scatter, which returns the counts to zero for the next rebuild, will not run
+    (void)hipMemsetAsync(V.cell_end, 0, sizeof(int) * (ncell + 1), st);
+    return (int)e;
+  }
   hipLaunchKernelGGL(k_cell_scatter, dim3(nb), dim3(256), 0, st, n, V.keys_in, V.vals_in, V.cell_start, V.cell_end,
                      V.vals_out);
   hipLaunchKernelGGL(k_verlet_scan<0>, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, r, V.ox, V.oy, V.cs, V.ncx,

@@ -260,3 +260,15 @@ void launch_halo_unpack(real* f, const LatticeView& L, int xl0_lo, int xl0_hi, i
   hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(9L * nrows * L.ly), 2), dim3(256), 0, st, f, L, xl0_lo, xl0_hi, nrows,
                      buf_lo, buf_hi);
 }
+
+// A plain copy, 16 bytes per lane and iteration, grid-stride: what this GPU's memory system moves when nothing else is asked
+// of it (lbmdem_measure_copy; bench.py reports the fused kernel's traffic rate against it, so that lines measured on
+// different boxes can be compared)
+__global__ __launch_bounds__(256) void k_plain_copy(const double2* __restrict__ src, double2* __restrict__ dst, long n2) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n2; k += stride) dst[k] = src[k];
+}
+
+void launch_plain_copy(const void* src, void* dst, size_t bytes, hipStream_t st) {
+  hipLaunchKernelGGL(k_plain_copy, dim3(256 * 32), dim3(256), 0, st, (const double2*)src, (double2*)dst, (long)(bytes / 16));
+}

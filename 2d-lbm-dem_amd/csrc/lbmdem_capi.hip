@@ -399,6 +399,7 @@ int lbmdem_destroy(lbmdem_handle* h) {
   carry_track_free(h->ct);
   for (hipEvent_t e : h->ev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev1) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev2) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return LBMDEM_OK;
@@ -431,11 +432,13 @@ static int prof_begin(lbmdem_handle* h, hipEvent_t* e1) {
   *e1 = nullptr;
   if (!h->prof) return LBMDEM_OK;
   if (h->ev_used == h->ev0.size()) {
-    hipEvent_t a, b;
+    hipEvent_t a, b, c2;
     HIP_TRY(hipEventCreate(&a));
     HIP_TRY(hipEventCreate(&b));
-    h->ev0.push_back(a); h->ev1.push_back(b);
+    HIP_TRY(hipEventCreate(&c2));
+    h->ev0.push_back(a); h->ev1.push_back(b); h->ev2.push_back(c2); h->ev2_set.push_back(0);
   }
+  h->ev2_set[h->ev_used] = 0;
   hipEvent_t e0 = h->ev0[h->ev_used];
   *e1 = h->ev1[h->ev_used];
   ++h->ev_used;
@@ -448,6 +451,7 @@ int lbmdem_collide_stream(lbmdem_handle* h) try {
   CHECK_H(h);
   PhaseRange range_("lbmdem:collide_stream");
   CHECK_NOT_SPLIT(h);
+  h->cs_prepared = false;   // (a lbmdem_collide_stream_prepare that no EDGES part followed)
   const int* ob_old = h->obst[h->ocur];
   const int* ob_new = h->obst_pending ? h->obst[1 - h->ocur] : h->obst[h->ocur];
   hipEvent_t e1 = nullptr;
@@ -485,7 +489,20 @@ int lbmdem_collide_stream_part(lbmdem_handle* h, int part) {
 // `st`: the stream the part's kernel goes to. EDGES prepares the launch (slot table emptied if need be, profiling start)
 // on the handle's stream and, when st is another stream, expects the caller to have made st wait for that point; the two
 // parts write disjoint rows from the same old lattice, so they may run concurrently.
+static int collide_stream_part_on_impl(lbmdem_handle* h, int part, hipStream_t st);
 int lbmdem_collide_stream_part_on(lbmdem_handle* h, int part, hipStream_t st) try {
+  const int rc = collide_stream_part_on_impl(h, part, st);
+  if (rc != LBMDEM_OK && h) h->cs_prepared = false;   // a failed part leaves no half-prepared launch behind
+  return rc;
+} catch (const std::bad_alloc&) {
+  if (h) h->cs_prepared = false;
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
+} catch (...) {
+  if (h) h->cs_prepared = false;
+  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
+}
+
+static int collide_stream_part_on_impl(lbmdem_handle* h, int part, hipStream_t st) {
   CHECK_H(h);
   PhaseRange range_("lbmdem:collide_stream_part");
   const LatticeView& L = h->L;
@@ -509,6 +526,8 @@ int lbmdem_collide_stream_part_on(lbmdem_handle* h, int part, hipStream_t st) tr
     h->cs_prepared = false;
     launch_collide_stream_edges(h->cs_fin, h->f[1 - h->fcur], h->cs_ob_old, h->cs_ob_new, L, gview(h), h->cs_slots, L.xo0,
                                 lo_end, hi_begin, L.xo1, st);
+    // the profiled interval of a split launch ends with whichever part ends last
+    if (h->prof && h->ev_used > 0) { HIP_TRY(hipEventRecord(h->ev2[h->ev_used - 1], st)); h->ev2_set[h->ev_used - 1] = 1; }
     HIP_TRY(hipGetLastError());
     h->fcur = 1 - h->fcur;
     if (h->obst_pending) { h->ocur = 1 - h->ocur; h->obst_pending = false; h->obst_reset_rows = 0; }
@@ -530,10 +549,6 @@ int lbmdem_collide_stream_part_on(lbmdem_handle* h, int part, hipStream_t st) tr
     return LBMDEM_OK;
   }
   return fail(LBMDEM_EINVAL, "part must be LBMDEM_CS_EDGES or LBMDEM_CS_INTERIOR");
-} catch (const std::bad_alloc&) {
-  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
-} catch (...) {
-  return fail(LBMDEM_EINVAL, "unexpected C++ exception");
 }
 
 int lbmdem_forces_fluid(lbmdem_handle* h) {
@@ -1130,6 +1145,37 @@ int lbmdem_sync(lbmdem_handle* h) {
   return LBMDEM_OK;
 }
 
+// bytes copied (read + written: 2 x `bytes`) per second by a plain copy kernel on this handle's device and stream, best of `reps`
+int lbmdem_measure_copy(lbmdem_handle* h, size_t bytes, int reps, double* gb_per_s) {
+  CHECK_H(h);
+  if (!gb_per_s || bytes < 16 || reps < 1) return fail(LBMDEM_EINVAL, "bad lbmdem_measure_copy arguments");
+  bytes &= ~(size_t)15;
+  void *a = nullptr, *b = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipMalloc(&a, bytes);
+  if (e == hipSuccess) e = hipMalloc(&b, bytes);
+  if (e == hipSuccess) e = hipMemsetAsync(a, 0x11, bytes, h->stream);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  float best = 0.f;
+  for (int k = 0; k <= reps && e == hipSuccess; ++k) {   // (the first pass is a warm-up)
+    e = hipEventRecord(e0, h->stream);
+    launch_plain_copy(a, b, bytes, h->stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (k > 0 && (best == 0.f || ms < best)) best = ms;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (a) (void)hipFree(a);
+  if (b) (void)hipFree(b);
+  HIP_TRY(e);
+  *gb_per_s = best > 0.f ? 2.0 * (double)bytes / (best * 1e-3) / 1e9 : 0.0;
+  return LBMDEM_OK;
+}
+
 int lbmdem_profile_enable(lbmdem_handle* h, int on) {
   CHECK_H(h);
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1145,6 +1191,12 @@ int lbmdem_profile_read(lbmdem_handle* h, double* mean_ms, long* launches) {
   for (size_t k = 0; k < h->ev_used; ++k) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0[k], h->ev1[k]));
+    if (h->ev2_set[k]) {   // the edge rows ran on another stream next to the interior rows
+      float ms2 = 0.f;
+      HIP_TRY(hipEventSynchronize(h->ev2[k]));
+      HIP_TRY(hipEventElapsedTime(&ms2, h->ev0[k], h->ev2[k]));
+      if (ms2 > ms) ms = ms2;
+    }
     tot += ms;
   }
   if (mean_ms) *mean_ms = h->ev_used ? tot / (double)h->ev_used : 0.0;

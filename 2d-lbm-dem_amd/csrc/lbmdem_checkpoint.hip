@@ -3,6 +3,8 @@
 
 #include "lbmdem_handle.h"
 
+#include <sys/stat.h>
+
 #pragma GCC visibility push(default)
 extern "C" {
 // ---- checkpoint / restart ------------------------------------------------------------------------
@@ -113,6 +115,14 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
     return fail(LBMDEM_EINVAL, "checkpoint '%s': implausible header (grains %d, lattice %d x %d, rows [%d, %d))", path,
                 hc.nbgrains, hc.lx, hc.ly, hc.x_begin, hc.x_end);
   const int n = H.cfg.nbgrains;
+  {   // nothing is allocated from a header the file itself cannot back: the fixed part alone is this long
+    struct stat stt;
+    const long long need = (long long)sizeof H + (long long)sizeof(double) * 14 * n + (long long)sizeof(int) * (n + 1) +
+                           (long long)sizeof(int) * H.nnbr + n + (long long)(sizeof(int) + 9 * sizeof(double)) * H.plane;
+    if (fstat(fileno(fp), &stt) != 0 || (long long)stt.st_size < need)
+      return fail(LBMDEM_EINVAL, "checkpoint '%s' is shorter than its header claims (%lld of at least %lld bytes)", path,
+                  (long long)stt.st_size, need);
+  }
   std::vector<double> r(n), kin(9 * (size_t)n);
   if (!rd(fp, r.data(), sizeof(double) * n) || !rd(fp, kin.data(), sizeof(double) * 9 * n)) return fail(LBMDEM_EINVAL, "checkpoint truncated");
   lbmdem_config cfg = H.cfg;
@@ -120,6 +130,10 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
   lbmdem_handle* h = nullptr;
   int rc = lbmdem_create(&cfg, r.data(), kin.data(), kin.data() + n, &h);  // x1, x2 are the first two columns
   if (rc != LBMDEM_OK) return rc;
+  struct HandleGuard {   // whatever leaves this function early -- a return, a bad_alloc in a staging buffer -- frees the handle
+    lbmdem_handle* h;
+    ~HandleGuard() { if (h) lbmdem_destroy(h); }
+  } guard{h};
   bool ok = h->L.plane == H.plane && H.nnbr <= h->V.cap;
   auto fill = [&](void* dev, size_t bytes) {
     if (!ok || bytes == 0) return;
@@ -130,8 +144,18 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
   h->kcur = 0;
   fill(h->fhf, sizeof(double) * 3 * n);
   fill(h->gp, sizeof(double) * n);
-  fill(h->V.offsets, sizeof(int) * (n + 1));
-  fill(h->V.nbr, sizeof(int) * (size_t)H.nnbr);
+  {   // the pair list goes straight into kernels that index with it: checked here, on the host
+    std::vector<int> off((size_t)n + 1), nb((size_t)H.nnbr);
+    if (ok) ok = rd(fp, off.data(), sizeof(int) * off.size()) && rd(fp, nb.data(), sizeof(int) * nb.size());
+    if (ok && H.verlet_ok) {
+      ok = off[0] == 0 && off[n] == H.nnbr;
+      for (int i = 0; i < n && ok; ++i) ok = off[i] <= off[i + 1];
+      for (long k = 0; k < H.nnbr && ok; ++k) ok = nb[k] >= 0 && nb[k] < n;
+      if (!ok) return fail(LBMDEM_EINVAL, "checkpoint '%s': the pair list is inconsistent", path);
+    }
+    if (ok) ok = hipMemcpy(h->V.offsets, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice) == hipSuccess &&
+                 (H.nnbr == 0 || hipMemcpy(h->V.nbr, nb.data(), sizeof(int) * nb.size(), hipMemcpyHostToDevice) == hipSuccess);
+  }
   fill(h->V.wallflags, n);
   fill(h->obst[0], sizeof(int) * (size_t)h->L.plane);
   h->ocur = 0; h->obst_pending = false;
@@ -144,16 +168,14 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
          lbmdem_dist_enable_caps(h, D.margin, D.cap_g, D.cap_t, D.cap_l) == LBMDEM_OK;
     if (ok) { fill(h->dd.active, n); fill(h->dd.fluidmask, n); fill(h->owner, n); h->dist_poison = D.poison != 0; }
   }
-  if (!ok) { lbmdem_destroy(h); return fail(LBMDEM_EINVAL, "checkpoint '%s' is truncated or from a different decomposition", path); }
+  if (!ok) return fail(LBMDEM_EINVAL, "checkpoint '%s' is truncated or from a different decomposition", path);
   h->cfg = cfg;  // wall positions as saved
   h->force_mode = H.force_mode;
   h->L.lid6 = H.lid6;
   h->diag_always = H.diag_always != 0;
   if (H.has_carry) {  // the "previous contact" carries continue across the restart (no records yet: ct.carry stands)
-    if (hipMemcpy(h->ct.carry, H.carry, sizeof H.carry, hipMemcpyHostToDevice) != hipSuccess) {
-      lbmdem_destroy(h);
+    if (hipMemcpy(h->ct.carry, H.carry, sizeof H.carry, hipMemcpyHostToDevice) != hipSuccess)
       return fail(LBMDEM_EHIP, "checkpoint: carries not restored");
-    }
   }
   h->nbsteps = H.nbsteps;
   h->verlet_ok = H.verlet_ok != 0;
@@ -161,8 +183,9 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
   if (h->verlet_ok) {  // the entry -> grain map is derived from the offsets
     launch_fill_own(h->V, n, h->stream);
     launch_tile_halo(h->V, n, h->stream);
-    if (hipStreamSynchronize(h->stream) != hipSuccess) { lbmdem_destroy(h); return fail(LBMDEM_EHIP, "k_fill_own failed"); }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(LBMDEM_EHIP, "k_fill_own failed");
   }
+  guard.h = nullptr;
   *out = h;
   return LBMDEM_OK;
 } catch (const std::bad_alloc&) {

@@ -36,6 +36,8 @@ int rccl_load() {
   if (named && *named) {
     lib = dlopen(named, RTLD_NOW | RTLD_LOCAL);
     if (!lib) return fail(LBMDEM_EHIP, "cannot load LBMDEM_RCCL_LIBRARY=%s: %s", named, dlerror());
+    // said once, loudly: a production run must not use a stand-in for RCCL without anybody noticing
+    fprintf(stderr, "liblbmdem_hip: the communication library is LBMDEM_RCCL_LIBRARY=%s, not the system's RCCL\n", named);
   }
   if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
   if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
@@ -381,25 +383,37 @@ int lbmdem_comm_write_vtk(lbmdem_handle* h, lbmdem_comm* c, const char* dir, int
   const LatticeView& L = h->L;
   const int nx = L.xo1 - L.xo0, x0 = L.gx0 + L.xo0;
   const size_t part = (size_t)nx * ly;
-  std::vector<float> loc(11 * part);
-  RC_TRY(lbmdem_download_vtk_fields(h, loc.data(), loc.data() + part, loc.data() + 4 * part, loc.data() + 7 * part, loc.data() + 8 * part));
-  // who owns which columns
-  std::vector<double> strips(2 * (size_t)W, 0.0);
+  // Every local step that can fail comes BEFORE a vote over all ranks: a rank that returned early would leave rank 0
+  // blocked in its receive for ever (no time-out in RCCL).
+  std::vector<float> loc;
+  int rc_local = LBMDEM_OK;
+  try { loc.resize(11 * part); } catch (const std::bad_alloc&) { rc_local = fail(LBMDEM_ENOMEM, "host memory allocation failed"); }
+  if (rc_local == LBMDEM_OK)
+    rc_local = lbmdem_download_vtk_fields(h, loc.data(), loc.data() + part, loc.data() + 4 * part, loc.data() + 7 * part, loc.data() + 8 * part);
+  // who owns which columns; last entry: ranks that failed so far
+  if (2 * W + 1 > 1024) return fail(LBMDEM_EINVAL, "too many ranks");
+  std::vector<double> strips(2 * (size_t)W + 1, 0.0);
   strips[2 * (size_t)c->rank] = x0; strips[2 * (size_t)c->rank + 1] = nx;
-  if (W > 1) {
-    if (2 * W > 1024) return fail(LBMDEM_EINVAL, "too many ranks");
-    RC_TRY(lbmdem_comm_allreduce_sum(c, strips.data(), 2 * W));
-  }
+  strips[2 * (size_t)W] = rc_local == LBMDEM_OK ? 0.0 : 1.0;
+  if (W > 1) RC_TRY(lbmdem_comm_allreduce_sum(c, strips.data(), 2 * W + 1));
+  if (strips[2 * (size_t)W] != 0.0)
+    return rc_local != LBMDEM_OK ? rc_local : fail(LBMDEM_EHIP, "write_vtk: %d rank(s) could not render their columns", (int)strips[2 * (size_t)W]);
   size_t widest = 0, covered = 0;
   for (int r = 0; r < W; ++r) { const size_t w = (size_t)strips[2 * (size_t)r + 1]; if (w > widest) widest = w; covered += w; }
-  if (covered != (size_t)lx) return fail(LBMDEM_EINVAL, "the ranks' strips cover %zu of %d columns", covered, lx);
-  if (W > 1 && c->vtk_floats < 11 * widest * ly) {
-    if (c->vtk_dev) { HIP_TRY(hipFree(c->vtk_dev)); c->vtk_dev = nullptr; c->vtk_floats = 0; }
-    HIP_TRY(hipMalloc((void**)&c->vtk_dev, sizeof(float) * 11 * widest * ly));
-    c->vtk_floats = 11 * widest * ly;
+  if (covered != (size_t)lx) return fail(LBMDEM_EINVAL, "the ranks' strips cover %zu of %d columns", covered, lx);   // (the same on every rank)
+  if (W > 1) {
+    hipError_t e = hipSuccess;
+    if (c->vtk_floats < 11 * widest * ly) {
+      if (c->vtk_dev) { (void)hipFree(c->vtk_dev); c->vtk_dev = nullptr; c->vtk_floats = 0; }
+      e = hipMalloc((void**)&c->vtk_dev, sizeof(float) * 11 * widest * ly);
+      if (e == hipSuccess) c->vtk_floats = 11 * widest * ly;
+    }
+    if (e == hipSuccess && c->rank != 0) e = hipMemcpy(c->vtk_dev, loc.data(), sizeof(float) * loc.size(), hipMemcpyHostToDevice);
+    double bad = e == hipSuccess ? 0.0 : 1.0;
+    RC_TRY(lbmdem_comm_allreduce_sum(c, &bad, 1));   // second vote: the staging buffers stand on every rank
+    if (bad != 0.0) return fail(LBMDEM_EHIP, "write_vtk: staging buffer on %d rank(s) failed%s%s", (int)bad, e == hipSuccess ? "" : ": ", e == hipSuccess ? "" : hipGetErrorString(e));
   }
   if (c->rank != 0) {
-    HIP_TRY(hipMemcpy(c->vtk_dev, loc.data(), sizeof(float) * loc.size(), hipMemcpyHostToDevice));
     NCCL_TRY(g_rccl.Send(c->vtk_dev, loc.size(), ncclFloat, 0, c->nccl[0], c->side[0]));
     HIP_TRY(hipStreamSynchronize(c->side[0]));
     return LBMDEM_OK;

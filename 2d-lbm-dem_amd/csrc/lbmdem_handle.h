@@ -108,6 +108,8 @@ struct lbmdem_handle {
   // profiling of the dominant kernel
   bool prof = false;
   std::vector<hipEvent_t> ev0, ev1;
+  std::vector<hipEvent_t> ev2;      // end of the EDGES part of a split launch (it may run on another stream, next to INTERIOR)
+  std::vector<char> ev2_set;
   size_t ev_used = 0;
 };
 

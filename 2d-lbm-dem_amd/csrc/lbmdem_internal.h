@@ -216,6 +216,7 @@ void launch_aos_to_soa(const real* aos_rows, real* f, const LatticeView& L, hipS
 void launch_soa_to_aos(const real* f, real* aos_rows, const LatticeView& L, int xl0, int nrows,
                        hipStream_t st);
 void launch_fill_equilibrium(real* f, const LatticeView& L, hipStream_t st);
+void launch_plain_copy(const void* src, void* dst, size_t bytes, hipStream_t st);
 void launch_macro(const real* f, const LatticeView& L, int xl0, int nrows, real* rho, real* ux,
                   real* uy, hipStream_t st);
 void launch_density_partial(const real* f, const LatticeView& L, double* partial, int nblocks,

@@ -116,7 +116,7 @@ int lbmdem_force_stats(lbmdem_handle* h, int* from_table, int* gathered);
  * < ~20 nodes, reductionR < 1), info4[1] its slots per direction, info4[2] the lowest-cover record that keeps `act` exact
  * where three or more reduced discs overlap (< 2^20 grains; else the two-disc rule), info4[3] the marching fused kernel. */
 int lbmdem_path_info(lbmdem_handle* h, int* info4);
-/* How the fused kernel's launch over this handle's rows is cut into work items (windows of 62 columns x segments of rows):
+/* How the fused kernel's launch over this handle's rows is cut into work items (windows of 60 columns -- MARCH_WW -- x segments of rows):
  * info12 = {levels, rows per XCD band, rows per interleaved chunk, segment rows of level 0..3, band rows cut at level 0..3,
  * work items in all}. levels == 0: uniform segments of info12[3] rows (short row ranges: strips, small lattices); else the
  * tapered order (long segments first, short ones last) of DESIGN.md section 4. Host-side arithmetic only. */
@@ -238,6 +238,9 @@ int lbmdem_sync(lbmdem_handle* h);
  * enable, run steps, then read the mean duration and the launch count. */
 int lbmdem_profile_enable(lbmdem_handle* h, int on);
 int lbmdem_profile_read(lbmdem_handle* h, double* mean_ms, long* launches);
+/* GB/s (bytes read + bytes written) of a plain copy kernel moving `bytes` on this handle's device and stream, best of `reps`
+ * passes after a warm-up: the yardstick bench.py puts next to the fused kernel's traffic rate (boxes differ by +-5 %). */
+int lbmdem_measure_copy(lbmdem_handle* h, size_t bytes, int reps, double* gb_per_s);
 
 /* Strip decomposition along x (one process per GPU); halo >= 2 rows (with REPLICATED grains, i.e. without
  * lbmdem_dist_enable, halo >= 2 + the largest grain radius in nodes). After collide_stream the `halo` outermost

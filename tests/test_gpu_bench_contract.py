@@ -30,6 +30,12 @@ def test_single_process_line():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["warmup"] == 1 and d["config"]["settle_steps"] == 40      # the untimed steps before the warm-up are reported
+    # comparable across boxes and rounds: the driver's own protocol (K steps straight after W warm-up steps) next to the
+    # headline, and a plain copy of the same traffic on the same GPU as the yardstick
+    assert d["ms_per_step_unsettled"] > 0 and 2000 < d["hbm_copy_gbs"] < 8000
+    assert abs(r["achieved_over_copy"] - r["achieved"] / d["hbm_copy_gbs"]) < 1e-3
+    assert r["frac_of_copy"] is None or 0.3 < r["frac_of_copy"] < 1.2
+    assert d["config"]["dem_chain"]["launches"] > 0 and d["config"]["dem_chain"]["resident"] == d["config"]["dem_chain"]["tile_slots"]
 
 
 def test_settle_steps_can_be_switched_off():
@@ -39,6 +45,7 @@ def test_settle_steps_can_be_switched_off():
     assert out.returncode == 0, out.stderr[-500:]
     d = _last_json(out.stdout)
     assert d["steps"] == 3 and d["config"]["settle_steps"] == 0 and d["value"] > 1000
+    assert d["ms_per_step_unsettled"] == d["ms_per_step"]            # nothing to tell apart
 
 
 def test_launcher_path_one_rank():
