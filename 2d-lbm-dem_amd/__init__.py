@@ -129,6 +129,8 @@ def _open_library(LIB_PATH):
     L.lbmdem_checkpoint_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     L.lbmdem_set_force_mode.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_set_dem_chain.argtypes = [C.c_void_p, C.c_int]
+    L.lbmdem_set_obst_update.argtypes = [C.c_void_p, C.c_int]
+    L.lbmdem_obst_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
     L.lbmdem_measure_copy.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     L.lbmdem_dem_chain_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lbmdem_set_lid.argtypes = [C.c_void_p, C.c_double]
@@ -508,6 +510,16 @@ class LbmDem:
     def set_dem_chain(self, max_substeps):
         """Longest run of ordinary sub-steps renderScene hands to ONE launch (< 2: one launch per sub-step)."""
         _chk(self._L.lbmdem_set_dem_chain(self._h, int(max_substeps)))
+
+    def set_obst_update(self, on=True):
+        """obst_construction writes only the nodes whose owner changes (default) / clears and repaints the map (False)"""
+        _chk(self._L.lbmdem_set_obst_update(self._h, 1 if on else 0))
+
+    def obst_stats(self):
+        """(rasterisations that updated the map in place, rasterisations that cleared and repainted it)"""
+        a, b = C.c_long(0), C.c_long(0)
+        _chk(self._L.lbmdem_obst_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def measure_copy(self, nbytes=1200 * 1000 * 1000, reps=5):
         """GB/s (read + written) of a plain copy of `nbytes` on this handle's device: the box's yardstick"""

@@ -1081,9 +1081,11 @@ __device__ __forceinline__ int cell_coord(real x, real o, real cs, int nc) {
 // list does not depend on it.
 __global__ void k_cell_count(int n, const real* __restrict__ x1, const real* __restrict__ x2, real ox,
                              real oy, real cs, int ncx, int ncy, unsigned int* __restrict__ keys,
-                             int* __restrict__ rank, int* __restrict__ cell_cnt) {
+                             int* __restrict__ rank, int* __restrict__ cell_cnt, real* __restrict__ xreb,
+                             real* __restrict__ yreb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  xreb[i] = x1[i]; yreb[i] = x2[i];   // where the list found the grain: how far it has moved since decides whether the list still holds every close pair (k_obst_update)
   const unsigned c = (unsigned)(cell_coord(x2[i], oy, cs, ncy) * ncx + cell_coord(x1[i], ox, cs, ncx));
   keys[i] = c;
   rank[i] = atomicAdd(&cell_cnt[c], 1);
@@ -1315,8 +1317,10 @@ int verlet_alloc(VerletDevice& V, int n, real cs, real ox, real oy, real wx, rea
     A((void**)&V.halo_ids, sizeof(int) * tiles * DEM_CHAIN_HALO); A((void**)&V.halo_cnt, sizeof(int) * tiles);
     A((void**)&V.emeta, sizeof(unsigned) * V.cap);
     A((void**)&V.tile_far, tiles);
+    A((void**)&V.xreb, sizeof(real) * 2 * (size_t)n);
   }
   if (e != hipSuccess) return -1;
+  V.yreb = V.xreb + n;
   V.scan_tmp_bytes = 0;
   size_t cells_tmp = 0;
   if (hipcub::DeviceScan::ExclusiveSum(nullptr, V.scan_tmp_bytes, V.counts, V.offsets, n) != hipSuccess) return -1;
@@ -1335,7 +1339,7 @@ int verlet_alloc(VerletDevice& V, int n, real cs, real ox, real oy, real wx, rea
 
 void verlet_free(VerletDevice& V) {
   void* ps[] = {V.keys_in, V.vals_in, V.vals_out, V.cell_start, V.cell_end,
-                V.scan_tmp, V.counts, V.offsets, V.nbr, V.own, V.wallflags, V.overflow, V.halo_ids, V.halo_cnt, V.emeta, V.tile_far};
+                V.scan_tmp, V.counts, V.offsets, V.nbr, V.own, V.wallflags, V.overflow, V.halo_ids, V.halo_cnt, V.emeta, V.tile_far, V.xreb};
   for (void* p : ps) if (p) (void)hipFree(p);
   V = VerletDevice{};
 }
@@ -1349,7 +1353,7 @@ int launch_verlet_rebuild(VerletDevice& V, const Kin& K, const real* r, const De
   // 9 dependent launches (20 before the counting sort and the folded offset / wall-flag kernels: a rebuild is launch
   // latency, 130 us per 100 DEM steps for a few us of work)
   hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, V.ox, V.oy, V.cs, V.ncx, V.ncy,
-                     V.keys_in, V.vals_in, V.cell_end);
+                     V.keys_in, V.vals_in, V.cell_end, V.xreb, V.yreb);
   e = hipcub::DeviceScan::ExclusiveSum(V.scan_tmp, V.scan_tmp_bytes, V.cell_end, V.cell_start, (int)(ncell + 1), st);
   if (e != hipSuccess) {   // k_cell_scatter, which returns the counts to zero for the next rebuild, will not run
     (void)hipMemsetAsync(V.cell_end, 0, sizeof(int) * (ncell + 1), st);

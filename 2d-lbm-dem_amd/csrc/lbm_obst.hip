@@ -39,7 +39,7 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
                              unsigned char* __restrict__ touched, const unsigned char* __restrict__ mask,
                              unsigned* __restrict__ mincov, unsigned epoch, const int* __restrict__ list,
                              const int* __restrict__ list_count, int list_cap, const int* __restrict__ voff,
-                             const int* __restrict__ vnbr) {
+                             const int* __restrict__ vnbr, ObstSnap snap_out) {
   // FOUR grains per wavefront, PAINT_LANES = 16 lanes each, sweeping their boxes (11 ... 19 columns) in chunks of 16 columns:
   // the per-grain set-up -- geometry, three divisions, the partner test -- is paid once per four grains and the sweep's lanes
   // are mostly busy. One wavefront per grain 46 us (the kernel was bound by its 50 000 short waves), 32 lanes per grain 32.5,
@@ -63,6 +63,7 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
     oxc[i] = xc; oyc[i] = yc; or2[i] = r2; orbl0[i] = rbl0;
     real* o = pk + (long)i * 8;
     o[0] = gx1; o[1] = gx2; o[2] = v1[i]; o[3] = v2[i]; o[4] = v3[i]; o[5] = xc; o[6] = yc; o[7] = r2;
+    if (snap_out.xc) { snap_out.xc[i] = xc; snap_out.yc[i] = yc; snap_out.mode[i] = 1; }   // what k_obst_update starts from
   }
   const real R2 = rbl0 * rbl0;
   int xi = (int)(xc - rbl0), xf = (int)(xc + rbl0);
@@ -143,6 +144,147 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The map updated in place
+// ---------------------------------------------------------------------------------------------
+//
+// obst_construction (main.c:991-1065) clears the map and paints every disc again because it is serial C. Between two
+// fluid steps a grain moves by a fraction of a node, so the canvas this rasterisation writes to -- the map of TWO steps
+// ago, the other buffer is the "previous map" of reinit_obst_density -- already holds nearly every node right. Each map
+// buffer remembers the centres its discs were painted at (ObstSnap); a grain compares its footprint THEN with its
+// footprint NOW, node by node with the reference's own test (main.c:1027), and writes only the nodes that differ: no reset
+// of the canvas (67 MB per step at 4096^2), a few thousand stores instead of 11 M.
+//   * A disc that keeps clear (1.5 nodes) of the discs of all its partners in the pair list -- at the old AND the new
+//     centres, all four combinations -- shares no node with another disc in either picture: plain stores.
+//   * Any other disc settles every node with the grains that can reach it, whatever order the grains are processed in:
+//     a node it leaves goes to the highest-index partner whose NEW disc covers it (else to the fluid) by compare-and-swap
+//     on its own id; a node it covers takes atomicMax (main.c:1028: the highest index wins). A stale higher owner that
+//     has moved away hands the node over the same way. Overlap flags and the lowest-cover records (`touched`, `mincov`)
+//     come from the partners' disc tests, not from what the atomics return (which may be a stale owner here).
+// Same maps, bit for bit, as clear + repaint (tests: every golden runs through it; tests/test_gpu_obst_update.py).
+struct DiscGeo {
+  real xc, yc, r2, R2;
+  int xi, xf, yi, yf;
+  bool any;
+};
+__device__ __forceinline__ DiscGeo disc_geo(const LatticeView& L, real xc, real yc, real rlb, real rbl0, bool valid) {
+  DiscGeo g;
+  g.xc = xc; g.yc = yc; g.r2 = rlb * rlb; g.R2 = rbl0 * rbl0;
+  g.xi = (int)(xc - rbl0); g.xf = (int)(xc + rbl0);   // main.c:1016-1023, as k_obst_paint
+  if (g.xi < 1) g.xi = 1;
+  if (g.xf >= L.lx - 1) g.xf = L.lx - 2;
+  g.yi = (int)(yc - rbl0); g.yf = (int)(yc + rbl0);
+  if (g.yi < 1) g.yi = 1;
+  if (g.yf >= L.ly - 1) g.yf = L.ly - 2;
+  if (g.xi < L.gx0) g.xi = L.gx0;
+  if (g.xf > L.gx0 + L.nxl - 1) g.xf = L.gx0 + L.nxl - 1;
+  g.any = valid && g.xi <= g.xf && g.yi <= g.yf;
+  return g;
+}
+__device__ __forceinline__ bool disc_has(const DiscGeo& g, int x, int y) {
+  if (!g.any || x < g.xi || x > g.xf || y < g.yi || y > g.yf) return false;
+  const real d2 = (x - g.xc) * (x - g.xc) + (y - g.yc) * (y - g.yc);
+  return d2 <= g.R2 && d2 <= g.r2;
+}
+
+template <int GL>
+__global__ void k_obst_update(int* __restrict__ obst, LatticeView L, int n, const real* __restrict__ x1,
+                              const real* __restrict__ x2, const real* __restrict__ r,
+                              const real* __restrict__ rLB, const real* __restrict__ v1,
+                              const real* __restrict__ v2, const real* __restrict__ v3,
+                              real* __restrict__ oxc, real* __restrict__ oyc, real* __restrict__ or2,
+                              real* __restrict__ orbl0, real* __restrict__ pk,
+                              unsigned char* __restrict__ touched, unsigned* __restrict__ mincov, unsigned epoch,
+                              const int* __restrict__ voff, const int* __restrict__ vnbr, ObstSnap was, ObstSnap now,
+                              const real* __restrict__ xreb, const real* __restrict__ yreb, real moved_limit,
+                              int* __restrict__ moved_flag, int list_generation) {
+  const int lane = threadIdx.x & 63, half = lane / GL, hl = lane % GL;
+  const int bslots = (int)gridDim.x >> 3;   // XCD k takes the k-th contiguous eighth of the grains (k_obst_paint)
+  const int blk = ((int)blockIdx.x & 7) * bslots + ((int)blockIdx.x >> 3);
+  const int i = (int)(((long)blk * blockDim.x + threadIdx.x) / GL);
+  if (i >= n) return;
+  const real gx1 = x1[i], gx2 = x2[i], ri = rLB[i];
+  const real xc = (gx1 - L.Mgx) / L.dx, yc = (gx2 - L.Mby) / L.dx, r2 = ri * ri, rbl0 = r[i] / L.dx;
+  const bool had = was.mode[i] != 0;
+  const real pxc = was.xc[i], pyc = was.yc[i];
+  {
+    // The list holds every pair within distVerlet of touching WHEN IT WAS BUILT; a disc can only have met one that is not
+    // in its list if a grain has travelled more than half that distance since. Said to the host (pinned word, the list's
+    // generation): it clears and repaints with atomics until the next rebuild.
+    const real mx = (gx1 - xreb[i]) / L.dx, my = (gx2 - yreb[i]) / L.dx;
+    if (hl == 0 && !(mx * mx + my * my <= moved_limit * moved_limit)) *moved_flag = list_generation;
+  }
+  if (hl == 0) {
+    oxc[i] = xc; oyc[i] = yc; or2[i] = r2; orbl0[i] = rbl0;
+    real* o = pk + (long)i * 8;
+    o[0] = gx1; o[1] = gx2; o[2] = v1[i]; o[3] = v2[i]; o[4] = v3[i]; o[5] = xc; o[6] = yc; o[7] = r2;
+    now.xc[i] = xc; now.yc[i] = yc; now.mode[i] = 1;
+  }
+  const DiscGeo gn = disc_geo(L, xc, yc, ri, rbl0, true), go = disc_geo(L, pxc, pyc, ri, rbl0, had);
+  const int k0 = voff[i], k1 = voff[i + 1];
+  bool near = false;
+  for (int k = k0 + hl; k < k1; k += GL) {
+    const int j = vnbr[k];
+    const real jx = (x1[j] - L.Mgx) / L.dx, jy = (x2[j] - L.Mby) / L.dx, rr = ri + rLB[j] + 1.5;
+    const bool jhad = was.mode[j] != 0;
+    const real qx = was.xc[j], qy = was.yc[j];
+    auto close = [&](real ax, real ay, real bx, real by) { return !((ax - bx) * (ax - bx) + (ay - by) * (ay - by) >= rr * rr); };   // also true for a NaN
+    near |= close(xc, yc, jx, jy);
+    if (had) near |= close(pxc, pyc, jx, jy);
+    if (jhad) near |= close(xc, yc, qx, qy);
+    if (had && jhad) near |= close(pxc, pyc, qx, qy);
+  }
+  const bool alone = ((__ballot(near) >> ((GL * half) & 63)) & (GL >= 64 ? ~0ull : (1ull << (GL & 63)) - 1)) == 0;   // this grain's lanes
+  if (!gn.any && !go.any) return;
+  if (alone) {
+    const int xi = !go.any ? gn.xi : (!gn.any ? go.xi : (go.xi < gn.xi ? go.xi : gn.xi));
+    const int xf = !go.any ? gn.xf : (!gn.any ? go.xf : (go.xf > gn.xf ? go.xf : gn.xf));
+    const int yi = !go.any ? gn.yi : (!gn.any ? go.yi : (go.yi < gn.yi ? go.yi : gn.yi));
+    const int yf = !go.any ? gn.yf : (!gn.any ? go.yf : (go.yf > gn.yf ? go.yf : gn.yf));
+    for (int y = yi + hl; y <= yf; y += GL)
+      for (int x = xi; x <= xf; ++x) {
+        const bool bo = disc_has(go, x, y), bn = disc_has(gn, x, y);
+        if (bn != bo) obst[(long)(x - L.gx0) * L.sy + y] = bn ? i : -1;
+      }
+    return;
+  }
+  auto partner_geo = [&](int j) {
+    const real jr = rLB[j];
+    return disc_geo(L, (x1[j] - L.Mgx) / L.dx, (x2[j] - L.Mby) / L.dx, jr, r[j] / L.dx, true);
+  };
+  if (go.any) {   // the nodes this disc has left: to the highest partner that covers them now, else to the fluid
+    const int ny = go.yf - go.yi + 1, total = (go.xf - go.xi + 1) * ny;
+    for (int k = hl; k < total; k += GL) {
+      const int x = go.xi + k / ny, y = go.yi + k % ny;
+      if (!disc_has(go, x, y) || disc_has(gn, x, y)) continue;
+      int v = -1;
+      for (int e = k0; e < k1; ++e) {
+        const int j = vnbr[e];
+        if (j > v && disc_has(partner_geo(j), x, y)) v = j;
+      }
+      atomicCAS(&obst[(long)(x - L.gx0) * L.sy + y], i, v);
+    }
+  }
+  if (gn.any) {   // the nodes it covers: highest index wins (main.c:1028); who else covers them, from the partners' discs
+    const int ny = gn.yf - gn.yi + 1, total = (gn.xf - gn.xi + 1) * ny;
+    for (int k = hl; k < total; k += GL) {
+      const int x = gn.xi + k / ny, y = gn.yi + k % ny;
+      if (!disc_has(gn, x, y)) continue;
+      const long node = (long)(x - L.gx0) * L.sy + y;
+      atomicMax(&obst[node], i);
+      for (int e = k0; e < k1; ++e) {
+        const int j = vnbr[e];
+        if (!disc_has(partner_geo(j), x, y)) continue;
+        touched[i] = 1; touched[j] = 1;
+        if (mincov) {
+          atomicMax(&mincov[node], (epoch & 0xFFFu) << 20 | (0xFFFFFu - (unsigned)i));
+          atomicMax(&mincov[node], (epoch & 0xFFFu) << 20 | (0xFFFFFu - (unsigned)j));
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st) { launch_obst_fill_rows(obst, L, 0, L.nxl, st); }
@@ -156,15 +298,27 @@ void launch_obst_paint(int* obst, const LatticeView& L, int n, const real* x1, c
                        const real* rLB, const real* v1, const real* v2, const real* v3, real* xc,
                        real* yc, real* r2, real* rbl0, real* pk, unsigned char* touched,
                        const unsigned char* mask, unsigned* mincov, unsigned epoch, const int* list,
-                       const int* list_count, int list_cap, const int* voff, const int* vnbr, hipStream_t st) {
+                       const int* list_count, int list_cap, const int* voff, const int* vnbr, const ObstSnap& snap_out,
+                       hipStream_t st) {
   const int gl = voff ? PAINT_LANES : 64;
   const long threads = (long)(list ? list_cap : n) * gl;
   const unsigned pgrid = (unsigned)(((threads + 255) / 256 + 7) / 8 * 8);   // a multiple of the 8 XCDs (see the kernel)
   if (voff)
     hipLaunchKernelGGL(k_obst_paint<PAINT_LANES>, dim3(pgrid), dim3(256), 0, st, obst, L, n, x1, x2, r, rLB, v1, v2, v3, xc, yc, r2,
-                       rbl0, pk, touched, mask, mincov, epoch, list, list_count, list_cap, voff, vnbr);
+                       rbl0, pk, touched, mask, mincov, epoch, list, list_count, list_cap, voff, vnbr, snap_out);
   else
     hipLaunchKernelGGL(k_obst_paint<64>, dim3(pgrid), dim3(256), 0, st, obst, L, n, x1, x2, r, rLB, v1, v2, v3, xc, yc, r2, rbl0, pk,
-                       touched, mask, mincov, epoch, list, list_count, list_cap, voff, vnbr);
+                       touched, mask, mincov, epoch, list, list_count, list_cap, voff, vnbr, snap_out);
 }
 
+
+void launch_obst_update(int* obst, const LatticeView& L, int n, const real* x1, const real* x2, const real* r,
+                        const real* rLB, const real* v1, const real* v2, const real* v3, real* xc, real* yc, real* r2,
+                        real* rbl0, real* pk, unsigned char* touched, unsigned* mincov, unsigned epoch, const int* voff,
+                        const int* vnbr, const ObstSnap& was, const ObstSnap& now, const real* xreb, const real* yreb,
+                        real moved_limit, int* moved_flag, int list_generation, hipStream_t st) {
+  const long threads = (long)n * PAINT_LANES;
+  const unsigned pgrid = (unsigned)(((threads + 255) / 256 + 7) / 8 * 8);
+  hipLaunchKernelGGL(k_obst_update<PAINT_LANES>, dim3(pgrid), dim3(256), 0, st, obst, L, n, x1, x2, r, rLB, v1, v2, v3, xc, yc, r2,
+                     rbl0, pk, touched, mincov, epoch, voff, vnbr, was, now, xreb, yreb, moved_limit, moved_flag, list_generation);
+}

@@ -145,15 +145,33 @@ static int paint_into(lbmdem_handle* h, int* obst) {
       h->paint_epoch = 1;
     }
   }
-  launch_obst_fill_rows(obst, h->L, obst == h->obst[1 - h->ocur] ? h->obst_reset_rows : 0, h->L.nxl, h->stream);
+  const int b = obst == h->obst[1] ? 1 : 0;
+  // the pair list tells which discs cannot share a node with another one (plain stores instead of atomics). Not with
+  // distributed grains: a rank's list is only right for the grains it integrates
+  const bool list_ok = h->verlet_ok && h->verlet_tracks_positions && !h->dist && !*h->ovf_host &&
+                       *h->moved_host != h->list_generation;   // (a grain has outrun the list: atomics for everybody)
+  const int reset_rows = obst == h->obst[1 - h->ocur] ? h->obst_reset_rows : 0;
+  const ObstSnap was = h->snap[b][h->snap_cur[b]], now = h->snap[b][1 - h->snap_cur[b]];
+  if (h->obst_update && list_ok && h->snap_ok[b] && reset_rows == 0 && was.xc) {
+    // the canvas holds this buffer's last picture: only the nodes whose owner changes are written
+    launch_obst_update(obst, h->L, h->n, K.x1, K.x2, h->r, h->rLB, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0, h->pk,
+                       h->fs.touched, h->mincov, h->paint_epoch, h->V.offsets, h->V.nbr, was, now, h->V.xreb, h->V.yreb,
+                       (real)(0.5 * h->cfg.phys.distVerlet / h->cfg.dx), h->moved_dev, h->list_generation, h->stream);
+    h->snap_cur[b] = 1 - h->snap_cur[b];
+    h->obst_updates++;
+  } else {
+    launch_obst_fill_rows(obst, h->L, reset_rows, h->L.nxl, h->stream);
+    const bool record = !h->dist && now.xc != nullptr;   // (every grain leaves its disc in the cleared canvas)
+    launch_obst_paint(obst, h->L, h->n, K.x1, K.x2, h->r, h->rLB, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0, h->pk,
+                      h->fs.touched, h->dist ? h->dd.fluidmask : nullptr, h->mincov, h->paint_epoch,
+                      h->dist ? h->dd.local_list : nullptr, h->dist ? h->dd.counters + 6 : nullptr, h->dist ? h->dd.cap_l : 0,
+                      list_ok ? h->V.offsets : nullptr, list_ok ? h->V.nbr : nullptr, record ? now : ObstSnap{nullptr, nullptr, nullptr},
+                      h->stream);
+    if (record) h->snap_cur[b] = 1 - h->snap_cur[b];
+    h->snap_ok[b] = record;
+    h->obst_repaints++;
+  }
   h->obst_reset_rows = 0;
-  launch_obst_paint(obst, h->L, h->n, K.x1, K.x2, h->r, h->rLB, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0, h->pk,
-                    h->fs.touched, h->dist ? h->dd.fluidmask : nullptr, h->mincov, h->paint_epoch,
-                    h->dist ? h->dd.local_list : nullptr, h->dist ? h->dd.counters + 6 : nullptr, h->dist ? h->dd.cap_l : 0,
-                    // the pair list tells which discs cannot share a node with another one (plain stores instead of
-                    // atomics). Not with distributed grains: a rank's list is only right for the grains it integrates
-                    (h->verlet_ok && h->verlet_tracks_positions && !h->dist && !*h->ovf_host) ? h->V.offsets : nullptr,
-                    (h->verlet_ok && h->verlet_tracks_positions && !h->dist && !*h->ovf_host) ? h->V.nbr : nullptr, h->stream);
   h->slots_valid = false;  // the grain geometry the table is indexed with has changed
   HIP_TRY(hipGetLastError());
   return LBMDEM_OK;
@@ -277,6 +295,13 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
   }
   CREATE_TRY(hipMalloc((void**)&h->owner, n));
   CREATE_TRY(hipMemsetAsync(h->owner, 1, n, h->stream));
+  for (int b = 0; b < 2; ++b)
+    for (int k = 0; k < 2; ++k) {
+      CREATE_TRY(hipMalloc((void**)&h->snap[b][k].xc, sizeof(real) * 2 * (size_t)n + n));
+      h->snap[b][k].yc = h->snap[b][k].xc + n;
+      h->snap[b][k].mode = reinterpret_cast<unsigned char*>(h->snap[b][k].xc + 2 * (size_t)n);
+      CREATE_TRY(hipMemsetAsync(h->snap[b][k].xc, 0, sizeof(real) * 2 * (size_t)n + n, h->stream));
+    }
   if (carry_track_alloc(h->ct, n) != 0) {
     lbmdem_destroy(h);
     return fail(LBMDEM_ENOMEM, "carry records: hipMalloc failed");
@@ -353,6 +378,9 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
   }
   CREATE_TRY(hipHostMalloc((void**)&h->ovf_host, sizeof(int), hipHostMallocDefault));
   *h->ovf_host = 0;
+  CREATE_TRY(hipHostMalloc((void**)&h->moved_host, sizeof(int), hipHostMallocDefault));
+  *h->moved_host = -1;
+  CREATE_TRY(hipHostGetDevicePointer((void**)&h->moved_dev, (void*)h->moved_host, 0));
   CREATE_TRY(hipHostMalloc((void**)&h->ferr_host, sizeof(int), hipHostMallocDefault));
   *h->ferr_host = 0;
   CREATE_TRY(hipHostGetDevicePointer((void**)&h->ferr_mirror, (void*)h->ferr_host, 0));
@@ -382,6 +410,9 @@ int lbmdem_destroy(lbmdem_handle* h) {
     if (h->obst[b]) (void)hipFree(h->obst[b]);
   }
   if (h->gbuf) (void)hipFree(h->gbuf);
+  for (int b = 0; b < 2; ++b)
+    for (int k = 0; k < 2; ++k)
+      if (h->snap[b][k].xc) (void)hipFree(h->snap[b][k].xc);
   if (h->owner) (void)hipFree(h->owner);
   if (h->mincov) (void)hipFree(h->mincov);
   if (h->fs.touched) (void)hipFree(h->fs.touched);
@@ -395,6 +426,7 @@ int lbmdem_destroy(lbmdem_handle* h) {
   dist_free(h->dd);
   if (h->ovf_host) (void)hipHostFree((void*)h->ovf_host);
   if (h->ferr_host) (void)hipHostFree((void*)h->ferr_host);
+  if (h->moved_host) (void)hipHostFree((void*)h->moved_host);
   diag_extra_free(h->dx);
   carry_track_free(h->ct);
   for (hipEvent_t e : h->ev0) (void)hipEventDestroy(e);
@@ -675,6 +707,7 @@ int lbmdem_verlet_build_lists(lbmdem_handle* h) {
   HIP_TRY(hipMemcpyAsync((void*)h->ovf_host, h->V.overflow, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   h->verlet_ok = true;
   h->verlet_tracks_positions = true;
+  h->list_generation++;
   return LBMDEM_OK;
 }
 
@@ -710,7 +743,7 @@ int lbmdem_dem_substep(lbmdem_handle* h) {
   const DemParams P = dem_params(h);
   // a slice of the next rasterisation's canvas is reset under this sub-step (npDEM slices between two fluid steps)
   ObstFillJob fill{nullptr, h->L, 0, 0};
-  if (!h->obst_pending && !h->cs_interior_pending && h->obst_reset_rows < h->L.nxl) {
+  if (!h->obst_pending && !h->cs_interior_pending && h->obst_reset_rows < h->L.nxl && !obst_update_planned(h)) {
     const int slice = (h->L.nxl + h->cfg.npDEM - 1) / h->cfg.npDEM;
     fill.map = h->obst[1 - h->ocur];
     fill.row0 = h->obst_reset_rows;
@@ -766,7 +799,7 @@ int lbmdem_dem_chain(lbmdem_handle* h, long k) {
   if (CHAIN_FAILED(h)) return fail(LBMDEM_EHIP, CHAIN_FAIL_MSG);
   const DemParams P = dem_params(h);
   ObstFillJob fill{nullptr, h->L, 0, 0};   // k slices of the next rasterisation's canvas (lbmdem_dem_substep: one each)
-  if (!h->obst_pending && !h->cs_interior_pending && h->obst_reset_rows < h->L.nxl) {
+  if (!h->obst_pending && !h->cs_interior_pending && h->obst_reset_rows < h->L.nxl && !obst_update_planned(h)) {
     const long slice = (h->L.nxl + h->cfg.npDEM - 1) / h->cfg.npDEM;
     fill.map = h->obst[1 - h->ocur];
     fill.row0 = h->obst_reset_rows;
@@ -783,6 +816,19 @@ int lbmdem_dem_chain(lbmdem_handle* h, long k) {
   HIP_TRY(hipGetLastError());
   h->kcur = 1 - h->kcur;
   h->nbsteps += k;
+  return LBMDEM_OK;
+}
+
+int lbmdem_set_obst_update(lbmdem_handle* h, int on) {
+  if (!h) return fail(LBMDEM_EINVAL, "null handle");
+  h->obst_update = on != 0;
+  return LBMDEM_OK;
+}
+
+int lbmdem_obst_stats(lbmdem_handle* h, long* updates, long* repaints) {
+  if (!h) return fail(LBMDEM_EINVAL, "null handle");
+  if (updates) *updates = h->obst_updates;
+  if (repaints) *repaints = h->obst_repaints;
   return LBMDEM_OK;
 }
 

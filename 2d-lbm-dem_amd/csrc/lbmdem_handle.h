@@ -48,6 +48,16 @@ struct lbmdem_handle {
   // grains" in slices by the DEM sub-step launches (single domain) or all at once by the launch that unpacks the
   // neighbours' messages (C transport): local rows [0, obst_reset_rows) are done; obst_construction does the rest
   int obst_reset_rows = 0;
+  // the map updated in place (k_obst_update, lbm_obst.hip): per map buffer the centres its discs were painted at, in two
+  // slots (the update reads one and writes the other: partners look at each other's old centres meanwhile)
+  ObstSnap snap[2][2] = {};
+  int snap_cur[2] = {0, 0};
+  bool snap_ok[2] = {false, false};   // snap[b][snap_cur[b]] describes what obst[b] holds
+  bool obst_update = true;            // lbmdem_set_obst_update
+  long obst_updates = 0, obst_repaints = 0;   // lbmdem_obst_stats
+  int list_generation = 0;            // rebuilds so far
+  volatile int* moved_host = nullptr; // pinned: the generation of the list in which k_obst_update found a grain too far from where the list found it
+  int* moved_dev = nullptr;
   // collide_stream in two parts (lbmdem_collide_stream_part): after EDGES the interior rows of f[fcur] are
   // still missing; the operands of the launch are kept for INTERIOR
   bool cs_interior_pending = false;
@@ -186,6 +196,11 @@ static inline DemParams dem_params(const lbmdem_handle* h) {
 #define LBMDEM_INTERNAL extern "C" __attribute__((visibility("hidden")))
 LBMDEM_INTERNAL int lbmdem_write_vtk_file(const char* path, int nx, int ny, const char* name, int dim, const float* data);
 LBMDEM_INTERNAL int lbmdem_verlet_build_lists(lbmdem_handle* h);
+// the next obst_construction will update obst[1 - ocur] in place: nobody resets that canvas beforehand
+static inline bool obst_update_planned(const lbmdem_handle* h) {
+  return h->obst_update && !h->dist && h->snap_ok[1 - h->ocur] && h->verlet_ok && h->verlet_tracks_positions &&
+         !*h->ovf_host && h->obst_reset_rows == 0 && *h->moved_host != h->list_generation;
+}
 // the coming ordinary sub-steps that nothing separates (fluid step when `fluid`, list rebuild, film law, table sub-step), at
 // most `remaining`; 0 when the run is shorter than 2 or the multi-sub-step kernel cannot be used -- and that many sub-steps
 LBMDEM_INTERNAL long lbmdem_dem_chain_length(lbmdem_handle* h, long remaining, int fluid);

@@ -143,12 +143,22 @@ struct Kin {
 // lbm_fused.hip, lbm_forces.hip, lbm_obst.hip, lbm_lattice.hip
 void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st);
 // fills xc, yc, r2, rbl0, pk (per-grain lattice geometry, main.c:1009-1013) and paints the reduced discs
+// The lattice-unit centres a map buffer's discs were painted at (mode: 0 = the grain left nothing in that buffer):
+// what the in-place update of the map (k_obst_update) compares the new centres with. Null pointers: not recorded.
+struct ObstSnap { real* xc; real* yc; unsigned char* mode; };
 void launch_obst_paint(int* obst, const LatticeView& L, int n, const real* x1, const real* x2, const real* r,
                        const real* rLB, const real* v1, const real* v2, const real* v3, real* xc,
                        real* yc, real* r2, real* rbl0, real* pk, unsigned char* touched,
                        const unsigned char* mask, unsigned* mincov, unsigned epoch, const int* list,
                        const int* list_count, int list_cap, const int* verlet_offsets, const int* verlet_nbr,
+                       const ObstSnap& snap_out,
                        hipStream_t st);   // verlet_*: the symmetric pair list (null: every grain takes the atomic path)
+// the same outputs, the map written only where a disc's footprint differs from the one `was` describes (needs the list)
+void launch_obst_update(int* obst, const LatticeView& L, int n, const real* x1, const real* x2, const real* r,
+                        const real* rLB, const real* v1, const real* v2, const real* v3, real* xc, real* yc, real* r2,
+                        real* rbl0, real* pk, unsigned char* touched, unsigned* mincov, unsigned epoch, const int* voff,
+                        const int* vnbr, const ObstSnap& was, const ObstSnap& now, const real* xreb, const real* yreb,
+                        real moved_limit, int* moved_flag, int list_generation, hipStream_t st);
 void launch_collide_stream(const real* fin, real* fout, const int* obst_old, const int* obst_new,
                            const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, hipStream_t st);
 // the two edge-row ranges [lo0, lo1) and [hi0, hi1) of a strip (either may be empty): one launch when they are equally
@@ -262,6 +272,7 @@ struct VerletDevice {
   int* halo_cnt;             // [tiles]
   unsigned* emeta;           // [cap] own grain's index in its tile | (own < partner) << 6 | partner's staging slot << 8
   unsigned char* tile_far;   // [tiles] the tile has a partner in a tile that is expected on another XCD
+  real *xreb, *yreb;         // [n] the positions the list was built from
 };
 constexpr int DEM_CHAIN_HALO = 320;          // halo grains staged per tile; partners beyond that are read from memory per entry
 constexpr unsigned DEM_CHAIN_DIRECT = 0xFFFFu;   // emeta slot value of such a partner

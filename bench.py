@@ -298,6 +298,8 @@ def main():
     ap.add_argument("--dem-chain", type=int, default=None,
                     help="longest run of DEM sub-steps handed to one launch (lbmdem_set_dem_chain; default: the library's, "
                          "128); 0 = one launch per sub-step (A/B)")
+    ap.add_argument("--obst-update", type=int, default=None,
+                    help="1 = the obstacle map is updated in place (the library's default), 0 = cleared and repainted every step (A/B)")
     ap.add_argument("--strips", action="store_true",
                     help="use the strip-decomposition driver (torch.distributed) even with one rank")
     args = ap.parse_args()
@@ -335,6 +337,8 @@ def main():
         sim.set_force_mode(args.force_mode)
         if args.dem_chain is not None:
             sim.set_dem_chain(args.dem_chain)
+        if args.obst_update is not None:
+            sim.set_obst_update(bool(args.obst_update))
         npdem = sim.cfg.npDEM
 
         def run_steps(k):
@@ -467,6 +471,8 @@ def main():
             s2.set_force_mode(args.force_mode)
             if args.dem_chain is not None:
                 s2.set_dem_chain(args.dem_chain)
+            if args.obst_update is not None:
+                s2.set_obst_update(bool(args.obst_update))
             return s2
         nsub = 100 * npdem
         leg = fresh()
@@ -535,6 +541,7 @@ def main():
                        "step": "1 fluid step + npDEM DEM sub-steps (+ Verlet rebuild every 100 DEM steps)",
                        "force_kernel": "parity" if args.force_mode == 0 else "fast",
                        "dem_chain": dict(zip(("launches", "substeps", "tile_slots", "resident"), chain_stats)),
+                       "obst_map": dict(zip(("updated_in_place", "cleared_and_repainted"), sim.obst_stats())),
                        "settle_steps": args.settle,   # untimed steps of this run before the warm-up (GPU clocks; see --settle)
                        "driver": None if runner is None else ("C (lbmdem_comm_run, RCCL send/recv inside the library)" if
                                                                 isinstance(runner, strips.CCommRunner) else "torch.distributed (strips.py)"),

@@ -155,6 +155,14 @@ int lbmdem_set_force_mode(lbmdem_handle* h, int mode);
  * their drifted state (main.c:1748-1753) to their partners' tiles through tagged cache-line records instead of kernel
  * boundaries. Same bits as lbmdem_dem_substep called that many times. < 2: one launch per sub-step. Default 128. The
  * library falls back to one launch per sub-step by itself where the tiles of a packing cannot all be resident at once. */
+/* obst_construction (main.c:991-1065) clears the map and paints every disc again; between two fluid steps a disc moves by
+ * a fraction of a node. on = 1 (default): the rasteriser compares every disc's footprint at the centre it was last painted
+ * at in that map buffer with its footprint now and writes only the nodes whose owner changes (no reset of the canvas;
+ * needs the pair list: falls back to clear + repaint by itself before the first list, after an upload of positions, with
+ * distributed grains). Same maps bit for bit. on = 0: clear + repaint every step. lbmdem_obst_stats: how often each ran. */
+int lbmdem_set_obst_update(lbmdem_handle* h, int on);
+int lbmdem_obst_stats(lbmdem_handle* h, long* updates, long* repaints);
+
 int lbmdem_set_dem_chain(lbmdem_handle* h, int max_substeps);
 /* what that path has done so far: launches, sub-steps they covered, the workgroups ("tile slots": 64 grains each) one
  * launch needs resident at once, and how many the census found resident (-1: not taken yet, 0: they do not fit) */
