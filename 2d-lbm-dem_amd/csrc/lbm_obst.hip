@@ -63,7 +63,7 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
     oxc[i] = xc; oyc[i] = yc; or2[i] = r2; orbl0[i] = rbl0;
     real* o = pk + (long)i * 8;
     o[0] = gx1; o[1] = gx2; o[2] = v1[i]; o[3] = v2[i]; o[4] = v3[i]; o[5] = xc; o[6] = yc; o[7] = r2;
-    if (snap_out.xc) { snap_out.xc[i] = xc; snap_out.yc[i] = yc; snap_out.mode[i] = 1; }   // what k_obst_update starts from
+    if (snap_out.xc) { snap_out.xc[i] = xc; snap_out.yc[i] = yc; snap_out.still2[i] = 0.; snap_out.mode[i] = 1; }   // what k_obst_update starts from
   }
   const real R2 = rbl0 * rbl0;
   int xi = (int)(xc - rbl0), xf = (int)(xc + rbl0);
@@ -154,8 +154,8 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
 // buffer remembers the centres its discs were painted at (ObstSnap); a grain compares its footprint THEN with its
 // footprint NOW, node by node with the reference's own test (main.c:1027), and writes only the nodes that differ: no reset
 // of the canvas (67 MB per step at 4096^2), a few thousand stores instead of 11 M.
-//   * A disc that keeps clear (1.5 nodes) of the discs of all its partners in the pair list -- at the old AND the new
-//     centres, all four combinations -- shares no node with another disc in either picture: plain stores.
+//   * A disc that has moved less than half a node since and keeps clear (1.1 nodes) of the discs of all its partners in
+//     the pair list shares no node with another disc in either picture: plain stores.
 //   * Any other disc settles every node with the grains that can reach it, whatever order the grains are processed in:
 //     a node it leaves goes to the highest-index partner whose NEW disc covers it (else to the fluid) by compare-and-swap
 //     on its own id; a node it covers takes atomicMax (main.c:1028: the highest index wins). A stale higher owner that
@@ -211,41 +211,69 @@ __global__ void k_obst_update(int* __restrict__ obst, LatticeView L, int n, cons
     // The list holds every pair within distVerlet of touching WHEN IT WAS BUILT; a disc can only have met one that is not
     // in its list if a grain has travelled more than half that distance since. Said to the host (pinned word, the list's
     // generation): it clears and repaints with atomics until the next rebuild.
-    const real mx = (gx1 - xreb[i]) / L.dx, my = (gx2 - yreb[i]) / L.dx;
+    const real mx = gx1 - xreb[i], my = gx2 - yreb[i];
     if (hl == 0 && !(mx * mx + my * my <= moved_limit * moved_limit)) *moved_flag = list_generation;
   }
   if (hl == 0) {
     oxc[i] = xc; oyc[i] = yc; or2[i] = r2; orbl0[i] = rbl0;
     real* o = pk + (long)i * 8;
     o[0] = gx1; o[1] = gx2; o[2] = v1[i]; o[3] = v2[i]; o[4] = v3[i]; o[5] = xc; o[6] = yc; o[7] = r2;
-    now.xc[i] = xc; now.yc[i] = yc; now.mode[i] = 1;
   }
   const DiscGeo gn = disc_geo(L, xc, yc, ri, rbl0, true), go = disc_geo(L, pxc, pyc, ri, rbl0, had);
   const int k0 = voff[i], k1 = voff[i + 1];
-  bool near = false;
+  // Alone = this disc has moved less than half a node since it was painted into this buffer, and its circle keeps 1.1
+  // nodes clear of the NEW circles of all its partners (two discs share a node only if their circles meet; touching grains
+  // leave 0.15 (r_i + r_j) = 1.5 ... 2.4 nodes between their reduced discs). That is enough without looking at where the
+  // partners were: one that has moved less than half a node left the same gap open in the old picture; one that has moved
+  // more is not alone itself and hands over by compare-and-swap whatever it owned near this disc -- to the fluid, or to
+  // this disc where it covers the node (nothing else can: a third disc there would be within 1.1 nodes of this one).
+  // (Physical units: no division per partner.)
+  bool near = had && !((xc - pxc) * (xc - pxc) + (yc - pyc) * (yc - pyc) < 0.25);
   for (int k = k0 + hl; k < k1; k += GL) {
     const int j = vnbr[k];
-    const real jx = (x1[j] - L.Mgx) / L.dx, jy = (x2[j] - L.Mby) / L.dx, rr = ri + rLB[j] + 1.5;
-    const bool jhad = was.mode[j] != 0;
-    const real qx = was.xc[j], qy = was.yc[j];
-    auto close = [&](real ax, real ay, real bx, real by) { return !((ax - bx) * (ax - bx) + (ay - by) * (ay - by) >= rr * rr); };   // also true for a NaN
-    near |= close(xc, yc, jx, jy);
-    if (had) near |= close(pxc, pyc, jx, jy);
-    if (jhad) near |= close(xc, yc, qx, qy);
-    if (had && jhad) near |= close(pxc, pyc, qx, qy);
+    const real ddx = x1[j] - gx1, ddy = x2[j] - gx2, rr = (ri + rLB[j] + 1.1) * L.dx;
+    near |= !(ddx * ddx + ddy * ddy >= rr * rr);   // also true for a NaN
   }
   const bool alone = ((__ballot(near) >> ((GL * half) & 63)) & (GL >= 64 ? ~0ull : (1ull << (GL & 63)) - 1)) == 0;   // this grain's lanes
+  // ---- the new picture's record. A disc that has stayed where it was painted, near enough that no node can have changed
+  // sides (see `still2` below), leaves the map AND the record as they are: the next comparison is again with the centre
+  // the nodes were really painted at.
+  const real moved2 = (xc - pxc) * (xc - pxc) + (yc - pyc) * (yc - pyc);
+  if (alone && had && moved2 < was.still2[i]) {
+    if (hl == 0) { now.xc[i] = pxc; now.yc[i] = pyc; now.still2[i] = was.still2[i]; now.mode[i] = 1; }
+    return;
+  }
+  if (hl == 0) { now.xc[i] = xc; now.yc[i] = yc; now.still2[i] = 0.; now.mode[i] = 1; }
   if (!gn.any && !go.any) return;
   if (alone) {
-    const int xi = !go.any ? gn.xi : (!gn.any ? go.xi : (go.xi < gn.xi ? go.xi : gn.xi));
-    const int xf = !go.any ? gn.xf : (!gn.any ? go.xf : (go.xf > gn.xf ? go.xf : gn.xf));
-    const int yi = !go.any ? gn.yi : (!gn.any ? go.yi : (go.yi < gn.yi ? go.yi : gn.yi));
-    const int yf = !go.any ? gn.yf : (!gn.any ? go.yf : (go.yf > gn.yf ? go.yf : gn.yf));
+    // the union of the two boxes and one node around it: the nodes whose owner changes are written; on the way, how far
+    // the nearest node is from changing sides, as a gap in d2 = |P - C|^2 against min(r2, R2) -- a node at distance
+    // <= sqrt(2) (rbl0 + 2) from the centre sees its d2 change by at most (2 sqrt(2) (rbl0 + 2) + |D|) |D| when the centre
+    // moves by D, so for |D| <= 1 nothing changes sides while |D| < gap / (2 sqrt(2) (rbl0 + 2) + 1)
+    int xi = !go.any ? gn.xi : (!gn.any ? go.xi : (go.xi < gn.xi ? go.xi : gn.xi));
+    int xf = !go.any ? gn.xf : (!gn.any ? go.xf : (go.xf > gn.xf ? go.xf : gn.xf));
+    int yi = !go.any ? gn.yi : (!gn.any ? go.yi : (go.yi < gn.yi ? go.yi : gn.yi));
+    int yf = !go.any ? gn.yf : (!gn.any ? go.yf : (go.yf > gn.yf ? go.yf : gn.yf));
+    --xi; ++xf; --yi; ++yf;
+    const real rm2 = gn.r2 < gn.R2 ? gn.r2 : gn.R2;
+    real gap = 1e30;
     for (int y = yi + hl; y <= yf; y += GL)
       for (int x = xi; x <= xf; ++x) {
         const bool bo = disc_has(go, x, y), bn = disc_has(gn, x, y);
         if (bn != bo) obst[(long)(x - L.gx0) * L.sy + y] = bn ? i : -1;
+        const real d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc), g = d2 > rm2 ? d2 - rm2 : rm2 - d2;
+        gap = g < gap ? g : gap;
       }
+#pragma unroll
+    for (int d = 1; d < GL && d < 64; d <<= 1) {   // over this grain's lanes (GL = a power of two)
+      const real o = __shfl_xor(gap, d);
+      gap = o < gap ? o : gap;
+    }
+    if (hl == 0 && gn.any && gn.xi > 1 && gn.xf < L.lx - 2 && gn.yi > 1 && gn.yf < L.ly - 2 && gn.xi > L.gx0 &&
+        gn.xf < L.gx0 + L.nxl - 1) {   // (not next to a clamp of the box: there the argument above does not cover the nodes it cuts off)
+      const real lim = (gap - 1e-9) / (2.83 * (rbl0 + 2.) + 1.);
+      now.still2[i] = lim > 0. ? (lim < 1. ? lim * lim : 1.) : 0.;
+    }
     return;
   }
   auto partner_geo = [&](int j) {
@@ -265,16 +293,21 @@ __global__ void k_obst_update(int* __restrict__ obst, LatticeView L, int n, cons
       atomicCAS(&obst[(long)(x - L.gx0) * L.sy + y], i, v);
     }
   }
-  if (gn.any) {   // the nodes it covers: highest index wins (main.c:1028); who else covers them, from the partners' discs
+  if (gn.any) {   // the nodes it covers: highest index wins (main.c:1028) ...
     const int ny = gn.yf - gn.yi + 1, total = (gn.xf - gn.xi + 1) * ny;
     for (int k = hl; k < total; k += GL) {
       const int x = gn.xi + k / ny, y = gn.yi + k % ny;
-      if (!disc_has(gn, x, y)) continue;
-      const long node = (long)(x - L.gx0) * L.sy + y;
-      atomicMax(&obst[node], i);
-      for (int e = k0; e < k1; ++e) {
-        const int j = vnbr[e];
-        if (!disc_has(partner_geo(j), x, y)) continue;
+      if (disc_has(gn, x, y)) atomicMax(&obst[(long)(x - L.gx0) * L.sy + y], i);
+    }
+    // ... and who else covers them, from the partners' own disc tests (one partner at a time: its geometry once)
+    for (int e = k0; e < k1; ++e) {
+      const int j = vnbr[e];
+      const DiscGeo gj = partner_geo(j);
+      if (!gj.any || gj.xi > gn.xf || gj.xf < gn.xi || gj.yi > gn.yf || gj.yf < gn.yi) continue;
+      for (int k = hl; k < total; k += GL) {
+        const int x = gn.xi + k / ny, y = gn.yi + k % ny;
+        if (!disc_has(gn, x, y) || !disc_has(gj, x, y)) continue;
+        const long node = (long)(x - L.gx0) * L.sy + y;
         touched[i] = 1; touched[j] = 1;
         if (mincov) {
           atomicMax(&mincov[node], (epoch & 0xFFFu) << 20 | (0xFFFFFu - (unsigned)i));

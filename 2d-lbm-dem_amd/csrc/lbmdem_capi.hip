@@ -156,7 +156,7 @@ static int paint_into(lbmdem_handle* h, int* obst) {
     // the canvas holds this buffer's last picture: only the nodes whose owner changes are written
     launch_obst_update(obst, h->L, h->n, K.x1, K.x2, h->r, h->rLB, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0, h->pk,
                        h->fs.touched, h->mincov, h->paint_epoch, h->V.offsets, h->V.nbr, was, now, h->V.xreb, h->V.yreb,
-                       (real)(0.5 * h->cfg.phys.distVerlet / h->cfg.dx), h->moved_dev, h->list_generation, h->stream);
+                       (real)(0.5 * h->cfg.phys.distVerlet), h->moved_dev, h->list_generation, h->stream);
     h->snap_cur[b] = 1 - h->snap_cur[b];
     h->obst_updates++;
   } else {
@@ -165,7 +165,7 @@ static int paint_into(lbmdem_handle* h, int* obst) {
     launch_obst_paint(obst, h->L, h->n, K.x1, K.x2, h->r, h->rLB, K.v1, K.v2, K.v3, h->xc, h->yc, h->r2, h->rbl0, h->pk,
                       h->fs.touched, h->dist ? h->dd.fluidmask : nullptr, h->mincov, h->paint_epoch,
                       h->dist ? h->dd.local_list : nullptr, h->dist ? h->dd.counters + 6 : nullptr, h->dist ? h->dd.cap_l : 0,
-                      list_ok ? h->V.offsets : nullptr, list_ok ? h->V.nbr : nullptr, record ? now : ObstSnap{nullptr, nullptr, nullptr},
+                      list_ok ? h->V.offsets : nullptr, list_ok ? h->V.nbr : nullptr, record ? now : ObstSnap{nullptr, nullptr, nullptr, nullptr},
                       h->stream);
     if (record) h->snap_cur[b] = 1 - h->snap_cur[b];
     h->snap_ok[b] = record;
@@ -297,10 +297,11 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
   CREATE_TRY(hipMemsetAsync(h->owner, 1, n, h->stream));
   for (int b = 0; b < 2; ++b)
     for (int k = 0; k < 2; ++k) {
-      CREATE_TRY(hipMalloc((void**)&h->snap[b][k].xc, sizeof(real) * 2 * (size_t)n + n));
+      CREATE_TRY(hipMalloc((void**)&h->snap[b][k].xc, sizeof(real) * 3 * (size_t)n + n));
       h->snap[b][k].yc = h->snap[b][k].xc + n;
-      h->snap[b][k].mode = reinterpret_cast<unsigned char*>(h->snap[b][k].xc + 2 * (size_t)n);
-      CREATE_TRY(hipMemsetAsync(h->snap[b][k].xc, 0, sizeof(real) * 2 * (size_t)n + n, h->stream));
+      h->snap[b][k].still2 = h->snap[b][k].xc + 2 * (size_t)n;
+      h->snap[b][k].mode = reinterpret_cast<unsigned char*>(h->snap[b][k].xc + 3 * (size_t)n);
+      CREATE_TRY(hipMemsetAsync(h->snap[b][k].xc, 0, sizeof(real) * 3 * (size_t)n + n, h->stream));
     }
   if (carry_track_alloc(h->ct, n) != 0) {
     lbmdem_destroy(h);

@@ -145,7 +145,8 @@ void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st);
 // fills xc, yc, r2, rbl0, pk (per-grain lattice geometry, main.c:1009-1013) and paints the reduced discs
 // The lattice-unit centres a map buffer's discs were painted at (mode: 0 = the grain left nothing in that buffer):
 // what the in-place update of the map (k_obst_update) compares the new centres with. Null pointers: not recorded.
-struct ObstSnap { real* xc; real* yc; unsigned char* mode; };
+// `still2`: while the centre stays within sqrt(still2) of (xc, yc) no node of the disc changes sides (0: not known).
+struct ObstSnap { real* xc; real* yc; real* still2; unsigned char* mode; };
 void launch_obst_paint(int* obst, const LatticeView& L, int n, const real* x1, const real* x2, const real* r,
                        const real* rLB, const real* v1, const real* v2, const real* v3, real* xc,
                        real* yc, real* r2, real* rbl0, real* pk, unsigned char* touched,

@@ -32,6 +32,7 @@ def physics(pkg, reduction):
 def trio(pkg, po, lx, ly, r, x1, x2, reduction=None, vel=None, seed=1):
     kw = {} if reduction is None else {"physics": physics(pkg, reduction)}
     a = pkg.LbmDem(lx, ly, r, x1, x2, **kw)
+    a.set_obst_update(True)
     b = pkg.LbmDem(lx, ly, r, x1, x2, **kw)
     b.set_obst_update(False)
     ora = po.Oracle(lx, ly, r, x1, x2)
