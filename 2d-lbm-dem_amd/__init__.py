@@ -129,6 +129,7 @@ def _open_library(LIB_PATH):
     L.lbmdem_checkpoint_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     L.lbmdem_set_force_mode.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_set_dem_chain.argtypes = [C.c_void_p, C.c_int]
+    L.lbmdem_dem_chain_paints.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
     L.lbmdem_set_obst_update.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_obst_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
     L.lbmdem_measure_copy.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
@@ -532,6 +533,12 @@ class LbmDem:
         a, b, c, d = C.c_long(0), C.c_long(0), C.c_int(0), C.c_int(0)
         _chk(self._L.lbmdem_dem_chain_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return a.value, b.value, c.value, d.value
+
+    def dem_chain_paints(self):
+        """rasterisations done by the tail of a run of sub-steps instead of a launch of their own"""
+        a = C.c_long(0)
+        _chk(self._L.lbmdem_dem_chain_paints(self._h, C.byref(a)))
+        return a.value
 
     def force_stats(self):
         """(grains summed from the fused kernel's link table, grains gathered from the lattice) of the last

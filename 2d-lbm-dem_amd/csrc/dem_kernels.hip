@@ -504,7 +504,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
                                                            long long stamp0, const unsigned char* __restrict__ owner,
                                                            ObstFillJob fill, int tiles, int nsteps, void* pub,
                                                            unsigned pub_bytes, int* __restrict__ err, int* census,
-                                                           long long* dbg, int flags) {
+                                                           long long* dbg, int flags, ChainPaint paint) {
   __shared__ real sF1[CH_ENTRIES], sF2[CH_ENTRIES], sF3[CH_ENTRIES], sFn[CH_ENTRIES];
   __shared__ unsigned char sTouched[CH_ENTRIES];
   __shared__ real sS[5 * CH_SLOTS];     // drifted x1, x2, v1, v2, v3 of the staged grains, one array per field
@@ -515,6 +515,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
   // per grain of the tile, kept out of the registers: the angle (no contact needs it), the hydrodynamic force, 1 / the
   // inertia terms' divisors and the gravity terms
   __shared__ real sX3[DEM_TILE], sFh[3 * DEM_TILE], sMI[2 * DEM_TILE], sG[2 * DEM_TILE];
+  __shared__ int sK[2 * DEM_TILE];            // first and last list entry of the tile's grains (for the rasterisation at the end)
   __shared__ int sLast, sFail;
   const int tid = threadIdx.x;
   const bool one_xcd = (flags & 1) != 0;
@@ -848,6 +849,84 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
     }
     if (tid == 0) *err = 1;
     return;
+  }
+  if (paint.obst) {
+    // ---- obst_construction's rasterisation (main.c:1009-1032) of this tile's discs at the positions the run ends with:
+    // they are in LDS (the drift of the last sub-step), and so are those of every partner. Four lanes per grain.
+    __syncthreads();
+    if (tid < DEM_GRAINS) {   // the velocities of the fluid-side record are the final ones
+      sS[2 * CH_SLOTS + tid] = v1; sS[3 * CH_SLOTS + tid] = v2; sS[4 * CH_SLOTS + tid] = v3;
+      sK[tid] = k0; sK[DEM_TILE + tid] = k1;
+    }
+    __syncthreads();
+    const LatticeView& L = paint.L;
+    const int g = tid >> 2, hl = tid & 3, gi = g0 + g;
+    const bool there = gi < P.n;
+    const long long stamp_l = stamp0 + nsteps - 1;
+    const real gx1 = sS[g], gx2 = sS[CH_SLOTS + g];
+    const real rl = there ? paint.rLB[gi] : (real)1.;
+    const real xc = (gx1 - L.Mgx) / L.dx, yc = (gx2 - L.Mby) / L.dx, r2 = rl * rl, rbl0 = sR[g] / L.dx;   // main.c:1009-1013
+    if (there && hl == 0) {
+      paint.xc[gi] = xc; paint.yc[gi] = yc; paint.r2[gi] = r2; paint.rbl0[gi] = rbl0;
+      real* o = paint.pk + (long)gi * 8;
+      o[0] = gx1; o[1] = gx2; o[2] = sS[2 * CH_SLOTS + g]; o[3] = sS[3 * CH_SLOTS + g]; o[4] = sS[4 * CH_SLOTS + g];
+      o[5] = xc; o[6] = yc; o[7] = r2;
+    }
+    // alone = 1.5 nodes clear of the discs of all partners (k_obst_paint's test, on the same positions)
+    bool near = false;
+    if (there) {
+      for (int k = sK[g] + hl; k < sK[DEM_TILE + g]; k += 4) {
+        const unsigned w = (k - e0 < CH_META) ? sMeta[k - e0] : emeta[k];
+        const unsigned slot = w >> 8;
+        const int j = nbr[k];
+        real jx = 0., jy = 0.;
+        if (slot != DEM_CHAIN_DIRECT) { jx = sS[slot]; jy = sS[CH_SLOTS + slot]; }
+        else {
+          const unsigned off = remote + ((stamp_l & 1) ? line_par : 0u) + (unsigned)j * 128u;
+          if (!chain_read_slot(rs, off, chain_tag(stamp_l), stag, jx) || !chain_read_slot(rs, off + 16u, chain_tag(stamp_l), stag, jy)) near = true;
+        }
+        const real ddx = (jx - gx1) / L.dx, ddy = (jy - gx2) / L.dx, rr = rl + paint.rLB[j] + 1.5;
+        near |= !(ddx * ddx + ddy * ddy >= rr * rr);   // also true for a NaN
+      }
+    }
+    const bool alone = ((__ballot(near) >> (4 * ((tid & 63) >> 2))) & 0xFull) == 0;   // this grain's four lanes
+    if (there) {
+      const real R2 = rbl0 * rbl0;
+      int xi = (int)(xc - rbl0), xf = (int)(xc + rbl0);
+      if (xi < 1) xi = 1;
+      if (xf >= L.lx - 1) xf = L.lx - 2;
+      int yi = (int)(yc - rbl0), yf = (int)(yc + rbl0);
+      if (yi < 1) yi = 1;
+      if (yf >= L.ly - 1) yf = L.ly - 2;
+      if (xi < L.gx0) xi = L.gx0;
+      if (xf > L.gx0 + L.nxl - 1) xf = L.gx0 + L.nxl - 1;
+      auto in_disc = [&](int x, int y) {
+        const real d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc);
+        return d2 <= R2 && d2 <= r2;
+      };
+      if (xi <= xf && yi <= yf) {
+        if (alone) {
+          for (int y = yi + hl; y <= yf; y += 4)
+            for (int x = xi; x <= xf; ++x)
+              if (in_disc(x, y)) paint.obst[(long)(x - L.gx0) * L.sy + y] = gi;
+        } else {   // highest index wins (main.c:1028); whoever finds a previous owner records the overlap (k_obst_paint)
+          const int ny = yf - yi + 1, total = (xf - xi + 1) * ny;
+          for (int k = hl; k < total; k += 4) {
+            const int x = xi + k / ny, y = yi + k % ny;
+            if (!in_disc(x, y)) continue;
+            const long node = (long)(x - L.gx0) * L.sy + y;
+            const int old = atomicMax(&paint.obst[node], gi);
+            if (old >= 0 && old < P.n && old != gi) {
+              paint.touched[gi] = 1; paint.touched[old] = 1;
+              if (paint.mincov) {
+                atomicMax(&paint.mincov[node], (paint.epoch & 0xFFFu) << 20 | (0xFFFFFu - (unsigned)gi));
+                atomicMax(&paint.mincov[node], (paint.epoch & 0xFFFu) << 20 | (0xFFFFFu - (unsigned)old));
+              }
+            }
+          }
+        }
+      }
+    }
   }
   if (have) {   // grains this rank does not integrate keep their state, in the buffer that is current from now on
     out.x1[i] = x1; out.x2[i] = x2; out.x3[i] = sX3[tid];
@@ -1507,7 +1586,7 @@ int dem_chain_census(DemChain& C, int tslots, hipStream_t st) {
   *C.err_host = 0;
   hipLaunchKernelGGL(k_dem_chain, dim3(tslots), dim3(DEM_THREADS), 0, st, Kin{}, Kin{}, nullptr, nullptr, nullptr, nullptr,
                      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, DemParams{}, nullptr, CarryTrack{}, 0ll,
-                     nullptr, ObstFillJob{}, tslots, -1, C.pub, (unsigned)C.pub_bytes, C.err, C.census, nullptr, 0);
+                     nullptr, ObstFillJob{}, tslots, -1, C.pub, (unsigned)C.pub_bytes, C.err, C.census, nullptr, 0, ChainPaint{});
   int seen[4] = {0, 0, 0, 0};
   if (hipMemcpyAsync(seen, C.census, sizeof(seen), hipMemcpyDeviceToHost, st) != hipSuccess) return 0;
   if (hipStreamSynchronize(st) != hipSuccess) return 0;
@@ -1529,7 +1608,7 @@ int dem_chain_census(DemChain& C, int tslots, hipStream_t st) {
 void launch_dem_chain(const Kin& in, const Kin& out, const real* r, const real* m, const real* It, const real* fhf,
                       const VerletDevice& V, real* pout, const DemParams& P, const unsigned char* active,
                       const CarryTrack* track, long long stamp0, const unsigned char* owner, const ObstFillJob& fill,
-                      const DemChain& C, int nsteps, hipStream_t st) {
+                      const DemChain& C, int nsteps, const ChainPaint& paint, hipStream_t st) {
   const int n = P.n;
   const CarryTrack T = track ? *track : CarryTrack{};
   const int nbe = (n + DEM_GRAINS - 1) / DEM_GRAINS;
@@ -1548,5 +1627,5 @@ void launch_dem_chain(const Kin& in, const Kin& out, const real* r, const real* 
 #endif
   hipLaunchKernelGGL(k_dem_chain, dim3(((one_xcd & 1) ? nbe * 8 : DEM_GRID(nbe)) + extra), dim3(DEM_THREADS), 0, st, in, out, r, m, It, fhf, V.offsets,
                      V.nbr, V.emeta, V.halo_ids, V.halo_cnt, V.tile_far, V.wallflags, pout, P, active, T, stamp0, owner, fill, nbe, nsteps,
-                     C.pub, (unsigned)C.pub_bytes, C.err, C.census, C.dbg, one_xcd);
+                     C.pub, (unsigned)C.pub_bytes, C.err, C.census, C.dbg, one_xcd, paint);
 }

@@ -266,8 +266,16 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const real* __re
                                                                 const int* __restrict__ list,
                                                                 const int* __restrict__ list_count,
                                                                 PackSides sides,
-                                                                const unsigned char* __restrict__ mask, int list_cap) {
+                                                                const unsigned char* __restrict__ mask, int list_cap,
+                                                                ObstFillJob fill, int nfill) {
   extern __shared__ real sDyn[];
+  // the first `nfill` workgroups reset the obstacle map the next rasterisation starts from (the fused kernel has just
+  // finished with it; this kernel is bound by its arithmetic, the 67 MB of stores disappear beside it)
+  if ((int)blockIdx.x < nfill) {
+    obst_fill_range(fill.map, fill.L, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)nfill * blockDim.x, fill.row0, fill.row1);
+    return;
+  }
+  const int bx = (int)blockIdx.x - nfill;
   __shared__ __attribute__((aligned(16))) real sZero[8];   // phase B: what a lane adds once its own list has ended
   real* __restrict__ packbuf = nullptr;
   if (mode == FT_PACK) {
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const real* __re
                                              (size_t)FT_WAVES * nw64 * 3);
   const int lane = threadIdx.x & 63;
   const int gslot0 = wave * GW;                       // this wave's grains within the workgroup
-  const int g0 = (blockIdx.x * FT_WAVES + wave) * GW; // position in the list (or the grain index itself without a list)
+  const int g0 = (bx * FT_WAVES + wave) * GW; // position in the list (or the grain index itself without a list)
   const int ntodo = list ? (*list_count < list_cap ? *list_count : list_cap) : L.n;   // (an overflowing list is flagged by its producer)
   auto grain_at = [&](int pos) { return list ? list[pos] : pos; };
   const int own_lo = L.gx0 + L.xo0, own_hi = L.gx0 + L.xo1;  // rows whose links this rank produces: [own_lo, own_hi)
@@ -575,7 +583,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const real* __re
     }
   }
   if (mode == FT_PACK) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) packbuf[0] = (real)ntodo;
+    if (bx == 0 && threadIdx.x == 0) packbuf[0] = (real)ntodo;
     return;
   }
   if (threadIdx.x < 8) sZero[threadIdx.x] = 0.0;
@@ -732,7 +740,7 @@ void launch_forces_parity(const real* f, const int* obst, const LatticeView& L,
 template <int GW, int PASSES>
 static void launch_forces_table_t(const real* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
                                   const ForceSlots& S, double scale12, double scale3, real* fhf, unsigned char* owner,
-                                  int fast, hipStream_t st) {
+                                  int fast, const ObstFillJob& fill, hipStream_t st) {
   const int HB = S.hb, B = 2 * HB + 1;
   const int nw64 = (B * B * 8 + 63) / 64;
   // addends per accumulator: one link per direction and lattice line meeting the disc (<= spd lines for the
@@ -742,9 +750,15 @@ static void launch_forces_table_t(const real* f, const int* obst, const LatticeV
   const size_t lds = lists_doubles * 8 + (size_t)FT_WAVES * nw64 * 24 + (size_t)FT_WAVES * GW * 20;
   const int per_block = FT_WAVES * GW;
   const int ntodo = S.local_list ? S.local_cap : L.n;   // strips: the compacted list of local grains bounds the launch
-  hipLaunchKernelGGL((k_forces_table<GW, PASSES>), dim3((ntodo + per_block - 1) / per_block), dim3(64 * FT_WAVES), lds, st,
+  int nfill = 0;
+  if (fill.map && fill.row1 > fill.row0) {   // ~64 16-byte stores per thread
+    const long v4 = (long)(fill.row1 - fill.row0) * fill.L.sy / 4;
+    nfill = (int)((v4 + 64L * FT_WAVES * 64 - 1) / (64L * FT_WAVES * 64));
+    if (nfill > 512) nfill = 512;
+  }
+  hipLaunchKernelGGL((k_forces_table<GW, PASSES>), dim3(nfill + (ntodo + per_block - 1) / per_block), dim3(64 * FT_WAVES), lds, st,
                      f, obst, L, G, S, cap1, cap3, nw64, scale12, scale3, fhf, owner, fast ? (int)FT_FAST : (int)FT_CONSUME, S.local_list,
-                     S.local_count, PackSides{}, S.mask, S.local_cap);
+                     S.local_count, PackSides{}, S.mask, S.local_cap, fill, nfill);
   const int grid = L.n < 256 ? L.n : 256;
   hipLaunchKernelGGL(k_forces_gather_queue, dim3(grid), dim3(64), 0, st, f, obst, L, G, S, scale12, scale3, fhf);
 }
@@ -761,16 +775,16 @@ void launch_forces_table_pack(const real* f, const int* obst, const LatticeView&
   if (S.spd <= 32)
     hipLaunchKernelGGL((k_forces_table<1, 2>), dim3(blocks, 2), dim3(64 * FT_WAVES), lds, st, f, obst, L, G, S, cap1, cap3,
                        nw64, 0.0, 0.0, (real*)nullptr, (unsigned char*)nullptr, (int)FT_PACK, (const int*)nullptr,
-                       (const int*)nullptr, P, S.mask, cap);
+                       (const int*)nullptr, P, S.mask, cap, ObstFillJob{}, 0);
   else
     hipLaunchKernelGGL((k_forces_table<1, 4>), dim3(blocks, 2), dim3(64 * FT_WAVES), lds, st, f, obst, L, G, S, cap1, cap3,
                        nw64, 0.0, 0.0, (real*)nullptr, (unsigned char*)nullptr, (int)FT_PACK, (const int*)nullptr,
-                       (const int*)nullptr, P, S.mask, cap);
+                       (const int*)nullptr, P, S.mask, cap, ObstFillJob{}, 0);
 }
 
 void launch_forces_slots(const real* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
                          const ForceSlots& S, double scale12, double scale3, real* fhf, unsigned char* owner,
-                         int fast, hipStream_t st) {
+                         int fast, const ObstFillJob& fill, hipStream_t st) {
 #ifdef LBMDEM_AB
   static const int gw = getenv("LBMDEM_FORCE_GW") ? atoi(getenv("LBMDEM_FORCE_GW")) : 1;
 #else
@@ -779,14 +793,14 @@ void launch_forces_slots(const real* f, const int* obst, const LatticeView& L, c
   if (S.spd <= 32) {
     switch (gw) {
 #ifdef LBMDEM_AB
-      case 2: launch_forces_table_t<2, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, st); break;
-      case 3: launch_forces_table_t<3, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, st); break;
-      case 5: launch_forces_table_t<5, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, st); break;
+      case 2: launch_forces_table_t<2, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, fill, st); break;
+      case 3: launch_forces_table_t<3, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, fill, st); break;
+      case 5: launch_forces_table_t<5, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, fill, st); break;
 #endif
-      default: launch_forces_table_t<1, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, st); break;
+      default: launch_forces_table_t<1, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, fill, st); break;
     }
   } else {
-    launch_forces_table_t<1, 4>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, st);
+    launch_forces_table_t<1, 4>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, fill, st);
   }
 }
 

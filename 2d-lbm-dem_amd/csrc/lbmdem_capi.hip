@@ -137,14 +137,28 @@ int lbmdem_read_sample(const char* path, int* nbgrains, double** r_out, double**
 
 void lbmdem_free_host(void* p) { free(p); }
 
-static int paint_into(lbmdem_handle* h, int* obst) {
-  const Kin& K = h->kin[h->kcur];
+static int next_paint_epoch(lbmdem_handle* h) {
   if (h->mincov) {   // records of an older rasterisation lose against this one's; the 12-bit epoch is wound back rarely
     if (++h->paint_epoch > 0xFFFu) {
       HIP_TRY(hipMemsetAsync(h->mincov, 0, sizeof(unsigned) * (size_t)h->L.plane, h->stream));
       h->paint_epoch = 1;
     }
   }
+  return LBMDEM_OK;
+}
+
+static int paint_into(lbmdem_handle* h, int* obst) {
+  const Kin& K = h->kin[h->kcur];
+  if (h->chain_painted && obst == h->obst[1 - h->ocur]) {
+    // the run of sub-steps that ended here has painted the discs at these very positions (k_dem_chain, ChainPaint)
+    h->chain_painted = false;
+    h->obst_reset_rows = 0;
+    h->snap_ok[obst == h->obst[1] ? 1 : 0] = false;
+    h->slots_valid = false;
+    return LBMDEM_OK;
+  }
+  drop_chain_paint(h);
+  RC_TRY(next_paint_epoch(h));
   const int b = obst == h->obst[1] ? 1 : 0;
   // the pair list tells which discs cannot share a node with another one (plain stores instead of atomics). Not with
   // distributed grains: a rank's list is only right for the grains it integrates
@@ -601,8 +615,16 @@ int lbmdem_forces_fluid(lbmdem_handle* h) {
   if (h->slots_valid && !h->obst_pending) {
     // the link sums were left in the slot table by the fused kernel; the kernel empties the table again
     { int* t = h->fs.gathered; h->fs.gathered = h->fs.gathered_next; h->fs.gathered_next = t; }  // zeroed by the last queue kernel
+    // the map the fused kernel has just finished with is the next rasterisation's canvas: reset beside the force kernel
+    // (single domain; a strip's is reset by the launch that unpacks the neighbours' messages)
+    ObstFillJob fill{nullptr, h->L, 0, 0};
+    if (!h->dist && !h->cs_interior_pending && h->obst_reset_rows == 0 && !obst_update_planned(h)) {
+      fill.map = h->obst[1 - h->ocur];
+      fill.row1 = h->L.nxl;
+      h->obst_reset_rows = h->L.nxl;
+    }
     launch_forces_slots(h->f[h->fcur], ob, h->L, gview(h), h->fs, h->fscale12, h->fscale3, h->fhf, h->owner,
-                        h->force_mode != 0, h->stream);
+                        h->force_mode != 0, fill, h->stream);
     h->last_forces_from_table = true;
     h->dist_period_open = false;
     h->slots_valid = false;
@@ -719,6 +741,7 @@ int lbmdem_dem_substep(lbmdem_handle* h) {
   if (!h->verlet_ok) return fail(LBMDEM_EINVAL, "lbmdem_dem_substep before the first lbmdem_verlet_rebuild");
   if (*h->ovf_host) return fail(LBMDEM_ENOMEM, "Verlet list overflow (more than %ld symmetric entries)", h->V.cap);
   if (CHAIN_FAILED(h)) return fail(LBMDEM_EHIP, CHAIN_FAIL_MSG);
+  drop_chain_paint(h);
   const int film = (h->nbsteps % h->cfg.phys.stepFilm == 0) ? 1 : 0;  // main.c:1342
   // contact diagnostics are only needed by write_DEM, which renderScene calls when the step counter
   // reaches a multiple of stepStrob = 4000 (main.c:142,1773): produce them in exactly that sub-step
@@ -791,14 +814,25 @@ long lbmdem_dem_chain_length(lbmdem_handle* h, long remaining, int fluid) {
 }
 
 // k ordinary sub-steps (lbmdem_dem_chain_length said so) in one launch
-int lbmdem_dem_chain(lbmdem_handle* h, long k) {
+int lbmdem_dem_chain(lbmdem_handle* h, long k, int fluid) {
   CHECK_H(h);
   PhaseRange range_("lbmdem:dem_chain");
   CHECK_NOT_SPLIT(h);
   if (!h->verlet_ok) return fail(LBMDEM_EINVAL, "lbmdem_dem_substep before the first lbmdem_verlet_rebuild");
   if (*h->ovf_host) return fail(LBMDEM_ENOMEM, "Verlet list overflow (more than %ld symmetric entries)", h->V.cap);
   if (CHAIN_FAILED(h)) return fail(LBMDEM_EHIP, CHAIN_FAIL_MSG);
+  drop_chain_paint(h);
   const DemParams P = dem_params(h);
+  // A run that ends where the next fluid step begins rasterises the discs itself (the positions are in the tiles' LDS)
+  // -- when the canvas is clean already (reset beside the force kernel), the pair list is the one the rasteriser would use,
+  // and nothing about the map is pending.
+  ChainPaint paint{};
+  if (fluid && h->chain_paint && !h->dist && !h->obst_update && (h->nbsteps + k) % h->cfg.npDEM == 0 && !h->obst_pending &&
+      !h->cs_interior_pending && h->obst_reset_rows == h->L.nxl && h->verlet_tracks_positions && !*h->ovf_host &&
+      h->cfg.x_begin == 0 && h->cfg.x_end == h->cfg.lx) {
+    RC_TRY(next_paint_epoch(h));
+    paint = ChainPaint{h->obst[1 - h->ocur], h->L, h->rLB, h->xc, h->yc, h->r2, h->rbl0, h->pk, h->fs.touched, h->mincov, h->paint_epoch};
+  }
   ObstFillJob fill{nullptr, h->L, 0, 0};   // k slices of the next rasterisation's canvas (lbmdem_dem_substep: one each)
   if (!h->obst_pending && !h->cs_interior_pending && h->obst_reset_rows < h->L.nxl && !obst_update_planned(h)) {
     const long slice = (h->L.nxl + h->cfg.npDEM - 1) / h->cfg.npDEM;
@@ -809,7 +843,8 @@ int lbmdem_dem_chain(lbmdem_handle* h, long k) {
   }
   launch_dem_chain(h->kin[h->kcur], h->kin[1 - h->kcur], h->r, h->m, h->It, h->fhf, h->V, h->gp, P,
                    h->dist ? h->dd.active : nullptr, &h->ct, h->substep_seq, h->dist ? h->owner : nullptr, fill, h->chain,
-                   (int)k, h->stream);
+                   (int)k, paint, h->stream);
+  if (paint.obst) { h->chain_painted = true; h->chain_paints++; }
   if (h->dist && h->dist_poison) launch_dist_poison(h->dd, h->kin[0], h->kin[1], h->n, h->stream);
   h->substep_seq += k;
   h->chain_launches++; h->chain_substeps += k;
@@ -835,6 +870,7 @@ int lbmdem_obst_stats(lbmdem_handle* h, long* updates, long* repaints) {
 
 int lbmdem_set_dem_chain(lbmdem_handle* h, int max_substeps) {
   if (!h) return fail(LBMDEM_EINVAL, "null handle");
+  if (max_substeps < 0) { h->chain_paint = false; return LBMDEM_OK; }   // (A/B: runs as before, without the rasterisation at their end)
   h->chain_max = max_substeps;
   return LBMDEM_OK;
 }
@@ -848,6 +884,12 @@ int lbmdem_dem_chain_stats(lbmdem_handle* h, long* launches, long* substeps, int
   return LBMDEM_OK;
 }
 
+int lbmdem_dem_chain_paints(lbmdem_handle* h, long* paints) {
+  if (!h || !paints) return fail(LBMDEM_EINVAL, "null argument");
+  *paints = h->chain_paints;
+  return LBMDEM_OK;
+}
+
 int lbmdem_run(lbmdem_handle* h, long n_dem_steps) {
   CHECK_H(h);
   for (long k = 0; k < n_dem_steps;) {
@@ -856,7 +898,7 @@ int lbmdem_run(lbmdem_handle* h, long n_dem_steps) {
     if (rc == LBMDEM_OK && h->nbsteps % h->cfg.phys.updateVerlet == 0) rc = lbmdem_verlet_rebuild(h);  // main.c:1721-1724
     if (rc != LBMDEM_OK) return rc;
     const long run = lbmdem_dem_chain_length(h, n_dem_steps - k, 1);
-    if (run) { rc = lbmdem_dem_chain(h, run); k += run; }
+    if (run) { rc = lbmdem_dem_chain(h, run, 1); k += run; }
     else { rc = lbmdem_dem_substep(h); ++k; }                                                     // main.c:1733-1764
     if (rc != LBMDEM_OK) return rc;
   }
@@ -870,7 +912,7 @@ int lbmdem_run_dem(lbmdem_handle* h, long n_dem_steps) {
     if (h->nbsteps % h->cfg.phys.updateVerlet == 0) rc = lbmdem_verlet_rebuild(h);  // main.c:1721-1724
     if (rc != LBMDEM_OK) return rc;
     const long run = lbmdem_dem_chain_length(h, n_dem_steps - k, 0);
-    if (run) { rc = lbmdem_dem_chain(h, run); k += run; }
+    if (run) { rc = lbmdem_dem_chain(h, run, 0); k += run; }
     else { rc = lbmdem_dem_substep(h); ++k; }                                       // main.c:1733-1764
     if (rc != LBMDEM_OK) return rc;
   }
@@ -1063,6 +1105,7 @@ int lbmdem_upload_kinematics(lbmdem_handle* h, const double* k9) try {
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(h->kin[h->kcur].x1, soa.data(), sizeof(real) * 9 * n, hipMemcpyHostToDevice));
   h->verlet_tracks_positions = false;   // the pair list no longer bounds which discs can meet (obst_construction: atomics)
+  drop_chain_paint(h);
   return LBMDEM_OK;
 } catch (const std::bad_alloc&) {
   return fail(LBMDEM_ENOMEM, "host memory allocation failed");

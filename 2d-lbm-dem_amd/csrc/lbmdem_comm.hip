@@ -367,7 +367,7 @@ int lbmdem_comm_run(lbmdem_handle* h, lbmdem_comm* c, long n_dem_steps) {
     if (h->nbsteps % h->cfg.phys.updateVerlet == 0) RC_TRY(lbmdem_verlet_rebuild(h));            // main.c:1721-1724
     if ((h->nbsteps + 1) % 4000 == 0) { RC_TRY(comm_table_substep(h, c)); continue; }            // feeds write_DEM, main.c:1773
     const long run = lbmdem_dem_chain_length(h, n_dem_steps - k, 1);
-    if (run) { RC_TRY(lbmdem_dem_chain(h, run)); k += run - 1; }
+    if (run) { RC_TRY(lbmdem_dem_chain(h, run, 1)); k += run - 1; }
     else RC_TRY(lbmdem_dem_substep(h));                                                          // main.c:1733-1764
   }
   return LBMDEM_OK;

@@ -110,6 +110,11 @@ struct lbmdem_handle {
   int chain_max = 128;         // longest run handed to one launch; < 2: one launch per sub-step (lbmdem_set_dem_chain)
   bool chain_checked = false;  // the residency census has run (chain.capacity says what it found)
   long chain_launches = 0, chain_substeps = 0;   // lbmdem_dem_chain_stats
+  // the run of sub-steps that ended at a fluid step has rasterised the discs into obst[1 - ocur] itself (ChainPaint): the
+  // next obst_construction has nothing to launch. Dropped (and the canvas marked dirty) by whatever moves a grain first.
+  bool chain_painted = false;
+  bool chain_paint = true;     // (lbmdem_set_dem_chain: max_substeps < 0 switches only this off, for A/B)
+  long chain_paints = 0;
   long nbsteps = 0;
   int force_mode = 0;
   // derived scalars
@@ -204,7 +209,10 @@ static inline bool obst_update_planned(const lbmdem_handle* h) {
 // the coming ordinary sub-steps that nothing separates (fluid step when `fluid`, list rebuild, film law, table sub-step), at
 // most `remaining`; 0 when the run is shorter than 2 or the multi-sub-step kernel cannot be used -- and that many sub-steps
 LBMDEM_INTERNAL long lbmdem_dem_chain_length(lbmdem_handle* h, long remaining, int fluid);
-LBMDEM_INTERNAL int lbmdem_dem_chain(lbmdem_handle* h, long k);
+LBMDEM_INTERNAL int lbmdem_dem_chain(lbmdem_handle* h, long k, int fluid);   // fluid: a fluid step may follow (the run may rasterise for it)
+static inline void drop_chain_paint(lbmdem_handle* h) {
+  if (h->chain_painted) { h->chain_painted = false; h->obst_reset_rows = 0; }   // (the canvas holds a picture nobody will use)
+}
 // pieces of the fluid step for the C transport (lbmdem_comm.hip), which runs the edge rows on its halo lane's stream:
 LBMDEM_INTERNAL int lbmdem_collide_stream_prepare(lbmdem_handle* h);
 LBMDEM_INTERNAL int lbmdem_collide_stream_part_on(lbmdem_handle* h, int part, hipStream_t st);   // part on stream `st`

@@ -172,9 +172,10 @@ bool collide_stream_fills_slots(const LatticeView& L);
 void collide_stream_work_order(const LatticeView& L, int* info12);   // the launch's work items (lbmdem_fused_work_order)
 void launch_slots_clear(const ForceSlots& S, int n, hipStream_t st);
 // parity forces from the slot table (resets it to empty); grains whose table is incomplete gather from f
+struct ObstFillJob;   // (below) a range of rows of an obstacle map to reset beside the kernel's own work; map == nullptr: none
 void launch_forces_slots(const real* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
                          const ForceSlots& S, double scale12, double scale3, real* fhf, unsigned char* owner,
-                         int fast, hipStream_t st);
+                         int fast, const ObstFillJob& fill, hipStream_t st);
 // strip decomposition: this rank's part of the tables of the listed grains (owned by a neighbour rank), completed
 // and written as {count; count x {id, 8 * spd slots}} to a message buffer
 void launch_forces_table_pack(const real* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
@@ -349,6 +350,19 @@ struct DemChain {
   int capacity;         // tile slots the launch may use (all its workgroups must be resident at once); 0: not usable
   long long* dbg;       // experiment build only: [tiles][8] clocks of the last launch (lbmdem_debug_chain_times)
 };
+// The rasterisation of the reduced discs (k_obst_paint's work, main.c:1009-1032) done by the tiles of k_dem_chain when the
+// run of sub-steps ends where a fluid step begins: the final positions of a tile's grains and of all their partners are
+// in its LDS at that moment -- no launch, none of the three dependent rounds of loads the stand-alone kernel starts with.
+// The canvas must have been reset before the launch. obst == nullptr: not asked for.
+struct ChainPaint {
+  int* obst;
+  LatticeView L;
+  const real* rLB;
+  real *xc, *yc, *r2, *rbl0, *pk;
+  unsigned char* touched;
+  unsigned* mincov;
+  unsigned epoch;
+};
 int dem_chain_alloc(DemChain& C, int n);
 void dem_chain_free(DemChain& C);
 // how many workgroups of k_dem_chain this GPU keeps resident at once (occupancy x CUs), verified by a census launch of
@@ -358,4 +372,4 @@ int dem_chain_tslots(int n);
 void launch_dem_chain(const Kin& in, const Kin& out, const real* r, const real* m, const real* It, const real* fhf,
                       const VerletDevice& V, real* pout, const DemParams& P, const unsigned char* active,
                       const CarryTrack* track, long long stamp0, const unsigned char* owner, const ObstFillJob& fill,
-                      const DemChain& C, int nsteps, hipStream_t st);
+                      const DemChain& C, int nsteps, const ChainPaint& paint, hipStream_t st);

@@ -170,6 +170,11 @@ int lbmdem_set_dem_chain(lbmdem_handle* h, int max_substeps);
 /* what that path has done so far: launches, sub-steps they covered, the workgroups ("tile slots": 64 grains each) one
  * launch needs resident at once, and how many the census found resident (-1: not taken yet, 0: they do not fit) */
 int lbmdem_dem_chain_stats(lbmdem_handle* h, long* launches, long* substeps, int* tile_slots, int* resident);
+/* A run that ends where a fluid step begins also rasterises the reduced discs (obst_construction's paint, main.c:1009-1032)
+ * at the positions it ends with -- they and those of all partners are in the tiles' on-chip memory then: the next
+ * lbmdem_obst_construction has nothing left to launch. lbmdem_dem_chain_paints: how often that happened.
+ * lbmdem_set_dem_chain(h, -1) switches only this off (A/B). Same maps bit for bit. */
+int lbmdem_dem_chain_paints(lbmdem_handle* h, long* paints);
 
 /* ---- state in / out (host layout) ------------------------------------------------------------ */
 

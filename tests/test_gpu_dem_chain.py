@@ -87,3 +87,28 @@ def test_chain_across_film_and_table_substeps_matches_oracle(pkg, po):
                 assert np.array_equal(tg[:, c], to[:, c]), (sim.nbsteps, c)
     assert np.array_equal(sim.f, ora.get_f())
     sim.close()
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_rasterisation_by_the_tail_of_a_run_matches_the_rasteriser_and_the_oracle(pkg, po, shuffle):
+    """A run that ends where a fluid step begins paints the reduced discs itself (obst_construction, main.c:1009-1032: the
+    positions are in the tiles' on-chip memory); lbmdem_set_dem_chain(-1) leaves that to k_obst_paint. Same maps, same f,
+    same forces -- against each other and against the oracle; shuffled indices: partners beyond the staged halo."""
+    lx, ly = 512, 384
+    r, x1, x2 = packing(lx, ly, 900, 13, shuffle)
+    a = pkg.LbmDem(lx, ly, r, x1, x2)
+    b = pkg.LbmDem(lx, ly, r, x1, x2)
+    b.set_dem_chain(-1)
+    ora = po.Oracle(lx, ly, r, x1, x2)
+    k = kick([a, b], len(r), 23, scale=(0.2, 0.2, 30.0))
+    ora.set_kinematics(k)
+    n = a.cfg.npDEM
+    for m in (2 * n, 5 * n + 3, 7 * n, 9 * n - 3):      # runs that end on and off the fluid steps
+        a.renderScene(m); b.renderScene(m); ora.steps(m)
+        oa = a.obst
+        assert np.array_equal(oa, b.obst) and np.array_equal(oa, ora.get_obst()), (shuffle, a.nbsteps)
+        assert np.array_equal(a.fhf, b.fhf) and np.array_equal(a.fhf, ora.get_fhf()), (shuffle, a.nbsteps)
+        assert np.array_equal(a.kinematics, ora.get_grains()[:, :9]), (shuffle, a.nbsteps)
+    assert np.array_equal(a.f, b.f) and np.array_equal(a.f, ora.get_f())
+    assert a.dem_chain_paints() >= 15 and b.dem_chain_paints() == 0, (a.dem_chain_paints(), b.dem_chain_paints())
+    a.close(); b.close()
