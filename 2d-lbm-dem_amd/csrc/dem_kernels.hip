@@ -853,6 +853,9 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
   if (paint.obst) {
     // ---- obst_construction's rasterisation (main.c:1009-1032) of this tile's discs at the positions the run ends with:
     // they are in LDS (the drift of the last sub-step), and so are those of every partner. Four lanes per grain.
+    // The stand-alone rasteriser spends its time on its 11 M scattered 4-byte stores (24 of 28 us here too, measured with
+    // the stores taken out): with `paint.was` the canvas already holds the picture of two fluid steps ago and only the
+    // nodes whose owner changes are written (k_obst_update's rules, lbm_obst.hip) -- the tests cost 4 us.
     __syncthreads();
     if (tid < DEM_GRAINS) {   // the velocities of the fluid-side record are the final ones
       sS[2 * CH_SLOTS + tid] = v1; sS[3 * CH_SLOTS + tid] = v2; sS[4 * CH_SLOTS + tid] = v3;
@@ -862,65 +865,115 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
     const LatticeView& L = paint.L;
     const int g = tid >> 2, hl = tid & 3, gi = g0 + g;
     const bool there = gi < P.n;
+    const bool inplace = paint.was.xc != nullptr;
     const long long stamp_l = stamp0 + nsteps - 1;
     const real gx1 = sS[g], gx2 = sS[CH_SLOTS + g];
     const real rl = there ? paint.rLB[gi] : (real)1.;
     const real xc = (gx1 - L.Mgx) / L.dx, yc = (gx2 - L.Mby) / L.dx, r2 = rl * rl, rbl0 = sR[g] / L.dx;   // main.c:1009-1013
+    bool had = false;
+    real pxc = 0., pyc = 0., still2 = 0.;
+    if (there && inplace) { had = paint.was.mode[gi] != 0; pxc = paint.was.xc[gi]; pyc = paint.was.yc[gi]; still2 = paint.was.still2[gi]; }
     if (there && hl == 0) {
       paint.xc[gi] = xc; paint.yc[gi] = yc; paint.r2[gi] = r2; paint.rbl0[gi] = rbl0;
       real* o = paint.pk + (long)gi * 8;
       o[0] = gx1; o[1] = gx2; o[2] = sS[2 * CH_SLOTS + g]; o[3] = sS[3 * CH_SLOTS + g]; o[4] = sS[4 * CH_SLOTS + g];
       o[5] = xc; o[6] = yc; o[7] = r2;
+      if (inplace) {   // has a grain outrun the pair list? (k_obst_update)
+        const real mx = gx1 - paint.xreb[gi], my = gx2 - paint.yreb[gi];
+        if (!(mx * mx + my * my <= paint.moved_limit * paint.moved_limit)) *paint.moved_flag = paint.list_generation;
+      }
     }
-    // alone = 1.5 nodes clear of the discs of all partners (k_obst_paint's test, on the same positions)
-    bool near = false;
+    // the partners' final positions: staged slot, or (beyond the staged halo) the published line
+    auto partner_pos = [&](int k, real& jx, real& jy) {
+      const unsigned w = (k - e0 < CH_META) ? sMeta[k - e0] : emeta[k];
+      const unsigned slot = w >> 8;
+      if (slot != DEM_CHAIN_DIRECT) { jx = sS[slot]; jy = sS[CH_SLOTS + slot]; return true; }
+      const unsigned off = remote + ((stamp_l & 1) ? line_par : 0u) + (unsigned)nbr[k] * 128u;
+      return chain_read_slot(rs, off, chain_tag(stamp_l), stag, jx) && chain_read_slot(rs, off + 16u, chain_tag(stamp_l), stag, jy);
+    };
+    // alone: clear of the discs of all partners -- 1.5 nodes for a fresh picture (k_obst_paint's test); in place: this disc
+    // has moved less than half a node since it was painted and the circles keep 1.1 nodes apart (k_obst_update's)
+    const real moved2 = (xc - pxc) * (xc - pxc) + (yc - pyc) * (yc - pyc);
+    bool near = inplace && had && !(moved2 < 0.25);
     if (there) {
       for (int k = sK[g] + hl; k < sK[DEM_TILE + g]; k += 4) {
-        const unsigned w = (k - e0 < CH_META) ? sMeta[k - e0] : emeta[k];
-        const unsigned slot = w >> 8;
-        const int j = nbr[k];
         real jx = 0., jy = 0.;
-        if (slot != DEM_CHAIN_DIRECT) { jx = sS[slot]; jy = sS[CH_SLOTS + slot]; }
-        else {
-          const unsigned off = remote + ((stamp_l & 1) ? line_par : 0u) + (unsigned)j * 128u;
-          if (!chain_read_slot(rs, off, chain_tag(stamp_l), stag, jx) || !chain_read_slot(rs, off + 16u, chain_tag(stamp_l), stag, jy)) near = true;
-        }
-        const real ddx = (jx - gx1) / L.dx, ddy = (jy - gx2) / L.dx, rr = rl + paint.rLB[j] + 1.5;
+        if (!partner_pos(k, jx, jy)) near = true;
+        const real ddx = jx - gx1, ddy = jy - gx2, rr = (rl + paint.rLB[nbr[k]] + (inplace ? 1.1 : 1.5)) * L.dx;
         near |= !(ddx * ddx + ddy * ddy >= rr * rr);   // also true for a NaN
       }
     }
     const bool alone = ((__ballot(near) >> (4 * ((tid & 63) >> 2))) & 0xFull) == 0;   // this grain's four lanes
     if (there) {
-      const real R2 = rbl0 * rbl0;
-      int xi = (int)(xc - rbl0), xf = (int)(xc + rbl0);
-      if (xi < 1) xi = 1;
-      if (xf >= L.lx - 1) xf = L.lx - 2;
-      int yi = (int)(yc - rbl0), yf = (int)(yc + rbl0);
-      if (yi < 1) yi = 1;
-      if (yf >= L.ly - 1) yf = L.ly - 2;
-      if (xi < L.gx0) xi = L.gx0;
-      if (xf > L.gx0 + L.nxl - 1) xf = L.gx0 + L.nxl - 1;
-      auto in_disc = [&](int x, int y) {
-        const real d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc);
-        return d2 <= R2 && d2 <= r2;
-      };
-      if (xi <= xf && yi <= yf) {
-        if (alone) {
+      const DiscGeo gn = disc_geo(L, xc, yc, rl, rbl0, true), go = disc_geo(L, pxc, pyc, rl, rbl0, had);
+      if (inplace && alone && had && moved2 < still2) {
+        // nothing can have changed sides: map and record stay (the next comparison is again with the painted centre)
+        if (hl == 0) { paint.now.xc[gi] = pxc; paint.now.yc[gi] = pyc; paint.now.still2[gi] = still2; paint.now.mode[gi] = 1; }
+      } else {
+        if (hl == 0) { paint.now.xc[gi] = xc; paint.now.yc[gi] = yc; paint.now.still2[gi] = 0.; paint.now.mode[gi] = 1; }
+        if (alone && (gn.any || go.any)) {
+          int xi = !go.any ? gn.xi : (!gn.any ? go.xi : (go.xi < gn.xi ? go.xi : gn.xi));
+          int xf = !go.any ? gn.xf : (!gn.any ? go.xf : (go.xf > gn.xf ? go.xf : gn.xf));
+          int yi = !go.any ? gn.yi : (!gn.any ? go.yi : (go.yi < gn.yi ? go.yi : gn.yi));
+          int yf = !go.any ? gn.yf : (!gn.any ? go.yf : (go.yf > gn.yf ? go.yf : gn.yf));
+          --xi; ++xf; --yi; ++yf;   // (one node around: how far is the nearest node from changing sides, see k_obst_update)
+          const real rm2 = gn.r2 < gn.R2 ? gn.r2 : gn.R2;
+          real gap = 1e30;
           for (int y = yi + hl; y <= yf; y += 4)
-            for (int x = xi; x <= xf; ++x)
-              if (in_disc(x, y)) paint.obst[(long)(x - L.gx0) * L.sy + y] = gi;
-        } else {   // highest index wins (main.c:1028); whoever finds a previous owner records the overlap (k_obst_paint)
-          const int ny = yf - yi + 1, total = (xf - xi + 1) * ny;
-          for (int k = hl; k < total; k += 4) {
-            const int x = xi + k / ny, y = yi + k % ny;
-            if (!in_disc(x, y)) continue;
-            const long node = (long)(x - L.gx0) * L.sy + y;
-            const int old = atomicMax(&paint.obst[node], gi);
-            if (old >= 0 && old < P.n && old != gi) {
-              paint.touched[gi] = 1; paint.touched[old] = 1;
-              if (paint.mincov) {
-                atomicMax(&paint.mincov[node], (paint.epoch & 0xFFFu) << 20 | (0xFFFFFu - (unsigned)gi));
-                atomicMax(&paint.mincov[node], (paint.epoch & 0xFFFu) << 20 | (0xFFFFFu - (unsigned)old));
+            for (int x = xi; x <= xf; ++x) {
+              const bool bo = disc_has(go, x, y), bn = disc_has(gn, x, y);
+              if (bn != bo) paint.obst[(long)(x - L.gx0) * L.sy + y] = bn ? gi : -1;
+              const real d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc), gg = d2 > rm2 ? d2 - rm2 : rm2 - d2;
+              gap = gg < gap ? gg : gap;
+            }
+          { real o = __shfl_xor(gap, 1); gap = o < gap ? o : gap; o = __shfl_xor(gap, 2); gap = o < gap ? o : gap; }
+          if (hl == 0 && gn.any && gn.xi > 1 && gn.xf < L.lx - 2 && gn.yi > 1 && gn.yf < L.ly - 2 && gn.xi > L.gx0 &&
+              gn.xf < L.gx0 + L.nxl - 1) {
+            const real lim = (gap - 1e-9) / (2.83 * (rbl0 + 2.) + 1.);
+            paint.now.still2[gi] = lim > 0. ? (lim < 1. ? lim * lim : 1.) : 0.;
+          }
+        } else if (!alone) {
+          auto partner_geo = [&](int k, bool& ok) {
+            real jx = 0., jy = 0.;
+            ok = partner_pos(k, jx, jy);
+            const int j = nbr[k];
+            return disc_geo(L, (jx - L.Mgx) / L.dx, (jy - L.Mby) / L.dx, paint.rLB[j], paint.r[j] / L.dx, ok);
+          };
+          const int k0g = sK[g], k1g = sK[DEM_TILE + g];
+          if (go.any) {   // the nodes this disc has left: to the highest partner that covers them now, else to the fluid
+            const int ny = go.yf - go.yi + 1, total = (go.xf - go.xi + 1) * ny;
+            for (int k = hl; k < total; k += 4) {
+              const int x = go.xi + k / ny, y = go.yi + k % ny;
+              if (!disc_has(go, x, y) || disc_has(gn, x, y)) continue;
+              int v = -1;
+              for (int e = k0g; e < k1g; ++e) {
+                bool ok;
+                const DiscGeo gj = partner_geo(e, ok);
+                if (nbr[e] > v && disc_has(gj, x, y)) v = nbr[e];
+              }
+              atomicCAS(&paint.obst[(long)(x - L.gx0) * L.sy + y], gi, v);
+            }
+          }
+          if (gn.any) {   // the nodes it covers: highest index wins (main.c:1028); who else covers them, from the partners' discs
+            const int ny = gn.yf - gn.yi + 1, total = (gn.xf - gn.xi + 1) * ny;
+            for (int k = hl; k < total; k += 4) {
+              const int x = gn.xi + k / ny, y = gn.yi + k % ny;
+              if (disc_has(gn, x, y)) atomicMax(&paint.obst[(long)(x - L.gx0) * L.sy + y], gi);
+            }
+            for (int e = k0g; e < k1g; ++e) {
+              bool ok;
+              const DiscGeo gj = partner_geo(e, ok);
+              const int j = nbr[e];
+              if (!gj.any || gj.xi > gn.xf || gj.xf < gn.xi || gj.yi > gn.yf || gj.yf < gn.yi) continue;
+              for (int k = hl; k < total; k += 4) {
+                const int x = gn.xi + k / ny, y = gn.yi + k % ny;
+                if (!disc_has(gn, x, y) || !disc_has(gj, x, y)) continue;
+                const long node = (long)(x - L.gx0) * L.sy + y;
+                paint.touched[gi] = 1; paint.touched[j] = 1;
+                if (paint.mincov) {
+                  atomicMax(&paint.mincov[node], (paint.epoch & 0xFFFu) << 20 | (0xFFFFFu - (unsigned)gi));
+                  atomicMax(&paint.mincov[node], (paint.epoch & 0xFFFu) << 20 | (0xFFFFFu - (unsigned)j));
+                }
               }
             }
           }

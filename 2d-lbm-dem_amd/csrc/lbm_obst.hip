@@ -162,31 +162,6 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
 //     has moved away hands the node over the same way. Overlap flags and the lowest-cover records (`touched`, `mincov`)
 //     come from the partners' disc tests, not from what the atomics return (which may be a stale owner here).
 // Same maps, bit for bit, as clear + repaint (tests: every golden runs through it; tests/test_gpu_obst_update.py).
-struct DiscGeo {
-  real xc, yc, r2, R2;
-  int xi, xf, yi, yf;
-  bool any;
-};
-__device__ __forceinline__ DiscGeo disc_geo(const LatticeView& L, real xc, real yc, real rlb, real rbl0, bool valid) {
-  DiscGeo g;
-  g.xc = xc; g.yc = yc; g.r2 = rlb * rlb; g.R2 = rbl0 * rbl0;
-  g.xi = (int)(xc - rbl0); g.xf = (int)(xc + rbl0);   // main.c:1016-1023, as k_obst_paint
-  if (g.xi < 1) g.xi = 1;
-  if (g.xf >= L.lx - 1) g.xf = L.lx - 2;
-  g.yi = (int)(yc - rbl0); g.yf = (int)(yc + rbl0);
-  if (g.yi < 1) g.yi = 1;
-  if (g.yf >= L.ly - 1) g.yf = L.ly - 2;
-  if (g.xi < L.gx0) g.xi = L.gx0;
-  if (g.xf > L.gx0 + L.nxl - 1) g.xf = L.gx0 + L.nxl - 1;
-  g.any = valid && g.xi <= g.xf && g.yi <= g.yf;
-  return g;
-}
-__device__ __forceinline__ bool disc_has(const DiscGeo& g, int x, int y) {
-  if (!g.any || x < g.xi || x > g.xf || y < g.yi || y > g.yf) return false;
-  const real d2 = (x - g.xc) * (x - g.xc) + (y - g.yc) * (y - g.yc);
-  return d2 <= g.R2 && d2 <= g.r2;
-}
-
 template <int GL>
 __global__ void k_obst_update(int* __restrict__ obst, LatticeView L, int n, const real* __restrict__ x1,
                               const real* __restrict__ x2, const real* __restrict__ r,

@@ -153,7 +153,6 @@ static int paint_into(lbmdem_handle* h, int* obst) {
     // the run of sub-steps that ended here has painted the discs at these very positions (k_dem_chain, ChainPaint)
     h->chain_painted = false;
     h->obst_reset_rows = 0;
-    h->snap_ok[obst == h->obst[1] ? 1 : 0] = false;
     h->slots_valid = false;
     return LBMDEM_OK;
   }
@@ -827,11 +826,22 @@ int lbmdem_dem_chain(lbmdem_handle* h, long k, int fluid) {
   // -- when the canvas is clean already (reset beside the force kernel), the pair list is the one the rasteriser would use,
   // and nothing about the map is pending.
   ChainPaint paint{};
-  if (fluid && h->chain_paint && !h->dist && !h->obst_update && (h->nbsteps + k) % h->cfg.npDEM == 0 && !h->obst_pending &&
-      !h->cs_interior_pending && h->obst_reset_rows == h->L.nxl && h->verlet_tracks_positions && !*h->ovf_host &&
-      h->cfg.x_begin == 0 && h->cfg.x_end == h->cfg.lx) {
-    RC_TRY(next_paint_epoch(h));
-    paint = ChainPaint{h->obst[1 - h->ocur], h->L, h->rLB, h->xc, h->yc, h->r2, h->rbl0, h->pk, h->fs.touched, h->mincov, h->paint_epoch};
+  if (fluid && h->chain_paint && !h->dist && (h->nbsteps + k) % h->cfg.npDEM == 0 && !h->obst_pending &&
+      !h->cs_interior_pending && h->verlet_tracks_positions && !*h->ovf_host && h->cfg.x_begin == 0 && h->cfg.x_end == h->cfg.lx) {
+    const int b = 1 - h->ocur;
+    // in place (the canvas holds the picture its record describes, nobody has touched it) or onto a clean canvas
+    const bool inplace = h->obst_update && h->snap_ok[b] && h->obst_reset_rows == 0 && *h->moved_host != h->list_generation;
+    const bool clean = h->obst_reset_rows == h->L.nxl;
+    if (inplace || clean) {
+      RC_TRY(next_paint_epoch(h));
+      paint = ChainPaint{h->obst[b], h->L, h->rLB, h->xc, h->yc, h->r2, h->rbl0, h->pk, h->fs.touched, h->mincov, h->paint_epoch,
+                         inplace ? h->snap[b][h->snap_cur[b]] : ObstSnap{nullptr, nullptr, nullptr, nullptr},
+                         h->snap[b][1 - h->snap_cur[b]], h->r, h->V.xreb, h->V.yreb, (real)(0.5 * h->cfg.phys.distVerlet),
+                         h->moved_dev, h->list_generation};
+      h->snap_cur[b] = 1 - h->snap_cur[b];
+      h->snap_ok[b] = true;
+      if (inplace) h->obst_updates++; else h->obst_repaints++;
+    }
   }
   ObstFillJob fill{nullptr, h->L, 0, 0};   // k slices of the next rasterisation's canvas (lbmdem_dem_substep: one each)
   if (!h->obst_pending && !h->cs_interior_pending && h->obst_reset_rows < h->L.nxl && !obst_update_planned(h)) {

@@ -53,7 +53,7 @@ struct lbmdem_handle {
   ObstSnap snap[2][2] = {};
   int snap_cur[2] = {0, 0};
   bool snap_ok[2] = {false, false};   // snap[b][snap_cur[b]] describes what obst[b] holds
-  bool obst_update = false;           // lbmdem_set_obst_update (off by default: measured no faster than clear + repaint on the bench packing)
+  bool obst_update = true;            // lbmdem_set_obst_update: maps are updated in place where a picture to start from exists
   long obst_updates = 0, obst_repaints = 0;   // lbmdem_obst_stats
   int list_generation = 0;            // rebuilds so far
   volatile int* moved_host = nullptr; // pinned: the generation of the list in which k_obst_update found a grain too far from where the list found it

@@ -154,6 +154,33 @@ void launch_obst_paint(int* obst, const LatticeView& L, int n, const real* x1, c
                        const int* list_count, int list_cap, const int* verlet_offsets, const int* verlet_nbr,
                        const ObstSnap& snap_out,
                        hipStream_t st);   // verlet_*: the symmetric pair list (null: every grain takes the atomic path)
+// a reduced disc on the lattice: centre, squared radii, clamped bounding box (main.c:1009-1027); shared by k_obst_update and
+// the rasterisation at the end of k_dem_chain
+struct DiscGeo {
+  real xc, yc, r2, R2;
+  int xi, xf, yi, yf;
+  bool any;
+};
+__device__ __forceinline__ DiscGeo disc_geo(const LatticeView& L, real xc, real yc, real rlb, real rbl0, bool valid) {
+  DiscGeo g;
+  g.xc = xc; g.yc = yc; g.r2 = rlb * rlb; g.R2 = rbl0 * rbl0;
+  g.xi = (int)(xc - rbl0); g.xf = (int)(xc + rbl0);   // main.c:1016-1023, as k_obst_paint
+  if (g.xi < 1) g.xi = 1;
+  if (g.xf >= L.lx - 1) g.xf = L.lx - 2;
+  g.yi = (int)(yc - rbl0); g.yf = (int)(yc + rbl0);
+  if (g.yi < 1) g.yi = 1;
+  if (g.yf >= L.ly - 1) g.yf = L.ly - 2;
+  if (g.xi < L.gx0) g.xi = L.gx0;
+  if (g.xf > L.gx0 + L.nxl - 1) g.xf = L.gx0 + L.nxl - 1;
+  g.any = valid && g.xi <= g.xf && g.yi <= g.yf;
+  return g;
+}
+__device__ __forceinline__ bool disc_has(const DiscGeo& g, int x, int y) {
+  if (!g.any || x < g.xi || x > g.xf || y < g.yi || y > g.yf) return false;
+  const real d2 = (x - g.xc) * (x - g.xc) + (y - g.yc) * (y - g.yc);
+  return d2 <= g.R2 && d2 <= g.r2;
+}
+
 // the same outputs, the map written only where a disc's footprint differs from the one `was` describes (needs the list)
 void launch_obst_update(int* obst, const LatticeView& L, int n, const real* x1, const real* x2, const real* r,
                         const real* rLB, const real* v1, const real* v2, const real* v3, real* xc, real* yc, real* r2,
@@ -362,6 +389,14 @@ struct ChainPaint {
   unsigned char* touched;
   unsigned* mincov;
   unsigned epoch;
+  // was.xc == nullptr: the canvas is clean, every disc is painted; else the canvas holds the picture `was` describes and
+  // only the nodes whose owner changes are written (k_obst_update's rules). `now` records the new picture.
+  ObstSnap was, now;
+  const real* r;
+  const real *xreb, *yreb;   // where the pair list found the grains (has one outrun the list?)
+  real moved_limit;
+  int* moved_flag;
+  int list_generation;
 };
 int dem_chain_alloc(DemChain& C, int n);
 void dem_chain_free(DemChain& C);
