@@ -904,33 +904,51 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
       }
     }
     const bool alone = ((__ballot(near) >> (4 * ((tid & 63) >> 2))) & 0xFull) == 0;   // this grain's four lanes
-    if (there) {
+#ifdef LBMDEM_AB
+    const bool cut = (flags >> 16) & 1;   // experiment: the rasterisation without its node loops
+#else
+    const bool cut = false;
+#endif
+    // Discs that need their nodes looked at are listed in LDS and their lattice rows dealt out to ALL lanes of the
+    // workgroup afterwards: with the rows of a grain on its own four lanes, every wavefront walked through every kind
+    // of scan while half its lanes (the discs that have not moved enough to change a node) sat idle: 21 us; dealt out: half.
+    real* const recA = sF1;   // [slot][4] xc, yc, rl, rbl0 of a listed disc
+    real* const recB = sF2;   // [slot][4] pxc, pyc, smallest gap found (as bits), gi | kind << 28 | had << 30 (as bits)
+    int* const scan_count = &sLast;
+    int* const scan_rows = reinterpret_cast<int*>(sF3);
+    if (tid == 0) { *scan_count = 0; *scan_rows = 0; }
+    __syncthreads();
+    if (there && !cut) {
       const DiscGeo gn = disc_geo(L, xc, yc, rl, rbl0, true), go = disc_geo(L, pxc, pyc, rl, rbl0, had);
-      if (inplace && alone && had && moved2 < still2) {
+      const bool still = inplace && alone && had && moved2 < still2;
+      const bool ring = alone && inplace && had && gn.r2 <= gn.R2;
+#ifdef LBMDEM_AB   /* experiment build: which way the grains of the rasterisation go (dbg + tiles * 16: 4 counters) */
+      if (dbg && hl == 0)
+        atomicAdd(reinterpret_cast<unsigned long long*>(dbg + (long)tiles * 16 + (still ? 0 : (ring ? 1 : (alone ? 2 : 3)))), 1ull);
+#endif
+      if (still) {
         // nothing can have changed sides: map and record stay (the next comparison is again with the painted centre)
         if (hl == 0) { paint.now.xc[gi] = pxc; paint.now.yc[gi] = pyc; paint.now.still2[gi] = still2; paint.now.mode[gi] = 1; }
       } else {
         if (hl == 0) { paint.now.xc[gi] = xc; paint.now.yc[gi] = yc; paint.now.still2[gi] = 0.; paint.now.mode[gi] = 1; }
         if (alone && (gn.any || go.any)) {
-          int xi = !go.any ? gn.xi : (!gn.any ? go.xi : (go.xi < gn.xi ? go.xi : gn.xi));
-          int xf = !go.any ? gn.xf : (!gn.any ? go.xf : (go.xf > gn.xf ? go.xf : gn.xf));
-          int yi = !go.any ? gn.yi : (!gn.any ? go.yi : (go.yi < gn.yi ? go.yi : gn.yi));
-          int yf = !go.any ? gn.yf : (!gn.any ? go.yf : (go.yf > gn.yf ? go.yf : gn.yf));
-          --xi; ++xf; --yi; ++yf;   // (one node around: how far is the nearest node from changing sides, see k_obst_update)
-          const real rm2 = gn.r2 < gn.R2 ? gn.r2 : gn.R2;
-          real gap = 1e30;
-          for (int y = yi + hl; y <= yf; y += 4)
-            for (int x = xi; x <= xf; ++x) {
-              const bool bo = disc_has(go, x, y), bn = disc_has(gn, x, y);
-              if (bn != bo) paint.obst[(long)(x - L.gx0) * L.sy + y] = bn ? gi : -1;
-              const real d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc), gg = d2 > rm2 ? d2 - rm2 : rm2 - d2;
-              gap = gg < gap ? gg : gap;
+          if (hl == 0) {
+            // Ring: the disc has moved by |D| < 1/2 node, so a node at distance d from the new centre was at d -+ |D| from
+            // the old one: only nodes with |d - r| < 1/2 can have changed sides -- ~2 pi r nodes instead of the
+            // (2 r + 3)^2 of the box. (A node inside the ring's inner circle lies in both discs and both boxes, one outside
+            // its outer circle in neither disc: the boxes cannot change that.) Box: the union of the two boxes and a node
+            // around it (a first picture, or a disc whose box cuts into it).
+            int xlo, xhi;
+            if (ring) { xlo = (int)floor(xc - (rl + 0.5)) - 1; xhi = (int)ceil(xc + (rl + 0.5)) + 1; }
+            else {
+              xlo = (!go.any ? gn.xi : (!gn.any ? go.xi : (go.xi < gn.xi ? go.xi : gn.xi))) - 1;
+              xhi = (!go.any ? gn.xf : (!gn.any ? go.xf : (go.xf > gn.xf ? go.xf : gn.xf))) + 1;
             }
-          { real o = __shfl_xor(gap, 1); gap = o < gap ? o : gap; o = __shfl_xor(gap, 2); gap = o < gap ? o : gap; }
-          if (hl == 0 && gn.any && gn.xi > 1 && gn.xf < L.lx - 2 && gn.yi > 1 && gn.yf < L.ly - 2 && gn.xi > L.gx0 &&
-              gn.xf < L.gx0 + L.nxl - 1) {
-            const real lim = (gap - 1e-9) / (2.83 * (rbl0 + 2.) + 1.);
-            paint.now.still2[gi] = lim > 0. ? (lim < 1. ? lim * lim : 1.) : 0.;
+            const int slot = atomicAdd(scan_count, 1);
+            atomicMax(scan_rows, xhi - xlo + 1);
+            recA[slot * 4] = xc; recA[slot * 4 + 1] = yc; recA[slot * 4 + 2] = rl; recA[slot * 4 + 3] = rbl0;
+            recB[slot * 4] = pxc; recB[slot * 4 + 1] = pyc; recB[slot * 4 + 2] = 1e30;
+            reinterpret_cast<long long*>(recB)[slot * 4 + 3] = (long long)gi | ((long long)(ring ? 1 : 2) << 40) | ((long long)(had ? 1 : 0) << 44) | ((long long)g << 48);
           }
         } else if (!alone) {
           auto partner_geo = [&](int k, bool& ok) {
@@ -977,6 +995,60 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
               }
             }
           }
+        }
+      }
+    }
+    __syncthreads();
+    {   // ---- the listed discs' rows, one (disc, row) per lane and pass
+      const int nscan = *scan_count, nr = *scan_rows;
+      for (int t = tid; t < nscan * nr; t += DEM_THREADS) {
+        const int slot = t / nr, row = t - slot * nr;
+        const real cx = recA[slot * 4], cy = recA[slot * 4 + 1], crl = recA[slot * 4 + 2], crb = recA[slot * 4 + 3];
+        const long long bits = reinterpret_cast<const long long*>(recB)[slot * 4 + 3];
+        const int cgi = (int)(bits & 0xFFFFFFFFFFll), kind = (int)((bits >> 40) & 15);
+        const bool chad = ((bits >> 44) & 1) != 0;
+        const DiscGeo gn = disc_geo(L, cx, cy, crl, crb, true), go = disc_geo(L, recB[slot * 4], recB[slot * 4 + 1], crl, crb, chad);
+        const real rm2 = gn.r2 < gn.R2 ? gn.r2 : gn.R2;
+        real gap = 1e30;
+        auto settle = [&](int x, int y) {   // the reference's own test at both centres (disc_has: box and d2 <= r2, main.c:1027)
+          const bool bo = disc_has(go, x, y), bn = disc_has(gn, x, y);
+          if (bn != bo) paint.obst[(long)(x - L.gx0) * L.sy + y] = bn ? cgi : -1;
+          const real d2 = (x - cx) * (x - cx) + (y - cy) * (y - cy), gg = d2 > rm2 ? d2 - rm2 : rm2 - d2;
+          gap = gg < gap ? gg : gap;
+        };
+        if (kind == 1) {
+          // per lattice row two square roots give the ring's two stretches (one near the poles), one node beyond each end
+          // for the roots' rounding
+          const real ro = crl + 0.5, rin = crl > 0.5 ? crl - 0.5 : 0.;
+          const int x = (int)floor(cx - ro) - 1 + row;
+          const real dxn = x - cx, o2 = ro * ro - dxn * dxn;
+          if (x <= (int)ceil(cx + ro) + 1 && o2 >= 0.) {
+            const real yo = sqrt(o2), i2 = rin * rin - dxn * dxn, yn = i2 > 0. ? sqrt(i2) : 0.;
+            const int a0 = (int)floor(cy - yo) - 1, a1 = (int)ceil(cy - yn) + 1, b0 = (int)floor(cy + yn) - 1, b1 = (int)ceil(cy + yo) + 1;
+            if (a1 >= b0) { for (int y = a0; y <= b1; ++y) settle(x, y); }
+            else { for (int y = a0; y <= a1; ++y) settle(x, y); for (int y = b0; y <= b1; ++y) settle(x, y); }
+          }
+        } else {
+          const int xi = (!go.any ? gn.xi : (!gn.any ? go.xi : (go.xi < gn.xi ? go.xi : gn.xi))) - 1;
+          const int xf = (!go.any ? gn.xf : (!gn.any ? go.xf : (go.xf > gn.xf ? go.xf : gn.xf))) + 1;
+          const int yi = (!go.any ? gn.yi : (!gn.any ? go.yi : (go.yi < gn.yi ? go.yi : gn.yi))) - 1;
+          const int yf = (!go.any ? gn.yf : (!gn.any ? go.yf : (go.yf > gn.yf ? go.yf : gn.yf))) + 1;
+          const int x = xi + row;
+          if (x <= xf) for (int y = yi; y <= yf; ++y) settle(x, y);
+        }
+        // how far the nearest node is from changing sides (positive doubles order like their bit patterns)
+        atomicMin(reinterpret_cast<unsigned long long*>(recB) + slot * 4 + 2, (unsigned long long)__double_as_longlong((double)gap));
+      }
+      __syncthreads();
+      // a node at distance <= sqrt(2) (rbl0 + 2) from the centre sees its d2 change by at most (2 sqrt(2) (rbl0 + 2) + |D|) |D| when the
+      // centre moves by D: for |D| <= 1 nothing changes sides while |D| < gap / (2 sqrt(2) (rbl0 + 2) + 1) (k_obst_update)
+      if (tid < nscan) {
+        const real cx = recA[tid * 4], cy = recA[tid * 4 + 1], crl = recA[tid * 4 + 2], crb = recA[tid * 4 + 3];
+        const int cgi = (int)(reinterpret_cast<const long long*>(recB)[tid * 4 + 3] & 0xFFFFFFFFFFll);
+        const DiscGeo gn = disc_geo(L, cx, cy, crl, crb, true);
+        if (gn.any && gn.xi > 1 && gn.xf < L.lx - 2 && gn.yi > 1 && gn.yf < L.ly - 2 && gn.xi > L.gx0 && gn.xf < L.gx0 + L.nxl - 1) {
+          const real gap = recB[tid * 4 + 2], lim = (gap - 1e-9) / (2.83 * (crb + 2.) + 1.);
+          paint.now.still2[cgi] = lim > 0. ? (lim < 1. ? lim * lim : 1.) : 0.;
         }
       }
     }
@@ -1677,6 +1749,8 @@ void launch_dem_chain(const Kin& in, const Kin& out, const real* r, const real* 
   one_xcd = want_one && nbe <= 128 ? 1 : 0;
   static const int extra_sleep = getenv("LBMDEM_CHAIN_SLEEP") ? atoi(getenv("LBMDEM_CHAIN_SLEEP")) : 0;
   one_xcd |= (extra_sleep & 0xFF) << 8;
+  static const bool tail_cut = getenv("LBMDEM_CHAIN_TAILCUT") != nullptr;
+  if (tail_cut) one_xcd |= 1 << 16;
 #endif
   hipLaunchKernelGGL(k_dem_chain, dim3(((one_xcd & 1) ? nbe * 8 : DEM_GRID(nbe)) + extra), dim3(DEM_THREADS), 0, st, in, out, r, m, It, fhf, V.offsets,
                      V.nbr, V.emeta, V.halo_ids, V.halo_cnt, V.tile_far, V.wallflags, pout, P, active, T, stamp0, owner, fill, nbe, nsteps,

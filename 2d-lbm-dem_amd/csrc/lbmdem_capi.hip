@@ -675,13 +675,16 @@ int lbmdem_debug_chain_times(lbmdem_handle* h, long long* out, int tiles_cap) {
   CHECK_H(h);
   const int tiles = (h->n + DEM_TILE - 1) / DEM_TILE;
   if (!h->chain.dbg) {
-    HIP_TRY(hipMalloc((void**)&h->chain.dbg, sizeof(long long) * 16 * (size_t)tiles));
-    HIP_TRY(hipMemset(h->chain.dbg, 0, sizeof(long long) * 16 * (size_t)tiles));
+    HIP_TRY(hipMalloc((void**)&h->chain.dbg, sizeof(long long) * (16 * (size_t)tiles + 4)));
+    HIP_TRY(hipMemset(h->chain.dbg, 0, sizeof(long long) * (16 * (size_t)tiles + 4)));
     return 0;
   }
   HIP_TRY(hipStreamSynchronize(h->stream));
   const int nt = tiles < tiles_cap ? tiles : tiles_cap;
   HIP_TRY(hipMemcpy(out, h->chain.dbg, sizeof(long long) * 16 * (size_t)nt, hipMemcpyDeviceToHost));
+  long long paths[4];
+  HIP_TRY(hipMemcpy(paths, h->chain.dbg + 16 * (size_t)tiles, sizeof paths, hipMemcpyDeviceToHost));
+  fprintf(stderr, "rasterisation by the runs so far: %lld discs still, %lld ring scan, %lld box scan, %lld with partners near\n", paths[0], paths[1], paths[2], paths[3]);
   return nt;
 }
 int lbmdem_debug_gather_queue(lbmdem_handle* h, int* out, int cap) {   // experiment builds only
