@@ -516,7 +516,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
   // inertia terms' divisors and the gravity terms
   __shared__ real sX3[DEM_TILE], sFh[3 * DEM_TILE], sMI[2 * DEM_TILE], sG[2 * DEM_TILE];
   __shared__ int sK[2 * DEM_TILE];            // first and last list entry of the tile's grains (for the rasterisation at the end)
-  __shared__ int sLast, sFail;
+  __shared__ int sLast, sFail, sScan[2];
   const int tid = threadIdx.x;
   const bool one_xcd = (flags & 1) != 0;
   // one_xcd: every eighth block is a tile (they all land on one XCD, whose L2 then carries every hand-off), the others idle
@@ -912,10 +912,14 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
     // Discs that need their nodes looked at are listed in LDS and their lattice rows dealt out to ALL lanes of the
     // workgroup afterwards: with the rows of a grain on its own four lanes, every wavefront walked through every kind
     // of scan while half its lanes (the discs that have not moved enough to change a node) sat idle: 21 us; dealt out: half.
+    // (the staging arrays of phase 1 are free now; typed views, the same in the float build)
     real* const recA = sF1;   // [slot][4] xc, yc, rl, rbl0 of a listed disc
-    real* const recB = sF2;   // [slot][4] pxc, pyc, smallest gap found (as bits), gi | kind << 28 | had << 30 (as bits)
-    int* const scan_count = &sLast;
-    int* const scan_rows = reinterpret_cast<int*>(sF3);
+    real* const recP = sF2;   // [slot][2] the centre it was painted at
+    unsigned long long* const recG = reinterpret_cast<unsigned long long*>(sF3);   // [slot] smallest gap found, as the bits of a double
+    long long* const recI = reinterpret_cast<long long*>(sFn);                      // [slot] gi | kind << 40 | had << 44
+    static_assert(sizeof(real) * CH_ENTRIES >= 8 * DEM_TILE && CH_ENTRIES >= 4 * DEM_TILE, "LDS views of the rasterisation");
+    int* const scan_count = &sScan[0];
+    int* const scan_rows = &sScan[1];
     if (tid == 0) { *scan_count = 0; *scan_rows = 0; }
     __syncthreads();
     if (there && !cut) {
@@ -947,8 +951,9 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
             const int slot = atomicAdd(scan_count, 1);
             atomicMax(scan_rows, xhi - xlo + 1);
             recA[slot * 4] = xc; recA[slot * 4 + 1] = yc; recA[slot * 4 + 2] = rl; recA[slot * 4 + 3] = rbl0;
-            recB[slot * 4] = pxc; recB[slot * 4 + 1] = pyc; recB[slot * 4 + 2] = 1e30;
-            reinterpret_cast<long long*>(recB)[slot * 4 + 3] = (long long)gi | ((long long)(ring ? 1 : 2) << 40) | ((long long)(had ? 1 : 0) << 44) | ((long long)g << 48);
+            recP[slot * 2] = pxc; recP[slot * 2 + 1] = pyc;
+            recG[slot] = (unsigned long long)__double_as_longlong(1e30);
+            recI[slot] = (long long)gi | ((long long)(ring ? 1 : 2) << 40) | ((long long)(had ? 1 : 0) << 44);
           }
         } else if (!alone) {
           auto partner_geo = [&](int k, bool& ok) {
@@ -1004,17 +1009,17 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
       for (int t = tid; t < nscan * nr; t += DEM_THREADS) {
         const int slot = t / nr, row = t - slot * nr;
         const real cx = recA[slot * 4], cy = recA[slot * 4 + 1], crl = recA[slot * 4 + 2], crb = recA[slot * 4 + 3];
-        const long long bits = reinterpret_cast<const long long*>(recB)[slot * 4 + 3];
+        const long long bits = recI[slot];
         const int cgi = (int)(bits & 0xFFFFFFFFFFll), kind = (int)((bits >> 40) & 15);
         const bool chad = ((bits >> 44) & 1) != 0;
-        const DiscGeo gn = disc_geo(L, cx, cy, crl, crb, true), go = disc_geo(L, recB[slot * 4], recB[slot * 4 + 1], crl, crb, chad);
-        const real rm2 = gn.r2 < gn.R2 ? gn.r2 : gn.R2;
+        const DiscGeo gn = disc_geo(L, cx, cy, crl, crb, true), go = disc_geo(L, recP[slot * 2], recP[slot * 2 + 1], crl, crb, chad);
+        const real rm2 = gn.r2 < gn.R2 ? gn.r2 : gn.R2, near2 = (crl + 1.) * (crl + 1.);
         real gap = 1e30;
         auto settle = [&](int x, int y) {   // the reference's own test at both centres (disc_has: box and d2 <= r2, main.c:1027)
           const bool bo = disc_has(go, x, y), bn = disc_has(gn, x, y);
           if (bn != bo) paint.obst[(long)(x - L.gx0) * L.sy + y] = bn ? cgi : -1;
           const real d2 = (x - cx) * (x - cx) + (y - cy) * (y - cy), gg = d2 > rm2 ? d2 - rm2 : rm2 - d2;
-          gap = gg < gap ? gg : gap;
+          if (d2 <= near2) gap = gg < gap ? gg : gap;   // (nodes farther out than r + 1 stay outside whatever happens within half a node)
         };
         if (kind == 1) {
           // per lattice row two square roots give the ring's two stretches (one near the poles), one node beyond each end
@@ -1037,18 +1042,19 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
           if (x <= xf) for (int y = yi; y <= yf; ++y) settle(x, y);
         }
         // how far the nearest node is from changing sides (positive doubles order like their bit patterns)
-        atomicMin(reinterpret_cast<unsigned long long*>(recB) + slot * 4 + 2, (unsigned long long)__double_as_longlong((double)gap));
+        atomicMin(&recG[slot], (unsigned long long)__double_as_longlong((double)gap));
       }
       __syncthreads();
-      // a node at distance <= sqrt(2) (rbl0 + 2) from the centre sees its d2 change by at most (2 sqrt(2) (rbl0 + 2) + |D|) |D| when the
-      // centre moves by D: for |D| <= 1 nothing changes sides while |D| < gap / (2 sqrt(2) (rbl0 + 2) + 1) (k_obst_update)
+      // A node within r + 1 of the centre sees its d2 change by at most (2 (r + 1) + |D|) |D| < (2 r + 3) |D| when the centre moves
+      // by |D| < 1/2, a node farther out stays farther than r + 1/2: nothing changes sides while |D| < gap / (2 r + 3).
       if (tid < nscan) {
         const real cx = recA[tid * 4], cy = recA[tid * 4 + 1], crl = recA[tid * 4 + 2], crb = recA[tid * 4 + 3];
-        const int cgi = (int)(reinterpret_cast<const long long*>(recB)[tid * 4 + 3] & 0xFFFFFFFFFFll);
+        const int cgi = (int)(recI[tid] & 0xFFFFFFFFFFll);
         const DiscGeo gn = disc_geo(L, cx, cy, crl, crb, true);
         if (gn.any && gn.xi > 1 && gn.xf < L.lx - 2 && gn.yi > 1 && gn.yf < L.ly - 2 && gn.xi > L.gx0 && gn.xf < L.gx0 + L.nxl - 1) {
-          const real gap = recB[tid * 4 + 2], lim = (gap - 1e-9) / (2.83 * (crb + 2.) + 1.);
-          paint.now.still2[cgi] = lim > 0. ? (lim < 1. ? lim * lim : 1.) : 0.;
+          // (the slack: d2 as the test computes it carries rounding errors of a few ulps of ~100 -- 1e-13 in double, 1e-5 in the float build)
+          const real gap = (real)__longlong_as_double((long long)recG[tid]), lim = (gap - (sizeof(real) == 4 ? 1e-3 : 1e-9)) / (2. * crl + 3.);
+          paint.now.still2[cgi] = (gn.r2 <= gn.R2 && lim > 0.) ? (lim < 0.45 ? lim * lim : 0.2025) : 0.;
         }
       }
     }

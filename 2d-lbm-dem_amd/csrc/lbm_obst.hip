@@ -222,22 +222,22 @@ __global__ void k_obst_update(int* __restrict__ obst, LatticeView L, int n, cons
   if (!gn.any && !go.any) return;
   if (alone) {
     // the union of the two boxes and one node around it: the nodes whose owner changes are written; on the way, how far
-    // the nearest node is from changing sides, as a gap in d2 = |P - C|^2 against min(r2, R2) -- a node at distance
-    // <= sqrt(2) (rbl0 + 2) from the centre sees its d2 change by at most (2 sqrt(2) (rbl0 + 2) + |D|) |D| when the centre
-    // moves by D, so for |D| <= 1 nothing changes sides while |D| < gap / (2 sqrt(2) (rbl0 + 2) + 1)
+    // the nearest node is from changing sides, as a gap in d2 = |P - C|^2 against r2 -- a node within r + 1 of the centre sees
+    // its d2 change by less than (2 r + 3) |D| when the centre moves by |D| < 1/2, one farther out stays outside: nothing
+    // changes sides while |D| < gap / (2 r + 3)
     int xi = !go.any ? gn.xi : (!gn.any ? go.xi : (go.xi < gn.xi ? go.xi : gn.xi));
     int xf = !go.any ? gn.xf : (!gn.any ? go.xf : (go.xf > gn.xf ? go.xf : gn.xf));
     int yi = !go.any ? gn.yi : (!gn.any ? go.yi : (go.yi < gn.yi ? go.yi : gn.yi));
     int yf = !go.any ? gn.yf : (!gn.any ? go.yf : (go.yf > gn.yf ? go.yf : gn.yf));
     --xi; ++xf; --yi; ++yf;
-    const real rm2 = gn.r2 < gn.R2 ? gn.r2 : gn.R2;
+    const real rm2 = gn.r2 < gn.R2 ? gn.r2 : gn.R2, near2 = (ri + 1.) * (ri + 1.);
     real gap = 1e30;
     for (int y = yi + hl; y <= yf; y += GL)
       for (int x = xi; x <= xf; ++x) {
         const bool bo = disc_has(go, x, y), bn = disc_has(gn, x, y);
         if (bn != bo) obst[(long)(x - L.gx0) * L.sy + y] = bn ? i : -1;
         const real d2 = (x - xc) * (x - xc) + (y - yc) * (y - yc), g = d2 > rm2 ? d2 - rm2 : rm2 - d2;
-        gap = g < gap ? g : gap;
+        if (d2 <= near2) gap = g < gap ? g : gap;
       }
 #pragma unroll
     for (int d = 1; d < GL && d < 64; d <<= 1) {   // over this grain's lanes (GL = a power of two)
@@ -246,8 +246,8 @@ __global__ void k_obst_update(int* __restrict__ obst, LatticeView L, int n, cons
     }
     if (hl == 0 && gn.any && gn.xi > 1 && gn.xf < L.lx - 2 && gn.yi > 1 && gn.yf < L.ly - 2 && gn.xi > L.gx0 &&
         gn.xf < L.gx0 + L.nxl - 1) {   // (not next to a clamp of the box: there the argument above does not cover the nodes it cuts off)
-      const real lim = (gap - 1e-9) / (2.83 * (rbl0 + 2.) + 1.);
-      now.still2[i] = lim > 0. ? (lim < 1. ? lim * lim : 1.) : 0.;
+      const real lim = (gap - (sizeof(real) == 4 ? 1e-3 : 1e-9)) / (2. * ri + 3.);   // (slack for the rounding of d2: k_dem_chain)
+      now.still2[i] = (gn.r2 <= gn.R2 && lim > 0.) ? (lim < 0.45 ? lim * lim : 0.2025) : 0.;
     }
     return;
   }
