@@ -26,7 +26,7 @@ CT=$PWD/2d-lbm-dem_amd/liblbmdem_hip_ab_ct.so
 if [ -f $CT ]; then
   for n in 50000 12000 1000; do LBMDEM_HIP_LIBRARY=$CT python scripts/dem_chain_times.py $n 96 2>/dev/null >> $O/dem_chain_tiles.txt; echo >> $O/dem_chain_tiles.txt; done
 fi
-LBMDEM_RCCL_LIBRARY=$PWD/tests/rccl_shim/librccl.so.1 LBMDEM_BENCH_DEVICES=0,0 python bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_two_ranks_one_gpu.json 2>/dev/null
+LBMDEM_RCCL_LIBRARY=$PWD/tests/rccl_shim/librccl.so.1 LBMDEM_BENCH_DEVICES=0,0 python bench.py --gpus 2 --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_two_ranks_one_gpu.json
 bash scripts/strip_proxy_c.sh r05_final 8 4096 > $O/strip_proxy_c_4096.log 2>&1
 bash scripts/strip_proxy_c.sh r05_final8k 8 8192 > $O/strip_proxy_c_8192.log 2>&1
 LBMDEM_DEM_CHAIN=0 bash scripts/strip_proxy_c.sh r05_final_nochain 8 4096 > $O/strip_proxy_c_4096_one_launch_per_substep.log 2>&1
