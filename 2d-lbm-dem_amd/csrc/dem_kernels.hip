@@ -937,13 +937,15 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
         if (hl == 0) { paint.now.xc[gi] = xc; paint.now.yc[gi] = yc; paint.now.still2[gi] = 0.; paint.now.mode[gi] = 1; }
         if (alone && (gn.any || go.any)) {
           if (hl == 0) {
-            // Ring: the disc has moved by |D| < 1/2 node, so a node at distance d from the new centre was at d -+ |D| from
-            // the old one: only nodes with |d - r| < 1/2 can have changed sides -- ~2 pi r nodes instead of the
-            // (2 r + 3)^2 of the box. (A node inside the ring's inner circle lies in both discs and both boxes, one outside
-            // its outer circle in neither disc: the boxes cannot change that.) Box: the union of the two boxes and a node
-            // around it (a first picture, or a disc whose box cuts into it).
+            // Ring: the disc has moved by |D| (< 1/2 node), so a node at distance d from the new centre was at d -+ |D| from
+            // the old one: only nodes with |d - r| <= |D| can have changed sides -- an annulus a few hundredths of a node
+            // wide that holds a handful of nodes, instead of the (2 r + 3)^2 of the box. (A node inside its inner circle
+            // lies in both discs and both boxes, one outside its outer circle in neither disc: the boxes cannot change
+            // that.) Box: the union of the two boxes and a node around it (a first picture, or a disc whose box cuts into it).
+            // w = |D| + what the rounding of the test's d2 can amount to, in nodes.
+            const real w = (real)sqrt((double)moved2) + (sizeof(real) == 4 ? (real)(1e-3 + 5e-7 * (fabs((double)xc) + fabs((double)yc))) : (real)1e-6);   // (float: coordinates of a few thousand carry 1e-4 ... 1e-3 themselves)
             int xlo, xhi;
-            if (ring) { xlo = (int)floor(xc - (rl + 0.5)) - 1; xhi = (int)ceil(xc + (rl + 0.5)) + 1; }
+            if (ring) { xlo = (int)floor(xc - (rl + w)) - 1; xhi = (int)ceil(xc + (rl + w)) + 1; }
             else {
               xlo = (!go.any ? gn.xi : (!gn.any ? go.xi : (go.xi < gn.xi ? go.xi : gn.xi))) - 1;
               xhi = (!go.any ? gn.xf : (!gn.any ? go.xf : (go.xf > gn.xf ? go.xf : gn.xf))) + 1;
@@ -952,7 +954,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
             atomicMax(scan_rows, xhi - xlo + 1);
             recA[slot * 4] = xc; recA[slot * 4 + 1] = yc; recA[slot * 4 + 2] = rl; recA[slot * 4 + 3] = rbl0;
             recP[slot * 2] = pxc; recP[slot * 2 + 1] = pyc;
-            recG[slot] = (unsigned long long)__double_as_longlong(1e30);
+            recG[slot] = (unsigned long long)__double_as_longlong(ring ? (double)w : 1e30);   // ring: its half-width; box: the smallest gap found
             recI[slot] = (long long)gi | ((long long)(ring ? 1 : 2) << 40) | ((long long)(had ? 1 : 0) << 44);
           }
         } else if (!alone) {
@@ -1022,14 +1024,15 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
           if (d2 <= near2) gap = gg < gap ? gg : gap;   // (nodes farther out than r + 1 stay outside whatever happens within half a node)
         };
         if (kind == 1) {
-          // per lattice row two square roots give the ring's two stretches (one near the poles), one node beyond each end
-          // for the roots' rounding
-          const real ro = crl + 0.5, rin = crl > 0.5 ? crl - 0.5 : 0.;
+          // per lattice row two square roots give the annulus' two stretches (one near the poles); the stretches are
+          // widened by w once more, which covers the roots' own rounding: most of them hold no node at all
+          const real w = (real)__longlong_as_double((long long)recG[slot]);
+          const real ro = crl + w, rin = crl > w ? crl - w : 0.;
           const int x = (int)floor(cx - ro) - 1 + row;
           const real dxn = x - cx, o2 = ro * ro - dxn * dxn;
           if (x <= (int)ceil(cx + ro) + 1 && o2 >= 0.) {
             const real yo = sqrt(o2), i2 = rin * rin - dxn * dxn, yn = i2 > 0. ? sqrt(i2) : 0.;
-            const int a0 = (int)floor(cy - yo) - 1, a1 = (int)ceil(cy - yn) + 1, b0 = (int)floor(cy + yn) - 1, b1 = (int)ceil(cy + yo) + 1;
+            const int a0 = (int)ceil(cy - yo - w), a1 = (int)floor(cy - yn + w), b0 = (int)ceil(cy + yn - w), b1 = (int)floor(cy + yo + w);
             if (a1 >= b0) { for (int y = a0; y <= b1; ++y) settle(x, y); }
             else { for (int y = a0; y <= a1; ++y) settle(x, y); for (int y = b0; y <= b1; ++y) settle(x, y); }
           }
@@ -1041,8 +1044,8 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
           const int x = xi + row;
           if (x <= xf) for (int y = yi; y <= yf; ++y) settle(x, y);
         }
-        // how far the nearest node is from changing sides (positive doubles order like their bit patterns)
-        atomicMin(&recG[slot], (unsigned long long)__double_as_longlong((double)gap));
+        // box scans: how far the nearest node is from changing sides (positive doubles order like their bit patterns)
+        if (kind != 1) atomicMin(&recG[slot], (unsigned long long)__double_as_longlong((double)gap));
       }
       __syncthreads();
       // A node within r + 1 of the centre sees its d2 change by at most (2 (r + 1) + |D|) |D| < (2 r + 3) |D| when the centre moves
@@ -1051,7 +1054,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
         const real cx = recA[tid * 4], cy = recA[tid * 4 + 1], crl = recA[tid * 4 + 2], crb = recA[tid * 4 + 3];
         const int cgi = (int)(recI[tid] & 0xFFFFFFFFFFll);
         const DiscGeo gn = disc_geo(L, cx, cy, crl, crb, true);
-        if (gn.any && gn.xi > 1 && gn.xf < L.lx - 2 && gn.yi > 1 && gn.yf < L.ly - 2 && gn.xi > L.gx0 && gn.xf < L.gx0 + L.nxl - 1) {
+        if (((recI[tid] >> 40) & 15) != 1 && gn.any && gn.xi > 1 && gn.xf < L.lx - 2 && gn.yi > 1 && gn.yf < L.ly - 2 && gn.xi > L.gx0 && gn.xf < L.gx0 + L.nxl - 1) {
           // (the slack: d2 as the test computes it carries rounding errors of a few ulps of ~100 -- 1e-13 in double, 1e-5 in the float build)
           const real gap = (real)__longlong_as_double((long long)recG[tid]), lim = (gap - (sizeof(real) == 4 ? 1e-3 : 1e-9)) / (2. * crl + 3.);
           paint.now.still2[cgi] = (gn.r2 <= gn.R2 && lim > 0.) ? (lim < 0.45 ? lim * lim : 0.2025) : 0.;
