@@ -57,8 +57,19 @@ def worker(rank, world, lx, idfile, outfile):
     t0 = time.perf_counter(); comm.run(sim, PERIODS * npdem); t_enq = time.perf_counter() - t0
     sync()
     ms = 1e3 * (time.perf_counter() - t0) / PERIODS
+    # The host floor (task 2a): 100 periods enqueued back to back return only as the GPU works them off (the
+    # queue fills up), so their enqueue time equals the GPU time whatever the host costs. Two periods at a time, onto an idle
+    # stream, the call returns when the HOST is done: its launches, event operations and RCCL groups per period.
+    host_only = []
+    for _ in range(30):
+        sync()
+        t0 = time.perf_counter(); comm.run(sim, 2 * npdem); host_only.append(1e3 * (time.perf_counter() - t0) / 2)
+    sync()
+    host_only.sort()
     a, g = sim.force_stats()
     json.dump({"rank": rank, "pid": os.getpid(), "alone_ms_per_step": round(ms, 4), "host_enqueue_ms_per_step": round(1e3 * t_enq / PERIODS, 4),
+               "host_only_ms_per_period_median_of_30_pairs_on_an_idle_stream": round(host_only[len(host_only) // 2], 4),
+               "host_only_ms_per_period_min": round(host_only[0], 4),
                "forces_from_table_and_gathered": [int(a), int(g)],
                "messages_doubles": {k: sim.dist_message_doubles(v) for k, v in (("kin", 0), ("fhf", 1), ("tables", 2))}},
               open(outfile, "w"))
