@@ -7,6 +7,8 @@
 
 #include "lbmdem_handle.h"
 
+#include <mutex>
+
 static thread_local char g_err[512] = "";
 
 int lbmdem_fail(int code, const char* fmt, ...) {
@@ -815,6 +817,30 @@ long lbmdem_dem_chain_length(lbmdem_handle* h, long remaining, int fluid) {
   return h->chain.capacity >= dem_chain_tslots(h->n) ? k : 0;
 }
 
+// Two launches of k_dem_chain must not share the GPU: each needs ALL its tiles resident at once, and two that are each half
+// resident wait for each other's slots until their spins run out. Within a process the launches are therefore chained by an
+// event per device whenever they come from different streams (two handles stepped side by side); another PROCESS on the
+// same GPU is the caller's business (ranks of a decomposition have few integrated tiles each and fit side by side).
+static std::mutex g_chain_mutex;
+static hipEvent_t g_chain_done[64] = {};
+static hipStream_t g_chain_stream[64] = {};
+static bool g_chain_any[64] = {};
+static int chain_serialise_begin(lbmdem_handle* h) {
+  const int d = h->cfg.device & 63;
+  std::lock_guard<std::mutex> lock(g_chain_mutex);
+  if (!g_chain_done[d]) HIP_TRY(hipEventCreateWithFlags(&g_chain_done[d], hipEventDisableTiming));
+  if (g_chain_any[d] && g_chain_stream[d] != h->stream) HIP_TRY(hipStreamWaitEvent(h->stream, g_chain_done[d], 0));
+  return LBMDEM_OK;
+}
+static int chain_serialise_end(lbmdem_handle* h) {
+  const int d = h->cfg.device & 63;
+  std::lock_guard<std::mutex> lock(g_chain_mutex);
+  HIP_TRY(hipEventRecord(g_chain_done[d], h->stream));
+  g_chain_stream[d] = h->stream;
+  g_chain_any[d] = true;
+  return LBMDEM_OK;
+}
+
 // k ordinary sub-steps (lbmdem_dem_chain_length said so) in one launch
 int lbmdem_dem_chain(lbmdem_handle* h, long k, int fluid) {
   CHECK_H(h);
@@ -854,9 +880,11 @@ int lbmdem_dem_chain(lbmdem_handle* h, long k, int fluid) {
     fill.row1 = fill.row0 + slice * k < h->L.nxl ? (int)(fill.row0 + slice * k) : h->L.nxl;
     h->obst_reset_rows = fill.row1;
   }
+  RC_TRY(chain_serialise_begin(h));
   launch_dem_chain(h->kin[h->kcur], h->kin[1 - h->kcur], h->r, h->m, h->It, h->fhf, h->V, h->gp, P,
                    h->dist ? h->dd.active : nullptr, &h->ct, h->substep_seq, h->dist ? h->owner : nullptr, fill, h->chain,
                    (int)k, paint, h->stream);
+  RC_TRY(chain_serialise_end(h));
   if (paint.obst) { h->chain_painted = true; h->chain_paints++; }
   if (h->dist && h->dist_poison) launch_dist_poison(h->dd, h->kin[0], h->kin[1], h->n, h->stream);
   h->substep_seq += k;

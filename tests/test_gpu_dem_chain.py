@@ -112,3 +112,21 @@ def test_rasterisation_by_the_tail_of_a_run_matches_the_rasteriser_and_the_oracl
     assert np.array_equal(a.f, b.f) and np.array_equal(a.f, ora.get_f())
     assert a.dem_chain_paints() >= 15 and b.dem_chain_paints() == 0, (a.dem_chain_paints(), b.dem_chain_paints())
     a.close(); b.close()
+
+
+def test_two_handles_on_their_own_streams_side_by_side(pkg):
+    """Two launches of the multi-sub-step kernel must not share the GPU (each needs all its tiles resident at once; two
+    half-resident ones would wait for each other until their spins run out): the library chains them by an event when
+    they come from different streams. Two handles with their own streams, stepped alternately without a synchronisation in
+    between, 50 000 grains each (782 of the 1024 workgroup slots: they cannot both be resident)."""
+    lx, ly = 4096, 4096
+    r, x, y = samples.row_packing(lx, ly, 50000, seed=1234)
+    r, x1, x2 = samples.to_metres(r, x, y)
+    a = pkg.LbmDem(lx, ly, r, x1, x2); a.use_own_stream()
+    b = pkg.LbmDem(lx, ly, r, x1, x2); b.use_own_stream()
+    for _ in range(40):
+        a.run_dem(23); b.run_dem(23)
+    a.sync(); b.sync()                       # (a tile that gave up would raise here)
+    assert np.array_equal(a.kinematics, b.kinematics)
+    assert a.dem_chain_stats()[3] == a.dem_chain_stats()[2] and a.dem_chain_stats()[0] >= 40
+    a.close(); b.close()
