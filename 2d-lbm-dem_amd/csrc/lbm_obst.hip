@@ -220,6 +220,29 @@ __global__ void k_obst_update(int* __restrict__ obst, LatticeView L, int n, cons
   }
   if (hl == 0) { now.xc[i] = xc; now.yc[i] = yc; now.still2[i] = 0.; now.mode[i] = 1; }
   if (!gn.any && !go.any) return;
+  if (alone && had && gn.r2 <= gn.R2) {
+    // The disc has moved by |D| (< 1/2 node): only nodes with |d - r| <= |D| can have changed sides (a node at distance d
+    // from the new centre was at d -+ |D| from the old one) -- an annulus a few hundredths of a node wide. Per lattice row
+    // two square roots give its two stretches, most of which hold no node; every candidate is settled by the reference's
+    // own test at both centres. w = |D| + what the rounding of the test's d2 can amount to, in nodes. (k_dem_chain's
+    // rasterisation does the same from LDS.) The record keeps still2 = 0: the next step scans again, which is cheap.
+    const real w = (real)sqrt((double)moved2) + (sizeof(real) == 4 ? (real)(1e-3 + 5e-7 * (fabs((double)xc) + fabs((double)yc))) : (real)1e-6);
+    const real ro = ri + w, rin = ri > w ? ri - w : 0.;
+    const int xlo = (int)floor(xc - ro) - 1, xhi = (int)ceil(xc + ro) + 1;
+    auto settle = [&](int x, int y) {
+      const bool bo = disc_has(go, x, y), bn = disc_has(gn, x, y);
+      if (bn != bo) obst[(long)(x - L.gx0) * L.sy + y] = bn ? i : -1;
+    };
+    for (int x = xlo + hl; x <= xhi; x += GL) {
+      const real dxn = x - xc, o2 = ro * ro - dxn * dxn;
+      if (!(o2 >= 0.)) continue;
+      const real yo = sqrt(o2), i2 = rin * rin - dxn * dxn, yn = i2 > 0. ? sqrt(i2) : 0.;
+      const int a0 = (int)ceil(yc - yo - w), a1 = (int)floor(yc - yn + w), b0 = (int)ceil(yc + yn - w), b1 = (int)floor(yc + yo + w);
+      if (a1 >= b0) { for (int y = a0; y <= b1; ++y) settle(x, y); }
+      else { for (int y = a0; y <= a1; ++y) settle(x, y); for (int y = b0; y <= b1; ++y) settle(x, y); }
+    }
+    return;
+  }
   if (alone) {
     // the union of the two boxes and one node around it: the nodes whose owner changes are written; on the way, how far
     // the nearest node is from changing sides, as a gap in d2 = |P - C|^2 against r2 -- a node within r + 1 of the centre sees
