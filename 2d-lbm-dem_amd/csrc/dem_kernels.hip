@@ -445,7 +445,7 @@ __global__ __launch_bounds__(DEM_THREADS) void k_dem_entries(Kin in, Kin out, co
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CH_SLOTS = DEM_TILE + DEM_CHAIN_HALO;   // grains staged in LDS: the tile's own, then its halo
-constexpr int CH_ENTRIES = 384;                       // list entries staged per round (k_dem_entries: DEM_ENTRIES)
+constexpr int CH_ENTRIES = 448;                       // list entries staged per round (k_dem_entries: DEM_ENTRIES); the reference's own 50 000-grain packing has up to 387 per tile
 constexpr int CH_META = 768;                          // list entries whose emeta word is kept in LDS
 constexpr int CH_ITEMS = 3;                          // 16-byte slots a lane has in flight per pass of the halo fetch (153 grains)
 constexpr unsigned CH_SPINS = 1u << 18;

@@ -303,7 +303,7 @@ struct VerletDevice {
   unsigned char* tile_far;   // [tiles] the tile has a partner in a tile that is expected on another XCD
   real *xreb, *yreb;         // [n] the positions the list was built from
 };
-constexpr int DEM_CHAIN_HALO = 320;          // halo grains staged per tile; partners beyond that are read from memory per entry
+constexpr int DEM_CHAIN_HALO = 256;          // halo grains staged per tile; partners beyond that are read from memory per entry
 constexpr unsigned DEM_CHAIN_DIRECT = 0xFFFFu;   // emeta slot value of such a partner
 int verlet_alloc(VerletDevice& V, int n, real cs, real ox, real oy, real wx, real wy);
 void verlet_free(VerletDevice& V);

@@ -10,8 +10,12 @@ import __graft_entry__ as ge, samples
 pkg = ge.load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 nsub = int(sys.argv[2]) if len(sys.argv) > 2 else 96
-r, x, y = samples.row_packing(4096, 4096, n, seed=1234)
-r, x1, x2 = samples.to_metres(r, x, y)
+if len(sys.argv) > 3 and sys.argv[3] == "real":   # the reference's own bin/50000.data geometry (fixture)
+    gfix = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "real_50000_4096x4096.npz"))
+    r, x1, x2 = gfix["r"], gfix["x1"], gfix["x2"]
+else:
+    r, x, y = samples.row_packing(4096, 4096, n, seed=1234)
+    r, x1, x2 = samples.to_metres(r, x, y)
 sim = pkg.LbmDem(4096, 4096, r, x1, x2)
 L = sim._L
 L.lbmdem_debug_chain_times.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
