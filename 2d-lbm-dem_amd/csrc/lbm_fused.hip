@@ -481,7 +481,7 @@ static int march_segment_rows(int rows, int nstrips) {
   return seg_rows;
 }
 
-// The tapered schedule of a LARGE row range (MarchPlan above): eight XCD bands, each cut into 32-row segments followed by
+// The tapered schedule of a LARGE row range (MarchPlan above): eight XCD bands, each cut into long main segments followed by
 // `tail` levels of shorter ones. Returns a plan with nlev == 0 when the range is too small for it (short ranges run uniform
 // short segments: march_segment_rows).
 static MarchPlan march_plan(int rows, int nstrips, int main_seg, const int (*tail)[2], int ntail, int chunk) {
@@ -526,8 +526,12 @@ static MarchPlan product_plan(int rows, int nstrips, int seg_rows) {
   MarchPlan P{};
   if (seg_rows < 32) return P;
   {
-    int main_seg = 32, ntail = 2;
-    int tail[3][2] = {{16, 64}, {8, 64}, {0, 0}};   // {rows per segment, rows of every band cut that way}
+    // Round 5: 64-row main segments and a 32-row level in front of the 16- and 8-row ones. A wavefront's rows do not get
+    // dearer with the segment length (profiles/r05_segment_length_counters.txt: wave-cycles +0.7 % at 64 rows, +2 % at 128),
+    // and every segment re-reads two prologue rows: -3 % of the read requests, fused kernel -0.4 % (interleaved A/B);
+    // 128-row segments lose 19 % to the end of the launch.
+    int main_seg = 64, ntail = 3;
+    int tail[3][2] = {{32, 64}, {16, 64}, {8, 64}};   // {rows per segment, rows of every band cut that way}
 #ifdef LBMDEM_AB   // LBMDEM_PLAN="seg:rows,seg:rows[,seg:rows]" (tail levels), LBMDEM_CS_ROWS = the main segment length
     if (getenv("LBMDEM_CS_ROWS")) main_seg = atoi(getenv("LBMDEM_CS_ROWS"));
     if (const char* e = getenv("LBMDEM_PLAN")) {

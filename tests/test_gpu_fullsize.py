@@ -38,14 +38,14 @@ def test_c3_2048_7000_grains_two_fluid_steps_exact(pkg, po):
 
 @pytest.mark.parametrize("lx,ly,n", [(4000, 2046, 12000), (3000, 2790, 12000)])
 def test_tapered_work_order_on_row_counts_that_are_no_multiple_of_its_bands(pkg, po, lx, ly, n):
-    """Large row ranges run the fused kernel with the tapered work order (eight XCD bands of interleaved 64-row chunks, 32-row
-    segments first, 16- and 8-row segments last: lbm_fused.hip march_plan). With lx = 4000 / 3000 the bands (8 x 512 / 8 x 384
+    """Large row ranges run the fused kernel with the tapered work order (eight XCD bands of interleaved 64-row chunks, 64-row
+    segments first, 32-, 16- and 8-row segments last: lbm_fused.hip march_plan). With lx = 4000 / 3000 the bands (8 x 512 / 8 x 384
     rows) reach beyond the lattice: items that start past the last row must do nothing, the item that straddles it must stop
     there. Two fluid steps and the sub-steps between them, every array against the CPU oracle."""
     r, x1, x2 = packing(lx, ly, n, seed=7)
     sim = pkg.LbmDem(lx, ly, r, x1, x2)
     wo = sim.fused_work_order()
-    assert wo["levels"] == 3 and wo["segment_rows"] == [32, 16, 8] and wo["chunk_rows"] == 64
+    assert wo["levels"] == 4 and wo["segment_rows"] == [64, 32, 16, 8] and wo["chunk_rows"] == 64
     assert 8 * wo["band_rows"] > lx and sum(wo["level_rows"]) == wo["band_rows"]     # the bands overshoot the lattice
     ora = po.Oracle(lx, ly, r, x1, x2)
     k = sim.cfg.npDEM + 1   # fluid steps at nbsteps 0 and npDEM
@@ -62,7 +62,7 @@ def test_c4_4096_50k_first_step_exact_then_properties(pkg, po):
     r, x1, x2 = packing(lx, ly, 50000)
     assert len(r) == 50000
     sim = pkg.LbmDem(lx, ly, r, x1, x2)
-    assert sim.fused_work_order()["levels"] == 3          # the headline lattice runs the tapered work order
+    assert sim.fused_work_order()["levels"] == 4          # the headline lattice runs the tapered work order
     ora = po.Oracle(lx, ly, r, x1, x2)
     # one renderScene: fluid step + O(N^2) Verlet build + DEM sub-step on the CPU (~10 s)
     sim.renderScene(1); ora.steps(1)
@@ -144,7 +144,7 @@ def test_two_strips_of_the_headline_lattice_equal_one_domain(pkg):
     for rank, strip in enumerate(parts):
         be = strips.GpuStripBackend(pkg, torch, lx, ly, r, x1, x2, strip, 2, 0, distributed=True, margin=margin, poison=True)
         runners.append(strips.DistStripRunner(be, LoopbackComm(), rank, 2))
-    assert runners[0].b.sim.fused_work_order()["levels"] == 3      # (whole strip; its interior rows take the same order)
+    assert runners[0].b.sim.fused_work_order()["levels"] == 4      # (whole strip; its interior rows take the same order)
     n = 3 * cfg.npDEM + 1
     lockstep_render_dist(runners, n)
     for R in runners:
