@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const real* __re
   // per grain of the workgroup: addends of fhf1 [cap1] | fhf2 [cap1] | fhf3 [cap3]
   // then per wave: the bitmap [nw64] and the three per-word prefix counts [3][nw64]; then [FT_WAVES * GW][4] counts
   const int per_grain = 2 * cap1 + cap3;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: the grain's scalars come through the scalar unit)
   const size_t lists_doubles = (size_t)FT_WAVES * GW * per_grain;
   unsigned long long* const bm = reinterpret_cast<unsigned long long*>(sDyn + lists_doubles) + (size_t)wave * nw64 * 3;
   int* const pw = reinterpret_cast<int*>(bm + nw64);  // 3 * nw64 ints = 1.5 * nw64 words: the wave's 3 * nw64 words hold both
@@ -317,35 +317,48 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const real* __re
   int n1[GW], n2[GW], n3[GW];                           // addends per accumulator; n1 < 0: gather
   int gid[GW];                                          // grain index, -1: nothing to do
   bool own[GW];
-  // ---- tables of all GW grains: fetch, reset (one round of global latency for the whole wave)
+  // ---- per grain: everything the wave needs from memory in ONE round -- the disc and the table rows. (The disc used to be
+  // re-read in phase A: the compiler cannot carry G.xc[i] across the table's reset stores, which may alias it for all it
+  // knows, so every wave paid a second dependent round trip before its first square root.) The table loads do not wait
+  // for `local` either: any grain's rows are valid addresses; only the reset stores are conditional.
+  real gxc[GW], gyc[GW], gr2[GW], grb[GW];
+  bool gtouched[GW];
 #pragma unroll
   for (int g = 0; g < GW; ++g) {
     gid[g] = g0 + g < ntodo ? grain_at(g0 + g) : -1;
-    const int i = gid[g];
+    const int i = gid[g], ii = i >= 0 ? i : 0;
+    gxc[g] = G.xc[ii]; gyc[g] = G.yc[ii]; gr2[g] = G.r2[ii]; grb[g] = G.rbl0[ii];
+    gtouched[g] = S.touched[ii] != 0;
+    unsigned long long* tg = reinterpret_cast<unsigned long long*>(S.tab) + (long)ii * 8 * spd;
+    unsigned long long tf[PASSES], tb[PASSES];
+#pragma unroll
+    for (int j = 0; j < PASSES; ++j) {
+      const int fm = j * FPP + lane / LPF;
+      const int q = fam_q(fm), qo = q - 4;
+      const int rb = S.half - c;  // the same line seen from the opposite direction
+      tf[j] = tb[j] = LBMDEM_SLOT_EMPTY;
+      if (lane_has_line) {
+        tf[j] = tg[(q - 1) * spd + rel];
+        if (rb >= 0 && rb < spd) tb[j] = tg[(qo - 1) * spd + rb];
+      }
+    }
     bool local = false;
     if (i >= 0 && mask) {
       local = mask[i] != 0;      // strip decomposition: the grains the rasteriser saw (the others' geometry is stale)
       if (!local) gid[g] = -1;
     } else if (i >= 0) {
-      const real xc = G.xc[i], rbl0 = G.rbl0[i];
-      local = xc + rbl0 + 2.0 >= (real)L.gx0 && xc - rbl0 - 2.0 <= (real)(L.gx0 + L.nxl);
+      local = gxc[g] + grb[g] + 2.0 >= (real)L.gx0 && gxc[g] - grb[g] - 2.0 <= (real)(L.gx0 + L.nxl);
     }
-    unsigned long long* tg = reinterpret_cast<unsigned long long*>(S.tab) + (long)(i >= 0 ? i : 0) * 8 * spd;
 #pragma unroll
     for (int j = 0; j < PASSES; ++j) {
       const int fm = j * FPP + lane / LPF;
       const int q = fam_q(fm), qo = q - 4;
-      fw[g][j] = bw[g][j] = LBMDEM_SLOT_EMPTY;
+      const int rb = S.half - c;
+      fw[g][j] = local ? tf[j] : LBMDEM_SLOT_EMPTY;
+      bw[g][j] = local ? tb[j] : LBMDEM_SLOT_EMPTY;
       if (local && lane_has_line) {
-        const int kf = (q - 1) * spd + rel;
-        fw[g][j] = tg[kf];
-        tg[kf] = LBMDEM_SLOT_EMPTY;
-        const int rb = S.half - c;  // the same line seen from the opposite direction
-        if (rb >= 0 && rb < spd) {
-          const int kb = (qo - 1) * spd + rb;
-          bw[g][j] = tg[kb];
-          tg[kb] = LBMDEM_SLOT_EMPTY;
-        }
+        tg[(q - 1) * spd + rel] = LBMDEM_SLOT_EMPTY;
+        if (rb >= 0 && rb < spd) tg[(qo - 1) * spd + rb] = LBMDEM_SLOT_EMPTY;
       }
     }
   }
@@ -356,12 +369,19 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const real* __re
     n1[g] = n2[g] = n3[g] = 0;
     own[g] = false;
     if (i < 0) continue;
-    const real xc = G.xc[i], yc = G.yc[i], r2 = G.r2[i];
+    const real xc = gxc[g], yc = gyc[g], r2 = gr2[g];
     own[g] = grain_owned(L, xc);
-    const bool was_touched = S.touched[i] != 0;
+    const bool was_touched = gtouched[g];
     if (was_touched && lane == 0 && consume) S.touched[i] = 0;  // the rasteriser sets it again while it applies
     int xi, xf, yi, yf;
-    const bool todo = (consume ? own[g] : !own[g]) && grain_box(L, G, i, xi, xf, yi, yf);
+    {
+      const real rbl0 = grb[g];   // grain_box() on the values already here
+      xi = (int)(xc - rbl0); if (xi < 1) xi = 1;                 // int max(real->int, 1): main.c:1300
+      xf = (int)(xc + rbl0); if (xf > L.lx - 2) xf = L.lx - 2;   // main.c:1301
+      yi = (int)(yc - rbl0); if (yi < 1) yi = 1;
+      yf = (int)(yc + rbl0); if (yf > L.ly - 2) yf = L.ly - 2;
+    }
+    const bool todo = (consume ? own[g] : !own[g]) && xi <= xf && yi <= yf;
     if (!todo) continue;
     // overlapping discs: a lattice line may then carry several links of one direction -- not a table case
     if (was_touched) {
@@ -502,6 +522,9 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const real* __re
       }
       continue;
     }
+#if defined(LBMDEM_AB) && defined(FT_ABLATE)
+    if (FT_ABLATE >= 2) continue;
+#endif
     __builtin_amdgcn_wave_barrier();
     // per-word exclusive prefixes of the three addend counts
     {
@@ -518,15 +541,15 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const real* __re
       const int mine3 = (cd + cx) | ((cd + cy) << 10) | ((2 * cd + cx + cy) << 20);
       const int incl = wave_inclusive_scan(mine3);
       const int excl = incl - mine3;
-      int r1 = excl & 1023, r2_ = (excl >> 10) & 1023, r3 = (excl >> 20) & 1023;
+      int r1 = excl & 1023, r2_ = (excl >> 10) & 1023;
       const int tot = __builtin_amdgcn_readlane(incl, 63);
       for (int u = 0; u < wpl; ++u) {
         const int w = lane * wpl + u;
         if (w < nw64) {
           const unsigned long long v = bm[w];
-          pw[w] = r1; pw[nw64 + w] = r2_; pw[2 * nw64 + w] = r3;
+          pw[w] = r1; pw[nw64 + w] = r2_;
           const int d = __popcll(v & M_DIAG), x = __popcll(v & M_XDIR), y = __popcll(v & M_YDIR);
-          r1 += d + x; r2_ += d + y; r3 += 2 * d + x + y;
+          r1 += d + x; r2_ += d + y;
         }
       }
       n1[g] = tot & 1023; n2[g] = (tot >> 10) & 1023; n3[g] = (tot >> 20) & 1023;
@@ -543,7 +566,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const real* __re
       const int w = key >> 6;
       const unsigned long long below = bm[w] & ((1ull << (key & 63)) - 1ull);
       const int bd = __popcll(below & M_DIAG), bx = __popcll(below & M_XDIR), by = __popcll(below & M_YDIR);
-      const int r1 = pw[w] + bd + bx, r2_ = pw[nw64 + w] + bd + by, r3 = pw[2 * nw64 + w] + 2 * bd + bx + by;
+      const int r1 = pw[w] + bd + bx, r2_ = pw[nw64 + w] + bd + by, r3 = r1 + r2_;   // (2 d + x + y = (d + x) + (d + y))
       const real sum = __longlong_as_double((long long)slot);
       const real fnx = sum * exo, fny = sum * eyo;  // main.c:1315-1316
       const real wx = x - xc, wy = y - yc;
@@ -588,6 +611,9 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const real* __re
   }
   if (threadIdx.x < 8) sZero[threadIdx.x] = 0.0;
   __syncthreads();
+#if defined(LBMDEM_AB) && defined(FT_ABLATE)   /* timing experiment (wrong results): 1 = no replay, 2 = no ranking / addends either */
+  if (FT_ABLATE >= 1) return;
+#endif
   if (wave != 0) return;
   // ---- phase B, first wave only: lane 3g + a replays accumulator a of grain g of the workgroup (the serial part
   // is shared by FT_WAVES * GW grains)
@@ -619,6 +645,8 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const real* __re
     // (Before: load 8, wait, add 8 under `if (t < mine)` -- every block paid the full LDS round trip plus a mask round trip,
     // ~2.5 us for the ~300 addends of a torque; the kernel ran 84 us against 61 us with the cross-lane reduction.)
     longest = __builtin_amdgcn_readfirstlane(longest);
+    // (s_setprio(3) for the replaying wavefront: 73.5 against 73.8 us -- the replay costs the workgroup's LIFETIME, during which
+    // its 26 KB of lists keep the next workgroup out, not issue slots: LABBOOK round 5, note 4)
     auto block_at = [&](int t) { return reinterpret_cast<const real2*>(t < mine ? tl + t : sZero); };
     auto fetch = [&](real2 (&v)[4], int t) {
       const real2* p = block_at(t);
@@ -743,9 +771,12 @@ static void launch_forces_table_t(const real* f, const int* obst, const LatticeV
                                   int fast, const ObstFillJob& fill, hipStream_t st) {
   const int HB = S.hb, B = 2 * HB + 1;
   const int nw64 = (B * B * 8 + 63) / 64;
-  // addends per accumulator: one link per direction and lattice line meeting the disc (<= spd lines for the
-  // diagonal families, <= 2 hb + 1 for the axis families); fhf3 takes two addends per diagonal link
-  const int cap1 = (4 * S.spd + 2 * B + 7) & ~7, cap3 = (8 * S.spd + 4 * B + 7) & ~7;
+  // addends per accumulator: one link per direction and lattice line meeting the disc; fhf3 takes two addends per diagonal
+  // link. A disc of reduced radius R <= hb - 1 meets at most 2 ceil(R sqrt 2) + 1 = 2 half - 3 lines of a diagonal family and
+  // 2 hb - 1 of an axis family (the table itself has spd >= 2 half + 1 and 2 hb + 1 rows: 25 % more, which at 26 KB of lists
+  // per workgroup was a seventh workgroup per CU); a grain that exceeds the lists anyway is gathered (n1 = -1 below).
+  const int nd = 2 * S.half - 3, na = 2 * HB - 1;
+  const int cap1 = (4 * nd + 2 * na + 7) & ~7, cap3 = (8 * nd + 4 * na + 7) & ~7;
   const size_t lists_doubles = (size_t)FT_WAVES * GW * (2 * cap1 + cap3);
   const size_t lds = lists_doubles * 8 + (size_t)FT_WAVES * nw64 * 24 + (size_t)FT_WAVES * GW * 20;
   const int per_block = FT_WAVES * GW;
@@ -768,7 +799,8 @@ void launch_forces_table_pack(const real* f, const int* obst, const LatticeView&
                               real* const buf[2], hipStream_t st) {
   const int HB = S.hb, B = 2 * HB + 1;
   const int nw64 = (B * B * 8 + 63) / 64;
-  const int cap1 = (4 * S.spd + 2 * B + 7) & ~7, cap3 = (8 * S.spd + 4 * B + 7) & ~7;
+  const int nd = 2 * S.half - 3, na = 2 * HB - 1;   // as in launch_forces_table_t
+  const int cap1 = (4 * nd + 2 * na + 7) & ~7, cap3 = (8 * nd + 4 * na + 7) & ~7;
   const size_t lds = (size_t)FT_WAVES * (2 * cap1 + cap3) * 8 + (size_t)FT_WAVES * nw64 * 24 + (size_t)FT_WAVES * 20;
   const int blocks = (cap + FT_WAVES - 1) / FT_WAVES;   // the list lengths are only known on the device
   const PackSides P{{list[0], list[1]}, {list_count[0], list_count[1]}, {buf[0], buf[1]}};
@@ -785,23 +817,10 @@ void launch_forces_table_pack(const real* f, const int* obst, const LatticeView&
 void launch_forces_slots(const real* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
                          const ForceSlots& S, double scale12, double scale3, real* fhf, unsigned char* owner,
                          int fast, const ObstFillJob& fill, hipStream_t st) {
-#ifdef LBMDEM_AB
-  static const int gw = getenv("LBMDEM_FORCE_GW") ? atoi(getenv("LBMDEM_FORCE_GW")) : 1;
-#else
-  const int gw = 1;
-#endif
-  if (S.spd <= 32) {
-    switch (gw) {
-#ifdef LBMDEM_AB
-      case 2: launch_forces_table_t<2, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, fill, st); break;
-      case 3: launch_forces_table_t<3, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, fill, st); break;
-      case 5: launch_forces_table_t<5, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, fill, st); break;
-#endif
-      default: launch_forces_table_t<1, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, fill, st); break;
-    }
-  } else {
-    launch_forces_table_t<1, 4>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, fill, st);
-  }
+  // (several grains per wavefront sharing the serial replay were measured in round 2 -- 138-351 us against 92: the lists'
+  // LDS limits the occupancy -- and are no longer built)
+  if (S.spd <= 32) launch_forces_table_t<1, 2>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, fill, st);
+  else launch_forces_table_t<1, 4>(f, obst, L, G, S, scale12, scale3, fhf, owner, fast, fill, st);
 }
 
 void launch_forces_fast(const real* f, const int* obst, const LatticeView& L, const GrainFluidView& G,
