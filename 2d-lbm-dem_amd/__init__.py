@@ -132,6 +132,8 @@ def _open_library(LIB_PATH):
     L.lbmdem_dem_chain_paints.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
     L.lbmdem_set_obst_update.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_obst_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    L.lbmdem_set_change_mask.argtypes = [C.c_void_p, C.c_int]
+    L.lbmdem_change_mask_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
     L.lbmdem_measure_copy.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     L.lbmdem_dem_chain_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lbmdem_set_lid.argtypes = [C.c_void_p, C.c_double]
@@ -520,6 +522,17 @@ class LbmDem:
         """(rasterisations that updated the map in place, rasterisations that cleared and repainted it)"""
         a, b = C.c_long(0), C.c_long(0)
         _chk(self._L.lbmdem_obst_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def set_change_mask(self, mode=1):
+        """0: the fused kernel reads both obstacle maps everywhere; 1 (default): the previous map only in the rows the
+        rasterisation marked as changed; 2: as 1, every use verified against the two maps (change_mask_stats()[1] == 0)"""
+        _chk(self._L.lbmdem_set_change_mask(self._h, int(mode)))
+
+    def change_mask_stats(self):
+        """(fused launches that used the change bits, (row, window) pairs mode 2 found clear over differing maps)"""
+        a, b = C.c_long(0), C.c_long(0)
+        _chk(self._L.lbmdem_change_mask_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def measure_copy(self, nbytes=1200 * 1000 * 1000, reps=5):

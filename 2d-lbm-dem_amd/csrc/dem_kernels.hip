@@ -873,6 +873,24 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
     bool had = false;
     real pxc = 0., pyc = 0., still2 = 0.;
     if (there && inplace) { had = paint.was.mode[gi] != 0; pxc = paint.was.xc[gi]; pyc = paint.was.yc[gi]; still2 = paint.was.still2[gi]; }
+    // ... and the picture in the other map buffer (the previous fluid step's): where does this one differ from it?
+    const bool chg = inplace && paint.chg.bits != nullptr;
+    bool ohad = false;
+    real oxc = 0., oyc = 0., ostill2 = 0.;
+    if (there && chg) { ohad = paint.other.mode[gi] != 0; oxc = paint.other.xc[gi]; oyc = paint.other.yc[gi]; ostill2 = paint.other.still2[gi]; }
+    // bits of the rows x0..x1 in the windows that hold columns y0..y1 (window w = columns [w ww - off, w ww - off + 63])
+    auto flag_rows = [&](int x0, int x1, int y0, int y1, int lane_of, int lanes) {
+      const ObstChange& C = paint.chg;
+      int w0 = (y0 + C.off - 63 + C.ww - 1) / C.ww, w1 = (y1 + C.off) / C.ww;   // (y0 >= 0: the boxes are clamped to the lattice)
+      if (y0 + C.off - 63 < 0) w0 = 0;
+      if (w1 > paint.windows - 1) w1 = paint.windows - 1;
+      if (x0 < L.gx0) x0 = L.gx0;
+      if (x1 > L.gx0 + L.nxl - 1) x1 = L.gx0 + L.nxl - 1;
+      for (int x = x0 + lane_of; x <= x1; x += lanes) {
+        const int xl = x - L.gx0;
+        for (int w = w0; w <= w1; ++w) atomicOr(&C.bits[(long)w * C.words + (xl >> 5)], 1u << (xl & 31));
+      }
+    };
     if (there && hl == 0) {
       paint.xc[gi] = xc; paint.yc[gi] = yc; paint.r2[gi] = r2; paint.rbl0[gi] = rbl0;
       real* o = paint.pk + (long)gi * 8;
@@ -914,7 +932,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
     // of scan while half its lanes (the discs that have not moved enough to change a node) sat idle: 21 us; dealt out: half.
     // (the staging arrays of phase 1 are free now; typed views, the same in the float build)
     real* const recA = sF1;   // [slot][4] xc, yc, rl, rbl0 of a listed disc
-    real* const recP = sF2;   // [slot][2] the centre it was painted at
+    real* const recP = sF2;   // [slot][4] the centre it was painted at in this buffer, in the other buffer
     unsigned long long* const recG = reinterpret_cast<unsigned long long*>(sF3);   // [slot] smallest gap found, as the bits of a double
     long long* const recI = reinterpret_cast<long long*>(sFn);                      // [slot] gi | kind << 40 | had << 44
     static_assert(sizeof(real) * CH_ENTRIES >= 8 * DEM_TILE && CH_ENTRIES >= 4 * DEM_TILE, "LDS views of the rasterisation");
@@ -930,9 +948,34 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
       if (dbg && hl == 0)
         atomicAdd(reinterpret_cast<unsigned long long*>(dbg + (long)tiles * 16 + (still ? 0 : (ring ? 1 : (alone ? 2 : 3)))), 1ull);
 #endif
+      // Against the other buffer's picture: exact (its disc test beside the two others, in the ring scan) when this disc is
+      // alone now and has moved less than half a node from BOTH painted centres -- the pictures of two discs that keep 1.1
+      // nodes apart now then share no node in either map; a partner that fails this flags every row of its own boxes.
+      const real omoved2 = (xc - oxc) * (xc - oxc) + (yc - oyc) * (yc - oyc);
+      const DiscGeo gq = disc_geo(L, oxc, oyc, rl, rbl0, ohad);
+      const bool oexact = chg && alone && had && ohad && gn.any && gn.r2 <= gn.R2 && omoved2 < 0.25;
+      const bool ostill = oexact && omoved2 < ostill2;
+      if (chg && !oexact) {   // every row any of the three pictures of this disc reaches, and one around
+        int x0 = gn.any ? gn.xi : (1 << 30), x1 = gn.any ? gn.xf : -1, y0 = gn.any ? gn.yi : (1 << 30), y1 = gn.any ? gn.yf : -1;
+        if (go.any) { x0 = min(x0, go.xi); x1 = max(x1, go.xf); y0 = min(y0, go.yi); y1 = max(y1, go.yf); }
+        if (gq.any) { x0 = min(x0, gq.xi); x1 = max(x1, gq.xf); y0 = min(y0, gq.yi); y1 = max(y1, gq.yf); }
+        if (x1 >= x0) flag_rows(x0 - 1, x1 + 1, y0 > 0 ? y0 - 1 : 0, y1 + 1, hl, 4);
+      }
       if (still) {
         // nothing can have changed sides: map and record stay (the next comparison is again with the painted centre)
         if (hl == 0) { paint.now.xc[gi] = pxc; paint.now.yc[gi] = pyc; paint.now.still2[gi] = still2; paint.now.mode[gi] = 1; }
+        if (oexact && !ostill && hl == 0) {
+          // ... in THIS buffer; against the other one the ring is scanned for the bits alone (no node is written: the two
+          // tests of this buffer agree on every node)
+          const real w = (real)sqrt((double)omoved2) + (sizeof(real) == 4 ? (real)(1e-3 + 5e-7 * (fabs((double)xc) + fabs((double)yc))) : (real)1e-6);
+          const int xlo = (int)floor(xc - (rl + w)) - 1, xhi = (int)ceil(xc + (rl + w)) + 1;
+          const int slot = atomicAdd(scan_count, 1);
+          atomicMax(scan_rows, xhi - xlo + 1);
+          recA[slot * 4] = xc; recA[slot * 4 + 1] = yc; recA[slot * 4 + 2] = rl; recA[slot * 4 + 3] = rbl0;
+          recP[slot * 4] = pxc; recP[slot * 4 + 1] = pyc; recP[slot * 4 + 2] = oxc; recP[slot * 4 + 3] = oyc;
+          recG[slot] = (unsigned long long)__double_as_longlong((double)w);
+          recI[slot] = (long long)gi | (1ll << 40) | (1ll << 44) | ((long long)(ohad ? 1 : 0) << 45) | (1ll << 46);
+        }
       } else {
         if (hl == 0) { paint.now.xc[gi] = xc; paint.now.yc[gi] = yc; paint.now.still2[gi] = 0.; paint.now.mode[gi] = 1; }
         if (alone && (gn.any || go.any)) {
@@ -943,7 +986,9 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
             // lies in both discs and both boxes, one outside its outer circle in neither disc: the boxes cannot change
             // that.) Box: the union of the two boxes and a node around it (a first picture, or a disc whose box cuts into it).
             // w = |D| + what the rounding of the test's d2 can amount to, in nodes.
-            const real w = (real)sqrt((double)moved2) + (sizeof(real) == 4 ? (real)(1e-3 + 5e-7 * (fabs((double)xc) + fabs((double)yc))) : (real)1e-6);   // (float: coordinates of a few thousand carry 1e-4 ... 1e-3 themselves)
+            const bool ocmp = ring && oexact && !ostill;   // the other buffer's test rides in the same scan
+            const real mv2 = ocmp && omoved2 > moved2 ? omoved2 : moved2;
+            const real w = (real)sqrt((double)mv2) + (sizeof(real) == 4 ? (real)(1e-3 + 5e-7 * (fabs((double)xc) + fabs((double)yc))) : (real)1e-6);   // (float: coordinates of a few thousand carry 1e-4 ... 1e-3 themselves)
             int xlo, xhi;
             if (ring) { xlo = (int)floor(xc - (rl + w)) - 1; xhi = (int)ceil(xc + (rl + w)) + 1; }
             else {
@@ -953,9 +998,12 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
             const int slot = atomicAdd(scan_count, 1);
             atomicMax(scan_rows, xhi - xlo + 1);
             recA[slot * 4] = xc; recA[slot * 4 + 1] = yc; recA[slot * 4 + 2] = rl; recA[slot * 4 + 3] = rbl0;
-            recP[slot * 2] = pxc; recP[slot * 2 + 1] = pyc;
+            recP[slot * 4] = pxc; recP[slot * 4 + 1] = pyc; recP[slot * 4 + 2] = oxc; recP[slot * 4 + 3] = oyc;
             recG[slot] = (unsigned long long)__double_as_longlong(ring ? (double)w : 1e30);   // ring: its half-width; box: the smallest gap found
-            recI[slot] = (long long)gi | ((long long)(ring ? 1 : 2) << 40) | ((long long)(had ? 1 : 0) << 44);
+            // bit 45: the other buffer holds a picture of this disc, 46: compare with it (else the rows are flagged already,
+            // or -- a ring whose other picture has not moved -- need no bits), 47: bits where THIS buffer's node changes
+            recI[slot] = (long long)gi | ((long long)(ring ? 1 : 2) << 40) | ((long long)(had ? 1 : 0) << 44) |
+                         ((long long)(ohad ? 1 : 0) << 45) | ((long long)(ocmp ? 1 : 0) << 46);
           }
         } else if (!alone) {
           auto partner_geo = [&](int k, bool& ok) {
@@ -1014,12 +1062,20 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
         const long long bits = recI[slot];
         const int cgi = (int)(bits & 0xFFFFFFFFFFll), kind = (int)((bits >> 40) & 15);
         const bool chad = ((bits >> 44) & 1) != 0;
-        const DiscGeo gn = disc_geo(L, cx, cy, crl, crb, true), go = disc_geo(L, recP[slot * 2], recP[slot * 2 + 1], crl, crb, chad);
+        const DiscGeo gn = disc_geo(L, cx, cy, crl, crb, true), go = disc_geo(L, recP[slot * 4], recP[slot * 4 + 1], crl, crb, chad);
+        const bool ocmp = ((bits >> 46) & 1) != 0;
+        const DiscGeo gq = disc_geo(L, recP[slot * 4 + 2], recP[slot * 4 + 3], crl, crb, ((bits >> 45) & 1) != 0);
         const real rm2 = gn.r2 < gn.R2 ? gn.r2 : gn.R2, near2 = (crl + 1.) * (crl + 1.);
         real gap = 1e30;
         auto settle = [&](int x, int y) {   // the reference's own test at both centres (disc_has: box and d2 <= r2, main.c:1027)
           const bool bo = disc_has(go, x, y), bn = disc_has(gn, x, y);
           if (bn != bo) paint.obst[(long)(x - L.gx0) * L.sy + y] = bn ? cgi : -1;
+          if (ocmp && disc_has(gq, x, y) != bn) {   // the other map's owner of this node is not this picture's
+            const ObstChange& C = paint.chg;
+            const int xl = x - L.gx0, w0 = (y + C.off - 63 + C.ww - 1) / C.ww, w1 = (y + C.off) / C.ww;
+            for (int w = (y + C.off - 63 < 0 ? 0 : w0); w <= w1 && w < paint.windows; ++w)
+              atomicOr(&C.bits[(long)w * C.words + (xl >> 5)], 1u << (xl & 31));
+          }
           const real d2 = (x - cx) * (x - cx) + (y - cy) * (y - cy), gg = d2 > rm2 ? d2 - rm2 : rm2 - d2;
           if (d2 <= near2) gap = gg < gap ? gg : gap;   // (nodes farther out than r + 1 stay outside whatever happens within half a node)
         };

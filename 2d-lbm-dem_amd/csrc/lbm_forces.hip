@@ -681,9 +681,11 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const real* __re
 // The queued grains, gathered from obst and f: one wavefront per grain, a fixed grid strides over the queue.
 __global__ __launch_bounds__(64) void k_forces_gather_queue(const real* __restrict__ f, const int* __restrict__ obst,
                                                             LatticeView L, GrainFluidView G, ForceSlots S,
-                                                            double scale12, double scale3, real* __restrict__ fhf) {
+                                                            double scale12, double scale3, real* __restrict__ fhf,
+                                                            unsigned* __restrict__ clear, int nclear) {
   __shared__ ForceLds sh;
   const int lane = threadIdx.x;
+  for (int k = blockIdx.x * 64 + lane; k < nclear; k += gridDim.x * 64) clear[k] = 0u;   // (ObstFillJob::clear)
   const int count = *S.gathered;
   if (blockIdx.x == 0 && lane == 0) *S.gathered_next = 0;   // the next step's counter (nobody reads or adds to it now)
   if (lane == 0) sh.sT[FORCE_TERMS_CAP * 4] = 0.0;
@@ -791,7 +793,8 @@ static void launch_forces_table_t(const real* f, const int* obst, const LatticeV
                      f, obst, L, G, S, cap1, cap3, nw64, scale12, scale3, fhf, owner, fast ? (int)FT_FAST : (int)FT_CONSUME, S.local_list,
                      S.local_count, PackSides{}, S.mask, S.local_cap, fill, nfill);
   const int grid = L.n < 256 ? L.n : 256;
-  hipLaunchKernelGGL(k_forces_gather_queue, dim3(grid), dim3(64), 0, st, f, obst, L, G, S, scale12, scale3, fhf);
+  hipLaunchKernelGGL(k_forces_gather_queue, dim3(grid), dim3(64), 0, st, f, obst, L, G, S, scale12, scale3, fhf, fill.clear,
+                     fill.clear ? fill.nclear : 0);
 }
 
 void launch_forces_table_pack(const real* f, const int* obst, const LatticeView& L, const GrainFluidView& G,

@@ -153,12 +153,12 @@ struct MarchPlan {
   int first[5];   // first item of level l within the band's item list; first[nlev] = items per band
 };
 
-template <int LX, int MINW, int WW>
+template <int LX, int MINW, int WW, bool CHG = false>
 __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__ fin, real* __restrict__ fout,
                                                   const int* __restrict__ ob_old,
                                                   const int* __restrict__ ob_new, LatticeView L,
                                                   GrainFluidView G, ForceSlots S, int nstrips, int nwork,
-                                                  int xcd_remap, int seg_rows, int seg_stride, MarchPlan P) {
+                                                  int xcd_remap, int seg_rows, int seg_stride, MarchPlan P, ObstChange CH) {
   const int lane = threadIdx.x & 63;
   int blk = blockIdx.x;
   int w, strip, xs, rows_per_wave;
@@ -229,7 +229,45 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
   // unconditional (clamped address): every use is guarded by interior(xl), and grain_rec clamps the
   // id. (A `row_ok ? v : -1` select here makes the compiler sink the load into a branch followed by
   // s_waitcnt vmcnt(0), which drains the whole prefetch pipeline once per iteration.)
-  auto load_old = [&](int xl) { return ob_old[node_of(xl)]; };
+  // The previous map's ids. With an ObstChange (CHG: the launch of a whole single-domain step after a rasterisation in
+  // place) the wave knows the rows of its window in which the two maps differ -- a few per cent of them -- and takes the id
+  // from the current map, which it holds anyway, everywhere else: the second map's 4 bytes per node were 2.2 % of the
+  // kernel's traffic. The load stays in the instruction stream for every row (the in-order vmcnt bookkeeping of the
+  // prefetch pipeline must not depend on data; under a branch it cost more than it saved): a buffer load whose offset
+  // lies beyond the resource's records returns 0 and moves nothing. The rows a wave asks for are consecutive (xs - 1,
+  // xs, ...): their bits sit in a 64-bit shift register in scalar registers, lowest bit = the next row, ones shifted in
+  // (rows beyond the 64th are read from both maps).
+  unsigned long long cm = ~0ull;
+  // (the resource starts at the wave's first row: 32-bit offsets whatever the size of the map)
+  const int old_row0 = CHG ? __builtin_amdgcn_readfirstlane(xs - 1 < 0 ? 0 : xs - 1) : 0;
+  const long old_left = (long)(L.nxl - old_row0) * L.sy * 4;
+  const __amdgpu_buffer_rsrc_t old_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int*>(ob_old + (long)old_row0 * L.sy), 0, old_left < 0x7FFFFFF0L ? (int)old_left : 0x7FFFFFF0, 0x00020000);
+  const int old_col = (ycl - old_row0 * L.sy) * 4;
+  if (CHG) {
+    const int r0 = xs - 1, first = r0 < 0 ? 0 : r0;
+    const unsigned* wp = CH.bits + (long)strip * CH.words + (first >> 5);   // (a window's words are padded by four)
+    const unsigned w0 = __builtin_amdgcn_readfirstlane(wp[0]), w1 = __builtin_amdgcn_readfirstlane(wp[1]);
+    const unsigned w2 = __builtin_amdgcn_readfirstlane(wp[2]);
+    const int sh = __builtin_amdgcn_readfirstlane(first & 31);
+    cm = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
+    if (sh) cm = (cm >> sh) | ((unsigned long long)w2 << (64 - sh));
+    if (r0 < 0) cm <<= 1;   // row -1 is never used
+  }
+  auto load_old = [&](int xl, int same) {
+    if (!CHG) return ob_old[node_of(xl)];
+    const int keep = (cm & 1ull) ? 0 : -1;   // scalar: -1 = the maps agree in this row
+    cm = (cm >> 1) | (1ull << 63);
+    const int xcl = xl < 0 ? 0 : (xl >= L.nxl ? L.nxl - 1 : xl);
+    // (offset bit 31: beyond the resource's < 2^31 bytes, and far from wrapping round in the range check)
+    const int v = __builtin_amdgcn_raw_buffer_load_b32(old_rs, (xcl * L.sy * 4 + old_col) | (keep & (int)0x80000000), 0, 0);
+    return v | (same & keep);
+  };
+#if defined(LBMDEM_AB) && defined(MARCH_NO_OLD)   /* timing experiment (wrong where the maps differ): the second map is not read */
+#define MARCH_OLD(xl, same) (same)
+#else
+#define MARCH_OLD(xl, same) load_old(xl, same)
+#endif
   // off-lattice positions load a clamped neighbour's values; they are never used (pull_one tests the
   // bounds of the source node before touching its populations)
   auto load_raw = [&](int xl, real (&raw)[9]) {
@@ -261,10 +299,10 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
   Ids3 iD = load_ids(ob_new, L, xs + 1, y);  // row x+1
   Ids3 iE = load_ids(ob_new, L, xs + 2, y);  // row x+2
   {
-    int oo = load_old(xs - 1);
+    int oo = MARCH_OLD(xs - 1, iB.c);
     load_raw(xs - 1, Fm);
     make_fstar(xs - 1, Fm, oo, grain_rec(oo), iB.c);
-    oo = load_old(xs);
+    oo = MARCH_OLD(xs, iC.c);
     load_raw(xs, F0);
     make_fstar(xs, F0, oo, grain_rec(oo), iC.c);
   }
@@ -273,10 +311,10 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
   ring.put(xs, lane, grain_rec(iC.c));
   ring.put(xs + 1, lane, grain_rec(iD.c));
   ring.put(xs + 2, lane, grain_rec(iE.c));
-  int oo1 = load_old(xs + 1);   // previous-map ids of rows x+1, x+2, x+3
-  int oo2 = load_old(xs + 2);
-  int oo3 = load_old(xs + 3);
   Ids3 inext = load_ids(ob_new, L, xs + 3, y);
+  int oo1 = MARCH_OLD(xs + 1, iD.c);   // previous-map ids of rows x+1, x+2, x+3
+  int oo2 = MARCH_OLD(xs + 2, iE.c);
+  int oo3 = MARCH_OLD(xs + 3, inext.c);
   GP gre = grain_rec(oo1);      // reinit record for row x+1
   GP rec_next = grain_rec(inext.c);  // owner record of row x+3, goes into the ring next iteration
   load_raw(xs + 1, bufA);
@@ -303,7 +341,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
     oo2 = oo3;
     gre = grain_rec(oo1);                      // reinit record of row x+2
     inext = load_ids(ob_new, L, x + 4, y);
-    oo3 = load_old(x + 4);
+    oo3 = MARCH_OLD(x + 4, inext.c);
     __builtin_amdgcn_sched_barrier(0);
     // ---- (2) the big loads: populations of row x+3
     // (rows beyond xe are never consumed: the last two prefetches of a segment re-request row xe, which the wave loaded
@@ -574,9 +612,10 @@ constexpr int MARCH_WW = 60;
 template <int LX, int MINW, int WW = MARCH_WW>
 static void launch_march(const real* fin, real* fout, const int* obst_old, const int* obst_new,
                          const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, int remap,
-                         hipStream_t st) {
+                         hipStream_t st, ObstChange chg = ObstChange{nullptr, 0, 0, 0}) {
   const int rows = L.xo1 - L.xo0;
   const int nstrips = (L.ly + WW - 1) / WW;
+  if (chg.ww != WW || chg.off != (64 - WW) / 2) chg = ObstChange{nullptr, 0, 0, 0};   // (bits cut for other windows)
   int seg_rows = LX;
   if (LX == 0) {
     // run-time segment length for SHORT row ranges (a strip of a multi-GPU decomposition, the rows next to a cut):
@@ -612,8 +651,13 @@ static void launch_march(const real* fin, real* fout, const int* obst_old, const
   static const int env_lds = getenv("LBMDEM_MARCH_DYNLDS") ? atoi(getenv("LBMDEM_MARCH_DYNLDS")) : 0;
   dyn_lds = (unsigned)env_lds;
 #endif
+  if (LX == 0 && chg.bits != nullptr) {
+    hipLaunchKernelGGL((k_cs_march<LX, MINW, WW, LX == 0>), dim3(grid), dim3(256), dyn_lds, st, fin, fout, obst_old, obst_new, L, G,
+                       S, nstrips, nwork, remap, seg_rows, seg_rows, P, chg);
+    return;
+  }
   hipLaunchKernelGGL((k_cs_march<LX, MINW, WW>), dim3(grid), dim3(256), dyn_lds, st, fin, fout, obst_old, obst_new, L, G,
-                     S, nstrips, nwork, remap, seg_rows, seg_rows, P);
+                     S, nstrips, nwork, remap, seg_rows, seg_rows, P, chg);
 }
 
 // Two row ranges of equal width w <= 32 (the rows next to the two cuts of a strip) in ONE launch: two segments of w rows,
@@ -635,7 +679,7 @@ static void launch_march_two_ranges(const real* fin, real* fout, const int* obst
   }
 #endif
   hipLaunchKernelGGL((k_cs_march<0, 2, WW>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, Ls, G, S, nstrips,
-                     nwork, 0, w, hi0 - lo0, MarchPlan{});
+                     nwork, 0, w, hi0 - lo0, MarchPlan{}, ObstChange{nullptr, 0, 0, 0});
 }
 
 // The marching kernel assumes reductionR < 1 (always true in the reference); other configurations run the
@@ -663,8 +707,11 @@ void collide_stream_work_order(const LatticeView& L, int* info) {
   info[11] = 8 * P.first[P.nlev];
 }
 
+void collide_stream_windows(int* ww, int* off) { *ww = MARCH_WW; *off = (64 - MARCH_WW) / 2; }
+
 void launch_collide_stream(const real* fin, real* fout, const int* obst_old, const int* obst_new,
-                           const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, hipStream_t st) {
+                           const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, hipStream_t st,
+                           const ObstChange& chg) {
 #ifdef LBMDEM_AB
   if (getenv("LBMDEM_CS_VARIANT")) {   // experiments with other kernel shapes; without the variable: the product's choice
     int v = cs_variant();
@@ -691,7 +738,7 @@ void launch_collide_stream(const real* fin, real* fout, const int* obst_old, con
       return;
     }
 #endif
-    launch_march<0, 2>(fin, fout, obst_old, obst_new, L, G, S, /*xcd remap*/ 1, st);
+    launch_march<0, 2>(fin, fout, obst_old, obst_new, L, G, S, /*xcd remap*/ 1, st, chg);
   }
   else launch_cs<4, 64>(fin, fout, obst_old, obst_new, L, G, 0, st);
 }

@@ -316,6 +316,25 @@ __global__ void k_obst_update(int* __restrict__ obst, LatticeView L, int n, cons
   }
 }
 
+// test aid: values that differ between two lattices (the fused kernel run with and without the change bits)
+__global__ void k_count_differences(const real* __restrict__ a, const real* __restrict__ b, long n, int* __restrict__ bad) {
+  int mine = 0;
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x)
+    mine += __double_as_longlong((double)a[k]) != __double_as_longlong((double)b[k]) ? 1 : 0;
+  if (mine) atomicAdd(bad, mine);
+}
+
+// test aid (lbmdem_set_change_mask(h, 2)): one wavefront per (row, window) -- does a clear bit hide a difference?
+__global__ __launch_bounds__(64) void k_change_verify(const int* __restrict__ ob_old, const int* __restrict__ ob_new,
+                                                      LatticeView L, ObstChange C, int windows, int* __restrict__ bad) {
+  const int xl = blockIdx.x / windows, w = blockIdx.x - xl * windows;
+  const int y = w * C.ww - C.off + (int)threadIdx.x;
+  const bool set = (C.bits[(long)w * C.words + (xl >> 5)] >> (xl & 31)) & 1u;
+  bool differ = false;
+  if (y >= 0 && y < L.ly) differ = ob_old[(long)xl * L.sy + y] != ob_new[(long)xl * L.sy + y];
+  if (__any(differ) && !set && threadIdx.x == 0) atomicAdd(bad, 1);
+}
+
 }  // namespace
 
 void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st) { launch_obst_fill_rows(obst, L, 0, L.nxl, st); }
@@ -352,4 +371,13 @@ void launch_obst_update(int* obst, const LatticeView& L, int n, const real* x1, 
   const unsigned pgrid = (unsigned)(((threads + 255) / 256 + 7) / 8 * 8);
   hipLaunchKernelGGL(k_obst_update<PAINT_LANES>, dim3(pgrid), dim3(256), 0, st, obst, L, n, x1, x2, r, rLB, v1, v2, v3, xc, yc, r2,
                      rbl0, pk, touched, mincov, epoch, voff, vnbr, was, now, xreb, yreb, moved_limit, moved_flag, list_generation);
+}
+
+void launch_change_verify(const int* ob_old, const int* ob_new, const LatticeView& L, const ObstChange& chg, int windows, int* bad,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(k_change_verify, dim3((unsigned)(L.nxl * windows)), dim3(64), 0, st, ob_old, ob_new, L, chg, windows, bad);
+}
+
+void launch_count_differences(const real* a, const real* b, long n, int* bad, hipStream_t st) {
+  hipLaunchKernelGGL(k_count_differences, dim3(2048), dim3(256), 0, st, a, b, n, bad);
 }

@@ -161,6 +161,7 @@ static int paint_into(lbmdem_handle* h, int* obst) {
   drop_chain_paint(h);
   RC_TRY(next_paint_epoch(h));
   const int b = obst == h->obst[1] ? 1 : 0;
+  h->chg_state[b] = 0;   // (this rasterisation keeps no account of what it changes)
   // the pair list tells which discs cannot share a node with another one (plain stores instead of atomics). Not with
   // distributed grains: a rank's list is only right for the grains it integrates
   const bool list_ok = h->verlet_ok && h->verlet_tracks_positions && !h->dist && !*h->ovf_host &&
@@ -397,6 +398,17 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
   CREATE_TRY(hipHostMalloc((void**)&h->moved_host, sizeof(int), hipHostMallocDefault));
   *h->moved_host = -1;
   CREATE_TRY(hipHostGetDevicePointer((void**)&h->moved_dev, (void*)h->moved_host, 0));
+  if (cfg->x_begin == 0 && cfg->x_end == cfg->lx) {   // (a strip's maps are painted by the stand-alone rasteriser)
+    collide_stream_windows(&h->chg_ww, &h->chg_off);
+    h->chg_windows = (cfg->ly + h->chg_ww - 1) / h->chg_ww;
+    h->chg_words = (L.nxl + 31) / 32 + 4;   // four words of padding: a wave reads 128 rows' worth from its first row on
+    for (int b = 0; b < 2; ++b) {
+      CREATE_TRY(hipMalloc((void**)&h->chg[b], sizeof(unsigned) * (size_t)h->chg_windows * h->chg_words));
+      CREATE_TRY(hipMemset(h->chg[b], 0, sizeof(unsigned) * (size_t)h->chg_windows * h->chg_words));
+    }
+    CREATE_TRY(hipMalloc((void**)&h->chg_bad, 2 * sizeof(int)));
+    CREATE_TRY(hipMemset(h->chg_bad, 0, 2 * sizeof(int)));
+  }
   CREATE_TRY(hipHostMalloc((void**)&h->ferr_host, sizeof(int), hipHostMallocDefault));
   *h->ferr_host = 0;
   CREATE_TRY(hipHostGetDevicePointer((void**)&h->ferr_mirror, (void*)h->ferr_host, 0));
@@ -443,6 +455,9 @@ int lbmdem_destroy(lbmdem_handle* h) {
   if (h->ovf_host) (void)hipHostFree((void*)h->ovf_host);
   if (h->ferr_host) (void)hipHostFree((void*)h->ferr_host);
   if (h->moved_host) (void)hipHostFree((void*)h->moved_host);
+  for (int b = 0; b < 2; ++b) if (h->chg[b]) (void)hipFree(h->chg[b]);
+  if (h->chg_bad) (void)hipFree(h->chg_bad);
+  if (h->chg_fcheck) (void)hipFree(h->chg_fcheck);
   diag_extra_free(h->dx);
   carry_track_free(h->ct);
   for (hipEvent_t e : h->ev0) (void)hipEventDestroy(e);
@@ -505,7 +520,24 @@ int lbmdem_collide_stream(lbmdem_handle* h) try {
   hipEvent_t e1 = nullptr;
   int rc = prof_begin(h, &e1);
   if (rc != LBMDEM_OK) return rc;
-  launch_collide_stream(h->f[h->fcur], h->f[1 - h->fcur], ob_old, ob_new, h->L, gview(h), slots_for_launch(h), h->stream);
+  ObstChange chg{nullptr, 0, 0, 0};
+  {
+    const int bn = 1 - h->ocur;   // the new map's buffer
+    if (h->obst_pending && h->chg_on && h->chg[bn] && h->chg_state[bn] == 2) {
+      chg = ObstChange{h->chg[bn], h->chg_words, h->chg_ww, h->chg_off};
+      h->chg_used++;
+      if (h->chg_verify) launch_change_verify(ob_old, ob_new, h->L, chg, h->chg_windows, h->chg_bad, h->stream);
+    }
+  }
+  const ForceSlots S_launch = slots_for_launch(h);
+  launch_collide_stream(h->f[h->fcur], h->f[1 - h->fcur], ob_old, ob_new, h->L, gview(h), S_launch, h->stream, chg);
+  if (chg.bits && h->chg_verify) {   // the same launch with both maps read everywhere: the same populations (and the same link sums again)
+    const size_t fbytes = sizeof(real) * 9 * (size_t)h->L.plane;
+    if (!h->chg_fcheck) HIP_TRY(hipMalloc((void**)&h->chg_fcheck, fbytes));
+    HIP_TRY(hipMemcpyAsync(h->chg_fcheck, h->f[1 - h->fcur], fbytes, hipMemcpyDeviceToDevice, h->stream));   // (rows the launch does not write)
+    launch_collide_stream(h->f[h->fcur], h->chg_fcheck, ob_old, ob_new, h->L, gview(h), S_launch, h->stream);
+    launch_count_differences(h->f[1 - h->fcur], h->chg_fcheck, 9 * (long)h->L.plane, h->chg_bad + 1, h->stream);
+  }
   if (e1) HIP_TRY(hipEventRecord(e1, h->stream));
   h->slots_valid = h->fs.tab != nullptr;
   HIP_TRY(hipGetLastError());
@@ -623,6 +655,15 @@ int lbmdem_forces_fluid(lbmdem_handle* h) {
       fill.map = h->obst[1 - h->ocur];
       fill.row1 = h->L.nxl;
       h->obst_reset_rows = h->L.nxl;
+    }
+    {
+      // the change bits of the map that is painted next (ObstChange) are cleared beside the gather queue
+      const int b = 1 - h->ocur;
+      if (h->chg[b] && h->chg_on && !h->dist && !h->cs_interior_pending && h->chg_state[b] != 1) {
+        fill.clear = h->chg[b];
+        fill.nclear = h->chg_windows * h->chg_words;
+        h->chg_state[b] = 1;
+      }
     }
     launch_forces_slots(h->f[h->fcur], ob, h->L, gview(h), h->fs, h->fscale12, h->fscale3, h->fhf, h->owner,
                         h->force_mode != 0, fill, h->stream);
@@ -867,6 +908,14 @@ int lbmdem_dem_chain(lbmdem_handle* h, long k, int fluid) {
                          inplace ? h->snap[b][h->snap_cur[b]] : ObstSnap{nullptr, nullptr, nullptr, nullptr},
                          h->snap[b][1 - h->snap_cur[b]], h->r, h->V.xreb, h->V.yreb, (real)(0.5 * h->cfg.phys.distVerlet),
                          h->moved_dev, h->list_generation};
+      // ... and, in place, against the picture in the other buffer: the rows in which the two maps of the coming fluid step
+      // differ (ObstChange; the bits were cleared beside the last force kernels and nobody has painted this buffer since)
+      if (inplace && h->chg[b] && h->chg_on && h->chg_state[b] == 1 && h->snap_ok[1 - b]) {
+        paint.chg = ObstChange{h->chg[b], h->chg_words, h->chg_ww, h->chg_off};
+        paint.other = h->snap[1 - b][h->snap_cur[1 - b]];
+        paint.windows = h->chg_windows;
+        h->chg_state[b] = 2;
+      } else h->chg_state[b] = 0;
       h->snap_cur[b] = 1 - h->snap_cur[b];
       h->snap_ok[b] = true;
       if (inplace) h->obst_updates++; else h->obst_repaints++;
@@ -899,6 +948,29 @@ int lbmdem_dem_chain(lbmdem_handle* h, long k, int fluid) {
 int lbmdem_set_obst_update(lbmdem_handle* h, int on) {
   if (!h) return fail(LBMDEM_EINVAL, "null handle");
   h->obst_update = on != 0;
+  return LBMDEM_OK;
+}
+
+int lbmdem_set_change_mask(lbmdem_handle* h, int mode) {
+  if (!h) return fail(LBMDEM_EINVAL, "null handle");
+  if (mode < 0 || mode > 2) return fail(LBMDEM_EINVAL, "lbmdem_set_change_mask: mode 0 (off), 1 (on) or 2 (on, every use verified)");
+  h->chg_on = mode != 0;
+  h->chg_verify = mode == 2;
+  if (!h->chg_on) h->chg_state[0] = h->chg_state[1] = 0;
+  return LBMDEM_OK;
+}
+
+int lbmdem_change_mask_stats(lbmdem_handle* h, long* used, long* hidden) {
+  CHECK_H(h);
+  if (used) *used = h->chg_used;
+  if (hidden) {
+    int bad[2] = {0, 0};
+    if (h->chg_bad) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      HIP_TRY(hipMemcpy(bad, h->chg_bad, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    *hidden = (long)bad[0] + ((long)bad[1] << 32);
+  }
   return LBMDEM_OK;
 }
 

@@ -159,6 +159,7 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
   fill(h->V.wallflags, n);
   fill(h->obst[0], sizeof(int) * (size_t)h->L.plane);
   h->ocur = 0; h->obst_pending = false;
+  h->chg_state[0] = h->chg_state[1] = 0;
   h->snap_ok[0] = h->snap_ok[1] = false;   // (the loaded map is not the picture lbmdem_create has just painted)
   for (int q = 0; q < 9 && ok; ++q) fill(h->f[0] + (size_t)q * h->L.plane, sizeof(double) * (size_t)h->L.plane);
   h->fcur = 0;

@@ -58,6 +58,18 @@ struct lbmdem_handle {
   int list_generation = 0;            // rebuilds so far
   volatile int* moved_host = nullptr; // pinned: the generation of the list in which k_obst_update found a grain too far from where the list found it
   int* moved_dev = nullptr;
+  // where the two maps of a fluid step differ (ObstChange, lbmdem_internal.h): chg[b] belongs to obst[b] as the NEW map.
+  // chg_state[b]: 0 = says nothing, 1 = all clear and nobody has painted obst[b] since, 2 = written by the rasterisation
+  // that painted obst[b] in place (k_dem_chain's tail) against the picture in obst[1 - b]
+  unsigned* chg[2] = {nullptr, nullptr};
+  int chg_state[2] = {0, 0};
+  int chg_words = 0, chg_windows = 0, chg_ww = 0, chg_off = 0;
+  bool chg_on = true;                 // lbmdem_set_change_mask
+  int chg_verify = 0;                 // ... 2: every use is checked against the two maps first (tests)
+  long chg_used = 0;                  // fused launches that read one map where the bits allowed it
+  int* chg_bad = nullptr;             // device counters of the verification: [0] clear bits over rows that differ, [1] populations
+                                      // that come out differently with and without the bits
+  real* chg_fcheck = nullptr;         // (mode 2) a second output lattice
   // collide_stream in two parts (lbmdem_collide_stream_part): after EDGES the interior rows of f[fcur] are
   // still missing; the operands of the launch are kept for INTERIOR
   bool cs_interior_pending = false;

@@ -147,6 +147,15 @@ void launch_obst_fill(int* obst, const LatticeView& L, hipStream_t st);
 // what the in-place update of the map (k_obst_update) compares the new centres with. Null pointers: not recorded.
 // `still2`: while the centre stays within sqrt(still2) of (xc, yc) no node of the disc changes sides (0: not known).
 struct ObstSnap { real* xc; real* yc; real* still2; unsigned char* mode; };
+// Where the two obstacle maps of a fluid step differ (reinit_obst_density needs the previous owner only there): one bit per
+// lattice row and 64-column window of the fused kernel -- bits[window * words + (row >> 5)] bit (row & 31), window w = columns
+// [w * ww - off, w * ww - off + 63] -- set by the rasterisation at the end of a run of sub-steps (ChainPaint). A window row
+// whose bit is clear is read from ONE map. bits == nullptr: not known, both maps are read everywhere.
+struct ObstChange { unsigned* bits; int words; int ww; int off; };
+void collide_stream_windows(int* ww, int* off);   // the fused kernel's window geometry (lbm_fused.hip)
+// test aid: counts the (row, window) pairs whose bit is clear although the two maps differ there (lbm_obst.hip)
+void launch_count_differences(const real* a, const real* b, long n, int* bad, hipStream_t st);
+void launch_change_verify(const int* ob_old, const int* ob_new, const LatticeView& L, const ObstChange& chg, int windows, int* bad, hipStream_t st);
 void launch_obst_paint(int* obst, const LatticeView& L, int n, const real* x1, const real* x2, const real* r,
                        const real* rLB, const real* v1, const real* v2, const real* v3, real* xc,
                        real* yc, real* r2, real* rbl0, real* pk, unsigned char* touched,
@@ -188,7 +197,8 @@ void launch_obst_update(int* obst, const LatticeView& L, int n, const real* x1, 
                         const int* vnbr, const ObstSnap& was, const ObstSnap& now, const real* xreb, const real* yreb,
                         real moved_limit, int* moved_flag, int list_generation, hipStream_t st);
 void launch_collide_stream(const real* fin, real* fout, const int* obst_old, const int* obst_new,
-                           const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, hipStream_t st);
+                           const LatticeView& L, const GrainFluidView& G, const ForceSlots& S, hipStream_t st,
+                           const ObstChange& chg = ObstChange{nullptr, 0, 0, 0});
 // the two edge-row ranges [lo0, lo1) and [hi0, hi1) of a strip (either may be empty): one launch when they are equally
 // wide (two segments), else one launch_collide_stream each
 void launch_collide_stream_edges(const real* fin, real* fout, const int* obst_old, const int* obst_new,
@@ -356,7 +366,8 @@ void launch_tile_halo(const VerletDevice& V, int n, hipStream_t st);   // halo_i
 // A slice of the obstacle map that the next rasterisation starts from (obst = -1 / wall codes, main.c:997-999), reset by
 // extra workgroups of a DEM sub-step launch: the sub-step kernel is a latency chain that leaves the GPU idle, the reset is
 // 67 MB of stores per fluid step -- in npDEM slices they disappear under the sub-steps. map == nullptr: nothing to do.
-struct ObstFillJob { int* map; LatticeView L; int row0, row1; };
+// (`clear`: words to zero beside the force kernels -- the change bits of the map that is painted next, lbmdem_forces_fluid)
+struct ObstFillJob { int* map; LatticeView L; int row0, row1; unsigned* clear; int nclear; };
 void launch_dem_substep(const Kin& in, const Kin& out, const real* r, const real* m,
                         const real* It, const real* fhf, const VerletDevice& V, real* pout,
                         const DemParams& P, int film, real* diag, const DiagExtra* X, const unsigned char* active,
@@ -397,6 +408,12 @@ struct ChainPaint {
   real moved_limit;
   int* moved_flag;
   int list_generation;
+  // chg.bits != nullptr (in place only): the (row, window) bits of the nodes whose owner differs between this picture and the
+  // one in the OTHER map buffer -- the previous fluid step's --, which `other` describes (the fused kernel then reads the
+  // previous owner only there). All clear on entry.
+  ObstChange chg;
+  ObstSnap other;
+  int windows;
 };
 int dem_chain_alloc(DemChain& C, int n);
 void dem_chain_free(DemChain& C);

@@ -300,6 +300,9 @@ def main():
                          "128); 0 = one launch per sub-step (A/B)")
     ap.add_argument("--obst-update", type=int, default=None,
                     help="1 = the obstacle map is updated in place (the library's default), 0 = cleared and repainted every step (A/B)")
+    ap.add_argument("--change-mask", type=int, default=None,
+                    help="1 = the fused kernel reads the previous obstacle map only in the rows the rasterisation marked as "
+                         "changed (the library's default), 0 = both maps everywhere (A/B)")
     ap.add_argument("--strips", action="store_true",
                     help="use the strip-decomposition driver (torch.distributed) even with one rank")
     args = ap.parse_args()
@@ -339,6 +342,8 @@ def main():
             sim.set_dem_chain(args.dem_chain)
         if args.obst_update is not None:
             sim.set_obst_update(bool(args.obst_update))
+        if args.change_mask is not None:
+            sim.set_change_mask(args.change_mask)
         npdem = sim.cfg.npDEM
 
         def run_steps(k):
@@ -473,6 +478,8 @@ def main():
                 s2.set_dem_chain(args.dem_chain)
             if args.obst_update is not None:
                 s2.set_obst_update(bool(args.obst_update))
+            if args.change_mask is not None:
+                s2.set_change_mask(args.change_mask)
             return s2
         nsub = 100 * npdem
         leg = fresh()
@@ -542,6 +549,7 @@ def main():
                        "force_kernel": "parity" if args.force_mode == 0 else "fast",
                        "dem_chain": dict(zip(("launches", "substeps", "tile_slots", "resident"), chain_stats)),
                        "obst_map": dict(zip(("updated_in_place", "cleared_and_repainted"), sim.obst_stats())),
+                       "fused_launches_reading_one_map": (sim.change_mask_stats()[0] if world == 1 and not args.strips else 0),
                        "settle_steps": args.settle,   # untimed steps of this run before the warm-up (GPU clocks; see --settle)
                        "driver": None if runner is None else ("C (lbmdem_comm_run, RCCL send/recv inside the library)" if
                                                                 isinstance(runner, strips.CCommRunner) else "torch.distributed (strips.py)"),

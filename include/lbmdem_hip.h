@@ -165,6 +165,15 @@ int lbmdem_set_force_mode(lbmdem_handle* h, int mode);
  * one at rest it is (16 us). lbmdem_obst_stats: how often each ran. */
 int lbmdem_set_obst_update(lbmdem_handle* h, int on);
 int lbmdem_obst_stats(lbmdem_handle* h, long* updates, long* repaints);
+/* reinit_obst_density (main.c:966-986) needs the PREVIOUS owner of a node, i.e. the map of the step before, at the few
+ * thousand nodes that changed hands. mode 1 (default): a rasterisation in place by the end of a run of sub-steps also
+ * leaves one bit per lattice row and 64-column window of the fused kernel -- "the two maps differ here" -- and the fused
+ * kernel of a whole single-domain step reads the second map only in those rows (4 of its 152 bytes per node otherwise).
+ * 0: both maps are read everywhere. 2: as 1, and every use is checked against the two maps first (tests).
+ * lbmdem_change_mask_stats: fused launches that used the bits; (row, window) pairs found clear over differing maps by
+ * mode 2 (must be 0). */
+int lbmdem_set_change_mask(lbmdem_handle* h, int mode);
+int lbmdem_change_mask_stats(lbmdem_handle* h, long* used, long* hidden);
 
 int lbmdem_set_dem_chain(lbmdem_handle* h, int max_substeps);
 /* what that path has done so far: launches, sub-steps they covered, the workgroups ("tile slots": 64 grains each) one
