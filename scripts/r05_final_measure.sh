@@ -8,7 +8,7 @@ python bench.py --steps 20 --warmup 5 > $O/bench_driver_form.json 2>/dev/null
 # what this round's changes are worth on this very GPU, interleaved: runs of sub-steps / one launch per sub-step; map updated in
 # place by the runs / cleared and repainted / runs without the rasterisation
 for rep in 1 2; do
-  for fl in "" "--dem-chain 0 --obst-update 0" "--obst-update 0" "--dem-chain -1"; do
+  for fl in "" "--dem-chain 0 --obst-update 0" "--obst-update 0" "--dem-chain -1" "--change-mask 0"; do
     python bench.py --steps 100 --warmup 10 --no-cpu-baseline $fl 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(json.dumps({'flags': '$fl', 'ms_per_step': d['ms_per_step'], 'unsettled': d['ms_per_step_unsettled'], 'dem_only_steps_per_s': d['dem_only_steps_per_s'], 'fused_ms': d['collide_stream_kernel_ms'], 'lbm_step_only_ms': d['lbm_step_only_ms'], 'hbm_copy_gbs': d['hbm_copy_gbs'], 'dem_chain': d['config']['dem_chain'], 'obst_map': d['config']['obst_map']}))" >> $O/ab_round5_changes.jsonl
   done
