@@ -31,6 +31,7 @@
  * through a file in a private temporary directory. Rank 0 prints and writes the VTK frames and DEM tables (merged over the ranks); checkpoints are single-GPU. */
 static int g_rank = 0, g_world = 1, g_use_comm = 0, g_dry = 0;
 static char g_iddir[256] = "";
+static double g_comm_timeout = 180.;   /* seconds the ranks' transport may take to come up (--comm-timeout, LBMDEM_COMM_TIMEOUT) */
 static int g_devices[64], g_ndevices = 0;   /* --devices */
 
 static int share_id(unsigned char* id) {
@@ -98,10 +99,12 @@ static int check_decomposition(int argc, char** argv, int gpus) {
 
 int main(int argc, char** argv) {
   int gpus = 1;
+  if (getenv("LBMDEM_COMM_TIMEOUT")) g_comm_timeout = atof(getenv("LBMDEM_COMM_TIMEOUT"));
   for (int a = 1; a < argc; ++a) {
     if (!strcmp(argv[a], "--gpus") && a + 1 < argc) gpus = atoi(argv[a + 1]);
     if (!strcmp(argv[a], "--comm")) g_use_comm = 1;   /* the RCCL path with a single rank */
     if (!strcmp(argv[a], "--dry")) g_dry = 1;
+    if (!strcmp(argv[a], "--comm-timeout") && a + 1 < argc) g_comm_timeout = atof(argv[a + 1]);
     if (!strcmp(argv[a], "--devices") && a + 1 < argc) {
       for (const char* p = argv[a + 1]; *p && g_ndevices < 64;) {
         char* end = NULL;
@@ -133,6 +136,47 @@ int main(int argc, char** argv) {
   }
   /* the first rank that fails takes the others with it: its peers would otherwise block for ever inside an RCCL call */
   int bad = 0, left = gpus;
+  /* ... and so does a transport that never comes up (a rank stuck in communicator creation or in its first exchange
+   * with a neighbour cannot report anything): every rank leaves a file once lbmdem_comm_selftest has passed; ranks that
+   * have not all done so after --comm-timeout seconds (default 180; LBMDEM_COMM_TIMEOUT) are killed with a message
+   * instead of hanging the job. bench.py guards its C driver the same way (a watchdogged trial). */
+  {
+    const double limit = g_comm_timeout;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    int up = 0;
+    while (left > 0 && !bad && !up && limit > 0) {
+      int st = 0;
+      pid_t p = waitpid(-1, &st, WNOHANG);
+      if (p > 0) {
+        --left;
+        for (int r = 0; r < gpus; ++r) if (pids[r] == p) pids[r] = 0;
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+          for (int r = 0; r < gpus; ++r) if (pids[r] > 0) kill(pids[r], SIGKILL);
+          bad = 1;
+        }
+        continue;
+      }
+      up = 1;
+      for (int r = 0; r < gpus && up; ++r) {
+        char f[320];
+        snprintf(f, sizeof f, "%s/up.%d", g_iddir, r);
+        if (access(f, F_OK) != 0) up = 0;
+      }
+      if (up) break;
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > limit) {
+        fprintf(stderr, "--gpus %d: the ranks' transport (RCCL communicators + a first exchange with both neighbours) did not "
+                        "come up within %.0f s: stopping all ranks (--comm-timeout S / LBMDEM_COMM_TIMEOUT to wait longer)\n",
+                gpus, limit);
+        for (int r = 0; r < gpus; ++r) if (pids[r] > 0) kill(pids[r], SIGKILL);
+        bad = 1;
+        break;
+      }
+      struct timespec nap = {0, 20 * 1000 * 1000};
+      nanosleep(&nap, NULL);
+    }
+  }
   while (left > 0) {
     int st = 0;
     pid_t p = waitpid(-1, &st, 0);
@@ -145,6 +189,7 @@ int main(int argc, char** argv) {
     }
   }
   char path[320];
+  for (int r = 0; r < gpus; ++r) { snprintf(path, sizeof path, "%s/up.%d", g_iddir, r); unlink(path); }
   snprintf(path, sizeof path, "%s/rccl_id", g_iddir); unlink(path); rmdir(g_iddir);
   return bad ? EXIT_FAILURE : 0;
 }
@@ -191,6 +236,7 @@ static int run(int argc, char** argv) {
     else if (!strcmp(argv[a], "--checkpoint") && a + 1 < argc) ckpt_out = argv[++a];
     else if (!strcmp(argv[a], "--restart") && a + 1 < argc) ckpt_in = argv[++a];
     else if (!strcmp(argv[a], "--gpus") && a + 1 < argc) ++a;
+    else if (!strcmp(argv[a], "--comm-timeout") && a + 1 < argc) ++a;
     else if (!strcmp(argv[a], "--devices") && a + 1 < argc) ++a;
     else if (!strcmp(argv[a], "--comm")) {}
     else if (!strcmp(argv[a], "--dry")) {}
@@ -198,7 +244,7 @@ static int run(int argc, char** argv) {
     else { sample = NULL; break; }
   }
   if (!sample) {
-    SAY("usage: usage %s <filename> [--lx N --ly N --scale S --duration T --steps N --device K --gpus N --devices a,b,.. --dry]\n", argv[0]);
+    SAY("usage: usage %s <filename> [--lx N --ly N --scale S --duration T --steps N --device K --gpus N --devices a,b,.. --comm-timeout S --dry]\n", argv[0]);
     exit(EXIT_FAILURE);
   }
   SAY("Opening file : %s\n", sample);
@@ -261,6 +307,12 @@ static int run(int argc, char** argv) {
     if (!ckpt_in) DIE(lbmdem_dist_enable(h, 0), "dist_enable");   /* a restarted strip comes back distributed */
     DIE(lbmdem_comm_create(id, g_rank, g_world, cfg.device, &comm), "comm_create");
     DIE(lbmdem_comm_selftest(comm, 4096), "comm_selftest");   /* one rank: to itself; several: with both neighbours */
+    if (g_iddir[0]) {   /* tell the parent that this rank's transport works (its start-up watchdog) */
+      char f[320];
+      snprintf(f, sizeof f, "%s/up.%d", g_iddir, g_rank);
+      FILE* u = fopen(f, "w");
+      if (u) fclose(u);
+    }
   }
   time_t now = time(NULL);
   SAY("Current local time and date: %s", asctime(localtime(&now)));

@@ -7,6 +7,7 @@ migration through the kinematics message, the table sub-step over the ranks, VTK
 import os
 import re
 import subprocess
+import time
 import sys
 import textwrap
 
@@ -193,6 +194,23 @@ def test_c_driver_restart_of_two_ranks(po, tmp_path):
     assert os.path.exists(tmp_path / "half.ckpt.rank0") and os.path.exists(tmp_path / "half.ckpt.rank1")
     fd = lambda o: re.search(r"final_density: ([0-9.]+)", o.stderr).group(1)
     assert fd(full) == fd(second)
+
+
+def test_c_driver_stops_all_ranks_when_the_transport_does_not_come_up(po, tmp_path):
+    """the start-up watchdog of `lbmdem --gpus N`: ranks whose communicators + first neighbour exchange are not up within
+    --comm-timeout seconds are killed with one message instead of hanging the job (here: a limit no start-up can meet)"""
+    lx, ly = 640, 160
+    r, x, y, _ = cut_sample(lx, ly, 230, seed=35)
+    sample = tmp_path / "packing.data"
+    po.write_sample(str(sample), r, x, y)
+    cmd = [EXE, str(sample), "--lx", str(lx), "--ly", str(ly), "--gpus", "2", "--devices", "0,0", "--steps", "40"]
+    t0 = time.time()
+    out = subprocess.run(cmd + ["--comm-timeout", "0.01"], capture_output=True, text=True, cwd=tmp_path, env=shim_env(), timeout=300)
+    assert out.returncode != 0 and "did not come up within" in out.stderr, (out.returncode, out.stderr[-600:])
+    assert time.time() - t0 < 60
+    # ... and with the default limit the same command runs
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp_path, env=shim_env(), timeout=600)
+    assert out.returncode == 0 and "final_density" in out.stderr, (out.stdout[-300:], out.stderr[-800:])
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])
