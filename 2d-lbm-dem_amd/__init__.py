@@ -571,7 +571,8 @@ class LbmDem:
         _chk(self._L.lbmdem_sync(self._h))
 
     def profile_enable(self, on=True):
-        _chk(self._L.lbmdem_profile_enable(self._h, int(bool(on))))
+        """HIP-event timing of the fused kernel; on = N > 1: every N-th launch only (two event records cost a step ~10 us)"""
+        _chk(self._L.lbmdem_profile_enable(self._h, int(on)))
 
     def profile_read(self):
         ms, cnt = C.c_double(0), C.c_long(0)

@@ -300,7 +300,11 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
   Ids3 iE = load_ids(ob_new, L, xs + 2, y);  // row x+2
   {
     int oo = MARCH_OLD(xs - 1, iB.c);
+#if defined(LBMDEM_AB) && defined(MARCH_NO_HALO_ROWS)   /* timing experiment (wrong results): the two rows a segment shares with its neighbours are not read */
+    load_raw(xs, Fm);
+#else
     load_raw(xs - 1, Fm);
+#endif
     make_fstar(xs - 1, Fm, oo, grain_rec(oo), iB.c);
     oo = MARCH_OLD(xs, iC.c);
     load_raw(xs, F0);
@@ -347,7 +351,11 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
     // (rows beyond xe are never consumed: the last two prefetches of a segment re-request row xe, which the wave loaded
     // one or two iterations ago, instead of two new rows -- 2 of the 36 rows a 32-row segment would read, 2 of 12 for 8 rows;
     // the loads stay unconditional so that the in-order vmcnt bookkeeping of the pipeline does not change)
+#if defined(LBMDEM_AB) && defined(MARCH_NO_HALO_ROWS)
+    load_raw(x + 3 < xe ? x + 3 : xe - 1, buf);
+#else
     load_raw(x + 3 < xe ? x + 3 : xe, buf);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     MT(2)
     // (the column re-declared opaque: otherwise (double)(y - 1), (double)y, (double)(y + 1) of node_active's rare path are

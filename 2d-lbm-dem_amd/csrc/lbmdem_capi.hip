@@ -139,6 +139,8 @@ int lbmdem_read_sample(const char* path, int* nbgrains, double** r_out, double**
 
 void lbmdem_free_host(void* p) { free(p); }
 
+static void chain_forget_stream(int device, hipStream_t st);   // (the launches of k_dem_chain are chained across streams: below)
+
 static int next_paint_epoch(lbmdem_handle* h) {
   if (h->mincov) {   // records of an older rasterisation lose against this one's; the 12-bit epoch is wound back rarely
     if (++h->paint_epoch > 0xFFFu) {
@@ -433,6 +435,7 @@ int lbmdem_destroy(lbmdem_handle* h) {
   if (!h) return LBMDEM_OK;
   (void)hipSetDevice(h->cfg.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  chain_forget_stream(h->cfg.device, h->stream);
   for (int b = 0; b < 2; ++b) {
     if (h->f[b]) (void)hipFree(h->f[b]);
     if (h->obst[b]) (void)hipFree(h->obst[b]);
@@ -493,7 +496,10 @@ static ForceSlots slots_for_launch(lbmdem_handle* h) {
 
 static int prof_begin(lbmdem_handle* h, hipEvent_t* e1) {
   *e1 = nullptr;
+  h->prof_this = false;
   if (!h->prof) return LBMDEM_OK;
+  if ((h->prof_count++ % h->prof_stride) != 0) return LBMDEM_OK;
+  h->prof_this = true;
   if (h->ev_used == h->ev0.size()) {
     hipEvent_t a, b, c2;
     HIP_TRY(hipEventCreate(&a));
@@ -607,7 +613,7 @@ static int collide_stream_part_on_impl(lbmdem_handle* h, int part, hipStream_t s
     launch_collide_stream_edges(h->cs_fin, h->f[1 - h->fcur], h->cs_ob_old, h->cs_ob_new, L, gview(h), h->cs_slots, L.xo0,
                                 lo_end, hi_begin, L.xo1, st);
     // the profiled interval of a split launch ends with whichever part ends last
-    if (h->prof && h->ev_used > 0) { HIP_TRY(hipEventRecord(h->ev2[h->ev_used - 1], st)); h->ev2_set[h->ev_used - 1] = 1; }
+    if (h->prof_this && h->ev_used > 0) { HIP_TRY(hipEventRecord(h->ev2[h->ev_used - 1], st)); h->ev2_set[h->ev_used - 1] = 1; }
     HIP_TRY(hipGetLastError());
     h->fcur = 1 - h->fcur;
     if (h->obst_pending) { h->ocur = 1 - h->ocur; h->obst_pending = false; h->obst_reset_rows = 0; }
@@ -623,7 +629,7 @@ static int collide_stream_part_on_impl(lbmdem_handle* h, int part, hipStream_t s
       launch_collide_stream(h->cs_fin, h->f[h->fcur], h->cs_ob_old, h->cs_ob_new, Ls, gview(h), h->cs_slots, st);
     }
     h->slots_valid = h->cs_slots.tab != nullptr;
-    if (h->prof && h->ev_used > 0) HIP_TRY(hipEventRecord(h->ev1[h->ev_used - 1], h->stream));
+    if (h->prof_this && h->ev_used > 0) HIP_TRY(hipEventRecord(h->ev1[h->ev_used - 1], h->stream));
     HIP_TRY(hipGetLastError());
     h->cs_interior_pending = false;
     return LBMDEM_OK;
@@ -866,20 +872,24 @@ static std::mutex g_chain_mutex;
 static hipEvent_t g_chain_done[64] = {};
 static hipStream_t g_chain_stream[64] = {};
 static bool g_chain_any[64] = {};
+// The event is recorded lazily, on the stream of the LAST launch at the moment a launch from another stream arrives (an event
+// recorded after every launch held the next dispatch back: 4.4 us per coupled step for something one handle never needs);
+// the caller holds g_chain_mutex from here until its own launch is enqueued.
 static int chain_serialise_begin(lbmdem_handle* h) {
   const int d = h->cfg.device & 63;
-  std::lock_guard<std::mutex> lock(g_chain_mutex);
-  if (!g_chain_done[d]) HIP_TRY(hipEventCreateWithFlags(&g_chain_done[d], hipEventDisableTiming));
-  if (g_chain_any[d] && g_chain_stream[d] != h->stream) HIP_TRY(hipStreamWaitEvent(h->stream, g_chain_done[d], 0));
-  return LBMDEM_OK;
-}
-static int chain_serialise_end(lbmdem_handle* h) {
-  const int d = h->cfg.device & 63;
-  std::lock_guard<std::mutex> lock(g_chain_mutex);
-  HIP_TRY(hipEventRecord(g_chain_done[d], h->stream));
+  if (g_chain_any[d] && g_chain_stream[d] != h->stream) {
+    if (!g_chain_done[d]) HIP_TRY(hipEventCreateWithFlags(&g_chain_done[d], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(g_chain_done[d], g_chain_stream[d]));
+    HIP_TRY(hipStreamWaitEvent(h->stream, g_chain_done[d], 0));
+  }
   g_chain_stream[d] = h->stream;
   g_chain_any[d] = true;
   return LBMDEM_OK;
+}
+// a stream that goes away or is replaced (synchronised by the caller): no later launch has to wait for it
+static void chain_forget_stream(int device, hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_chain_mutex);
+  if (g_chain_any[device & 63] && g_chain_stream[device & 63] == st) g_chain_any[device & 63] = false;
 }
 
 // k ordinary sub-steps (lbmdem_dem_chain_length said so) in one launch
@@ -929,11 +939,11 @@ int lbmdem_dem_chain(lbmdem_handle* h, long k, int fluid) {
     fill.row1 = fill.row0 + slice * k < h->L.nxl ? (int)(fill.row0 + slice * k) : h->L.nxl;
     h->obst_reset_rows = fill.row1;
   }
+  std::lock_guard<std::mutex> chain_lock(g_chain_mutex);
   RC_TRY(chain_serialise_begin(h));
   launch_dem_chain(h->kin[h->kcur], h->kin[1 - h->kcur], h->r, h->m, h->It, h->fhf, h->V, h->gp, P,
                    h->dist ? h->dd.active : nullptr, &h->ct, h->substep_seq, h->dist ? h->owner : nullptr, fill, h->chain,
                    (int)k, paint, h->stream);
-  RC_TRY(chain_serialise_end(h));
   if (paint.obst) { h->chain_painted = true; h->chain_paints++; }
   if (h->dist && h->dist_poison) launch_dist_poison(h->dd, h->kin[0], h->kin[1], h->n, h->stream);
   h->substep_seq += k;
@@ -1323,6 +1333,7 @@ int lbmdem_get_config(lbmdem_handle* h, lbmdem_config* out) {
 int lbmdem_set_stream(lbmdem_handle* h, void* hip_stream) {
   CHECK_H(h);
   HIP_TRY(hipStreamSynchronize(h->stream));
+  chain_forget_stream(h->cfg.device, h->stream);
   h->stream = (hipStream_t)hip_stream;
   return LBMDEM_OK;
 }
@@ -1330,6 +1341,7 @@ int lbmdem_set_stream(lbmdem_handle* h, void* hip_stream) {
 int lbmdem_use_own_stream(lbmdem_handle* h) {
   CHECK_H(h);
   HIP_TRY(hipStreamSynchronize(h->stream));
+  chain_forget_stream(h->cfg.device, h->stream);
   h->stream = h->own_stream;
   return LBMDEM_OK;
 }
@@ -1383,6 +1395,9 @@ int lbmdem_profile_enable(lbmdem_handle* h, int on) {
   CHECK_H(h);
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->prof = on != 0;
+  h->prof_stride = on > 1 ? on : 1;
+  h->prof_count = 0;
+  h->prof_this = false;
   h->ev_used = 0;
   return LBMDEM_OK;
 }

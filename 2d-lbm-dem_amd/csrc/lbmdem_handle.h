@@ -134,6 +134,9 @@ struct lbmdem_handle {
   double* dpartial = nullptr;
   // profiling of the dominant kernel
   bool prof = false;
+  int prof_stride = 1;      // every prof_stride-th launch of the fused kernel is timed (two event records cost the step ~10 us)
+  long prof_count = 0;
+  bool prof_this = false;   // the launch being issued is one of them
   std::vector<hipEvent_t> ev0, ev1;
   std::vector<hipEvent_t> ev2;      // end of the EDGES part of a split launch (it may run on another stream, next to INTERIOR)
   std::vector<char> ev2_set;

@@ -439,7 +439,11 @@ def main():
     sync()
     # the box's yardstick: a plain copy of 1.2 GB (2.4 GB of traffic, the fused kernel's algorithmic bytes) on the same stream
     copy_gbs = sim.measure_copy(1200 * 1000 * 1000, 5) if args.precision == "f64" else None
-    sim.profile_enable(True)
+    # HIP events around the fused kernel, on its stream, inside the timed region -- around every 4th launch (every 8th of a
+    # long run): the two records of a timed launch hold the next dispatch back, ~10 us per coupled step when every launch
+    # is timed (LBMDEM_BENCH_PROFILE=1 does that, =0 times none: the A/B)
+    prof_stride = int(os.environ.get("LBMDEM_BENCH_PROFILE", "8" if args.steps >= 100 else "4"))
+    sim.profile_enable(prof_stride)
     barrier(); sync()
     t0 = time.perf_counter()
     run_steps(args.steps)
@@ -575,7 +579,7 @@ def main():
                          # counter traffic for this build); and the algorithmic rate against the same yardstick
                          "frac_of_copy": round(traffic / (kernel_ms * 1e-3) / 1e9 / copy_gbs, 4) if (traffic and copy_gbs and kernel_ms > 0) else None,
                          "achieved_over_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
-                         "bytes_per_lup": bytes_per_lup, "launches_timed": launches,
+                         "bytes_per_lup": bytes_per_lup, "launches_timed": launches, "timed_every": prof_stride,
                          "note": "achieved = algorithmic 148 B/LUP x lattice nodes per launch / mean HIP-event "
                                  "duration; traffic = HBM bytes per launch from rocprofv3 FETCH_SIZE + WRITE_SIZE "
                                  "(separate passes, calibrated on copy kernels) -- reported only when the file was measured on this very library binary"},

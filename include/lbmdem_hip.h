@@ -260,7 +260,8 @@ int lbmdem_set_stream(lbmdem_handle* h, void* hip_stream);
 int lbmdem_use_own_stream(lbmdem_handle* h);
 int lbmdem_sync(lbmdem_handle* h);
 /* HIP-event timing of the dominant kernel (fused collide+stream), on the stream it is launched on.
- * enable, run steps, then read the mean duration and the launch count. */
+ * enable, run steps, then read the mean duration and the launch count. on = N > 1: every N-th launch is timed (the two
+ * event records around a launch hold the next dispatch back: ~10 us per coupled step when every launch is timed). */
 int lbmdem_profile_enable(lbmdem_handle* h, int on);
 int lbmdem_profile_read(lbmdem_handle* h, double* mean_ms, long* launches);
 /* GB/s (bytes read + bytes written) of a plain copy kernel moving `bytes` on this handle's device and stream, best of `reps`
