@@ -169,9 +169,10 @@ int lbmdem_obst_stats(lbmdem_handle* h, long* updates, long* repaints);
  * thousand nodes that changed hands. mode 1 (default): a rasterisation in place by the end of a run of sub-steps also
  * leaves one bit per lattice row and 64-column window of the fused kernel -- "the two maps differ here" -- and the fused
  * kernel of a whole single-domain step reads the second map only in those rows (4 of its 152 bytes per node otherwise).
- * 0: both maps are read everywhere. 2: as 1, and every use is checked against the two maps first (tests).
- * lbmdem_change_mask_stats: fused launches that used the bits; (row, window) pairs found clear over differing maps by
- * mode 2 (must be 0). */
+ * 0: both maps are read everywhere. 2: as 1, and every use is checked (tests): the bits against the two maps, and the
+ * populations against a second launch that reads both maps everywhere (into a scratch lattice).
+ * lbmdem_change_mask_stats: fused launches that used the bits; what mode 2 found wrong -- low 32 bits: (row, window)
+ * pairs whose bit was clear over differing maps, high 32 bits: populations that differed -- must be 0. */
 int lbmdem_set_change_mask(lbmdem_handle* h, int mode);
 int lbmdem_change_mask_stats(lbmdem_handle* h, long* used, long* hidden);
 
