@@ -130,3 +130,48 @@ def test_two_handles_on_their_own_streams_side_by_side(pkg):
     assert np.array_equal(a.kinematics, b.kinematics)
     assert a.dem_chain_stats()[3] == a.dem_chain_stats()[2] and a.dem_chain_stats()[0] >= 40
     a.close(); b.close()
+
+
+def test_streams_that_come_and_go_between_launches(pkg):
+    """The launches of the multi-sub-step kernel are chained across streams by an event recorded on the stream of the LAST
+    launch when a launch from another stream arrives: a handle that was destroyed, or has changed its stream, in between
+    must not be waited for (its stream may be gone). Three handles taking turns, one closed half way, one moved to the
+    default stream and back; the survivors stay bit-equal to a handle that ran alone."""
+    lx, ly = 768, 512
+    r, x1, x2 = packing(lx, ly, 1500, 21)
+    ref = pkg.LbmDem(lx, ly, r, x1, x2)
+    a = pkg.LbmDem(lx, ly, r, x1, x2); a.use_own_stream()
+    b = pkg.LbmDem(lx, ly, r, x1, x2); b.use_own_stream()
+    c = pkg.LbmDem(lx, ly, r, x1, x2); c.use_own_stream()
+    kick([ref, a, b, c], len(r), 8)
+    for k in range(6):
+        a.run_dem(17); b.run_dem(17); c.run_dem(17)
+    c.close()                                    # the last launch came from c's stream
+    for k in range(3):
+        a.run_dem(17); b.run_dem(17)
+    b.set_stream(None); b.run_dem(17); a.run_dem(17)      # b on the default stream, then back on its own
+    b.use_own_stream(); b.run_dem(17); a.run_dem(17)
+    ref.run_dem(17 * 11)
+    a.sync(); b.sync()
+    assert np.array_equal(a.kinematics, ref.kinematics) and np.array_equal(b.kinematics, ref.kinematics)
+    a.close(); b.close(); ref.close()
+
+
+def test_kernel_timing_of_every_nth_launch(pkg):
+    """lbmdem_profile_enable(h, N): the HIP events go around every N-th launch of the fused kernel only"""
+    lx, ly = 256, 192
+    r, x1, x2 = packing(lx, ly, 120, 4)
+    sim = pkg.LbmDem(lx, ly, r, x1, x2)
+    n = sim.cfg.npDEM
+    sim.renderScene(2 * n)
+    sim.profile_enable(4)
+    sim.renderScene(9 * n)
+    ms, cnt = sim.profile_read()
+    assert cnt == 3 and 0.0 < ms < 5.0, (ms, cnt)          # launches 0, 4 and 8 of the nine
+    sim.profile_enable(True)
+    sim.renderScene(3 * n)
+    assert sim.profile_read()[1] == 3
+    sim.profile_enable(False)
+    sim.renderScene(n)
+    assert sim.profile_read()[1] == 0
+    sim.close()
