@@ -211,6 +211,8 @@ def test_real_7000_grain_sample_30_coupled_steps_vs_oracle(pkg, po):
     assert np.array_equal(sim.fhf, ora.get_fhf())
     assert np.array_equal(sim.obst, ora.get_obst())
     assert np.array_equal(sim.f, ora.get_f())
+    # (most of these fluid steps read the previous obstacle map only in the rows marked as changed: lbmdem_set_change_mask)
+    assert sim.change_mask_stats()[0] >= 20, sim.change_mask_stats()
 
 
 def test_real_50000_grain_sample_six_coupled_steps_vs_oracle(pkg, po):
@@ -229,6 +231,7 @@ def test_real_50000_grain_sample_six_coupled_steps_vs_oracle(pkg, po):
     assert np.array_equal(sim.obst, ora.get_obst())
     got = sim.f
     assert np.array_equal(got, ora.get_f())
+    assert sim.change_mask_stats()[0] >= 2, sim.change_mask_stats()   # (the steps after both map buffers hold a picture)
 
 
 def test_configs4_8192x4096_as_eight_strips_against_the_reference_digests(pkg):
