@@ -588,7 +588,7 @@ def main():
         }
         if args.precision == "f32":
             out["metric"] += " -- float build (the reference's -DSINGLE_PRECISION mode), NOT the headline"
-            out["roofline"]["note"] = ("achieved = algorithmic 76 B/LUP x lattice nodes per launch / mean HIP-event duration; the "
+            out["roofline"]["note"] = ("achieved = algorithmic 76 B/LUP x lattice nodes per launch / mean HIP-event duration of every `timed_every`-th launch of the timed region; the "
                                        "float build mirrors the reference's mixed float/double arithmetic and gathers the hydrodynamic "
                                        "forces from the lattice (no link-sum table)")
         if args.gpus == 1 and not args.no_cpu_baseline and args.precision == "f64":
