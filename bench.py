@@ -581,7 +581,7 @@ def main():
                          "achieved_over_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
                          "bytes_per_lup": bytes_per_lup, "launches_timed": launches, "timed_every": prof_stride,
                          "note": "achieved = algorithmic 148 B/LUP x lattice nodes per launch / mean HIP-event "
-                                 "duration; traffic = HBM bytes per launch from rocprofv3 FETCH_SIZE + WRITE_SIZE "
+                                 "duration of every `timed_every`-th launch of the timed region; traffic = HBM bytes per launch from rocprofv3 FETCH_SIZE + WRITE_SIZE "
                                  "(separate passes, calibrated on copy kernels) -- reported only when the file was measured on this very library binary"},
             "fast_force_mode": fast,
             "total_mass": mass,
