@@ -52,6 +52,14 @@ __device__ __forceinline__ GP load_gp(const GrainFluidView& G, int i) {
   return GP{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
 }
 
+// what reinit_obst_density needs of it: position and velocities (main.c:974-975)
+struct GPv { real x1, x2, v1, v2, v3; };
+__device__ __forceinline__ GPv load_gpv(const GrainFluidView& G, int i) {
+  const real2* p = reinterpret_cast<const real2*>(G.pk + (long)i * 8);
+  const real2 a = p[0], b = p[1];
+  return GPv{a.x, a.y, b.x, b.y, G.pk[(long)i * 8 + 4]};
+}
+
 // Lowest index of the grains covering node `node` whose highest-index cover is `top` (GrainFluidView::mincov).
 __device__ __forceinline__ int min_cover(const GrainFluidView& G, long node, int top) {
   if (!G.mincov) return top;
@@ -133,6 +141,9 @@ __device__ __forceinline__ void grain_equilibrium_u(const LatticeView& L, real u
 __device__ __forceinline__ void grain_equilibrium(const LatticeView& L, const GP& g, int x, int y,
                                                   real (&f)[9]) {
   grain_equilibrium_u(L, wall_ux(L, g, y), wall_uy(L, g, x), f);
+}
+__device__ __forceinline__ void grain_equilibrium(const LatticeView& L, const GPv& g, int x, int y, real (&f)[9]) {
+  grain_equilibrium_u(L, g.v1 - (y * L.dx + L.Mby - g.x2) * g.v3, g.v2 + (x * L.dx + L.Mgx - g.x1) * g.v3, f);   // wall_ux, wall_uy
 }
 
 // wall distance along link q from solid node (x, y) of a disc (xc, yc, r2): main.c:1054-1058

@@ -24,6 +24,7 @@
 
 
 #include "lbm_march.h"
+#include <type_traits>
 #if defined(LBMDEM_AB) && (defined(MARCH_TIMING) || defined(MARCH_TRACE))
 #include "lbm_march_timing.h"
 #else
@@ -153,6 +154,436 @@ struct MarchPlan {
   int first[5];   // first item of level l within the band's item list; first[nlev] = items per band
 };
 
+// One work item of the marching kernel: window `strip`, rows [xs, xe). EDGE = false is the instantiation for items whose
+// 64 columns and rows xs - 2 .. xe + 1 are all interior nodes of the lattice and rows of this slab (94 % of a 4096^2
+// lattice's items): no clamp, no bounds test, no lattice-edge bounce-back anywhere in its loop -- and none of the registers
+// they hold. The kernel picks the instantiation per wavefront.
+constexpr int LINK_SLOTS = 64;   // link slots of a wavefront's compacted bounce-back evaluation
+
+template <int WW, bool CHG, bool EDGE>
+__device__ __forceinline__ void march_item(const real* __restrict__ fin, real* __restrict__ fout,
+                                           const int* __restrict__ ob_old, const int* __restrict__ ob_new,
+                                           const LatticeView& L, const GrainFluidView& G, const ForceSlots& S,
+                                           const ObstChange& CH, int strip, int xs, int xe, const RecRing ring,
+                                           real* const pay, int* const desc, int lane, int w) {
+  (void)w;   // (the experiment build's row trace indexes its buffer with it)
+  // WW producing lanes in the middle of the window, (64 - WW) / 2 feeding lanes on either side
+  constexpr int OFF = (64 - WW) / 2;
+  const int y = strip * WW - OFF + lane;
+  const bool yin = !EDGE || (y >= 0 && y < L.ly);
+  const bool writer = lane >= OFF && lane < OFF + WW && yin;
+  const bool deep_y = !EDGE || (strip * WW >= 2 && strip * WW + WW - 1 <= L.ly - 3);  // the producing lanes
+
+  // Software pipeline. In iteration x (producing row x) the wave issues, in this order,
+  //   (1) small gathers: new ids of row x+4, previous-map id of row x+4, the record of the grain that
+  //       owned (x+2, y) before (reinit of row x+2), the record of the grain that owns (x+3, y) now
+  //   (2) the nine populations of row x+3 into the row buffer it has just consumed (two buffers,
+  //       ping-pong, loop unrolled by two: no register copies, so the loads stay in flight for two
+  //       iterations)
+  //   (3) the nine stores of row x.
+  // gfx9 retires vector-memory operations in issue order (one vmcnt counter), so data must be consumed
+  // in the order it was requested; no other global load exists inside the loop.
+  const real wc_diag = L.wc_diag, wc_axis = L.wc_axis;  // kernel arguments: scalar registers
+  auto row_ok = [&](int xl) { return !EDGE || (yin && xl >= 0 && xl < L.nxl); };
+  const int ycl = !EDGE ? y : (y < 0 ? 0 : (y >= L.ly ? L.ly - 1 : y));
+  // unconditional (clamped address): every use is guarded by interior(xl), and grain_rec clamps the
+  // id. (A `row_ok ? v : -1` select here makes the compiler sink the load into a branch followed by
+  // s_waitcnt vmcnt(0), which drains the whole prefetch pipeline once per iteration.)
+  // The previous map's ids. With an ObstChange (CHG: the launch of a whole single-domain step after a rasterisation in
+  // place) the wave knows the rows of its window in which the two maps differ -- a few per cent of them -- and takes the id
+  // from the current map, which it holds anyway, everywhere else: the second map's 4 bytes per node were 2.2 % of the
+  // kernel's traffic. The load stays in the instruction stream for every row (the in-order vmcnt bookkeeping of the
+  // prefetch pipeline must not depend on data; under a branch it cost more than it saved): a buffer load whose offset
+  // lies beyond the resource's records returns 0 and moves nothing. The rows a wave asks for are consecutive (xs - 1,
+  // xs, ...): their bits sit in a 64-bit shift register in scalar registers, lowest bit = the next row, ones shifted in
+  // (rows beyond the 64th are read from both maps).
+  unsigned long long cm = ~0ull;
+  // The four streams of the loop through buffer resources that start at the item's first row (lbm_march.h): a lane keeps
+  // ONE column offset per stream, rows are scalar offsets.
+  const int row0 = __builtin_amdgcn_readfirstlane(xs - 2 < 0 ? 0 : xs - 2);
+  const int frow = L.sy * 9 * (int)sizeof(real), irow = L.sy * 4;   // bytes per row of populations / of ids
+  const __amdgpu_buffer_rsrc_t fin_rs = make_rs(fin + (long)row0 * L.sy * 9, (long)(L.nxl - row0) * frow);
+  const __amdgpu_buffer_rsrc_t fout_rs = make_rs(fout + (long)row0 * L.sy * 9, (long)(L.nxl - row0) * frow);
+  const __amdgpu_buffer_rsrc_t id_rs = make_rs(ob_new + (long)row0 * L.sy, (long)(L.nxl - row0) * irow);
+  const __amdgpu_buffer_rsrc_t old_rs = make_rs(ob_old + (long)row0 * L.sy, (long)(L.nxl - row0) * irow);
+  const int fcol = fcol_bytes(ycl), icol = ycl * 4;
+  auto rel_row = [&](int xl) { return (xl < 0 ? 0 : (xl >= L.nxl ? L.nxl - 1 : xl)) - row0; };   // clamped: always a valid row
+  if (CHG) {
+    const int r0 = xs - 1, first = r0 < 0 ? 0 : r0;
+    const unsigned* wp = CH.bits + (long)strip * CH.words + (first >> 5);   // (a window's words are padded by four)
+    const unsigned w0 = __builtin_amdgcn_readfirstlane(wp[0]), w1 = __builtin_amdgcn_readfirstlane(wp[1]);
+    const unsigned w2 = __builtin_amdgcn_readfirstlane(wp[2]);
+    const int sh = __builtin_amdgcn_readfirstlane(first & 31);
+    cm = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
+    if (sh) cm = (cm >> sh) | ((unsigned long long)w2 << (64 - sh));
+    if (r0 < 0) cm <<= 1;   // row -1 is never used
+  }
+  auto load_old = [&](int xl, int same) -> int {
+    if (!CHG) return __builtin_amdgcn_raw_buffer_load_b32(old_rs, icol, rel_row(xl) * irow, 0);
+    const int keep = (cm & 1ull) ? 0 : -1;   // scalar: -1 = the maps agree in this row
+    cm = (cm >> 1) | (1ull << 63);
+    // (offset bit 31: beyond the resource's < 2^31 bytes, and far from wrapping round in the range check)
+    const int v = __builtin_amdgcn_raw_buffer_load_b32(old_rs, (rel_row(xl) * irow + icol) | (keep & (int)0x80000000), 0, 0);
+    return v | (same & keep);
+  };
+  // the current map's id of (xl, y); off the lattice (EDGE items only) reads as "wall": never fluid
+  auto load_id = [&](int xl) -> int {
+    const int v = __builtin_amdgcn_raw_buffer_load_b32(id_rs, icol, rel_row(xl) * irow, 0);
+    if (!EDGE) return v;
+    return (xl >= 0 && xl < L.nxl && ycl == y) ? v : L.n;
+  };
+#if defined(LBMDEM_AB) && defined(MARCH_NO_OLD)   /* timing experiment (wrong where the maps differ): the second map is not read */
+#define MARCH_OLD(xl, same) (same)
+#else
+#define MARCH_OLD(xl, same) load_old(xl, same)
+#endif
+  // off-lattice positions load a clamped neighbour's values; they are never used (pull_one tests the
+  // bounds of the source node before touching its populations)
+  auto load_raw = [&](int xl, real (&raw)[9]) {
+    const int so = rel_row(xl) * frow;
+    raw[0] = buf_load_real<0 * F_QBYTES>(fin_rs, fcol, so); raw[1] = buf_load_real<1 * F_QBYTES>(fin_rs, fcol, so);
+    raw[2] = buf_load_real<2 * F_QBYTES>(fin_rs, fcol, so); raw[3] = buf_load_real<3 * F_QBYTES>(fin_rs, fcol, so);
+    raw[4] = buf_load_real<4 * F_QBYTES>(fin_rs, fcol, so); raw[5] = buf_load_real<5 * F_QBYTES>(fin_rs, fcol, so);
+    raw[6] = buf_load_real<6 * F_QBYTES>(fin_rs, fcol, so); raw[7] = buf_load_real<7 * F_QBYTES>(fin_rs, fcol, so);
+    raw[8] = buf_load_real<8 * F_QBYTES>(fin_rs, fcol, so);
+  };
+  auto interior = [&](int xl) {
+    const int gx = L.gx0 + xl;
+    return !EDGE || (row_ok(xl) && gx >= 1 && gx <= L.lx - 2 && y >= 1 && y <= L.ly - 2);
+  };
+  // f* of one node: reinit (previous map) + collide (current map)
+  auto make_fstar = [&](int xl, real (&f)[9], int oo, const GPv& g, int on) {
+    const bool in = interior(xl);
+    if (in && oo != -1) grain_equilibrium(L, g, L.gx0 + xl, y, f);
+    if (in && on == -1) mrt_collide(L, f);
+  };
+  auto grain_rec = [&](int id) { return load_gp(G, (id < 0 || id >= L.n) ? 0 : id); };
+  auto reinit_rec = [&](int id) { return load_gpv(G, (id < 0 || id >= L.n) ? 0 : id); };
+
+  real Fm[9], F0[9], Fp[9], bufA[9], bufB[9];
+
+  // the current map's ids: one per lane and row; a node's column neighbours are the neighbour lanes
+  const int iA = load_id(xs - 2);  // row x-2 (only needed for act of row x-1)
+  int iB = load_id(xs - 1);        // row x-1
+  int iC = load_id(xs);            // row x
+  int iD = load_id(xs + 1);        // row x+1
+  int iE = load_id(xs + 2);        // row x+2
+  {
+    int oo = MARCH_OLD(xs - 1, iB);
+#if defined(LBMDEM_AB) && defined(MARCH_NO_HALO_ROWS)   /* timing experiment (wrong results): the two rows a segment shares with its neighbours are not read */
+    load_raw(xs, Fm);
+#else
+    load_raw(xs - 1, Fm);
+#endif
+    make_fstar(xs - 1, Fm, oo, reinit_rec(oo), iB);
+    oo = MARCH_OLD(xs, iC);
+    load_raw(xs, F0);
+    make_fstar(xs, F0, oo, reinit_rec(oo), iC);
+  }
+  // records of the current owners of rows x-1 .. x+2 into the ring
+  ring.put(xs - 1, lane, grain_rec(iB), iB);
+  ring.put(xs, lane, grain_rec(iC), iC);
+  ring.put(xs + 1, lane, grain_rec(iD), iD);
+  ring.put(xs + 2, lane, grain_rec(iE), iE);
+  int inext = load_id(xs + 3);
+  int oo1 = MARCH_OLD(xs + 1, iD);   // previous-map ids of rows x+1, x+2
+  int oo2 = MARCH_OLD(xs + 2, iE);
+  GP rec_next = grain_rec(inext);  // owner record of row x+3, goes into the ring next iteration
+  load_raw(xs + 1, bufA);
+  load_raw(xs + 2, bufB);
+  // The flags of a row as lane masks (lbm_march.h): sol* = the node belongs to a grain or a lattice-edge wall (id != -1),
+  // act* = `act` (main.c:1039-1052). hm* = the highest id among a node and its two column neighbours.
+  auto sol_of = [&](int c) -> lmask { return __ballot(c != -1); };
+  auto hmax_of = [&](int c) { const int m = dpp_up1(c), p = dpp_dn1(c), t = m > c ? m : c; return t > p ? t : p; };
+  // `act` of the row with ids b (a, c = the rows before and after): a solid node with a fluid neighbour -- all masks --
+  // or, where reduced discs of different grains touch, with a neighbour that a HIGHER-index grain took from the fluid
+  // (node_active; asked only when some solid node without a fluid neighbour has a higher id next to it, wave-uniform)
+  auto act_of = [&](lmask sa, lmask sb, lmask sc, int hma, int hmb, int hmc, int a, int b, int c, int xl, int ycol) -> lmask {
+    const lmask enclosed = sb & m_enclosed(sa, sb, sc);
+    lmask act = sb & ~enclosed;
+    const int t = hma > hmb ? hma : hmb;
+    const lmask rare = __ballot((t > hmc ? t : hmc) > b) & enclosed;
+    if (rare != 0) {
+      const bool on = node_active(L, G, ids3_of(a), ids3_of(b), ids3_of(c), L.gx0 + xl, ycol, [&] { return ring.get(xl, lane); });
+      act |= __ballot(on) & rare;
+    }
+    return act;
+  };
+  lmask solB = sol_of(iB), solC = sol_of(iC), solD = sol_of(iD), solE = sol_of(iE);
+  int hmC = hmax_of(iC), hmD = hmax_of(iD), hmE = hmax_of(iE);
+  lmask actM = act_of(sol_of(iA), solB, solC, hmax_of(iA), hmax_of(iB), hmC, iA, iB, iC, xs - 1, y);
+  lmask act0 = act_of(solB, solC, solD, hmax_of(iB), hmC, hmD, iB, iC, iD, xs, y);
+  const lmask wmask = EDGE ? __ballot(writer) : (((lmask)1 << WW) - 1) << OFF;
+
+  MT_DECL
+  // one iteration; `buf` holds row x+1 on entry and is refilled with row x+3
+  // Bounce-back links wait in the wave's LDS slots until the second row of a pair has added its own (`pend` = links
+  // waiting): ONE compacted pass per two rows. The pass is a long dependent chain -- LDS round trips, a square root and three
+  // to six divisions per link -- at a third of the lanes per row; two rows per pass halve the number of chains.
+  int pend = 0;
+  GP rec_odd = rec_next;   // (set at the end of the first iteration)
+  auto iterate = [&](int x, real (&buf)[9], auto second_tag) {
+    constexpr bool SECOND = decltype(second_tag)::value;   // the second row of its pair: x - 1 was the first
+    MT(7)   // loop head
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Fp[q] = buf[q];
+#ifdef MARCH_TIMING   /* phase 0 = the wait for the row's populations alone */
+#pragma unroll
+    for (int q = 0; q < 9; ++q) asm volatile("" ::"v"(Fp[q]));
+    MT(0)
+#endif
+    // f* of row x+1. The record of a node's PREVIOUS owner (reinit_obst_density, main.c:966-986) is the ring's record of
+    // its current one except at the few nodes that have changed hands since the previous map: only a row that has such a
+    // node (wave-uniform) fetches records from memory -- nothing is carried in registers from the iteration before.
+    {
+      const bool in = interior(x + 1), re = in && oo1 != -1, moved = re && oo1 != iD;
+      GPv g = ring.getv(x + 1, lane);
+      // (opaque: otherwise the compiler selects between the two ADDRESSES and reads through a flat pointer, under the
+      // branch, with the wait that drains the row prefetch)
+      asm volatile("" : "+v"(g.x1), "+v"(g.x2), "+v"(g.v1), "+v"(g.v2), "+v"(g.v3));
+      if (__ballot(moved) != 0) {
+        if (moved) g = reinit_rec(oo1);
+      }
+#if !(defined(LBMDEM_AB) && defined(MARCH_ABL_NOREINIT))   /* timing experiments (wrong results): a phase left out */
+      if (re) grain_equilibrium(L, g, L.gx0 + x + 1, y, Fp);
+#endif
+#if !(defined(LBMDEM_AB) && defined(MARCH_ABL_NOCOLLIDE))
+      if (in && iD == -1) mrt_collide(L, Fp);
+#endif
+    }
+    MT(1)
+    const int iF = inext;  // row x+3
+    // ---- (1) small gathers
+    oo1 = oo2;
+    inext = load_id(x + 4);
+    oo2 = MARCH_OLD(x + 3, iF);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- (2) the big loads: populations of row x+3
+    // (rows beyond xe are never consumed: the last two prefetches of a segment re-request row xe, which the wave loaded
+    // one or two iterations ago, instead of two new rows -- 2 of the 36 rows a 32-row segment would read, 2 of 12 for 8 rows;
+    // the loads stay unconditional so that the in-order vmcnt bookkeeping of the pipeline does not change)
+#if defined(LBMDEM_AB) && defined(MARCH_NO_HALO_ROWS)
+    load_raw(x + 3 < xe ? x + 3 : xe - 1, buf);
+#else
+    load_raw(x + 3 < xe ? x + 3 : xe, buf);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    MT(2)
+    // (the column re-declared opaque: otherwise (double)(y - 1), (double)y, (double)(y + 1) of node_active's rare path are
+    // hoisted out of the loop into six registers the kernel does not have, and one pair ends up in scratch -- whose reload
+    // drains the row prefetch)
+    int y_act = y;
+    asm volatile("" : "+v"(y_act));
+#if defined(LBMDEM_AB) && defined(MARCH_ABL_NOACT)
+    const lmask actP = solD;
+#else
+    const lmask actP = act_of(solC, solD, solE, hmC, hmD, hmE, iC, iD, iE, x + 1, y_act);
+#endif
+    MT(3)
+
+    // the populations around P = (x, y): own row from the registers, the two column neighbours by DPP shifts
+    real Fo[9], In[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Fo[q] = F0[q];
+    In[0] = 0.0;
+    In[2] = Fm[6];            // (-1, 0): same lane, row x-1, slot opp(2) = 6
+    In[6] = Fp[2];            // ( 1, 0)
+    In[1] = shfl_dn1z(Fm[5]);  // (-1, 1): lane+1, row x-1, slot 5
+    In[8] = shfl_dn1z(F0[4]);  // ( 0, 1)
+    In[7] = shfl_dn1z(Fp[3]);  // ( 1, 1)
+    In[3] = shfl_up1z(Fm[7]);  // (-1,-1): lane-1
+    In[4] = shfl_up1z(F0[8]);  // ( 0,-1)
+    In[5] = shfl_up1z(Fp[1]);  // ( 1,-1)
+    {
+      const int gx = L.gx0 + x;
+      const int so_row = (x - row0) * frow;   // this row in the output lattice's resource
+      const long fb_row = EDGE ? fbase_xy(L, x, y) : 0;   // (edge rows store through the pointer; only used by the producing lanes)
+      // wave-uniform: is every producing lane of this row at least two nodes away from all edges?
+      const bool deep = !EDGE || (deep_y && gx >= 2 && gx <= L.lx - 3);
+      // (a) everything but the interpolated bounce-back links: computed and stored. Per direction q three lane masks come
+      // out: lk = (P, q) is a bounce-back link (P fluid, its source S = P - e_q a grain node), nn = the node two links
+      // out, NN = P + e_q, is interior, hz = NN is solid and its own update precedes S's (q <= 4).
+      // (the masks are formed where they are used -- three scalar instructions each -- instead of being carried: two
+      // dozen register pairs would not fit)
+      const lmask wm = x < xe ? wmask : 0;
+#define MARCH_SRC(Q) m_at<-EYq(Q)>(MARCH_ROW(-EXq(Q), solB, solC, solD))   /* S = P - e_q is solid */
+#define MARCH_LINK(Q) (wm & ~solC & MARCH_SRC(Q))
+#define MARCH_HAZ(Q) (Q <= 4 ? MARCH_LINK(Q) & m_at<EYq(Q)>(MARCH_ROW(EXq(Q), solB, solC, solD)) : 0)
+      unsigned ibb = 0, nnm = 0, hzm = 0;   // the same three per lane, bit q, where the masks do not apply (edge rows)
+      int T = 0;
+      if (deep) {
+        // Rows and lanes at least two nodes from every lattice edge (S, P and NN all interior), without a branch and
+        // without a vector compare: the eight pulls differ only in WHICH value they take -- the streamed population, or
+        // the weight w_q when both ends are solid and the source is an active node (main.c:1161-1162) -- and which is a
+        // matter of the rows' masks; all nine are stored, the slot of a bounce-back link gets the streamed value as a
+        // placeholder which the compacted pass overwrites (the stores of one wavefront to one address keep their order;
+        // a link whose wall distance fires neither formula keeps exactly this value, main.c:1166-1217).
+        if (lane_of(wm)) {
+          buf_store_real<0>(Fo[0], fout_rs, fcol, so_row);
+#define MARCH_STORE(Q)                                                                             \
+          buf_store_real<Q * F_QBYTES>(                                                            \
+              lane_of(solC & MARCH_SRC(Q) & m_at<-EYq(Q)>(MARCH_ROW(-EXq(Q), actM, act0, actP))) ? Wq(Q) : In[OPPq(Q)], \
+              fout_rs, fcol, so_row);
+          MARCH_STORE(1) MARCH_STORE(2) MARCH_STORE(3) MARCH_STORE(4) MARCH_STORE(5) MARCH_STORE(6) MARCH_STORE(7) MARCH_STORE(8)
+#undef MARCH_STORE
+        }
+        T = __popcll(MARCH_LINK(1)) + __popcll(MARCH_LINK(2)) + __popcll(MARCH_LINK(3)) + __popcll(MARCH_LINK(4)) +
+            __popcll(MARCH_LINK(5)) + __popcll(MARCH_LINK(6)) + __popcll(MARCH_LINK(7)) + __popcll(MARCH_LINK(8));
+      } else if constexpr (EDGE) {
+        // rows and windows next to a lattice edge: the general classification, per lane
+        RegCtx C;
+        C.ring = ring;
+        C.row = x;
+        C.lane = lane;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { C.Fo[q] = Fo[q]; C.In[q] = In[q]; }
+        const Ids3 b3 = ids3_of(iB), c3 = ids3_of(iC), d3 = ids3_of(iD);
+        C.o0 = iC;
+        C.onb[0] = 0;
+        C.onb[1] = b3.p; C.onb[2] = b3.c; C.onb[3] = b3.m; C.onb[4] = c3.m;
+        C.onb[5] = d3.m; C.onb[6] = d3.c; C.onb[7] = d3.p; C.onb[8] = c3.p;
+        C.act = 0;
+#define MARCH_ACTBIT(D) C.act |= lane_of(m_at<EYq(D)>(MARCH_ROW(EXq(D), actM, act0, actP))) ? 1u << D : 0u;
+        MARCH_ACTBIT(1) MARCH_ACTBIT(2) MARCH_ACTBIT(3) MARCH_ACTBIT(4) MARCH_ACTBIT(5) MARCH_ACTBIT(6) MARCH_ACTBIT(7) MARCH_ACTBIT(8)
+#undef MARCH_ACTBIT
+        if (writer && x < xe) classify_store_row<true>(C, L, gx, y, fout, fb_row, ibb, nnm, hzm);
+#pragma unroll
+        for (int q = 1; q < 9; ++q) T += __popcll(__ballot((ibb >> q) & 1u));
+      }
+      MT(4)
+      // (b) the bounce-back links of the row (typically ~20, spread over all eight directions and a few lanes) are
+      // compacted into dense lanes through LDS and evaluated with the direction as data, instead of ~3.5
+      // direction-specific divergent passes of ~130 instructions. rank of link (lane, q) within its row = number of links
+      // in directions < q + number in direction q on lower lanes; the links with ranks [done, done + n) go to the slots
+      // [pend, pend + n). The slots are evaluated when they are full or the pair of rows is complete.
+#if defined(LBMDEM_AB) && defined(MARCH_ABL_NOPASS)
+      T = 0;
+#endif
+      const int xp = SECOND ? x - 1 : x;   // first row of the pair: links carry their row as a bit
+      for (int done = 0; done < T || (SECOND && pend > 0);) {   // wave-uniform; one trip unless the 64 slots run over
+        const int room = LINK_SLOTS - pend, left = T - done, n = left < room ? left : room;
+        if (n > 0) {
+          const int shift = pend - done;   // slot = rank + shift
+          int before = 0;
+          if (deep) {
+#define MARCH_COMPACT(Q)                                                                           \
+            {                                                                                      \
+              const lmask b = MARCH_LINK(Q);                                                       \
+              const int r = before + (int)mbcnt(b);                                                \
+              before += __popcll(b);                                                               \
+              if (lane_of(b) && (unsigned)(r - done) < (unsigned)n) {                              \
+                const int t = r + shift;                                                           \
+                desc[t] = lane | (Q << 8) | (1 << 12) | (lane_of(MARCH_HAZ(Q)) ? 1 << 13 : 0) | (SECOND ? 1 << 14 : 0); \
+                pay[t * 4 + 0] = Fo[OPPq(Q)];                                                      \
+                pay[t * 4 + 1] = Fo[Q];                                                            \
+                pay[t * 4 + 2] = In[Q];                                                            \
+                pay[t * 4 + 3] = In[OPPq(Q)];                                                      \
+              }                                                                                    \
+            }
+            MARCH_COMPACT(1) MARCH_COMPACT(2) MARCH_COMPACT(3) MARCH_COMPACT(4)
+            MARCH_COMPACT(5) MARCH_COMPACT(6) MARCH_COMPACT(7) MARCH_COMPACT(8)
+#undef MARCH_COMPACT
+          } else if constexpr (EDGE) {
+#pragma unroll
+            for (int q = 1; q < 9; ++q) {
+              const lmask b = __ballot((ibb >> q) & 1u);
+              const int r = before + (int)mbcnt(b);
+              before += __popcll(b);
+              if (((ibb >> q) & 1u) && (unsigned)(r - done) < (unsigned)n) {
+                const int t = r + shift;
+                desc[t] = lane | (q << 8) | (((nnm >> q) & 1u) << 12) | (((hzm >> q) & 1u) << 13) | (SECOND ? 1 << 14 : 0);
+                pay[t * 4 + 0] = Fo[OPPq(q)];
+                pay[t * 4 + 1] = Fo[q];
+                pay[t * 4 + 2] = In[q];
+                pay[t * 4 + 3] = In[OPPq(q)];
+              }
+            }
+          }
+          pend += n;
+          done += n;
+        }
+        if (pend < LINK_SLOTS && !(SECOND && done >= T)) break;   // (the first row of a pair leaves its links waiting)
+        __builtin_amdgcn_wave_barrier();  // LDS operations of one wave execute in order
+        if (lane < pend) {
+          const int d = desc[lane];
+          const int src = d & 63;
+          const int xr = xp + ((d >> 14) & 1);   // the link's row
+          RtLink k;
+          k.q = (d >> 8) & 15;
+          k.gx = L.gx0 + xr;
+          k.gy = y - lane + src;
+          k.own_qo = pay[lane * 4 + 0];
+          k.own_q = pay[lane * 4 + 1];
+          k.in_q = pay[lane * 4 + 2];
+          k.in_qo = pay[lane * 4 + 3];
+          k.nn_int = (d >> 12) & 1;
+          k.hazard = (d >> 13) & 1;
+          // the result goes straight to the population it belongs to: node of lane `src`, plane q
+#if defined(LBMDEM_AB) && defined(MARCH_ABL_NOEVAL)
+          const real out = k.in_qo;
+#else
+          const real out =
+              ibb_eval_rt(L, k, wc_diag, wc_axis, [&](int dx, int dy) { return ring.get(xr + dx, src + dy); });
+#endif
+#if defined(LBMDEM_AB) && defined(MARCH_ABL_NOFSTORE)
+          asm volatile("" ::"v"(out));
+#else
+          buf_store_real<0>(out, fout_rs, fcol_bytes(k.gy) + k.q * F_QBYTES + ((d >> 14) & 1) * frow, (xp - row0) * frow);
+#endif
+          // ... and the link's momentum-exchange sum f_new[S][opp q] + f_new[P][q] (main.c:1313-1316; the first
+          // is f*[P][opp q], streamed unchanged into the solid node) to the slot table of the grain that owns S
+#if defined(LBMDEM_AB) && defined(MARCH_ABL_NOTAB)
+          if (false) {
+#else
+          if (S.tab != nullptr) {
+#endif
+            const int ex = (k.q >= 1 && k.q <= 3) ? -1 : ((k.q >= 5 && k.q <= 7) ? 1 : 0);
+            const int ey = (k.q == 1 || k.q >= 7) ? 1 : ((k.q >= 3 && k.q <= 5) ? -1 : 0);
+            real cx, cy;
+            ring.get_centre(xr - ex, src - ey, cx, cy);
+            const int rel = slot_line(k.gx - ex, k.gy - ey, ex, ey, cx, cy) + S.half;
+            if ((unsigned)rel < (unsigned)S.spd)
+              S.tab[((long)ring.get_id(xr - ex, src - ey) * 8 + (k.q - 1)) * S.spd + rel] = k.own_qo + out;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        pend = 0;
+      }
+#undef MARCH_HAZ
+#undef MARCH_LINK
+#undef MARCH_SRC
+      MT(5)
+    }
+    // row x-1 is no longer needed: its ring slot takes the owner records of row x+3; then request
+    // those of row x+4 (consumed at this point of the next iteration)
+    // (the records stay in registers until the pair's pass has read rows x-2 .. x+1 of the ring: two rows enter it at once)
+    if constexpr (SECOND) {
+      ring.put(x + 2, lane, rec_next, iE);   // row (x-1) + 3
+      ring.put(x + 3, lane, rec_odd, iF);    // row x + 3
+      rec_next = grain_rec(inext);           // row x + 4: the next pair's first
+    } else {
+      rec_odd = grain_rec(inext);            // row x + 4
+    }
+    // rotate
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { Fm[q] = F0[q]; F0[q] = Fp[q]; }
+    iB = iC; iC = iD; iD = iE; iE = iF;
+    solB = solC; solC = solD; solD = solE; solE = sol_of(iF);
+    hmC = hmD; hmD = hmE; hmE = hmax_of(iF);
+    actM = act0; act0 = actP;
+    MT(6)
+  };
+
+  // Both halves run unconditionally (a row >= xe stores nothing): with `if (x + 1 < xe)` around the second one the
+  // compiler cannot count its loads as younger than the first half's when it places s_waitcnt at the loop head, and
+  // waits for more of the pipeline than the data it needs (vmcnt(4) instead of vmcnt(9); 1.5-2 % of the kernel).
+  for (int x = xs; x < xe; x += 2) {
+    iterate(x, bufA, std::false_type{});
+    iterate(x + 1, bufB, std::true_type{});
+  }
+  MT_FLUSH
+}
+
 template <int LX, int MINW, int WW, bool CHG = false>
 __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__ fin, real* __restrict__ fout,
                                                   const int* __restrict__ ob_old,
@@ -191,295 +622,27 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
     // launch covers the two edge-row ranges of a strip
     xs = L.xo0 + seg * seg_stride;
   }
-  (void)w;   // (the experiment build's row trace indexes its buffer with it)
-  // WW producing lanes in the middle of the window, (64 - WW) / 2 feeding lanes on either side
-  constexpr int OFF = (64 - WW) / 2;
-  const int y = strip * WW - OFF + lane;
-  const bool yin = y >= 0 && y < L.ly;
-  const bool writer = lane >= OFF && lane < OFF + WW && yin;
-  const bool deep_y = strip * WW >= 2 && strip * WW + WW - 1 <= L.ly - 3;  // the producing lanes
-  const int xe = xs + rows_per_wave < L.xo1 ? xs + rows_per_wave : L.xo1;
-
-  // Software pipeline. In iteration x (producing row x) the wave issues, in this order,
-  //   (1) small gathers: new ids of row x+4, previous-map id of row x+4, the record of the grain that
-  //       owned (x+2, y) before (reinit of row x+2), the record of the grain that owns (x+3, y) now
-  //   (2) the nine populations of row x+3 into the row buffer it has just consumed (two buffers,
-  //       ping-pong, loop unrolled by two: no register copies, so the loads stay in flight for two
-  //       iterations)
-  //   (3) the nine stores of row x.
-  // gfx9 retires vector-memory operations in issue order (one vmcnt counter), so data must be consumed
-  // in the order it was requested; no other global load exists inside the loop.
+  // (the item is the wavefront's: window, rows and everything derived from them live in scalar registers)
+  strip = __builtin_amdgcn_readfirstlane(strip);
+  xs = __builtin_amdgcn_readfirstlane(xs);
+  const int xe = __builtin_amdgcn_readfirstlane(xs + rows_per_wave < L.xo1 ? xs + rows_per_wave : L.xo1);
   __shared__ real2 sRec[4 * REC_RING * 4 * 64];
-  const RecRing ring{sRec + (threadIdx.x >> 6) * (REC_RING * 4 * 64)};
+  __shared__ int sRid[4 * REC_RING * 64];
+  const RecRing ring{sRec + (threadIdx.x >> 6) * (REC_RING * 4 * 64), sRid + (threadIdx.x >> 6) * (REC_RING * 64)};
   // wave-private scratch for the compacted bounce-back evaluation: 64 link slots
   // (Round 3 measured a spare 65th slot that lanes without a link write to, instead of sitting out the writes under an
   // exec mask: eight mask round trips per row less, but 12 B of scratch and twice the scalar spill reloads: +1.7 %.)
-  constexpr int LINK_SLOTS = 64;
   __shared__ real sPay[4 * LINK_SLOTS * 4];
   __shared__ int sDesc[4 * LINK_SLOTS];
   real* const pay = sPay + (threadIdx.x >> 6) * (LINK_SLOTS * 4);
   int* const desc = sDesc + (threadIdx.x >> 6) * LINK_SLOTS;
-  const real wc_diag = L.wc_diag, wc_axis = L.wc_axis;  // kernel arguments: scalar registers
-  auto row_ok = [&](int xl) { return yin && xl >= 0 && xl < L.nxl; };
-  const int ycl = y < 0 ? 0 : (y >= L.ly ? L.ly - 1 : y);
-  auto node_of = [&](int xl) {  // clamped: always a valid address
-    const int xc = xl < 0 ? 0 : (xl >= L.nxl ? L.nxl - 1 : xl);
-    return (long)xc * L.sy + ycl;
-  };
-  // unconditional (clamped address): every use is guarded by interior(xl), and grain_rec clamps the
-  // id. (A `row_ok ? v : -1` select here makes the compiler sink the load into a branch followed by
-  // s_waitcnt vmcnt(0), which drains the whole prefetch pipeline once per iteration.)
-  // The previous map's ids. With an ObstChange (CHG: the launch of a whole single-domain step after a rasterisation in
-  // place) the wave knows the rows of its window in which the two maps differ -- a few per cent of them -- and takes the id
-  // from the current map, which it holds anyway, everywhere else: the second map's 4 bytes per node were 2.2 % of the
-  // kernel's traffic. The load stays in the instruction stream for every row (the in-order vmcnt bookkeeping of the
-  // prefetch pipeline must not depend on data; under a branch it cost more than it saved): a buffer load whose offset
-  // lies beyond the resource's records returns 0 and moves nothing. The rows a wave asks for are consecutive (xs - 1,
-  // xs, ...): their bits sit in a 64-bit shift register in scalar registers, lowest bit = the next row, ones shifted in
-  // (rows beyond the 64th are read from both maps).
-  unsigned long long cm = ~0ull;
-  // (the resource starts at the wave's first row: 32-bit offsets whatever the size of the map)
-  const int old_row0 = CHG ? __builtin_amdgcn_readfirstlane(xs - 1 < 0 ? 0 : xs - 1) : 0;
-  const long old_left = (long)(L.nxl - old_row0) * L.sy * 4;
-  const __amdgpu_buffer_rsrc_t old_rs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<int*>(ob_old + (long)old_row0 * L.sy), 0, old_left < 0x7FFFFFF0L ? (int)old_left : 0x7FFFFFF0, 0x00020000);
-  const int old_col = (ycl - old_row0 * L.sy) * 4;
-  if (CHG) {
-    const int r0 = xs - 1, first = r0 < 0 ? 0 : r0;
-    const unsigned* wp = CH.bits + (long)strip * CH.words + (first >> 5);   // (a window's words are padded by four)
-    const unsigned w0 = __builtin_amdgcn_readfirstlane(wp[0]), w1 = __builtin_amdgcn_readfirstlane(wp[1]);
-    const unsigned w2 = __builtin_amdgcn_readfirstlane(wp[2]);
-    const int sh = __builtin_amdgcn_readfirstlane(first & 31);
-    cm = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
-    if (sh) cm = (cm >> sh) | ((unsigned long long)w2 << (64 - sh));
-    if (r0 < 0) cm <<= 1;   // row -1 is never used
-  }
-  auto load_old = [&](int xl, int same) {
-    if (!CHG) return ob_old[node_of(xl)];
-    const int keep = (cm & 1ull) ? 0 : -1;   // scalar: -1 = the maps agree in this row
-    cm = (cm >> 1) | (1ull << 63);
-    const int xcl = xl < 0 ? 0 : (xl >= L.nxl ? L.nxl - 1 : xl);
-    // (offset bit 31: beyond the resource's < 2^31 bytes, and far from wrapping round in the range check)
-    const int v = __builtin_amdgcn_raw_buffer_load_b32(old_rs, (xcl * L.sy * 4 + old_col) | (keep & (int)0x80000000), 0, 0);
-    return v | (same & keep);
-  };
-#if defined(LBMDEM_AB) && defined(MARCH_NO_OLD)   /* timing experiment (wrong where the maps differ): the second map is not read */
-#define MARCH_OLD(xl, same) (same)
-#else
-#define MARCH_OLD(xl, same) load_old(xl, same)
-#endif
-  // off-lattice positions load a clamped neighbour's values; they are never used (pull_one tests the
-  // bounds of the source node before touching its populations)
-  auto load_raw = [&](int xl, real (&raw)[9]) {
-    const long fb = fbase_xy(L, xl < 0 ? 0 : (xl >= L.nxl ? L.nxl - 1 : xl), ycl);
-#pragma unroll
-#if defined(LBMDEM_AB) && defined(MARCH_NT_LOADS)   /* experiment: stream the populations past the L2's retention */
-    for (int q = 0; q < 9; ++q) raw[q] = __builtin_nontemporal_load(&fin[fb + q * F_QSTRIDE(L)]);
-#else
-    for (int q = 0; q < 9; ++q) raw[q] = fin[fb + q * F_QSTRIDE(L)];
-#endif
-  };
-  auto interior = [&](int xl) {
-    const int gx = L.gx0 + xl;
-    return row_ok(xl) && gx >= 1 && gx <= L.lx - 2 && y >= 1 && y <= L.ly - 2;
-  };
-  // f* of one node: reinit (previous map) + collide (current map)
-  auto make_fstar = [&](int xl, real (&f)[9], int oo, const GP& g, int on) {
-    const bool in = interior(xl);
-    if (in && oo != -1) grain_equilibrium(L, g, L.gx0 + xl, y, f);
-    if (in && on == -1) mrt_collide(L, f);
-  };
-  auto grain_rec = [&](int id) { return load_gp(G, (id < 0 || id >= L.n) ? 0 : id); };
-
-  real Fm[9], F0[9], Fp[9], bufA[9], bufB[9];
-
-  Ids3 iA = load_ids(ob_new, L, xs - 2, y);  // row x-2 (only needed for act of row x-1)
-  Ids3 iB = load_ids(ob_new, L, xs - 1, y);  // row x-1
-  Ids3 iC = load_ids(ob_new, L, xs, y);      // row x
-  Ids3 iD = load_ids(ob_new, L, xs + 1, y);  // row x+1
-  Ids3 iE = load_ids(ob_new, L, xs + 2, y);  // row x+2
-  {
-    int oo = MARCH_OLD(xs - 1, iB.c);
-#if defined(LBMDEM_AB) && defined(MARCH_NO_HALO_ROWS)   /* timing experiment (wrong results): the two rows a segment shares with its neighbours are not read */
-    load_raw(xs, Fm);
-#else
-    load_raw(xs - 1, Fm);
-#endif
-    make_fstar(xs - 1, Fm, oo, grain_rec(oo), iB.c);
-    oo = MARCH_OLD(xs, iC.c);
-    load_raw(xs, F0);
-    make_fstar(xs, F0, oo, grain_rec(oo), iC.c);
-  }
-  // records of the current owners of rows x-1 .. x+2 into the ring
-  ring.put(xs - 1, lane, grain_rec(iB.c));
-  ring.put(xs, lane, grain_rec(iC.c));
-  ring.put(xs + 1, lane, grain_rec(iD.c));
-  ring.put(xs + 2, lane, grain_rec(iE.c));
-  Ids3 inext = load_ids(ob_new, L, xs + 3, y);
-  int oo1 = MARCH_OLD(xs + 1, iD.c);   // previous-map ids of rows x+1, x+2, x+3
-  int oo2 = MARCH_OLD(xs + 2, iE.c);
-  int oo3 = MARCH_OLD(xs + 3, inext.c);
-  GP gre = grain_rec(oo1);      // reinit record for row x+1
-  GP rec_next = grain_rec(inext.c);  // owner record of row x+3, goes into the ring next iteration
-  load_raw(xs + 1, bufA);
-  load_raw(xs + 2, bufB);
-  bool actm = iB.c != -1 && node_active(L, G, iA, iB, iC, L.gx0 + xs - 1, y, [&] { return ring.get(xs - 1, lane); });
-  bool act0 = iC.c != -1 && node_active(L, G, iB, iC, iD, L.gx0 + xs, y, [&] { return ring.get(xs, lane); });
-
-  MT_DECL
-  // one iteration; `buf` holds row x+1 on entry and is refilled with row x+3
-  auto iterate = [&](int x, real (&buf)[9]) {
-    MT(7)   // loop head
-#pragma unroll
-    for (int q = 0; q < 9; ++q) Fp[q] = buf[q];
-#ifdef MARCH_TIMING   /* phase 0 = the wait for the row's populations alone */
-#pragma unroll
-    for (int q = 0; q < 9; ++q) asm volatile("" ::"v"(Fp[q]));
-    MT(0)
-#endif
-    make_fstar(x + 1, Fp, oo1, gre, iD.c);
-    MT(1)
-    const Ids3 iF = inext;  // row x+3
-    // ---- (1) small gathers
-    oo1 = oo2;
-    oo2 = oo3;
-    gre = grain_rec(oo1);                      // reinit record of row x+2
-    inext = load_ids(ob_new, L, x + 4, y);
-    oo3 = MARCH_OLD(x + 4, inext.c);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- (2) the big loads: populations of row x+3
-    // (rows beyond xe are never consumed: the last two prefetches of a segment re-request row xe, which the wave loaded
-    // one or two iterations ago, instead of two new rows -- 2 of the 36 rows a 32-row segment would read, 2 of 12 for 8 rows;
-    // the loads stay unconditional so that the in-order vmcnt bookkeeping of the pipeline does not change)
-#if defined(LBMDEM_AB) && defined(MARCH_NO_HALO_ROWS)
-    load_raw(x + 3 < xe ? x + 3 : xe - 1, buf);
-#else
-    load_raw(x + 3 < xe ? x + 3 : xe, buf);
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-    MT(2)
-    // (the column re-declared opaque: otherwise (double)(y - 1), (double)y, (double)(y + 1) of node_active's rare path are
-    // hoisted out of the loop into six registers the kernel does not have, and one pair ends up in scratch -- whose reload
-    // drains the row prefetch)
-    int y_act = y;
-    asm volatile("" : "+v"(y_act));
-    const bool actp = iD.c != -1 && node_active(L, G, iC, iD, iE, L.gx0 + x + 1, y_act, [&] { return ring.get(x + 1, lane); });
-    MT(3)
-
-    RegCtx C;
-    C.ring = ring;
-    C.row = x;
-    C.lane = lane;
-#pragma unroll
-    for (int q = 0; q < 9; ++q) C.Fo[q] = F0[q];
-    C.In[0] = 0.0;
-    C.In[2] = Fm[6];            // (-1, 0): same lane, row x-1, slot opp(2) = 6
-    C.In[6] = Fp[2];            // ( 1, 0)
-    C.In[1] = shfl_dn1(Fm[5]);  // (-1, 1): lane+1, row x-1, slot 5
-    C.In[8] = shfl_dn1(F0[4]);  // ( 0, 1)
-    C.In[7] = shfl_dn1(Fp[3]);  // ( 1, 1)
-    C.In[3] = shfl_up1(Fm[7]);  // (-1,-1): lane-1
-    C.In[4] = shfl_up1(F0[8]);  // ( 0,-1)
-    C.In[5] = shfl_up1(Fp[1]);  // ( 1,-1)
-    C.o0 = iC.c;
-    C.onb[0] = 0;
-    C.onb[1] = iB.p; C.onb[2] = iB.c; C.onb[3] = iB.m; C.onb[4] = iC.m;
-    C.onb[5] = iD.m; C.onb[6] = iD.c; C.onb[7] = iD.p; C.onb[8] = iC.p;
-    const int pack = (actm ? 1 : 0) | (act0 ? 2 : 0) | (actp ? 4 : 0);  // rows x-1, x, x+1 of this lane
-    const int pk_up = shfl_dn1(pack);                                  // lane+1 (y+1)
-    const int pk_dn = shfl_up1(pack);                                  // lane-1 (y-1)
-    C.act = (((pk_up >> 0) & 1u) << 1) | (((pack >> 0) & 1u) << 2) | (((pk_dn >> 0) & 1u) << 3) |
-            (((pk_dn >> 1) & 1u) << 4) | (((pk_dn >> 2) & 1u) << 5) | (((pack >> 2) & 1u) << 6) |
-            (((pk_up >> 2) & 1u) << 7) | (((pk_up >> 1) & 1u) << 8);
-    {
-      const int gx = L.gx0 + x;
-      const long fb_row = fbase_xy(L, x, y);   // (only used by the producing lanes: y is on the lattice there)
-      // wave-uniform: is every producing lane of this row at least two nodes away from all edges?
-      const bool deep = deep_y && gx >= 2 && gx <= L.lx - 3;
-      // (a) everything but the interpolated bounce-back links: computed and stored
-      unsigned ibb = 0, nnm = 0, hzm = 0;
-      if (writer && x < xe) {
-        if (deep) classify_store_row_deep(C, L, fout, fb_row, ibb, nnm, hzm);
-        else classify_store_row<true>(C, L, gx, y, fout, fb_row, ibb, nnm, hzm);
-      }
-      MT(4)
-      // (b) the bounce-back links of the whole row (typically ~20, spread over all eight directions
-      // and a few lanes) are compacted into dense lanes through LDS and evaluated in ONE pass with the
-      // direction as data, instead of ~3.5 direction-specific divergent passes of ~130 instructions.
-      // slot of link (lane, q) = number of links in directions < q + number in direction q on lower lanes
-      int T = 0;
-#pragma unroll
-      for (int q = 1; q < 9; ++q) T += __popcll(__ballot((ibb >> q) & 1u));
-      for (int base = 0; base < T; base += 64) {  // wave-uniform; a second round only if > 64 links
-        int before = 0;
-#pragma unroll
-        for (int q = 1; q < 9; ++q) {
-          const unsigned long long b = __ballot((ibb >> q) & 1u);
-          const int t = before + (int)mbcnt(b) - base;
-          before += __popcll(b);
-          if (((ibb >> q) & 1u) && t >= 0 && t < 64) {
-            // bits 14..31: the grain that owns S = P - e_q (the slot table is only used with < 2^18 grains)
-            desc[t] = lane | (q << 8) | (((nnm >> q) & 1u) << 12) | (((hzm >> q) & 1u) << 13) | (C.onb[OPPq(q)] << 14);
-            pay[t * 4 + 0] = C.Fo[OPPq(q)];
-            pay[t * 4 + 1] = C.Fo[q];
-            pay[t * 4 + 2] = C.In[q];
-            pay[t * 4 + 3] = C.In[OPPq(q)];
-          }
-        }
-        __builtin_amdgcn_wave_barrier();  // LDS operations of one wave execute in order
-        if (base + lane < T) {
-          const int d = desc[lane];
-          const int src = d & 63;
-          RtLink k;
-          k.q = (d >> 8) & 15;
-          k.gx = gx;
-          k.gy = y - lane + src;
-          k.own_qo = pay[lane * 4 + 0];
-          k.own_q = pay[lane * 4 + 1];
-          k.in_q = pay[lane * 4 + 2];
-          k.in_qo = pay[lane * 4 + 3];
-          k.nn_int = (d >> 12) & 1;
-          k.hazard = (d >> 13) & 1;
-          // the result goes straight to the population it belongs to: node of lane `src`, plane q
-          const real out =
-              ibb_eval_rt(L, k, wc_diag, wc_axis, [&](int dx, int dy) { return ring.get(x + dx, src + dy); });
-          fout[fbase_xy(L, x, k.gy) + k.q * F_QSTRIDE(L)] = out;
-          // ... and the link's momentum-exchange sum f_new[S][opp q] + f_new[P][q] (main.c:1313-1316; the first
-          // is f*[P][opp q], streamed unchanged into the solid node) to the owning grain's slot table
-          if (S.tab != nullptr) {
-            const int ex = (k.q >= 1 && k.q <= 3) ? -1 : ((k.q >= 5 && k.q <= 7) ? 1 : 0);
-            const int ey = (k.q == 1 || k.q >= 7) ? 1 : ((k.q >= 3 && k.q <= 5) ? -1 : 0);
-            real cx, cy;
-            ring.get_centre(x - ex, src - ey, cx, cy);
-            const int rel = slot_line(k.gx - ex, k.gy - ey, ex, ey, cx, cy) + S.half;
-            if ((unsigned)rel < (unsigned)S.spd)
-              S.tab[((long)((unsigned)d >> 14) * 8 + (k.q - 1)) * S.spd + rel] = k.own_qo + out;
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      MT(5)
-    }
-    // row x-1 is no longer needed: its ring slot takes the owner records of row x+3; then request
-    // those of row x+4 (consumed at this point of the next iteration)
-    ring.put(x + 3, lane, rec_next);
-    rec_next = grain_rec(inext.c);
-    // rotate
-#pragma unroll
-    for (int q = 0; q < 9; ++q) { Fm[q] = F0[q]; F0[q] = Fp[q]; }
-    iB = iC; iC = iD; iD = iE; iE = iF;
-    actm = act0; act0 = actp;
-    MT(6)
-  };
-
-  // Both halves run unconditionally (a row >= xe stores nothing): with `if (x + 1 < xe)` around the second one the
-  // compiler cannot count its loads as younger than the first half's when it places s_waitcnt at the loop head, and
-  // waits for more of the pipeline than the data it needs (vmcnt(4) instead of vmcnt(9); 1.5-2 % of the kernel).
-  for (int x = xs; x < xe; x += 2) {
-    iterate(x, bufA);
-    iterate(x + 1, bufB);
-  }
-  MT_FLUSH
+  // Is the whole item -- its 64 columns, its rows and the two rows either side -- interior? (wave-uniform)
+  constexpr int OFF = (64 - WW) / 2;
+  const int y_lo = strip * WW - OFF;
+  const bool inner = y_lo >= 1 && y_lo + 63 <= L.ly - 2 && L.gx0 + xs >= 2 && L.gx0 + xe <= L.lx - 2 && xs >= 2 &&
+                     xe + 2 <= L.nxl;
+  if (inner) march_item<WW, CHG, false>(fin, fout, ob_old, ob_new, L, G, S, CH, strip, xs, xe, ring, pay, desc, lane, w);
+  else march_item<WW, CHG, true>(fin, fout, ob_old, ob_new, L, G, S, CH, strip, xs, xe, ring, pay, desc, lane, w);
 }
 
 }  // namespace

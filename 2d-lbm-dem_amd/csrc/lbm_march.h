@@ -42,6 +42,19 @@ __device__ __forceinline__ Ids3 load_ids(const int* __restrict__ ob, const Latti
   return r;
 }
 
+// the id of (xl, y) alone, same rules; the two column neighbours of a lane are its neighbour lanes' ids (ids3_of)
+// (EDGE = false: the column is on the lattice and the row is one of the slab's, or a row whose ids nobody reads -- the
+// clamp only keeps the address valid)
+template <bool EDGE = true>
+__device__ __forceinline__ int load_id(const int* __restrict__ ob, const LatticeView& L, int xl, int y) {
+  const bool rok = xl >= 0 && xl < L.nxl;
+  const int xc = xl < 0 ? 0 : (xl >= L.nxl ? L.nxl - 1 : xl);
+  if (!EDGE) return ob[(long)xc * L.sy + y];
+  const int cc = y < 0 ? 0 : (y >= L.ly ? L.ly - 1 : y);
+  const int vc = ob[(long)xc * L.sy + cc];
+  return (rok && cc == y) ? vc : L.n;
+}
+
 // `act` of the centre node of a 3x3 block of ids (rows a = x-1, b = x, c = x+1); see Tile::active.
 // `own_rec()` returns the record of the grain that owns the centre node (only called on the rare
 // path where a neighbour belongs to a higher-index grain). Requires reductionR < 1 (then the paint
@@ -94,13 +107,22 @@ __device__ __forceinline__ bool node_active(const LatticeView& L, const GrainFlu
 constexpr int REC_RING = 4;
 struct RecRing {
   real2* base;  // this wave's [REC_RING][4][64] real2
-  __device__ __forceinline__ void put(int row, int lane, const GP& g) const {
+  int* ids;     // this wave's [REC_RING][64]: the grain the record belongs to (the owner of the node)
+  __device__ __forceinline__ void put(int row, int lane, const GP& g, int id) const {
     real2* p = base + (row & (REC_RING - 1)) * 4 * 64 + lane;
     p[0] = make_real2(g.x1, g.x2);
     p[64] = make_real2(g.v1, g.v2);
     p[128] = make_real2(g.v3, g.xc);
     p[192] = make_real2(g.yc, g.r2);
+    ids[(row & (REC_RING - 1)) * 64 + lane] = id;
   }
+  // position and velocities of that record (what reinit_obst_density needs)
+  __device__ __forceinline__ GPv getv(int row, int lane) const {
+    const real2* p = base + (row & (REC_RING - 1)) * 4 * 64 + lane;
+    const real2 a = p[0], b = p[64];
+    return GPv{a.x, a.y, b.x, b.y, p[128].x};
+  }
+  __device__ __forceinline__ int get_id(int row, int lane) const { return ids[(row & (REC_RING - 1)) * 64 + lane]; }
   // only the lattice-unit centre (xc, yc) of that record
   __device__ __forceinline__ void get_centre(int row, int lane, real& xc, real& yc) const {
     const real* p = reinterpret_cast<const real*>(base + (row & (REC_RING - 1)) * 4 * 64 + lane);
@@ -185,6 +207,57 @@ __device__ __forceinline__ void classify_store_row_deep(const Ctx& C, const Latt
   nnm = ibb;
 }
 
+// Buffer resources. The lattices and the maps are addressed as {descriptor in four scalar registers, 32-bit per-lane
+// offset, scalar offset, immediate}: a lane's column offset is loop-invariant (ONE register for all nine populations and all
+// rows), the row is the scalar offset, the direction the immediate -- where a flat 64-bit address per access costs a
+// register pair and three vector instructions. A descriptor starts at the work item's first row, so the offsets stay below
+// 2^31 whatever the size of the lattice.
+typedef __attribute__((ext_vector_type(2))) unsigned int buf_u2;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rs(const void* p, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes < 0x7FFFFFF0L ? (int)bytes : 0x7FFFFFF0, 0x00020000);
+}
+template <int IMM>
+__device__ __forceinline__ real buf_load_real(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+#ifdef LBMDEM_SINGLE_PRECISION
+  return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff + IMM, soff, 0));
+#else
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff + IMM, soff, 0));
+#endif
+}
+template <int IMM>
+__device__ __forceinline__ void buf_store_real(real v, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+#ifdef LBMDEM_SINGLE_PRECISION
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), rs, voff + IMM, soff, 0);
+#else
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(buf_u2, v), rs, voff + IMM, soff, 0);
+#endif
+}
+// byte offset of column y inside a row of populations (direction 0), layout f[x][y / TILE][q][y % TILE]
+__device__ __forceinline__ int fcol_bytes(int y) {
+  return ((y / LBMDEM_TILE_Y) * (9 * LBMDEM_TILE_Y) + (y % LBMDEM_TILE_Y)) * (int)sizeof(real);
+}
+constexpr int F_QBYTES = LBMDEM_TILE_Y * (int)sizeof(real);   // from one direction to the next
+
+// Lane masks. A per-lane boolean of a whole row is ONE wave-uniform 64-bit value in a scalar register pair (bit i = lane
+// i = column y0 + i), and the same boolean of the node one column up or down is that value shifted by one -- so the
+// tests "is the source of this pull a grain node", "is that node active", "has this solid node a fluid neighbour" of a
+// whole row are a handful of scalar instructions (which issue beside the other wavefront's vector instructions) instead
+// of a vector compare per lane, direction and neighbour. lane_of() hands a mask back to the vector unit as a condition
+// (v_cndmask / s_and_saveexec take the register pair as it is: no instruction). Bits shifted in at the window's two end
+// lanes are 0: those lanes only feed their neighbours' populations and ids, nothing reads their flags.
+typedef unsigned long long lmask;
+__device__ __forceinline__ bool lane_of(lmask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+// the mask of the nodes at lane + DY (column y + DY), aligned to this lane
+template <int DY>
+__device__ __forceinline__ lmask m_at(lmask m) { return DY > 0 ? m >> 1 : (DY < 0 ? m << 1 : m); }
+// of three rows x-1, x, x+1 the one at x + DX
+#define MARCH_ROW(DX, B, C, D) ((DX) < 0 ? (B) : ((DX) > 0 ? (D) : (C)))
+// nodes whose eight neighbours are all solid, from the solid masks of the row before, the row itself and the row after
+__device__ __forceinline__ lmask m_enclosed(lmask sa, lmask sb, lmask sc) {
+  const lmask ha = (sa >> 1) & sa & (sa << 1), hc = (sc >> 1) & sc & (sc << 1);
+  return ha & hc & (sb >> 1) & (sb << 1);
+}
+
 // the neighbour lanes' values of a pull: full-wave DPP shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1, GFX9) -- no LDS
 // round trip, no address registers; lane i <- lane i-1 / lane i+1, the end lane keeps its value. DPP reads nothing from
 // a lane that is switched off: only call these in wave-uniform control flow.
@@ -201,9 +274,27 @@ __device__ __forceinline__ real dpp_dn1(real v) {
   return __hiloint2double(dpp_dn1(__double2hiint(v)), dpp_dn1(__double2loint(v)));
 }
 #endif
+// (the same shifts with bound_ctrl: the end lane gets 0 instead of keeping its value -- the destination then needs no
+// copy of the source first; for the populations, whose end lanes' shifted values nobody reads)
+__device__ __forceinline__ int dpp_up1z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int dpp_dn1z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
+#ifdef LBMDEM_SINGLE_PRECISION
+__device__ __forceinline__ real shfl_up1z(real v) { return __int_as_float(dpp_up1z(__float_as_int(v))); }
+__device__ __forceinline__ real shfl_dn1z(real v) { return __int_as_float(dpp_dn1z(__float_as_int(v))); }
+#else
+__device__ __forceinline__ real shfl_up1z(real v) {
+  return __hiloint2double(dpp_up1z(__double2hiint(v)), dpp_up1z(__double2loint(v)));
+}
+__device__ __forceinline__ real shfl_dn1z(real v) {
+  return __hiloint2double(dpp_dn1z(__double2hiint(v)), dpp_dn1z(__double2loint(v)));
+}
+#endif
 __device__ __forceinline__ real shfl_up1(real v) { return dpp_up1(v); }
 __device__ __forceinline__ real shfl_dn1(real v) { return dpp_dn1(v); }
 __device__ __forceinline__ int shfl_up1(int v) { return dpp_up1(v); }
 __device__ __forceinline__ int shfl_dn1(int v) { return dpp_dn1(v); }
+// a row's ids at (y-1, y, y+1) from the lanes' own ids (wave-uniform control flow only); the window's two end lanes see
+// their own id beyond the window -- they only feed their neighbours, nothing reads what is derived from it
+__device__ __forceinline__ Ids3 ids3_of(int c) { return Ids3{dpp_up1(c), c, dpp_dn1(c)}; }
 
 }  // namespace
