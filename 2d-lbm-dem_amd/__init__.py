@@ -130,6 +130,10 @@ def _open_library(LIB_PATH):
     L.lbmdem_set_force_mode.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_set_dem_chain.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_dem_chain_paints.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+    if hasattr(L, "lbmdem_dem_chain_recoveries"):   # (older builds kept for A/B runs do not have it)
+        L.lbmdem_dem_chain_recoveries.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+    if hasattr(L, "lbmdem_debug_chain_giveup"):   # experiment build only
+        L.lbmdem_debug_chain_giveup.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_set_obst_update.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_obst_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
     L.lbmdem_set_change_mask.argtypes = [C.c_void_p, C.c_int]
@@ -552,6 +556,16 @@ class LbmDem:
         a = C.c_long(0)
         _chk(self._L.lbmdem_dem_chain_paints(self._h, C.byref(a)))
         return a.value
+
+    def dem_chain_recoveries(self):
+        """launches of the multi-sub-step kernel that gave up and were undone (the run went on one launch per sub-step)"""
+        a = C.c_long(0)
+        _chk(self._L.lbmdem_dem_chain_recoveries(self._h, C.byref(a)))
+        return a.value
+
+    def debug_chain_giveup(self, launch):
+        """experiment build: the launch of the multi-sub-step kernel with this number (from 0) gives up half way"""
+        _chk(self._L.lbmdem_debug_chain_giveup(self._h, int(launch)))
 
     def force_stats(self):
         """(grains summed from the fused kernel's link table, grains gathered from the lattice) of the last

@@ -193,6 +193,7 @@ __global__ void k_dem_substep(Kin in, Kin out, const real* __restrict__ r, const
                               const int* __restrict__ offsets, const int* __restrict__ nbr,
                               const unsigned char* __restrict__ wallflags, real* __restrict__ pout,
                               DiagOut D, DemParams P, const unsigned char* __restrict__ active) {
+  LBMDEM_GATE(P.gate);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
   if (active && !active[i]) { carry_over(in, out, i); return; }  // strip decomposition: a grain another rank integrates
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(DEM_THREADS) void k_dem_entries(Kin in, Kin out, co
                                                      const unsigned char* __restrict__ active, CarryTrack T,
                                                      long long stamp, const unsigned char* __restrict__ owner,
                                                      ObstFillJob fill, int tiles) {
+  LBMDEM_GATE(P.gate);
   __shared__ real sF1[DEM_ENTRIES], sF2[DEM_ENTRIES], sF3[DEM_ENTRIES], sFn[DEM_ENTRIES];
   __shared__ unsigned char sTouched[DEM_ENTRIES];
   __shared__ int sLast;   // highest list entry of this tile that is a touching contact in the reference's frame
@@ -431,17 +433,24 @@ __global__ __launch_bounds__(DEM_THREADS) void k_dem_entries(Kin in, Kin out, co
 //     version, profiles/r05_dem_chain_ab.txt). Tiles are laid out in contiguous eighths per XCD (block b runs on XCD
 //     b % 8 -- observed, not promised), so nearly all partners of a tile run on its own XCD, whose L2 IS coherent for
 //     them: the LOCAL copy is written with plain stores (they stay in that L2) and read with L1-bypassing loads (L2 hits),
-//     the REMOTE copy is written through to memory (sc1) for the readers on other XCDs. A reader picks the copy by the
-//     XCD the partner's tile is expected on, and switches an item to the remote copy when the local one stays stale
-//     (a workgroup that did not land where expected). The tags make a wrong guess slow, never wrong.
+//     the REMOTE copy is written through to memory (sc1) for the readers on other XCDs -- by the tiles that have a partner
+//     in another eighth (tile_far; the list is symmetric, so these are the tiles somebody reads from another eighth). A
+//     reader picks the copy by the XCD the partner's tile is expected on, for staged halo grains and for partners beyond
+//     the staging alike. A workgroup that did not land where expected leaves its readers waiting for a local copy they
+//     cannot see: their bounded spins run out, the launch gives up -- and is undone (below). The tags make a wrong guess
+//     slow, never wrong.
 //   * two parities suffice: a tile overwrites its sub-step s-1 line in sub-step s+1, i.e. after it has read the sub-step s
 //     state of every halo grain, which their tiles published after they had finished reading for sub-step s-1 (the list
 //     is symmetric: whoever reads this tile is read by it).
 //   * the drifted state is computed ONCE, by the owner, with the arithmetic every partner used to repeat (advance()):
 //     same bits. Phase 1 / phase 2 are those of k_dem_entries, fed from LDS.
-// Every spin is bounded; a tile that gives up poisons its lines so that its partners give up at once, and raises the
-// handle's error flag. All workgroups of the tile slots must be resident together (checked once per handle by a census
-// launch of the same kernel, dem_chain_census).
+// Every spin is bounded; a tile that gives up poisons its lines so that its partners give up at once, reports the launch
+// (its first sequence number) to the host and raises the handle's stop word, which every kernel of the step path reads
+// first: whatever is queued behind the launch does nothing, the device keeps the state the launch started from (its input
+// buffers are the other half of the ping-pong), and the host goes back there and repeats the sub-steps one launch each
+// (lbmdem_capi.hip, chain_settle_impl). All workgroups of the tile slots must be resident together -- checked once per
+// handle by a census launch of the same kernel (dem_chain_census), not promised by HIP afterwards: another process on the
+// GPU, a CU mask.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CH_SLOTS = DEM_TILE + DEM_CHAIN_HALO;   // grains staged in LDS: the tile's own, then its halo
@@ -504,7 +513,8 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
                                                            long long stamp0, const unsigned char* __restrict__ owner,
                                                            ObstFillJob fill, int tiles, int nsteps, void* pub,
                                                            unsigned pub_bytes, int* __restrict__ err, int* census,
-                                                           long long* dbg, int flags, ChainPaint paint) {
+                                                           long long* dbg, int flags, ChainPaint paint, int* gate) {
+  LBMDEM_GATE(P.gate);
   __shared__ real sF1[CH_ENTRIES], sF2[CH_ENTRIES], sF3[CH_ENTRIES], sFn[CH_ENTRIES];
   __shared__ unsigned char sTouched[CH_ENTRIES];
   __shared__ real sS[5 * CH_SLOTS];     // drifted x1, x2, v1, v2, v3 of the staged grains, one array per field
@@ -624,6 +634,10 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
   // A tile with a partner on another XCD publishes both copies (only the remote one, for all its readers: measured slower,
   // 137 k against 154 k sub-steps/s -- more tiles then wait for the fabric)
   const bool any_far = !one_xcd && tile_far[tile];
+  // which copy of grain g's lines a reader in THIS tile takes when g is not among the staged halo grains (as sHoff's bit 0)
+  auto direct_copy = [&](int g) -> unsigned {
+    return (!one_xcd && (g / DEM_TILE) / tiles_per_xcd != tile / tiles_per_xcd) ? remote : 0u;
+  };
   GrainState me{};
   me.r = tid < DEM_GRAINS ? sR[tid] : (real)0.;
   // drift + first half kick (main.c:1748-1753) of the sub-step with sequence number `stamp`, published to the partners'
@@ -658,6 +672,9 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
     const long long stamp = stamp0 + s;
     const unsigned tag = chain_tag(stamp);
     const unsigned pbase = (stamp & 1) ? line_par : 0u;
+#ifdef LBMDEM_AB   // lbmdem_debug_chain_giveup (tests): one tile behaves as if a partner never showed up
+    if (((flags >> 17) & 1) && tile == 3 % tiles && s == nsteps / 2 && tid == 0) sFail = 1;
+#endif
     // (the other wavefronts park here while the first one finishes the sub-step before)
     __syncthreads();
     CH_MARK(1);   // barrier A
@@ -688,7 +705,11 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
             }
             ok = ok && g;
           }
-        if (__any(bad) || ++spins > CH_SPINS) { sFail = 1; break; }
+        if (__any(bad) || ++spins > CH_SPINS) {
+#ifdef CHAIN_DEBUG_PRINT
+          if ((tid & 63) == 0) printf("tile %d s %d: halo fetch gave up, bad %d spins %u first %d\n", tile, s, (int)__any(bad), spins, first);
+#endif
+          sFail = 1; break; }
 #ifdef LBMDEM_CHAIN_TIMING
         ++n_spins;
 #endif
@@ -740,7 +761,15 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
         } else {
           const int gj = nbr[e];
           ChainRead R{};
-          if (!chain_read_direct(rs, remote + pbase + (unsigned)gj * 128u, tag, stag, R)) lost = true;
+          // (the copy its tile is expected to write: the remote one only exists for tiles with a partner in another XCD's
+          // eighth -- which a tile read from another eighth is, the list being symmetric)
+          if (!chain_read_direct(rs, direct_copy(gj) + pbase + (unsigned)gj * 128u, tag, stag, R)) {
+            lost = true;
+#ifdef CHAIN_DEBUG_PRINT
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, direct_copy(gj) + pbase + (unsigned)gj * 128u, 0, 16);
+            printf("tile %d s %d: direct read of grain %d (tile %d) lost: tags %u %u want %u copy %u\n", tile, s, gj, gj / DEM_TILE, v.y, v.w, tag, direct_copy(gj));
+#endif
+          }
           b.x1 = R.x1; b.x2 = R.x2; b.v1 = R.v1; b.v2 = R.v2; b.v3 = R.v3; b.r = r[gj];
         }
         bool touched;
@@ -847,7 +876,12 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
         chain_publish<16>(rs, remote + par * line_par + (unsigned)i * 128u, CH_POISON, 0., 0., 0., 0., 0.);
       }
     }
-    if (tid == 0) *err = 1;
+    if (tid == 0) {
+      // the launch's first sequence number (the host's key to the state before the launch), and the stop word: every
+      // kernel queued behind this launch returns at once
+      *err = (int)((unsigned long long)stamp0 & 0x3FFFFFFFull) + 1;
+      if (gate) __hip_atomic_store(gate, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     return;
   }
   if (paint.obst) {
@@ -906,7 +940,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
       const unsigned w = (k - e0 < CH_META) ? sMeta[k - e0] : emeta[k];
       const unsigned slot = w >> 8;
       if (slot != DEM_CHAIN_DIRECT) { jx = sS[slot]; jy = sS[CH_SLOTS + slot]; return true; }
-      const unsigned off = remote + ((stamp_l & 1) ? line_par : 0u) + (unsigned)nbr[k] * 128u;
+      const unsigned off = direct_copy(nbr[k]) + ((stamp_l & 1) ? line_par : 0u) + (unsigned)nbr[k] * 128u;
       return chain_read_slot(rs, off, chain_tag(stamp_l), stag, jx) && chain_read_slot(rs, off + 16u, chain_tag(stamp_l), stag, jy);
     };
     // alone: clear of the discs of all partners -- 1.5 nodes for a fresh picture (k_obst_paint's test); in place: this disc
@@ -1150,6 +1184,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
 // carries exactly before the next diagnostic sub-step.
 
 __global__ __launch_bounds__(1024) void k_diag_scan(DiagExtra X, const int* __restrict__ offsets, int n, real kt) {
+  LBMDEM_GATE(X.gate);
   __shared__ real sFt[1024], sF3[1024];
   __shared__ unsigned char sHas[1024];
   const int t = threadIdx.x;
@@ -1181,6 +1216,7 @@ __global__ __launch_bounds__(1024) void k_diag_scan(DiagExtra X, const int* __re
 
 template <bool FILM>
 __global__ void k_diag_accum(DiagExtra X, const int* __restrict__ offsets, const int* __restrict__ nbr, int n) {
+  LBMDEM_GATE(X.gate);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   real slip = 0., rw = 0.;
@@ -1203,6 +1239,7 @@ __global__ void k_diag_accum(DiagExtra X, const int* __restrict__ offsets, const
 
 // wall candidate lists in grain order (VerletWall, main.c:1563-1593): wave w builds list w
 __global__ __launch_bounds__(256) void k_diag_wall_lists(DiagExtra X, const unsigned char* __restrict__ wallflags, int n) {
+  LBMDEM_GATE(X.gate);
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const unsigned long long lt = (1ull << lane) - 1ull;
   int cnt = 0;
@@ -1217,6 +1254,7 @@ __global__ __launch_bounds__(256) void k_diag_wall_lists(DiagExtra X, const unsi
 }
 
 __global__ void k_diag_walls(DiagExtra X, Kin in, const real* __restrict__ r, DemParams P) {
+  LBMDEM_GATE(P.gate);
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   const int n = P.n;
   real pft = X.carry[0], pff = X.carry[1], pf = X.carry[2], ic = 0.0;  // ic: reset every sub-step (main.c:1743)
@@ -1299,6 +1337,7 @@ __global__ void k_diag_walls(DiagExtra X, Kin in, const real* __restrict__ r, De
 // The carries as the reference holds them now: per carry the youngest record among the kinds that assign it, in
 // program order (sub-step, then grain contacts < bottom < left < right wall, then grain index = tile).
 __global__ __launch_bounds__(256) void k_carry_resolve(CarryTrack T, long long min_stamp) {
+  LBMDEM_GATE(T.gate);
   __shared__ unsigned long long best[3];
   if (threadIdx.x < 3) best[threadIdx.x] = 0ull;
   __syncthreads();
@@ -1351,7 +1390,8 @@ __device__ __forceinline__ int cell_coord(real x, real o, real cs, int nc) {
 __global__ void k_cell_count(int n, const real* __restrict__ x1, const real* __restrict__ x2, real ox,
                              real oy, real cs, int ncx, int ncy, unsigned int* __restrict__ keys,
                              int* __restrict__ rank, int* __restrict__ cell_cnt, real* __restrict__ xreb,
-                             real* __restrict__ yreb) {
+                             real* __restrict__ yreb, const int* __restrict__ gate) {
+  LBMDEM_GATE(gate);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   xreb[i] = x1[i]; yreb[i] = x2[i];   // where the list found the grain: how far it has moved since decides whether the list still holds every close pair (k_obst_update)
@@ -1362,7 +1402,8 @@ __global__ void k_cell_count(int n, const real* __restrict__ x1, const real* __r
 
 __global__ void k_cell_scatter(int n, const unsigned int* __restrict__ keys, const int* __restrict__ rank,
                                const int* __restrict__ cell_start, int* __restrict__ cell_cnt,
-                               int* __restrict__ sorted) {
+                               int* __restrict__ sorted, const int* __restrict__ gate) {
+  LBMDEM_GATE(gate);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned c = keys[i];
@@ -1399,6 +1440,7 @@ __global__ void k_verlet_scan(int n, const real* __restrict__ x1, const real* __
                               const int* __restrict__ sorted, real dV, int* __restrict__ counts,
                               int* __restrict__ offsets, int* __restrict__ nbr, int* __restrict__ own,
                               long cap, int* __restrict__ overflow, DemParams P, unsigned char* __restrict__ wallflags) {
+  LBMDEM_GATE(P.gate);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const real xi = x1[i], yi = x2[i], ri = r[i];
@@ -1453,7 +1495,8 @@ __global__ void k_verlet_scan(int n, const real* __restrict__ x1, const real* __
 }
 
 // owner of every list entry, from the offsets (after a checkpoint load; k_verlet_scan<1> writes it directly)
-__global__ void k_fill_own(int n, const int* __restrict__ offsets, int* __restrict__ own) {
+__global__ void k_fill_own(int n, const int* __restrict__ offsets, int* __restrict__ own, const int* __restrict__ gate) {
+  LBMDEM_GATE(gate);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   for (int k = offsets[i]; k < offsets[i + 1]; ++k) own[k] = i;
@@ -1465,7 +1508,9 @@ __global__ void k_fill_own(int n, const int* __restrict__ offsets, int* __restri
 __global__ __launch_bounds__(256) void k_tile_halo(int n, const int* __restrict__ offsets, const int* __restrict__ nbr,
                                                    const int* __restrict__ own, int* __restrict__ halo_ids,
                                                    int* __restrict__ halo_cnt, unsigned* __restrict__ emeta,
-                                                   unsigned char* __restrict__ tile_far, int tiles_per_xcd) {
+                                                   unsigned char* __restrict__ tile_far, int tiles_per_xcd,
+                                                   const int* __restrict__ gate) {
+  LBMDEM_GATE(gate);
   constexpr int CELLS = 1024;
   __shared__ int table[CELLS], cidx[CELLS];
   __shared__ int wsum[4];
@@ -1622,14 +1667,14 @@ int launch_verlet_rebuild(VerletDevice& V, const Kin& K, const real* r, const De
   // 9 dependent launches (20 before the counting sort and the folded offset / wall-flag kernels: a rebuild is launch
   // latency, 130 us per 100 DEM steps for a few us of work)
   hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, V.ox, V.oy, V.cs, V.ncx, V.ncy,
-                     V.keys_in, V.vals_in, V.cell_end, V.xreb, V.yreb);
+                     V.keys_in, V.vals_in, V.cell_end, V.xreb, V.yreb, V.gate);
   e = hipcub::DeviceScan::ExclusiveSum(V.scan_tmp, V.scan_tmp_bytes, V.cell_end, V.cell_start, (int)(ncell + 1), st);
   if (e != hipSuccess) {   // k_cell_scatter, which returns the counts to zero for the next rebuild, will not run
     (void)hipMemsetAsync(V.cell_end, 0, sizeof(int) * (ncell + 1), st);
     return (int)e;
   }
   hipLaunchKernelGGL(k_cell_scatter, dim3(nb), dim3(256), 0, st, n, V.keys_in, V.vals_in, V.cell_start, V.cell_end,
-                     V.vals_out);
+                     V.vals_out, V.gate);
   hipLaunchKernelGGL(k_verlet_scan<0>, dim3(nb), dim3(256), 0, st, n, K.x1, K.x2, r, V.ox, V.oy, V.cs, V.ncx,
                      V.ncy, V.cell_start, V.vals_out, P.distVerlet, V.counts, V.offsets, V.nbr,
                      V.own, V.cap, V.overflow, P, V.wallflags);
@@ -1682,7 +1727,7 @@ void launch_diag_extra(const DiagExtra& X, const Kin& in, const real* r, const V
 }
 
 void launch_fill_own(const VerletDevice& V, int n, hipStream_t st) {
-  hipLaunchKernelGGL(k_fill_own, dim3((n + 255) / 256), dim3(256), 0, st, n, V.offsets, V.own);
+  hipLaunchKernelGGL(k_fill_own, dim3((n + 255) / 256), dim3(256), 0, st, n, V.offsets, V.own, V.gate);
 }
 
 void launch_dem_substep(const Kin& in, const Kin& out, const real* r, const real* m,
@@ -1734,7 +1779,7 @@ void launch_dem_substep(const Kin& in, const Kin& out, const real* r, const real
 void launch_tile_halo(const VerletDevice& V, int n, hipStream_t st) {
   const int tiles = (n + DEM_TILE - 1) / DEM_TILE;
   hipLaunchKernelGGL(k_tile_halo, dim3(tiles), dim3(256), 0, st, n, V.offsets, V.nbr, V.own, V.halo_ids, V.halo_cnt, V.emeta,
-                     V.tile_far, dem_chain_tslots(n) >> 3);
+                     V.tile_far, dem_chain_tslots(n) >> 3, V.gate);
 }
 
 int dem_chain_tslots(int n) { return DEM_GRID((n + DEM_GRAINS - 1) / DEM_GRAINS); }
@@ -1746,6 +1791,7 @@ int dem_chain_alloc(DemChain& C, int n) {
   if (hipMalloc(&C.pub, bytes ? bytes : 128) != hipSuccess) return -1;
   C.pub_bytes = bytes;
   if (hipMalloc((void**)&C.census, 4 * sizeof(int)) != hipSuccess) { dem_chain_free(C); return -1; }   // counter, pad, 64-bit placement map
+  if (hipMalloc((void**)&C.gate, sizeof(int)) != hipSuccess || hipMemset(C.gate, 0, sizeof(int)) != hipSuccess) { dem_chain_free(C); return -1; }
   if (hipHostMalloc((void**)&C.err_host, sizeof(int), hipHostMallocDefault) != hipSuccess) { dem_chain_free(C); return -1; }
   *C.err_host = 0;
   if (hipHostGetDevicePointer((void**)&C.err, (void*)C.err_host, 0) != hipSuccess) { dem_chain_free(C); return -1; }
@@ -1757,6 +1803,7 @@ int dem_chain_alloc(DemChain& C, int n) {
 void dem_chain_free(DemChain& C) {
   if (C.pub) (void)hipFree(C.pub);
   if (C.census) (void)hipFree(C.census);
+  if (C.gate) (void)hipFree(C.gate);
   if (C.err_host) (void)hipHostFree((void*)C.err_host);
   C = DemChain{};
 }
@@ -1776,7 +1823,7 @@ int dem_chain_census(DemChain& C, int tslots, hipStream_t st) {
   *C.err_host = 0;
   hipLaunchKernelGGL(k_dem_chain, dim3(tslots), dim3(DEM_THREADS), 0, st, Kin{}, Kin{}, nullptr, nullptr, nullptr, nullptr,
                      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, DemParams{}, nullptr, CarryTrack{}, 0ll,
-                     nullptr, ObstFillJob{}, tslots, -1, C.pub, (unsigned)C.pub_bytes, C.err, C.census, nullptr, 0, ChainPaint{});
+                     nullptr, ObstFillJob{}, tslots, -1, C.pub, (unsigned)C.pub_bytes, C.err, C.census, nullptr, 0, ChainPaint{}, nullptr);
   int seen[4] = {0, 0, 0, 0};
   if (hipMemcpyAsync(seen, C.census, sizeof(seen), hipMemcpyDeviceToHost, st) != hipSuccess) return 0;
   if (hipStreamSynchronize(st) != hipSuccess) return 0;
@@ -1816,8 +1863,9 @@ void launch_dem_chain(const Kin& in, const Kin& out, const real* r, const real* 
   one_xcd |= (extra_sleep & 0xFF) << 8;
   static const bool tail_cut = getenv("LBMDEM_CHAIN_TAILCUT") != nullptr;
   if (tail_cut) one_xcd |= 1 << 16;
+  if (C.capacity < 0) one_xcd |= 1 << 17;   // lbmdem_debug_chain_giveup: a tile of this launch gives up half way
 #endif
   hipLaunchKernelGGL(k_dem_chain, dim3(((one_xcd & 1) ? nbe * 8 : DEM_GRID(nbe)) + extra), dim3(DEM_THREADS), 0, st, in, out, r, m, It, fhf, V.offsets,
                      V.nbr, V.emeta, V.halo_ids, V.halo_cnt, V.tile_far, V.wallflags, pout, P, active, T, stamp0, owner, fill, nbe, nsteps,
-                     C.pub, (unsigned)C.pub_bytes, C.err, C.census, C.dbg, one_xcd, paint);
+                     C.pub, (unsigned)C.pub_bytes, C.err, C.census, C.dbg, one_xcd, paint, C.gate);
 }

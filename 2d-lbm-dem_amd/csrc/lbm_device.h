@@ -359,15 +359,15 @@ __device__ __forceinline__ real ibb_far_rt(const LatticeView& L, const IbbLink& 
   return fN_opp / (2 * k.d) + (2 * k.d - 1) * fN_q / (2 * k.d) + 3 * wc * k.uw / k.d;
 }
 
+// g = the record of the grain that owns S = P - e_q; rec_nn() = that of the grain that owns NN = P + e_q (hazard links only)
 template <class RecFn>
 __device__ __forceinline__ real ibb_eval_rt(const LatticeView& L, const RtLink& k, real wc_diag,
-                                              real wc_axis, RecFn rec_of) {
+                                              real wc_axis, const GP& g, RecFn rec_nn) {
   const int q = k.q;
   const int ex = (q >= 1 && q <= 3) ? -1 : ((q >= 5 && q <= 7) ? 1 : 0);
   const int ey = (q == 1 || q >= 7) ? 1 : ((q >= 3 && q <= 5) ? -1 : 0);
   const real wc = (q & 1) ? wc_diag : wc_axis;
   const int sx = k.gx - ex, sy = k.gy - ey;
-  const GP g = rec_of(-ex, -ey);  // record of the grain that owns S = P - e_q
   IbbLink a;
   a.d = link_delta_rt(sx, sy, ex, ey, g.xc, g.yc, g.r2);
   a.uw = ex * wall_ux(L, g, sy) + ey * wall_uy(L, g, sx);
@@ -380,7 +380,7 @@ __device__ __forceinline__ real ibb_eval_rt(const LatticeView& L, const RtLink& 
     f2 = k.in_q;
     if (k.hazard) {
       const int nx = k.gx + ex, ny = k.gy + ey;
-      const GP gn = rec_of(ex, ey);  // record of the grain that owns NN = P + e_q
+      const GP gn = rec_nn();
       IbbLink b;
       b.d = link_delta_rt(nx, ny, -ex, -ey, gn.xc, gn.yc, gn.r2);
       b.uw = (-ex) * wall_ux(L, gn, ny) + (-ey) * wall_uy(L, gn, nx);

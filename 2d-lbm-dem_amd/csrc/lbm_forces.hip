@@ -204,6 +204,7 @@ __global__ __launch_bounds__(64) void k_forces_parity(const real* __restrict__ f
                                                       GrainFluidView G, double scale12, double scale3,
                                                       real* __restrict__ fhf,
                                                       unsigned char* __restrict__ owner) {
+  LBMDEM_GATE(L.gate);
   __shared__ ForceLds sh;
   const int lane = threadIdx.x;
   const int i = blockIdx.x;
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) void k_forces_table(const real* __re
                                                                 PackSides sides,
                                                                 const unsigned char* __restrict__ mask, int list_cap,
                                                                 ObstFillJob fill, int nfill) {
+  LBMDEM_GATE(L.gate);
   extern __shared__ real sDyn[];
   // the first `nfill` workgroups reset the obstacle map the next rasterisation starts from (the fused kernel has just
   // finished with it; this kernel is bound by its arithmetic, the 67 MB of stores disappear beside it)
@@ -683,6 +685,7 @@ __global__ __launch_bounds__(64) void k_forces_gather_queue(const real* __restri
                                                             LatticeView L, GrainFluidView G, ForceSlots S,
                                                             double scale12, double scale3, real* __restrict__ fhf,
                                                             unsigned* __restrict__ clear, int nclear) {
+  LBMDEM_GATE(L.gate);
   __shared__ ForceLds sh;
   const int lane = threadIdx.x;
   for (int k = blockIdx.x * 64 + lane; k < nclear; k += gridDim.x * 64) clear[k] = 0u;   // (ObstFillJob::clear)
@@ -707,6 +710,7 @@ __global__ __launch_bounds__(64) void k_forces_gather_queue(const real* __restri
 __global__ void k_forces_fast(const real* __restrict__ f, const int* __restrict__ obst, LatticeView L,
                               GrainFluidView G, double scale12, double scale3,
                               real* __restrict__ fhf, unsigned char* __restrict__ owner) {
+  LBMDEM_GATE(L.gate);
   const int lane = threadIdx.x & 63;
   const int i = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (i >= L.n) return;

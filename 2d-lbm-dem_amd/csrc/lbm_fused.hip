@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void k_collide_stream(const real* __restrict__
                                                         const int* __restrict__ ob_new, LatticeView L,
                                                         GrainFluidView G, int tiles_y, int ntiles,
                                                         int xcd_remap) {
+  LBMDEM_GATE(L.gate);
   using TT = Tile<TX, TY>;
   __shared__ real sF[9 * TT::RX * TT::RY];
   __shared__ int sO[TT::OX * TT::OY];
@@ -163,8 +164,9 @@ constexpr int LINK_SLOTS = 64;   // link slots of a wavefront's compacted bounce
 template <int WW, bool CHG, bool EDGE>
 __device__ __forceinline__ void march_item(const real* __restrict__ fin, real* __restrict__ fout,
                                            const int* __restrict__ ob_old, const int* __restrict__ ob_new,
-                                           const LatticeView& L, const GrainFluidView& G, const ForceSlots& S,
-                                           const ObstChange& CH, int strip, int xs, int xe, const RecRing ring,
+                                           const LatticeView& L, const LatticeView& Lk, const GrainFluidView& G,
+                                           const ForceSlots& S, const ObstChange& CH, int strip, int xs, int xe,
+                                           const RecRing ring,
                                            real* const pay, int* const desc, int lane, int w) {
   (void)w;   // (the experiment build's row trace indexes its buffer with it)
   // WW producing lanes in the middle of the window, (64 - WW) / 2 feeding lanes on either side
@@ -183,7 +185,6 @@ __device__ __forceinline__ void march_item(const real* __restrict__ fin, real* _
   //   (3) the nine stores of row x.
   // gfx9 retires vector-memory operations in issue order (one vmcnt counter), so data must be consumed
   // in the order it was requested; no other global load exists inside the loop.
-  const real wc_diag = L.wc_diag, wc_axis = L.wc_axis;  // kernel arguments: scalar registers
   auto row_ok = [&](int xl) { return !EDGE || (yin && xl >= 0 && xl < L.nxl); };
   const int ycl = !EDGE ? y : (y < 0 ? 0 : (y >= L.ly ? L.ly - 1 : y));
   // unconditional (clamped address): every use is guarded by interior(xl), and grain_rec clamps the
@@ -317,13 +318,7 @@ __device__ __forceinline__ void march_item(const real* __restrict__ fin, real* _
 
   MT_DECL
   // one iteration; `buf` holds row x+1 on entry and is refilled with row x+3
-  // Bounce-back links wait in the wave's LDS slots until the second row of a pair has added its own (`pend` = links
-  // waiting): ONE compacted pass per two rows. The pass is a long dependent chain -- LDS round trips, a square root and three
-  // to six divisions per link -- at a third of the lanes per row; two rows per pass halve the number of chains.
-  int pend = 0;
-  GP rec_odd = rec_next;   // (set at the end of the first iteration)
-  auto iterate = [&](int x, real (&buf)[9], auto second_tag) {
-    constexpr bool SECOND = decltype(second_tag)::value;   // the second row of its pair: x - 1 was the first
+  auto iterate = [&](int x, real (&buf)[9]) {
     MT(7)   // loop head
 #pragma unroll
     for (int q = 0; q < 9; ++q) Fp[q] = buf[q];
@@ -345,10 +340,10 @@ __device__ __forceinline__ void march_item(const real* __restrict__ fin, real* _
         if (moved) g = reinit_rec(oo1);
       }
 #if !(defined(LBMDEM_AB) && defined(MARCH_ABL_NOREINIT))   /* timing experiments (wrong results): a phase left out */
-      if (re) grain_equilibrium(L, g, L.gx0 + x + 1, y, Fp);
+      if (re) grain_equilibrium(Lk, g, L.gx0 + x + 1, y, Fp);
 #endif
 #if !(defined(LBMDEM_AB) && defined(MARCH_ABL_NOCOLLIDE))
-      if (in && iD == -1) mrt_collide(L, Fp);
+      if (in && iD == -1) mrt_collide(Lk, Fp);
 #endif
     }
     MT(1)
@@ -397,40 +392,24 @@ __device__ __forceinline__ void march_item(const real* __restrict__ fin, real* _
     {
       const int gx = L.gx0 + x;
       const int so_row = (x - row0) * frow;   // this row in the output lattice's resource
-      const long fb_row = EDGE ? fbase_xy(L, x, y) : 0;   // (edge rows store through the pointer; only used by the producing lanes)
       // wave-uniform: is every producing lane of this row at least two nodes away from all edges?
       const bool deep = !EDGE || (deep_y && gx >= 2 && gx <= L.lx - 3);
-      // (a) everything but the interpolated bounce-back links: computed and stored. Per direction q three lane masks come
-      // out: lk = (P, q) is a bounce-back link (P fluid, its source S = P - e_q a grain node), nn = the node two links
-      // out, NN = P + e_q, is interior, hz = NN is solid and its own update precedes S's (q <= 4).
-      // (the masks are formed where they are used -- three scalar instructions each -- instead of being carried: two
-      // dozen register pairs would not fit)
+      // (a) Per direction q three lane masks: lk = (P, q) is a bounce-back link (P fluid, its source S = P - e_q a grain
+      // node), hz = the node two links out, NN = P + e_q, is solid and its own update precedes S's (q <= 4), rs = both ends
+      // solid and the source active: the slot takes the weight w_q (main.c:1161-1162). Formed where they are used -- three
+      // scalar instructions each -- instead of being carried: two dozen register pairs would not fit.
       const lmask wm = x < xe ? wmask : 0;
 #define MARCH_SRC(Q) m_at<-EYq(Q)>(MARCH_ROW(-EXq(Q), solB, solC, solD))   /* S = P - e_q is solid */
 #define MARCH_LINK(Q) (wm & ~solC & MARCH_SRC(Q))
 #define MARCH_HAZ(Q) (Q <= 4 ? MARCH_LINK(Q) & m_at<EYq(Q)>(MARCH_ROW(EXq(Q), solB, solC, solD)) : 0)
-      unsigned ibb = 0, nnm = 0, hzm = 0;   // the same three per lane, bit q, where the masks do not apply (edge rows)
+#define MARCH_RESET(Q) (solC & MARCH_SRC(Q) & m_at<-EYq(Q)>(MARCH_ROW(-EXq(Q), actM, act0, actP)))
+      unsigned ibb = 0, nnm = 0, hzm = 0;   // the same per lane, bit q, where the masks do not apply (edge rows)
       int T = 0;
       if (deep) {
-        // Rows and lanes at least two nodes from every lattice edge (S, P and NN all interior), without a branch and
-        // without a vector compare: the eight pulls differ only in WHICH value they take -- the streamed population, or
-        // the weight w_q when both ends are solid and the source is an active node (main.c:1161-1162) -- and which is a
-        // matter of the rows' masks; all nine are stored, the slot of a bounce-back link gets the streamed value as a
-        // placeholder which the compacted pass overwrites (the stores of one wavefront to one address keep their order;
-        // a link whose wall distance fires neither formula keeps exactly this value, main.c:1166-1217).
-        if (lane_of(wm)) {
-          buf_store_real<0>(Fo[0], fout_rs, fcol, so_row);
-#define MARCH_STORE(Q)                                                                             \
-          buf_store_real<Q * F_QBYTES>(                                                            \
-              lane_of(solC & MARCH_SRC(Q) & m_at<-EYq(Q)>(MARCH_ROW(-EXq(Q), actM, act0, actP))) ? Wq(Q) : In[OPPq(Q)], \
-              fout_rs, fcol, so_row);
-          MARCH_STORE(1) MARCH_STORE(2) MARCH_STORE(3) MARCH_STORE(4) MARCH_STORE(5) MARCH_STORE(6) MARCH_STORE(7) MARCH_STORE(8)
-#undef MARCH_STORE
-        }
         T = __popcll(MARCH_LINK(1)) + __popcll(MARCH_LINK(2)) + __popcll(MARCH_LINK(3)) + __popcll(MARCH_LINK(4)) +
             __popcll(MARCH_LINK(5)) + __popcll(MARCH_LINK(6)) + __popcll(MARCH_LINK(7)) + __popcll(MARCH_LINK(8));
       } else if constexpr (EDGE) {
-        // rows and windows next to a lattice edge: the general classification, per lane
+        // rows and windows next to a lattice edge: the general classification, per lane; everything but the links is stored
         RegCtx C;
         C.ring = ring;
         C.row = x;
@@ -446,71 +425,102 @@ __device__ __forceinline__ void march_item(const real* __restrict__ fin, real* _
 #define MARCH_ACTBIT(D) C.act |= lane_of(m_at<EYq(D)>(MARCH_ROW(EXq(D), actM, act0, actP))) ? 1u << D : 0u;
         MARCH_ACTBIT(1) MARCH_ACTBIT(2) MARCH_ACTBIT(3) MARCH_ACTBIT(4) MARCH_ACTBIT(5) MARCH_ACTBIT(6) MARCH_ACTBIT(7) MARCH_ACTBIT(8)
 #undef MARCH_ACTBIT
-        if (writer && x < xe) classify_store_row<true>(C, L, gx, y, fout, fb_row, ibb, nnm, hzm);
+        if (writer && x < xe) classify_store_row<true>(C, L, gx, y, fout, fbase_xy(L, x, y), ibb, nnm, hzm);
 #pragma unroll
         for (int q = 1; q < 9; ++q) T += __popcll(__ballot((ibb >> q) & 1u));
       }
       MT(4)
-      // (b) the bounce-back links of the row (typically ~20, spread over all eight directions and a few lanes) are
-      // compacted into dense lanes through LDS and evaluated with the direction as data, instead of ~3.5
-      // direction-specific divergent passes of ~130 instructions. rank of link (lane, q) within its row = number of links
-      // in directions < q + number in direction q on lower lanes; the links with ranks [done, done + n) go to the slots
-      // [pend, pend + n). The slots are evaluated when they are full or the pair of rows is complete.
+      // (b) The bounce-back links of the row (typically ~20, spread over all eight directions and a few lanes) are compacted
+      // into dense lanes through LDS and evaluated in ONE pass with the direction as data, instead of ~3.5
+      // direction-specific divergent passes of ~130 instructions. slot of link (lane, q) = number of links in directions
+      // < q + number in direction q on lower lanes. In a deep row with at most 64 links the pass leaves its results in the
+      // links' slots and the lanes pick them up for the row's nine coalesced stores (`merged`); else every population but
+      // the links' is stored first and the pass stores each result to the node it belongs to.
+      const bool merged = deep && T <= LINK_SLOTS;
+      auto store_row = [&](auto with_results) {   // the nine stores of a deep row
+        if (lane_of(wm)) {
+          buf_store_real<0>(Fo[0], fout_rs, fcol, so_row);
+          // (all eight results requested first, then ONE wait: a read and its wait per direction cost the row a
+          // thousand cycles)
+          real res[9];
+          if constexpr (decltype(with_results)::value) {
+            int before = 0;
+#define MARCH_RES(Q)                                                                               \
+            {                                                                                      \
+              const lmask b = MARCH_LINK(Q);                                                       \
+              res[Q] = pay[((before + (int)mbcnt(b)) & (LINK_SLOTS - 1)) * 4];                     \
+              before += __popcll(b);                                                               \
+            }
+            MARCH_RES(1) MARCH_RES(2) MARCH_RES(3) MARCH_RES(4) MARCH_RES(5) MARCH_RES(6) MARCH_RES(7) MARCH_RES(8)
+#undef MARCH_RES
+          }
+#define MARCH_STORE(Q)                                                                             \
+          {                                                                                        \
+            real v = lane_of(MARCH_RESET(Q)) ? Wq(Q) : In[OPPq(Q)];                                \
+            if constexpr (decltype(with_results)::value) v = lane_of(MARCH_LINK(Q)) ? res[Q] : v;  \
+            buf_store_real<Q * F_QBYTES>(v, fout_rs, fcol, so_row);                                \
+          }
+          MARCH_STORE(1) MARCH_STORE(2) MARCH_STORE(3) MARCH_STORE(4) MARCH_STORE(5) MARCH_STORE(6) MARCH_STORE(7) MARCH_STORE(8)
+#undef MARCH_STORE
+        }
+      };
+      if (deep && !merged) store_row(std::false_type{});   // (a link's slot gets the streamed value as a placeholder; the stores of one
+                                               // wavefront to one address keep their order, and a link whose wall distance
+                                               // fires neither formula keeps exactly this value, main.c:1166-1217)
 #if defined(LBMDEM_AB) && defined(MARCH_ABL_NOPASS)
       T = 0;
 #endif
-      const int xp = SECOND ? x - 1 : x;   // first row of the pair: links carry their row as a bit
-      for (int done = 0; done < T || (SECOND && pend > 0);) {   // wave-uniform; one trip unless the 64 slots run over
-        const int room = LINK_SLOTS - pend, left = T - done, n = left < room ? left : room;
-        if (n > 0) {
-          const int shift = pend - done;   // slot = rank + shift
-          int before = 0;
-          if (deep) {
+      MT(12)
+      for (int base = 0; base < T; base += LINK_SLOTS) {  // wave-uniform; a second round only if > 64 links
+        int before = 0;
+#if defined(LBMDEM_AB) && defined(MARCH_ABL_NOCOMPACT)
+        if (false) {
+#else
+        if (deep) {
+#endif
 #define MARCH_COMPACT(Q)                                                                           \
-            {                                                                                      \
-              const lmask b = MARCH_LINK(Q);                                                       \
-              const int r = before + (int)mbcnt(b);                                                \
-              before += __popcll(b);                                                               \
-              if (lane_of(b) && (unsigned)(r - done) < (unsigned)n) {                              \
-                const int t = r + shift;                                                           \
-                desc[t] = lane | (Q << 8) | (1 << 12) | (lane_of(MARCH_HAZ(Q)) ? 1 << 13 : 0) | (SECOND ? 1 << 14 : 0); \
-                pay[t * 4 + 0] = Fo[OPPq(Q)];                                                      \
-                pay[t * 4 + 1] = Fo[Q];                                                            \
-                pay[t * 4 + 2] = In[Q];                                                            \
-                pay[t * 4 + 3] = In[OPPq(Q)];                                                      \
-              }                                                                                    \
-            }
-            MARCH_COMPACT(1) MARCH_COMPACT(2) MARCH_COMPACT(3) MARCH_COMPACT(4)
-            MARCH_COMPACT(5) MARCH_COMPACT(6) MARCH_COMPACT(7) MARCH_COMPACT(8)
+          {                                                                                        \
+            const lmask b = MARCH_LINK(Q);                                                         \
+            const int t = before + (int)mbcnt(b) - base;                                           \
+            before += __popcll(b);                                                                 \
+            if (lane_of(b) && (unsigned)t < (unsigned)LINK_SLOTS) {                                \
+              desc[t] = lane | (Q << 8) | (1 << 12) | (lane_of(MARCH_HAZ(Q)) ? 1 << 13 : 0);       \
+              pay[t * 4 + 0] = Fo[OPPq(Q)];                                                        \
+              pay[t * 4 + 1] = Fo[Q];                                                              \
+              pay[t * 4 + 2] = In[Q];                                                              \
+              pay[t * 4 + 3] = In[OPPq(Q)];                                                        \
+            }                                                                                      \
+          }
+          MARCH_COMPACT(1) MARCH_COMPACT(2) MARCH_COMPACT(3) MARCH_COMPACT(4)
+          MARCH_COMPACT(5) MARCH_COMPACT(6) MARCH_COMPACT(7) MARCH_COMPACT(8)
 #undef MARCH_COMPACT
-          } else if constexpr (EDGE) {
+        } else if constexpr (EDGE) {
 #pragma unroll
-            for (int q = 1; q < 9; ++q) {
-              const lmask b = __ballot((ibb >> q) & 1u);
-              const int r = before + (int)mbcnt(b);
-              before += __popcll(b);
-              if (((ibb >> q) & 1u) && (unsigned)(r - done) < (unsigned)n) {
-                const int t = r + shift;
-                desc[t] = lane | (q << 8) | (((nnm >> q) & 1u) << 12) | (((hzm >> q) & 1u) << 13) | (SECOND ? 1 << 14 : 0);
-                pay[t * 4 + 0] = Fo[OPPq(q)];
-                pay[t * 4 + 1] = Fo[q];
-                pay[t * 4 + 2] = In[q];
-                pay[t * 4 + 3] = In[OPPq(q)];
-              }
+          for (int q = 1; q < 9; ++q) {
+            const lmask b = __ballot((ibb >> q) & 1u);
+            const int t = before + (int)mbcnt(b) - base;
+            before += __popcll(b);
+            if (((ibb >> q) & 1u) && (unsigned)t < (unsigned)LINK_SLOTS) {
+              desc[t] = lane | (q << 8) | (((nnm >> q) & 1u) << 12) | (((hzm >> q) & 1u) << 13);
+              pay[t * 4 + 0] = Fo[OPPq(q)];
+              pay[t * 4 + 1] = Fo[q];
+              pay[t * 4 + 2] = In[q];
+              pay[t * 4 + 3] = In[OPPq(q)];
             }
           }
-          pend += n;
-          done += n;
         }
-        if (pend < LINK_SLOTS && !(SECOND && done >= T)) break;   // (the first row of a pair leaves its links waiting)
         __builtin_amdgcn_wave_barrier();  // LDS operations of one wave execute in order
-        if (lane < pend) {
+        MT(10)
+#if defined(LBMDEM_AB) && defined(MARCH_ABL_NOEVALPASS)
+        if (false) {
+#else
+        if (base + lane < T) {
+#endif
           const int d = desc[lane];
           const int src = d & 63;
-          const int xr = xp + ((d >> 14) & 1);   // the link's row
           RtLink k;
           k.q = (d >> 8) & 15;
-          k.gx = L.gx0 + xr;
+          k.gx = gx;
           k.gy = y - lane + src;
           k.own_qo = pay[lane * 4 + 0];
           k.own_q = pay[lane * 4 + 1];
@@ -518,17 +528,19 @@ __device__ __forceinline__ void march_item(const real* __restrict__ fin, real* _
           k.in_qo = pay[lane * 4 + 3];
           k.nn_int = (d >> 12) & 1;
           k.hazard = (d >> 13) & 1;
-          // the result goes straight to the population it belongs to: node of lane `src`, plane q
+          const int ex = (k.q >= 1 && k.q <= 3) ? -1 : ((k.q >= 5 && k.q <= 7) ? 1 : 0);
+          const int ey = (k.q == 1 || k.q >= 7) ? 1 : ((k.q >= 3 && k.q <= 5) ? -1 : 0);
+          // the record of the grain that owns S = P - e_q, and which grain that is (one round of LDS reads)
+          const GP gS = ring.get(x - ex, src - ey);
+          const int owner = ring.get_id(x - ex, src - ey);
 #if defined(LBMDEM_AB) && defined(MARCH_ABL_NOEVAL)
           const real out = k.in_qo;
 #else
-          const real out =
-              ibb_eval_rt(L, k, wc_diag, wc_axis, [&](int dx, int dy) { return ring.get(xr + dx, src + dy); });
+          const real out = ibb_eval_rt(Lk, k, Lk.wc_diag, Lk.wc_axis, gS, [&] { return ring.get(x + ex, src + ey); });
 #endif
-#if defined(LBMDEM_AB) && defined(MARCH_ABL_NOFSTORE)
-          asm volatile("" ::"v"(out));
-#else
-          buf_store_real<0>(out, fout_rs, fcol_bytes(k.gy) + k.q * F_QBYTES + ((d >> 14) & 1) * frow, (xp - row0) * frow);
+          if (merged) pay[lane * 4] = out;   // picked up by the lane of node `src` for plane q of the row's stores
+#if !(defined(LBMDEM_AB) && defined(MARCH_ABL_NOFSTORE))
+          else buf_store_real<0>(out, fout_rs, fcol_bytes(k.gy) + k.q * F_QBYTES, so_row);
 #endif
           // ... and the link's momentum-exchange sum f_new[S][opp q] + f_new[P][q] (main.c:1313-1316; the first
           // is f*[P][opp q], streamed unchanged into the solid node) to the slot table of the grain that owns S
@@ -537,18 +549,19 @@ __device__ __forceinline__ void march_item(const real* __restrict__ fin, real* _
 #else
           if (S.tab != nullptr) {
 #endif
-            const int ex = (k.q >= 1 && k.q <= 3) ? -1 : ((k.q >= 5 && k.q <= 7) ? 1 : 0);
-            const int ey = (k.q == 1 || k.q >= 7) ? 1 : ((k.q >= 3 && k.q <= 5) ? -1 : 0);
-            real cx, cy;
-            ring.get_centre(xr - ex, src - ey, cx, cy);
-            const int rel = slot_line(k.gx - ex, k.gy - ey, ex, ey, cx, cy) + S.half;
+            const int rel = slot_line(k.gx - ex, k.gy - ey, ex, ey, gS.xc, gS.yc) + S.half;
             if ((unsigned)rel < (unsigned)S.spd)
-              S.tab[((long)ring.get_id(xr - ex, src - ey) * 8 + (k.q - 1)) * S.spd + rel] = k.own_qo + out;
+              S.tab[((long)owner * 8 + (k.q - 1)) * S.spd + rel] = k.own_qo + out;
           }
         }
         __builtin_amdgcn_wave_barrier();
-        pend = 0;
+        MT(11)
       }
+      if (merged) {
+        if (T > 0) store_row(std::true_type{});
+        else store_row(std::false_type{});
+      }
+#undef MARCH_RESET
 #undef MARCH_HAZ
 #undef MARCH_LINK
 #undef MARCH_SRC
@@ -556,14 +569,8 @@ __device__ __forceinline__ void march_item(const real* __restrict__ fin, real* _
     }
     // row x-1 is no longer needed: its ring slot takes the owner records of row x+3; then request
     // those of row x+4 (consumed at this point of the next iteration)
-    // (the records stay in registers until the pair's pass has read rows x-2 .. x+1 of the ring: two rows enter it at once)
-    if constexpr (SECOND) {
-      ring.put(x + 2, lane, rec_next, iE);   // row (x-1) + 3
-      ring.put(x + 3, lane, rec_odd, iF);    // row x + 3
-      rec_next = grain_rec(inext);           // row x + 4: the next pair's first
-    } else {
-      rec_odd = grain_rec(inext);            // row x + 4
-    }
+    ring.put(x + 3, lane, rec_next, iF);
+    rec_next = grain_rec(inext);
     // rotate
 #pragma unroll
     for (int q = 0; q < 9; ++q) { Fm[q] = F0[q]; F0[q] = Fp[q]; }
@@ -578,8 +585,8 @@ __device__ __forceinline__ void march_item(const real* __restrict__ fin, real* _
   // compiler cannot count its loads as younger than the first half's when it places s_waitcnt at the loop head, and
   // waits for more of the pipeline than the data it needs (vmcnt(4) instead of vmcnt(9); 1.5-2 % of the kernel).
   for (int x = xs; x < xe; x += 2) {
-    iterate(x, bufA, std::false_type{});
-    iterate(x + 1, bufB, std::true_type{});
+    iterate(x, bufA);
+    iterate(x + 1, bufB);
   }
   MT_FLUSH
 }
@@ -590,6 +597,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
                                                   const int* __restrict__ ob_new, LatticeView L,
                                                   GrainFluidView G, ForceSlots S, int nstrips, int nwork,
                                                   int xcd_remap, int seg_rows, int seg_stride, MarchPlan P, ObstChange CH) {
+  LBMDEM_GATE(L.gate);
   const int lane = threadIdx.x & 63;
   int blk = blockIdx.x;
   int w, strip, xs, rows_per_wave;
@@ -636,13 +644,20 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
   __shared__ int sDesc[4 * LINK_SLOTS];
   real* const pay = sPay + (threadIdx.x >> 6) * (LINK_SLOTS * 4);
   int* const desc = sDesc + (threadIdx.x >> 6) * LINK_SLOTS;
+  // The lattice's constants once more in LDS, wave-private: the arithmetic routines (collision, grain equilibrium,
+  // bounce-back) read their reals from there, at the point of use, through the vector unit -- thirteen doubles that would
+  // otherwise sit in 26 scalar registers for the whole loop, in a kernel whose scalar registers are spilled to vector lanes.
+  __shared__ LatticeView sLat[4];
+  LatticeView* const Lk = sLat + (threadIdx.x >> 6);
+  if (lane == 0) *Lk = L;
+  __builtin_amdgcn_wave_barrier();
   // Is the whole item -- its 64 columns, its rows and the two rows either side -- interior? (wave-uniform)
   constexpr int OFF = (64 - WW) / 2;
   const int y_lo = strip * WW - OFF;
   const bool inner = y_lo >= 1 && y_lo + 63 <= L.ly - 2 && L.gx0 + xs >= 2 && L.gx0 + xe <= L.lx - 2 && xs >= 2 &&
                      xe + 2 <= L.nxl;
-  if (inner) march_item<WW, CHG, false>(fin, fout, ob_old, ob_new, L, G, S, CH, strip, xs, xe, ring, pay, desc, lane, w);
-  else march_item<WW, CHG, true>(fin, fout, ob_old, ob_new, L, G, S, CH, strip, xs, xe, ring, pay, desc, lane, w);
+  if (inner) march_item<WW, CHG, false>(fin, fout, ob_old, ob_new, L, *Lk, G, S, CH, strip, xs, xe, ring, pay, desc, lane, w);
+  else march_item<WW, CHG, true>(fin, fout, ob_old, ob_new, L, *Lk, G, S, CH, strip, xs, xe, ring, pay, desc, lane, w);
 }
 
 }  // namespace

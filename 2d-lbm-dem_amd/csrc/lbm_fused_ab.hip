@@ -551,10 +551,9 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march3(const real* __restrict_
         } else {
           g = load_gp(G, (int)((unsigned)d >> 14));
         }
-        const real out = ibb_eval_rt(L, k, wc_diag, wc_axis, [&](int dx, int dy) {
-          if (dx == -ex && dy == -ey) return g;
+        const real out = ibb_eval_rt(L, k, wc_diag, wc_axis, g, [&] {
           // the hazard partner: the grain that owns NN = P + e_q (rare; its loads stay inside this branch)
-          return load_gp(G, ob_new[(long)(x + dx) * L.sy + (k.gy + dy)]);
+          return load_gp(G, ob_new[(long)(x + ex) * L.sy + (k.gy + ey)]);
         });
         fout[fidx(k.q, node - lane + src)] = out;
         if (S.tab != nullptr) {

@@ -261,14 +261,24 @@ void launch_halo_unpack(real* f, const LatticeView& L, int xl0_lo, int xl0_hi, i
                      buf_lo, buf_hi);
 }
 
-// A plain copy, 16 bytes per lane and iteration, grid-stride: what this GPU's memory system moves when nothing else is asked
-// of it (lbmdem_measure_copy; bench.py reports the fused kernel's traffic rate against it, so that lines measured on
-// different boxes can be compared)
-__global__ __launch_bounds__(256) void k_plain_copy(const double2* __restrict__ src, double2* __restrict__ dst, long n2) {
+// A plain copy, grid-stride, in several shapes (bytes per lane and iteration x workgroups): what this GPU's memory system
+// moves when nothing else is asked of it (lbmdem_measure_copy takes the best shape; bench.py reports the fused kernel's
+// traffic rate against it, so that lines measured on different boxes can be compared). The shapes are those of
+// scripts/micro/stream_pattern.hip: 8 bytes per lane from 2 048 workgroups was the best there (5.6 TB/s), 16 bytes from 8 192 --
+// the only shape until round 6 -- some 15 % behind it.
+template <class T>
+__global__ __launch_bounds__(256) void k_plain_copy(const T* __restrict__ src, T* __restrict__ dst, long n) {
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n2; k += stride) dst[k] = src[k];
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) dst[k] = src[k];
 }
 
-void launch_plain_copy(const void* src, void* dst, size_t bytes, hipStream_t st) {
-  hipLaunchKernelGGL(k_plain_copy, dim3(256 * 32), dim3(256), 0, st, (const double2*)src, (double2*)dst, (long)(bytes / 16));
+int plain_copy_shapes() { return 4; }
+
+void launch_plain_copy(const void* src, void* dst, size_t bytes, hipStream_t st, int shape) {
+  switch (shape) {
+    case 1: hipLaunchKernelGGL(k_plain_copy<double>, dim3(2048), dim3(256), 0, st, (const double*)src, (double*)dst, (long)(bytes / 8)); break;
+    case 2: hipLaunchKernelGGL(k_plain_copy<double2>, dim3(2048), dim3(256), 0, st, (const double2*)src, (double2*)dst, (long)(bytes / 16)); break;
+    case 3: hipLaunchKernelGGL(k_plain_copy<double>, dim3(4096), dim3(256), 0, st, (const double*)src, (double*)dst, (long)(bytes / 8)); break;
+    default: hipLaunchKernelGGL(k_plain_copy<double2>, dim3(256 * 32), dim3(256), 0, st, (const double2*)src, (double2*)dst, (long)(bytes / 16)); break;
+  }
 }

@@ -37,9 +37,10 @@ namespace {
 // MT(k == 0 ? 7 : k - 1) and boundary MT(k); a stamp is only consumed at the end of its phase, so it adds no s_waitcnt
 // of its own in between. scripts/march_timing.py reads the sums.
 __device__ unsigned long long g_march_t[16];
-#define MT_FROM (MARCH_TIMING == 0 ? 7 : MARCH_TIMING - 1)
+// boundaries in program order: 7 (loop head), 0, 1, 2, 3, 4, 10 (links compacted), 11 (links evaluated), 5, 6
+#define MT_FROM (MARCH_TIMING == 0 ? 7 : MARCH_TIMING == 10 ? 4 : MARCH_TIMING == 11 ? 10 : MARCH_TIMING == 5 ? 11 : MARCH_TIMING - 1)
 #define MT_DECL unsigned long long mt_acc_ = 0, mt_from_ = __builtin_readcyclecounter(); const unsigned long long mt_start_ = mt_from_;
-#define MT(i) { if ((i) == MT_FROM) { __builtin_amdgcn_sched_barrier(0); mt_from_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } \
+#define MT(i) { if ((i) == MT_FROM || ((i) == 12 && MARCH_TIMING == 5)) {   /* (12: before the links' loop, which a row without links skips) */ __builtin_amdgcn_sched_barrier(0); mt_from_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } \
                 if ((i) == MARCH_TIMING) { __builtin_amdgcn_sched_barrier(0); mt_acc_ += __builtin_readcyclecounter() - mt_from_; __builtin_amdgcn_sched_barrier(0); } }
 #define MT_FLUSH if (lane == 0) { atomicAdd(&g_march_t[MARCH_TIMING], mt_acc_); atomicAdd(&g_march_t[8], __builtin_readcyclecounter() - mt_start_); atomicAdd(&g_march_t[9], 1ull); }
 extern "C" __attribute__((visibility("default"))) int lbmdem_ab_march_timing(unsigned long long* out) {

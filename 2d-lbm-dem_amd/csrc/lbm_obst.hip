@@ -11,6 +11,7 @@ namespace {
 
 // obst = -1 in the interior, nbgrains on the four lattice edges (main.c:669-683, 997-999): obst_fill_range (lbmdem_internal.h)
 __global__ void k_obst_fill(int* __restrict__ obst, LatticeView L, int row0, int row1) {
+  LBMDEM_GATE(L.gate);
   obst_fill_range(obst, L, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x, row0, row1);
 }
 
@@ -40,6 +41,7 @@ __global__ void k_obst_paint(int* __restrict__ obst, LatticeView L, int n, const
                              unsigned* __restrict__ mincov, unsigned epoch, const int* __restrict__ list,
                              const int* __restrict__ list_count, int list_cap, const int* __restrict__ voff,
                              const int* __restrict__ vnbr, ObstSnap snap_out) {
+  LBMDEM_GATE(L.gate);
   // FOUR grains per wavefront, PAINT_LANES = 16 lanes each, sweeping their boxes (11 ... 19 columns) in chunks of 16 columns:
   // the per-grain set-up -- geometry, three divisions, the partner test -- is paid once per four grains and the sweep's lanes
   // are mostly busy. One wavefront per grain 46 us (the kernel was bound by its 50 000 short waves), 32 lanes per grain 32.5,
@@ -173,6 +175,7 @@ __global__ void k_obst_update(int* __restrict__ obst, LatticeView L, int n, cons
                               const int* __restrict__ voff, const int* __restrict__ vnbr, ObstSnap was, ObstSnap now,
                               const real* __restrict__ xreb, const real* __restrict__ yreb, real moved_limit,
                               int* __restrict__ moved_flag, int list_generation) {
+  LBMDEM_GATE(L.gate);
   const int lane = threadIdx.x & 63, half = lane / GL, hl = lane % GL;
   const int bslots = (int)gridDim.x >> 3;   // XCD k takes the k-th contiguous eighth of the grains (k_obst_paint)
   const int blk = ((int)blockIdx.x & 7) * bslots + ((int)blockIdx.x >> 3);

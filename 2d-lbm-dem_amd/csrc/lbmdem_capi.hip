@@ -395,6 +395,9 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
     lbmdem_destroy(h);
     return rc;
   }
+  h->L.gate = h->chain.gate;   // the stop word every kernel of the step path looks at first (LatticeView::gate)
+  h->V.gate = h->chain.gate;
+  h->ct.gate = h->chain.gate;
   CREATE_TRY(hipHostMalloc((void**)&h->ovf_host, sizeof(int), hipHostMallocDefault));
   *h->ovf_host = 0;
   CREATE_TRY(hipHostMalloc((void**)&h->moved_host, sizeof(int), hipHostMallocDefault));
@@ -791,7 +794,7 @@ int lbmdem_dem_substep(lbmdem_handle* h) {
   CHECK_NOT_SPLIT(h);
   if (!h->verlet_ok) return fail(LBMDEM_EINVAL, "lbmdem_dem_substep before the first lbmdem_verlet_rebuild");
   if (*h->ovf_host) return fail(LBMDEM_ENOMEM, "Verlet list overflow (more than %ld symmetric entries)", h->V.cap);
-  if (CHAIN_FAILED(h)) return fail(LBMDEM_EHIP, CHAIN_FAIL_MSG);
+  if (h->dist && CHAIN_FAILED(h)) return fail(LBMDEM_EHIP, CHAIN_FAIL_MSG);
   drop_chain_paint(h);
   const int film = (h->nbsteps % h->cfg.phys.stepFilm == 0) ? 1 : 0;  // main.c:1342
   // contact diagnostics are only needed by write_DEM, which renderScene calls when the step counter
@@ -805,6 +808,7 @@ int lbmdem_dem_substep(lbmdem_handle* h) {
   if (want_diag && !h->dx_ready) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (diag_extra_alloc(h->dx, h->n, h->V.cap, h->ct.carry) != 0) return fail(LBMDEM_ENOMEM, "diagnostic buffers: hipMalloc failed");
+    h->dx.gate = h->chain.gate;
     h->dx_ready = true;
   }
   if (want_diag && h->carry_from < h->substep_seq) launch_carry_resolve(h->ct, h->carry_from, h->stream);
@@ -845,25 +849,6 @@ int lbmdem_dem_substep(lbmdem_handle* h) {
   return LBMDEM_OK;
 }
 
-long lbmdem_dem_chain_length(lbmdem_handle* h, long remaining, int fluid) {
-  if (h->chain_max < 2 || remaining < 2 || h->diag_always || !h->chain.pub) return 0;
-  const lbmdem_config& c = h->cfg;
-  const long cap = remaining < h->chain_max ? remaining : h->chain_max;
-  long k = 0;
-  for (; k < cap; ++k) {
-    const long t = h->nbsteps + k;
-    if (k > 0 && ((fluid && t % c.npDEM == 0) || t % c.phys.updateVerlet == 0)) break;   // main.c:1710, 1721
-    if (t % c.phys.stepFilm == 0) break;                                                  // film law, main.c:1342
-    if ((t + 1) % 4000 == 0) break;                                                       // feeds write_DEM, main.c:1773
-  }
-  if (k < 2) return 0;
-  if (!h->chain_checked) {   // once per handle: do all tiles of this packing run at the same time on this GPU?
-    h->chain_checked = true;
-    (void)dem_chain_census(h->chain, dem_chain_tslots(h->n), h->stream);
-  }
-  return h->chain.capacity >= dem_chain_tslots(h->n) ? k : 0;
-}
-
 // Two launches of k_dem_chain must not share the GPU: each needs ALL its tiles resident at once, and two that are each half
 // resident wait for each other's slots until their spins run out. Within a process the launches are therefore chained by an
 // event per device whenever they come from different streams (two handles stepped side by side); another PROCESS on the
@@ -892,6 +877,31 @@ static void chain_forget_stream(int device, hipStream_t st) {
   if (g_chain_any[device & 63] && g_chain_stream[device & 63] == st) g_chain_any[device & 63] = false;
 }
 
+long lbmdem_dem_chain_length(lbmdem_handle* h, long remaining, int fluid) {
+  if (h->chain_max < 2 || remaining < 2 || h->diag_always || !h->chain.pub) return 0;
+  const lbmdem_config& c = h->cfg;
+  const long cap = remaining < h->chain_max ? remaining : h->chain_max;
+  long k = 0;
+  for (; k < cap; ++k) {
+    const long t = h->nbsteps + k;
+    if (k > 0 && ((fluid && t % c.npDEM == 0) || t % c.phys.updateVerlet == 0)) break;   // main.c:1710, 1721
+    if (t % c.phys.stepFilm == 0) break;                                                  // film law, main.c:1342
+    if ((t + 1) % 4000 == 0) break;                                                       // feeds write_DEM, main.c:1773
+  }
+  if (k < 2) return 0;
+  if (!h->chain_checked) {   // once per handle: do all tiles of this packing run at the same time on this GPU?
+    h->chain_checked = true;
+    // (the census needs the whole GPU like the kernel itself: behind the last launch of any other handle's stream, and nobody
+    // launches until it has finished -- beside a running launch neither would get all its workgroups in, and whose spins
+    // run out first was a matter of clocks)
+    std::lock_guard<std::mutex> chain_lock(g_chain_mutex);
+    if (chain_serialise_begin(h) == LBMDEM_OK) (void)dem_chain_census(h->chain, dem_chain_tslots(h->n), h->stream);
+  }
+  return h->chain.capacity >= dem_chain_tslots(h->n) ? k : 0;
+}
+
+static ChainSnap chain_snapshot(const lbmdem_handle* h);
+
 // k ordinary sub-steps (lbmdem_dem_chain_length said so) in one launch
 int lbmdem_dem_chain(lbmdem_handle* h, long k, int fluid) {
   CHECK_H(h);
@@ -899,7 +909,8 @@ int lbmdem_dem_chain(lbmdem_handle* h, long k, int fluid) {
   CHECK_NOT_SPLIT(h);
   if (!h->verlet_ok) return fail(LBMDEM_EINVAL, "lbmdem_dem_substep before the first lbmdem_verlet_rebuild");
   if (*h->ovf_host) return fail(LBMDEM_ENOMEM, "Verlet list overflow (more than %ld symmetric entries)", h->V.cap);
-  if (CHAIN_FAILED(h)) return fail(LBMDEM_EHIP, CHAIN_FAIL_MSG);
+  if (h->dist && CHAIN_FAILED(h)) return fail(LBMDEM_EHIP, CHAIN_FAIL_MSG);
+  if (!h->dist && h->run_logged) h->chain_pending.push_back(chain_snapshot(h));   // (the caller has set log_idx / done: see run_steps)
   drop_chain_paint(h);
   const DemParams P = dem_params(h);
   // A run that ends where the next fluid step begins rasterises the discs itself (the positions are in the tiles' LDS)
@@ -911,7 +922,9 @@ int lbmdem_dem_chain(lbmdem_handle* h, long k, int fluid) {
     const int b = 1 - h->ocur;
     // in place (the canvas holds the picture its record describes, nobody has touched it) or onto a clean canvas
     const bool inplace = h->obst_update && h->snap_ok[b] && h->obst_reset_rows == 0 && *h->moved_host != h->list_generation;
-    const bool clean = h->obst_reset_rows == h->L.nxl;
+    // (a grain that has outrun the pair list: the tail's "alone according to the list" is not to be trusted -- the stand-alone
+    // rasteriser with atomics for everybody paints this step)
+    const bool clean = h->obst_reset_rows == h->L.nxl && *h->moved_host != h->list_generation;
     if (inplace || clean) {
       RC_TRY(next_paint_epoch(h));
       paint = ChainPaint{h->obst[b], h->L, h->rLB, h->xc, h->yc, h->r2, h->rbl0, h->pk, h->fs.touched, h->mincov, h->paint_epoch,
@@ -941,8 +954,12 @@ int lbmdem_dem_chain(lbmdem_handle* h, long k, int fluid) {
   }
   std::lock_guard<std::mutex> chain_lock(g_chain_mutex);
   RC_TRY(chain_serialise_begin(h));
+  DemChain chain = h->chain;
+#ifdef LBMDEM_AB   // lbmdem_debug_chain_giveup: this launch is made to give up half way (tests/test_gpu_dem_chain.py)
+  if (h->chain_giveup_at >= 0 && h->chain_launches == h->chain_giveup_at) chain.capacity = -1;
+#endif
   launch_dem_chain(h->kin[h->kcur], h->kin[1 - h->kcur], h->r, h->m, h->It, h->fhf, h->V, h->gp, P,
-                   h->dist ? h->dd.active : nullptr, &h->ct, h->substep_seq, h->dist ? h->owner : nullptr, fill, h->chain,
+                   h->dist ? h->dd.active : nullptr, &h->ct, h->substep_seq, h->dist ? h->owner : nullptr, fill, chain,
                    (int)k, paint, h->stream);
   if (paint.obst) { h->chain_painted = true; h->chain_paints++; }
   if (h->dist && h->dist_poison) launch_dist_poison(h->dd, h->kin[0], h->kin[1], h->n, h->stream);
@@ -1013,34 +1030,163 @@ int lbmdem_dem_chain_paints(lbmdem_handle* h, long* paints) {
   return LBMDEM_OK;
 }
 
-int lbmdem_run(lbmdem_handle* h, long n_dem_steps) {
-  CHECK_H(h);
-  for (long k = 0; k < n_dem_steps;) {
+// ---- runs of sub-steps that a failed launch of k_dem_chain cannot end -----------------------------------------------------
+// Every launch of k_dem_chain is remembered with the host's state before it (ChainSnap) until the stream has been seen to
+// drain without the failure word; the calls of lbmdem_run / lbmdem_run_dem since then are in the run log. A launch that
+// gives up raises the handle's stop word: the kernels queued behind it do nothing, so the device still holds the state the
+// launch started from. chain_recover puts the host back there, switches the multi-sub-step kernel off for the handle and
+// repeats the logged sub-steps one launch each -- the same bits (tests/test_gpu_dem_chain.py forces a give-up mid-run).
+constexpr size_t CHAIN_PENDING_CAP = 256;   // unconfirmed launches before a run loop drains the stream itself
+
+static ChainSnap chain_snapshot(const lbmdem_handle* h) {
+  ChainSnap s{};
+  s.seq = h->substep_seq;
+  s.log_idx = (long)h->runlog.size() - 1;
+  s.done = 0;   // (set by run_steps)
+  s.fcur = h->fcur; s.ocur = h->ocur; s.kcur = h->kcur; s.obst_reset_rows = h->obst_reset_rows;
+  for (int b = 0; b < 2; ++b) { s.snap_cur[b] = h->snap_cur[b]; s.snap_ok[b] = h->snap_ok[b]; s.chg_state[b] = h->chg_state[b]; }
+  s.list_generation = h->list_generation;
+  s.obst_pending = h->obst_pending; s.diag_valid = h->diag_valid; s.slots_clean = h->slots_clean;
+  s.last_forces_from_table = h->last_forces_from_table; s.slots_valid = h->slots_valid; s.verlet_ok = h->verlet_ok;
+  s.verlet_tracks_positions = h->verlet_tracks_positions; s.chain_painted = h->chain_painted;
+  s.substep_seq = h->substep_seq; s.carry_from = h->carry_from;
+  s.gathered = h->fs.gathered; s.gathered_next = h->fs.gathered_next;
+  s.nbsteps = h->nbsteps; s.Mdx = h->cfg.Mdx; s.Mhy = h->cfg.Mhy;
+  return s;
+}
+
+static void chain_restore(lbmdem_handle* h, const ChainSnap& s) {
+  h->fcur = s.fcur; h->ocur = s.ocur; h->kcur = s.kcur;
+  for (int b = 0; b < 2; ++b) { h->snap_cur[b] = s.snap_cur[b]; h->snap_ok[b] = s.snap_ok[b]; h->chg_state[b] = s.chg_state[b]; }
+  h->list_generation = s.list_generation;
+  h->obst_pending = s.obst_pending; h->diag_valid = s.diag_valid; h->slots_clean = s.slots_clean;
+  h->last_forces_from_table = s.last_forces_from_table; h->slots_valid = s.slots_valid; h->verlet_ok = s.verlet_ok;
+  h->verlet_tracks_positions = s.verlet_tracks_positions;
+  h->substep_seq = s.substep_seq; h->carry_from = s.carry_from;
+  h->fs.gathered = s.gathered; h->fs.gathered_next = s.gathered_next;
+  h->nbsteps = s.nbsteps; h->cfg.Mdx = s.Mdx; h->cfg.Mhy = s.Mhy;
+  // what the failed launch may have written on its way: slices of the next map's canvas, and -- by the tiles that did
+  // finish -- their discs, in place. The map the next fluid step paints starts from a clean canvas again.
+  const int b = 1 - s.ocur;
+  h->snap_ok[b] = false; h->chg_state[b] = 0;
+  h->obst_reset_rows = 0; h->chain_painted = false;
+}
+
+static int run_steps(lbmdem_handle* h, int fluid, long n, bool logged, bool resumed = false);
+
+// the stream drained; a launch that gave up undone and everything since repeated. `live`: called from the run loop of the
+// log's last entry, which goes on by itself from sub-step *rewind of its call (-1: as it was)
+static int chain_settle_impl(lbmdem_handle* h, bool live, long* rewind) {
+  if (rewind) *rewind = -1;
+  if (h->chain_pending.empty()) return LBMDEM_OK;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int code = *h->chain.err_host;
+  if (code == 0) {   // all of them finished: nothing older than the live call has to be remembered
+    h->chain_pending.clear();
+    if (live) h->runlog.erase(h->runlog.begin(), h->runlog.end() - 1); else h->runlog.clear();
+    return LBMDEM_OK;
+  }
+  size_t i = 0;
+  while (i < h->chain_pending.size() && (int)((unsigned long long)h->chain_pending[i].seq & 0x3FFFFFFFull) + 1 != code) ++i;
+  if (i == h->chain_pending.size())
+    return fail(LBMDEM_EHIP, "a launch of the multi-sub-step DEM kernel gave up and is not among the %zu the handle remembers (code %d)",
+                h->chain_pending.size(), code);
+  const ChainSnap s = h->chain_pending[i];
+  const std::vector<RunLogEntry> log(h->runlog.begin() + s.log_idx, h->runlog.end());
+  chain_restore(h, s);
+  h->chain_pending.clear();
+  // the multi-sub-step kernel stays off for this handle (lbmdem_set_dem_chain switches it back on, with a new census); its
+  // lines hold the give-up marks of the tiles
+  h->chain_max = 0;
+  h->chain_checked = false; h->chain.capacity = 0;
+  h->chain_recoveries++;
+  HIP_TRY(hipMemsetAsync(h->chain.gate, 0, sizeof(int), h->stream));
+  if (h->chain.pub) HIP_TRY(hipMemsetAsync(h->chain.pub, 0, h->chain.pub_bytes ? h->chain.pub_bytes : 128, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *h->chain.err_host = 0;
+  // replay: the rest of the call the launch belonged to, then every later call -- except the live one, whose loop goes on
+  const bool was_logged = h->run_logged;
+  const int was_in = h->in_run;
+  h->run_logged = false;
+  const size_t upto = live ? log.size() - 1 : log.size();
+  int rc = LBMDEM_OK;
+  // (the state is that of the moment before the launch: the fluid step and the list rebuild that were due at its first
+  // sub-step have been done -- `resumed`)
+  for (size_t j = 0; j < upto && rc == LBMDEM_OK; ++j) rc = run_steps(h, log[j].fluid, log[j].n - (j == 0 ? s.done : 0), false, j == 0);
+  h->run_logged = was_logged; h->in_run = was_in;
+  if (live) {
+    h->runlog.erase(h->runlog.begin(), h->runlog.end() - 1);
+    if (rewind) *rewind = log.size() == 1 ? s.done : -2;   // -2: the live call starts over (the launch belonged to an earlier one)
+  } else h->runlog.clear();
+  return rc;
+}
+
+int lbmdem_chain_settle(lbmdem_handle* h) { return chain_settle_impl(h, false, nullptr); }
+
+// renderScene() x n (main.c:1697-1765), with or without the fluid (`_FLUIDE_`)
+// (`resumed`: the state is that of a launch of k_dem_chain about to be made -- what precedes the first sub-step is done)
+static int run_steps(lbmdem_handle* h, int fluid, long n, bool logged, bool resumed) {
+  struct Scope {
+    lbmdem_handle* h; bool was;
+    Scope(lbmdem_handle* h_, bool logged_) : h(h_), was(h_->run_logged) { ++h->in_run; h->run_logged = logged_; }
+    ~Scope() { --h->in_run; h->run_logged = was; }
+  } scope(h, logged);
+  if (logged) h->runlog.push_back(RunLogEntry{fluid, n});
+  for (long k = 0; k < n;) {
+    size_t cap = CHAIN_PENDING_CAP;
+#ifdef LBMDEM_AB   // (tests: a small cap makes the run loop itself find the failed launch)
+    static const int env_cap = getenv("LBMDEM_CHAIN_CAP") ? atoi(getenv("LBMDEM_CHAIN_CAP")) : 0;
+    if (env_cap > 0) cap = (size_t)env_cap;
+#endif
+    if (logged && h->chain_pending.size() >= cap) {
+      long rewind = -1;
+      RC_TRY(chain_settle_impl(h, true, &rewind));
+      if (rewind >= 0) { k = rewind; resumed = true; continue; }
+      if (rewind == -2) { k = 0; continue; }
+    }
     int rc = LBMDEM_OK;
-    if (h->nbsteps % h->cfg.npDEM == 0) rc = lbmdem_lbm_step(h);                                  // main.c:1710-1718
-    if (rc == LBMDEM_OK && h->nbsteps % h->cfg.phys.updateVerlet == 0) rc = lbmdem_verlet_rebuild(h);  // main.c:1721-1724
-    if (rc != LBMDEM_OK) return rc;
-    const long run = lbmdem_dem_chain_length(h, n_dem_steps - k, 1);
-    if (run) { rc = lbmdem_dem_chain(h, run, 1); k += run; }
-    else { rc = lbmdem_dem_substep(h); ++k; }                                                     // main.c:1733-1764
+    if (!resumed) {
+      if (fluid && h->nbsteps % h->cfg.npDEM == 0) rc = lbmdem_lbm_step(h);                           // main.c:1710-1718
+      if (rc == LBMDEM_OK && h->nbsteps % h->cfg.phys.updateVerlet == 0) rc = lbmdem_verlet_rebuild(h);  // main.c:1721-1724
+      if (rc != LBMDEM_OK) return rc;
+    }
+    resumed = false;
+    const long run = lbmdem_dem_chain_length(h, n - k, fluid);
+    if (run) {
+      rc = lbmdem_dem_chain(h, run, fluid);
+      if (rc == LBMDEM_OK && logged && !h->dist && !h->chain_pending.empty()) h->chain_pending.back().done = k;
+      k += run;
+    } else { rc = lbmdem_dem_substep(h); ++k; }                                                     // main.c:1733-1764
     if (rc != LBMDEM_OK) return rc;
   }
   return LBMDEM_OK;
 }
 
+int lbmdem_run(lbmdem_handle* h, long n_dem_steps) {
+  CHECK_H_RUNNING(h);   // (no settling here: these are the calls that stay asynchronous)
+  return run_steps(h, 1, n_dem_steps, !h->dist && h->in_run == 0);
+}
+
 int lbmdem_run_dem(lbmdem_handle* h, long n_dem_steps) {
-  CHECK_H(h);
-  for (long k = 0; k < n_dem_steps;) {
-    int rc = LBMDEM_OK;
-    if (h->nbsteps % h->cfg.phys.updateVerlet == 0) rc = lbmdem_verlet_rebuild(h);  // main.c:1721-1724
-    if (rc != LBMDEM_OK) return rc;
-    const long run = lbmdem_dem_chain_length(h, n_dem_steps - k, 0);
-    if (run) { rc = lbmdem_dem_chain(h, run, 0); k += run; }
-    else { rc = lbmdem_dem_substep(h); ++k; }                                       // main.c:1733-1764
-    if (rc != LBMDEM_OK) return rc;
-  }
+  CHECK_H_RUNNING(h);
+  return run_steps(h, 0, n_dem_steps, !h->dist && h->in_run == 0);
+}
+
+int lbmdem_dem_chain_recoveries(lbmdem_handle* h, long* count) {
+  if (!h || !count) return fail(LBMDEM_EINVAL, "null argument");
+  *count = h->chain_recoveries;
   return LBMDEM_OK;
 }
+
+#ifdef LBMDEM_AB
+// experiment build: the launch of k_dem_chain with this number (counted from 0 over the handle's life; -1: none) gives up
+// half way through its sub-steps, as if a partner's workgroup were not resident
+int lbmdem_debug_chain_giveup(lbmdem_handle* h, int launch) {
+  if (!h) return fail(LBMDEM_EINVAL, "null handle");
+  h->chain_giveup_at = launch;
+  return LBMDEM_OK;
+}
+#endif
 
 int lbmdem_set_lid(lbmdem_handle* h, double uw_h) {
   if (!h) return fail(LBMDEM_EINVAL, "null handle");
@@ -1352,7 +1498,7 @@ int lbmdem_sync(lbmdem_handle* h) {
   int ovf = 0;
   HIP_TRY(hipMemcpy(&ovf, h->V.overflow, sizeof(int), hipMemcpyDeviceToHost));
   if (ovf) return fail(LBMDEM_ENOMEM, "Verlet list overflow (more than %ld symmetric entries)", h->V.cap);
-  if (CHAIN_FAILED(h)) return fail(LBMDEM_EHIP, CHAIN_FAIL_MSG);
+  if (h->dist && CHAIN_FAILED(h)) return fail(LBMDEM_EHIP, CHAIN_FAIL_MSG);
   int ferr = 0;
   HIP_TRY(hipMemcpy(&ferr, h->fs.error, sizeof(int), hipMemcpyDeviceToHost));
   if (ferr) return fail(LBMDEM_EINVAL, "hydrodynamic force of a grain cut by a strip boundary could not be formed (code %d: "
@@ -1373,15 +1519,16 @@ int lbmdem_measure_copy(lbmdem_handle* h, size_t bytes, int reps, double* gb_per
   if (e == hipSuccess) e = hipEventCreate(&e0);
   if (e == hipSuccess) e = hipEventCreate(&e1);
   float best = 0.f;
-  for (int k = 0; k <= reps && e == hipSuccess; ++k) {   // (the first pass is a warm-up)
-    e = hipEventRecord(e0, h->stream);
-    launch_plain_copy(a, b, bytes, h->stream);
-    if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
-    if (e == hipSuccess) e = hipEventSynchronize(e1);
-    float ms = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    if (k > 0 && (best == 0.f || ms < best)) best = ms;
-  }
+  for (int shape = 0; shape < plain_copy_shapes(); ++shape)   // the best of the copy shapes lbm_lattice.hip knows
+    for (int k = 0; k <= reps && e == hipSuccess; ++k) {      // (the first pass of each is a warm-up)
+      e = hipEventRecord(e0, h->stream);
+      launch_plain_copy(a, b, bytes, h->stream, shape);
+      if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+      if (e == hipSuccess) e = hipEventSynchronize(e1);
+      float ms = 0.f;
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+      if (k > 0 && (best == 0.f || ms < best)) best = ms;
+    }
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
   if (a) (void)hipFree(a);

@@ -116,10 +116,11 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
                 hc.nbgrains, hc.lx, hc.ly, hc.x_begin, hc.x_end);
   const int n = H.cfg.nbgrains;
   {   // nothing is allocated from a header the file itself cannot back: the fixed part alone is this long
-    struct stat stt;
+    struct stat stt{};
     const long long need = (long long)sizeof H + (long long)sizeof(double) * 14 * n + (long long)sizeof(int) * (n + 1) +
                            (long long)sizeof(int) * H.nnbr + n + (long long)(sizeof(int) + 9 * sizeof(double)) * H.plane;
-    if (fstat(fileno(fp), &stt) != 0 || (long long)stt.st_size < need)
+    if (fstat(fileno(fp), &stt) != 0) return fail(LBMDEM_EINVAL, "checkpoint '%s': cannot take its size (at least %lld bytes needed)", path, need);
+    if ((long long)stt.st_size < need)
       return fail(LBMDEM_EINVAL, "checkpoint '%s' is shorter than its header claims (%lld of at least %lld bytes)", path,
                   (long long)stt.st_size, need);
   }
@@ -182,6 +183,9 @@ int lbmdem_checkpoint_load(const char* path, int device, lbmdem_handle** out) tr
   h->nbsteps = H.nbsteps;
   h->verlet_ok = H.verlet_ok != 0;
   h->verlet_tracks_positions = h->verlet_ok;
+  // (the positions the list was built from, V.xreb / V.yreb, are not in the file: until the next rebuild the rasterisers
+  // treat the list as outrun -- clear + repaint with atomics, never the list-based plain stores or the update in place)
+  *h->moved_host = h->list_generation;
   if (h->verlet_ok) {  // the entry -> grain map is derived from the offsets
     launch_fill_own(h->V, n, h->stream);
     launch_tile_halo(h->V, n, h->stream);

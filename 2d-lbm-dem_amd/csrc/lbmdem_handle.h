@@ -33,6 +33,24 @@ int lbmdem_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2,
   } while (0)
 #define RC_TRY(expr) do { int rc_ = (expr); if (rc_ != LBMDEM_OK) return rc_; } while (0)
 
+// What lbmdem_run / lbmdem_run_dem were asked for, call by call, since the stream was last known to be sound ...
+struct RunLogEntry { int fluid; long n; };
+// ... and the host's side of the handle as of just before a launch of k_dem_chain (everything that moves from launch to
+// launch): if that launch gives up, every kernel behind it returns at once (the stop word, LatticeView::gate), the device
+// holds exactly this state, and the host goes back to it and replays the log one launch per sub-step (chain_recover,
+// lbmdem_capi.hip).
+struct ChainSnap {
+  long long seq;      // sequence number of the launch's first sub-step (what the failing kernel reports)
+  long log_idx, done; // the run-log entry the launch belongs to, and the sub-steps of that call that were done before it
+  int fcur, ocur, kcur, obst_reset_rows, snap_cur[2], chg_state[2], list_generation;
+  bool obst_pending, snap_ok[2], diag_valid, slots_clean, last_forces_from_table, slots_valid, verlet_ok,
+      verlet_tracks_positions, chain_painted;
+  long long substep_seq, carry_from;
+  int *gathered, *gathered_next;
+  long nbsteps;
+  double Mdx, Mhy;
+};
+
 struct lbmdem_handle {
   lbmdem_config cfg;
   LatticeView L;
@@ -127,6 +145,13 @@ struct lbmdem_handle {
   bool chain_painted = false;
   bool chain_paint = true;     // (lbmdem_set_dem_chain: max_substeps < 0 switches only this off, for A/B)
   long chain_paints = 0;
+  // launches of k_dem_chain that have not been seen to finish, the calls they belong to, and how often one had to be undone
+  std::vector<ChainSnap> chain_pending;
+  std::vector<RunLogEntry> runlog;
+  int in_run = 0;              // inside lbmdem_run / lbmdem_run_dem (their pieces do not settle on their own)
+  bool run_logged = false;     // ... of a call that is in the log (a replay is not)
+  long chain_recoveries = 0;
+  int chain_giveup_at = -1;    // (experiment build: the launch, counted from 0, that is made to give up; lbmdem_debug_chain_giveup)
   long nbsteps = 0;
   int force_mode = 0;
   // derived scalars
@@ -143,11 +168,17 @@ struct lbmdem_handle {
   size_t ev_used = 0;
 };
 
-#define CHECK_H(h) do { if (!(h)) return fail(LBMDEM_EINVAL, "null handle"); HIP_TRY(hipSetDevice((h)->cfg.device)); } while (0)
+// Every entry point starts here. Outside lbmdem_run / lbmdem_run_dem a handle with unconfirmed launches of k_dem_chain is
+// settled first: the stream is drained and, if one of them gave up, the state is taken back to that launch and the calls since
+// are replayed (so a download, a checkpoint, a file writer, an upload never meet a state that a failed launch left behind).
+#define CHECK_H(h) do { if (!(h)) return fail(LBMDEM_EINVAL, "null handle"); HIP_TRY(hipSetDevice((h)->cfg.device)); \
+                        if (!(h)->in_run && !(h)->chain_pending.empty()) RC_TRY(lbmdem_chain_settle(h)); } while (0)
+#define CHECK_H_RUNNING(h) do { if (!(h)) return fail(LBMDEM_EINVAL, "null handle"); HIP_TRY(hipSetDevice((h)->cfg.device)); } while (0)
 #define CHECK_NOT_SPLIT(h) do { if ((h)->cs_interior_pending) return fail(LBMDEM_EINVAL, "lbmdem_collide_stream_part(LBMDEM_CS_INTERIOR) has not been called after LBMDEM_CS_EDGES"); } while (0)
 
+// (distributed handles only: a rank cannot go back on its own -- its neighbours have moved on; single-domain handles recover)
 #define CHAIN_FAILED(h) ((h)->chain.err_host && *(h)->chain.err_host)
-#define CHAIN_FAIL_MSG "a tile of the multi-sub-step DEM kernel gave up waiting for its partners' state (workgroups not co-resident?); the grain state is undefined"
+#define CHAIN_FAIL_MSG "a launch of the multi-sub-step DEM kernel could not finish on this rank (workgroups not co-resident?): every kernel behind it was held back, the rank's state is that of the launch's first sub-step; restart the decomposition from its last checkpoint with lbmdem_set_dem_chain(h, 0)"
 
 // Named ranges for rocprofv3 --marker-trace around the phases of a step (LBMDEM_ROCTX=1; lbmdem_capi.hip)
 struct PhaseRange {
@@ -199,6 +230,7 @@ static inline DemParams dem_params(const lbmdem_handle* h) {
   const lbmdem_config& c = h->cfg;
   const lbmdem_physics& p = c.phys;
   DemParams P;
+  P.gate = h->chain.gate;
   P.n = h->n; P.dt = (real)c.dt; P.dt2 = (real)c.dt2;
   P.kg = (real)p.kg; P.nug = (real)p.nug; P.kt = (real)p.kt; P.mu = (real)p.mu; P.murf = (real)p.murf;
   P.km = (real)p.km; P.num = (real)p.num; P.ktm = (real)p.ktm; P.mumb = (real)p.mumb; P.mum = (real)p.mum; P.nugt = (real)p.nugt;
@@ -216,6 +248,7 @@ static inline DemParams dem_params(const lbmdem_handle* h) {
 #define LBMDEM_INTERNAL extern "C" __attribute__((visibility("hidden")))
 LBMDEM_INTERNAL int lbmdem_write_vtk_file(const char* path, int nx, int ny, const char* name, int dim, const float* data);
 LBMDEM_INTERNAL int lbmdem_verlet_build_lists(lbmdem_handle* h);
+LBMDEM_INTERNAL int lbmdem_chain_settle(lbmdem_handle* h);
 // the next obst_construction will update obst[1 - ocur] in place: nobody resets that canvas beforehand
 static inline bool obst_update_planned(const lbmdem_handle* h) {
   return h->obst_update && !h->dist && h->snap_ok[1 - h->ocur] && h->verlet_ok && h->verlet_tracks_positions &&

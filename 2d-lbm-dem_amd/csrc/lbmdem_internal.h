@@ -50,6 +50,11 @@ struct LatticeView {
   // recip_ok = 0 when a divisor's significand is all ones (the one case the construction does not cover)
   real rc, rcc;
   int recip_ok;
+  // The stop word of the handle (device memory, 0 = go): a kernel that finds it set returns at once. Raised by a launch of the
+  // multi-sub-step DEM kernel that could not finish (k_dem_chain), it turns everything queued behind that launch into
+  // nothing, so that the host finds the state exactly as it was before the launch and replays from there (lbmdem_capi.hip,
+  // chain_recover). null: no such word.
+  const int* gate;
   real lid6;               // EXTENSION: uw_h / 6 of the lid terms commented out at main.c:1129-1130; 0 = off
   real cc;                 // c * c
   real wc_diag, wc_axis;   // w_q / c for the diagonal and the axis directions (main.c:1174,1184)
@@ -120,8 +125,11 @@ struct ForceSlots {
 #define LBMDEM_SLOT_EMPTY 0x7FF8C0DE5107E117ull  /* a quiet NaN no arithmetic produces (double build; the float build has no table) */
 constexpr int LBMDEM_SPD_MAX = 64;               // larger grains (reduced radius > ~20 nodes): feature off
 
+#define LBMDEM_GATE(g) do { if ((g) != nullptr && *(g) != 0) return; } while (0)   /* first statement of a gated kernel */
+
 struct DemParams {
   int n;
+  const int* gate;                       // the handle's stop word (LatticeView::gate)
   real dt, dt2;
   real kg, nug, kt, mu, murf;            // grain-grain (main.c:104-113)
   real km, num, ktm, mumb, mum, nugt;    // walls
@@ -265,7 +273,8 @@ void launch_aos_to_soa(const real* aos_rows, real* f, const LatticeView& L, hipS
 void launch_soa_to_aos(const real* f, real* aos_rows, const LatticeView& L, int xl0, int nrows,
                        hipStream_t st);
 void launch_fill_equilibrium(real* f, const LatticeView& L, hipStream_t st);
-void launch_plain_copy(const void* src, void* dst, size_t bytes, hipStream_t st);
+void launch_plain_copy(const void* src, void* dst, size_t bytes, hipStream_t st, int shape = 0);
+int plain_copy_shapes();
 void launch_macro(const real* f, const LatticeView& L, int xl0, int nrows, real* rho, real* ux,
                   real* uy, hipStream_t st);
 void launch_density_partial(const real* f, const LatticeView& L, double* partial, int nblocks,
@@ -312,6 +321,7 @@ struct VerletDevice {
   unsigned* emeta;           // [cap] own grain's index in its tile | (own < partner) << 6 | partner's staging slot << 8
   unsigned char* tile_far;   // [tiles] the tile has a partner in a tile that is expected on another XCD
   real *xreb, *yreb;         // [n] the positions the list was built from
+  const int* gate;           // the handle's stop word (LatticeView::gate): a rebuild behind a failed launch leaves the list alone
 };
 constexpr int DEM_CHAIN_HALO = 256;          // halo grains staged per tile; partners beyond that are read from memory per entry
 constexpr unsigned DEM_CHAIN_DIRECT = 0xFFFFu;   // emeta slot value of such a partner
@@ -333,6 +343,7 @@ struct DiagExtra {
   int* wlist;                            // [4][n] wall candidate lists (bottom, top, left, right), grains ascending
   int* wcount;                           // [4]
   real* carry;                         // pft, pff, pf: persist from sub-step to sub-step
+  const int* gate;                     // the handle's stop word (LatticeView::gate)
 };
 int diag_extra_alloc(DiagExtra& X, int n, long cap, real* carry);
 
@@ -351,6 +362,7 @@ struct CarryTrack {
   int tiles;
   long long* who;       // [tiles][4] the contact of the record: (grain << 32) | partner (walls: partner 0)
   long long* best_key;  // [3][2] left by launch_carry_resolve: {(stamp + 1) * 4 + kind, who} of the record each carry came from
+  const int* gate;      // the handle's stop word (LatticeView::gate)
 };
 int carry_track_alloc(CarryTrack& T, int n);
 void carry_track_free(CarryTrack& T);
@@ -382,8 +394,10 @@ void launch_obst_fill_rows(int* obst, const LatticeView& L, int row0, int row1, 
 struct DemChain {
   void* pub;            // [local copy, remote copy][2 parities][n] lines of 128 bytes
   size_t pub_bytes;
-  volatile int* err_host;  // pinned host word: a tile gave up waiting for a partner (every spin is bounded) ...
+  volatile int* err_host;  // pinned host word: a tile gave up waiting for a partner (every spin is bounded): 1 + the low bits of
+                           // the launch's first sequence number ...
   int* err;             // ... and its device address
+  int* gate;            // device word raised together with it: the handle's stop word (LatticeView::gate)
   int* census;          // device counter of the residency check
   int capacity;         // tile slots the launch may use (all its workgroups must be resident at once); 0: not usable
   long long* dbg;       // experiment build only: [tiles][8] clocks of the last launch (lbmdem_debug_chain_times)

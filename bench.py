@@ -303,6 +303,13 @@ def main():
     ap.add_argument("--change-mask", type=int, default=None,
                     help="1 = the fused kernel reads the previous obstacle map only in the rows the rasterisation marked as "
                          "changed (the library's default), 0 = both maps everywhere (A/B)")
+    ap.add_argument("--long-steps", type=int, default=200,
+                    help="after the timed region, in the same process: this many more coupled steps of the same run, reported "
+                         "as ms_per_step_200 / collide_stream_kernel_ms_200 (SURVEY 8-d's window; skipped when --steps is "
+                         "already that long; 0 = none)")
+    ap.add_argument("--real-steps", type=int, default=60,
+                    help="... and this many coupled steps of the reference's own bin/50000.data geometry on a handle of its "
+                         "own (real50k_ms_per_step; metric workload at one GPU only; 0 = none)")
     ap.add_argument("--strips", action="store_true",
                     help="use the strip-decomposition driver (torch.distributed) even with one rank")
     args = ap.parse_args()
@@ -502,6 +509,33 @@ def main():
         lbm_only_ms = 1e3 * (t1 - t0) / nl
         leg.close()
 
+    # In the same process, after the driver's timed region (its --steps 20 are 17 ms): SURVEY 8-d's window -- 200 coupled
+    # steps of the SAME run, the fused kernel timed around every 8th launch (25 launches) ...
+    long_leg = None
+    if world == 1 and not args.strips and args.long_steps > 0 and args.steps < args.long_steps:
+        sim.profile_enable(8)
+        sync()
+        t0 = time.perf_counter(); run_steps(args.long_steps); sync(); t1 = time.perf_counter()
+        lk_ms, lk_n = sim.profile_read()
+        sim.profile_enable(False)
+        long_leg = {"steps": args.long_steps, "ms_per_step": 1e3 * (t1 - t0) / args.long_steps, "kernel_ms": lk_ms, "launches_timed": lk_n}
+    # ... and the reference's OWN geometry (bin/50000.data as its reader parsed it, 49 987 grains, not row-coherent: 5.8 list
+    # entries per grain against the synthetic packing's 3.4), on a handle of its own
+    real_leg = None
+    real_fixture = os.path.join(ROOT, "tests", "golden", "real_50000_4096x4096.npz")
+    if world == 1 and not args.strips and args.workload == "metric" and args.real_steps > 0 and os.path.exists(real_fixture):
+        wr = workload("real50k")
+        (rr, rx1, rx2), _ = make_sample(wr)
+        s3 = pkg.LbmDem(wr["lx"], wr["ly"], rr, rx1, rx2, device=local_rank, precision=args.precision)
+        s3.set_force_mode(args.force_mode)
+        s3.renderScene(20 * npdem); s3.sync()
+        s3.profile_enable(4)
+        t0 = time.perf_counter(); s3.renderScene(args.real_steps * npdem); s3.sync(); t1 = time.perf_counter()
+        rk_ms, _rk_n = s3.profile_read()
+        real_leg = {"steps": args.real_steps, "ms_per_step": 1e3 * (t1 - t0) / args.real_steps, "kernel_ms": rk_ms,
+                    "recoveries": s3.dem_chain_recoveries()}
+        s3.close()
+
     # informative: the fast (shuffle-tree) force kernel on the same state: drift against the parity kernel's
     # bits for one and the same lattice, and the coupled-step rate with it (SURVEY hard part 11)
     fast = None
@@ -570,10 +604,24 @@ def main():
             "dem_only_steps_per_s": round(dem_only, 1) if dem_only else None,
             "lbm_step_only_ms": round(lbm_only_ms, 4) if lbm_only_ms else None,
             "lbm_step_only_mlups": round(1e-3 * lx * ly / lbm_only_ms, 1) if lbm_only_ms else None,
+            # the same run 200 steps on (fused kernel: mean over 25 timed launches), and the reference's own geometry
+            "ms_per_step_200": round(long_leg["ms_per_step"], 4) if long_leg else None,
+            "collide_stream_kernel_ms_200": round(long_leg["kernel_ms"], 4) if long_leg else None,
+            "launches_timed_200": long_leg["launches_timed"] if long_leg else None,
+            "real50k_ms_per_step": round(real_leg["ms_per_step"], 4) if real_leg else None,
+            "real50k_mlups": round(1e-3 * lx * ly / real_leg["ms_per_step"], 1) if real_leg else None,
+            "real50k_collide_stream_kernel_ms": round(real_leg["kernel_ms"], 4) if real_leg else None,
+            "dem_chain_recoveries": sim.dem_chain_recoveries(),
             "collide_stream_kernel_ms": round(kernel_ms, 4),
             "collide_stream_kernel_mlups": round(1e-6 * rows * ly / (kernel_ms * 1e-3), 1) if kernel_ms > 0 else None,
             "roofline": {"bound": "hbm", "kernel": "k_cs_march (fused reinit+collide+IBB+stream)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         # the whole coupled step priced the same way: `value` x 148 B / peak (north_star's 40 % is asked of this)
+                         "step_frac": round(mlups * 1e6 * bytes_per_lup / 1e9 / HBM_PEAK_GBS, 4),
+                         "frac_200": (round(bytes_per_lup * rows * ly / (long_leg["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                      if long_leg and long_leg["kernel_ms"] > 0 else None),
+                         "step_frac_200": (round(bytes_per_lup * rows * ly / (long_leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                           if long_leg else None),
                          "traffic": traffic, "traffic_source": traffic_source,
                          # the kernel's REAL traffic rate against what a plain copy moves on this very GPU (null without
                          # counter traffic for this build); and the algorithmic rate against the same yardstick
@@ -582,7 +630,10 @@ def main():
                          "bytes_per_lup": bytes_per_lup, "launches_timed": launches, "timed_every": prof_stride,
                          "note": "achieved = algorithmic 148 B/LUP x lattice nodes per launch / mean HIP-event "
                                  "duration of every `timed_every`-th launch of the timed region; traffic = HBM bytes per launch from rocprofv3 FETCH_SIZE + WRITE_SIZE "
-                                 "(separate passes, calibrated on copy kernels) -- reported only when the file was measured on this very library binary"},
+                                 "(separate passes, calibrated on copy kernels) -- reported only when the file was measured on this very library binary; "
+                                 "hbm_copy_gbs = the best of four plain-copy shapes on this GPU in this process (8 / 16 B per lane, 2 048 - 8 192 "
+                                 "workgroups; the guide's own copy figure for the part is 6.29 TB/s: this yardstick compares boxes, it is "
+                                 "not the memory system's ceiling); step_frac / *_200 = the coupled step, and the 200-step leg, priced like frac"},
             "fast_force_mode": fast,
             "total_mass": mass,
         }

@@ -185,6 +185,14 @@ int lbmdem_dem_chain_stats(lbmdem_handle* h, long* launches, long* substeps, int
  * lbmdem_obst_construction has nothing left to launch. lbmdem_dem_chain_paints: how often that happened.
  * lbmdem_set_dem_chain(h, -1) switches only this off (A/B). Same maps bit for bit. */
 int lbmdem_dem_chain_paints(lbmdem_handle* h, long* paints);
+/* A launch of that kernel needs all its workgroups on the GPU at once, which HIP does not promise (another process, a CU
+ * mask): every wait in it is bounded, and a launch that gives up cannot end a run -- the reference's loop (main.c:1733-1763)
+ * cannot fail either. It raises a stop word that every kernel queued behind it looks at first, so the device keeps the
+ * state the launch started from; the next call that is not lbmdem_run / lbmdem_run_dem (or the 256th launch since) drains
+ * the stream, takes the handle back to that launch, switches the multi-sub-step kernel off for the handle and repeats the
+ * sub-steps since, one launch each: the same bits. lbmdem_dem_chain_recoveries: how often that has happened (0 on a GPU of
+ * its own). Distributed handles (lbmdem_dist_*) report the failure instead: a rank cannot go back alone. */
+int lbmdem_dem_chain_recoveries(lbmdem_handle* h, long* count);
 
 /* ---- state in / out (host layout) ------------------------------------------------------------ */
 
@@ -265,8 +273,9 @@ int lbmdem_sync(lbmdem_handle* h);
  * event records around a launch hold the next dispatch back: ~10 us per coupled step when every launch is timed). */
 int lbmdem_profile_enable(lbmdem_handle* h, int on);
 int lbmdem_profile_read(lbmdem_handle* h, double* mean_ms, long* launches);
-/* GB/s (bytes read + bytes written) of a plain copy kernel moving `bytes` on this handle's device and stream, best of `reps`
- * passes after a warm-up: the yardstick bench.py puts next to the fused kernel's traffic rate (boxes differ by +-5 %). */
+/* GB/s (bytes read + bytes written) of a plain copy kernel moving `bytes` on this handle's device and stream: the best of
+ * four shapes (8 or 16 bytes per lane, 2 048 to 8 192 workgroups), each the best of `reps` passes after a warm-up: the
+ * yardstick bench.py puts next to the fused kernel's traffic rate (boxes differ by +-5 %). */
 int lbmdem_measure_copy(lbmdem_handle* h, size_t bytes, int reps, double* gb_per_s);
 
 /* Strip decomposition along x (one process per GPU); halo >= 2 rows (with REPLICATED grains, i.e. without
@@ -316,8 +325,6 @@ int lbmdem_dist_unpack(lbmdem_handle* h, int kind, int side, const void* dev_buf
 /* both sides in one launch (a null buffer skips the side): fewer dependent kernel launches per fluid step */
 int lbmdem_dist_pack2(lbmdem_handle* h, int kind, void* buf_lo, void* buf_hi);
 int lbmdem_dist_unpack2(lbmdem_handle* h, int kind, const void* buf_lo, const void* buf_hi);
-/* diagnostic: after every sub-step, grains this rank does not integrate are overwritten with NaN */
-int lbmdem_dist_set_poison(lbmdem_handle* h, int on);
 
 /* ---- RCCL transport of that protocol for a C host (the driver 2d-lbm-dem_amd/host/lbmdem --gpus N); strips.py does
  * the same over torch.distributed. One process per GPU; rank k talks to ranks k-1 and k+1 only: ncclSend / ncclRecv
@@ -383,6 +390,20 @@ int lbmdem_fhf_import(lbmdem_handle* h, const void* dev_buf);
 
 const char* lbmdem_last_error(void);
 const char* lbmdem_version(void);
+
+/* ---- test aids -----------------------------------------------------------------------------------
+ * Nothing a host needs; the GPU test suite checks the library's short cuts against its own slow paths through these.
+ * Collected here so that the list above is the product's surface:
+ *   lbmdem_set_change_mask(h, 2)   every fused launch is repeated with both maps read everywhere and compared (above)
+ *   lbmdem_set_dem_chain(h, -1)    runs of sub-steps without the rasterisation at their end (above)
+ *   lbmdem_set_obst_update(h, 0), lbmdem_set_dem_chain(h, 0), lbmdem_set_change_mask(h, 0), lbmdem_set_force_mode(h, 1)
+ *                                  the A/B switches of bench.py (--obst-update, --dem-chain, --change-mask, --force-mode)
+ *   the *_stats / lbmdem_dem_chain_paints / lbmdem_dem_chain_recoveries counters
+ *   LBMDEM_RCCL_LIBRARY            (environment) the RCCL library lbmdem_comm_create loads; the tests point it at
+ *                                  tests/rccl_shim to run several ranks on ONE GPU; announced on stderr when set
+ * and, only here: */
+/* after every sub-step, grains this rank does not integrate are overwritten with NaN (strip tests: nothing may read them) */
+int lbmdem_dist_set_poison(lbmdem_handle* h, int on);
 
 #pragma pop_macro("scale")
 #pragma pop_macro("ly")

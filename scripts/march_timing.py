@@ -29,10 +29,13 @@ kernel_ms, launches = sim.profile_read()
 assert fn(out) == 0
 t = [int(v) for v in out]
 names = ["wait for the populations of row x+1", "reinit + collide of row x+1", "gathers + issue of the row prefetch",
-         "node_active of row x+1", "shifts + classify + stores", "compacted bounce-back pass", "ring put + rotate", "loop head"]
+         "act of row x+1 (lane masks)", "DPP shifts + classification (edge rows: + their stores)",
+         "after the links: the row's nine stores (results merged in)", "ring put + rotate", "loop head", "", "",
+         "links compacted into LDS slots", "links evaluated (LDS reads, bounce-back, result, table store)"]
 tot = t[8]
+phase = t[:8] + [0, 0] + t[10:12]
 res = {"fused_kernel_ms": round(kernel_ms, 4), "waves": t[9] // steps,
-       "cycles_per_wave": round(tot / max(t[9], 1)), "sum_of_phases_frac": round(sum(t[:8]) / tot, 4),
-       "phases_frac_of_wave_time": {n: round(v / tot, 4) for n, v in zip(names, t[:8])}}
+       "cycles_per_wave": round(tot / max(t[9], 1)), "sum_of_phases_frac": round(sum(phase) / tot, 4),
+       "phases_frac_of_wave_time": {n: round(v / tot, 4) for n, v in zip(names, phase) if n}}
 res["phases_frac_of_wave_time"] = {n: v for n, v in res["phases_frac_of_wave_time"].items() if v}
 print(json.dumps(res))

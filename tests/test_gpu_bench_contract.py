@@ -36,6 +36,13 @@ def test_single_process_line():
     assert abs(r["achieved_over_copy"] - r["achieved"] / d["hbm_copy_gbs"]) < 1e-3
     assert r["frac_of_copy"] is None or 0.3 < r["frac_of_copy"] < 1.2
     assert d["config"]["dem_chain"]["launches"] > 0 and d["config"]["dem_chain"]["resident"] == d["config"]["dem_chain"]["tile_slots"]
+    # what the README quotes is in the driver-timed record itself: SURVEY 8-d's 200-step window of the same run (the fused
+    # kernel averaged over 25 timed launches), the reference's own 50000.data geometry, and the whole step priced like the kernel
+    assert 0.3 < d["ms_per_step_200"] < 5.0 and d["launches_timed_200"] >= 25 and 0.2 < d["collide_stream_kernel_ms_200"] < d["ms_per_step_200"]
+    assert 0.3 < d["real50k_ms_per_step"] < 5.0 and d["real50k_mlups"] > 1000
+    assert abs(r["step_frac"] - d["value"] * 1e6 * 148.0 / 8e12) < 2e-3 and 0.05 < r["step_frac"] < r["frac"]
+    assert r["frac_200"] > 0.2 and r["step_frac_200"] < r["frac_200"]
+    assert d["dem_chain_recoveries"] == 0
 
 
 def test_settle_steps_can_be_switched_off():

@@ -175,3 +175,111 @@ def test_kernel_timing_of_every_nth_launch(pkg):
     sim.renderScene(n)
     assert sim.profile_read()[1] == 0
     sim.close()
+
+
+def test_partners_beyond_the_staged_halo_inside_one_xcd_eighth(pkg):
+    """A tile reads a partner that is not among its 256 staged halo grains straight from that grain's lines -- from the
+    LOCAL copy when the partner's tile belongs to the same XCD eighth: the remote copy only exists for tiles with a partner
+    in another eighth. Eight clusters of 512 grains, far apart, each numbered at random within its own index range
+    (= one eighth of the 64 tiles): every tile has ~350 distinct partners outside itself, none of them in another eighth."""
+    lxc, gap_mm = 600, 2.5
+    rs, xs, ys = [], [], []
+    y0 = 0.0
+    for c in range(8):
+        r, x, y = samples.row_packing(lxc, 4000, 512, seed=100 + c, rmin=0.2, rmax=0.3)   # small grains: ~12 list partners each
+        assert len(r) == 512
+        p = np.random.default_rng(c).permutation(512)
+        rs.append(r[p]); xs.append(x[p]); ys.append(y[p] + y0)
+        y0 += y.max() + 0.3 + gap_mm
+    r, x, y = np.concatenate(rs), np.concatenate(xs), np.concatenate(ys)
+    lx, ly = lxc, int(10 * (y0 + 1.0)) // 16 * 16 + 16
+    r, x1, x2 = samples.to_metres(r, x, y)
+    a = pkg.LbmDem(lx, ly, r, x1, x2)
+    b = pkg.LbmDem(lx, ly, r, x1, x2)
+    b.set_dem_chain(0)
+    kick([a, b], len(r), 31)
+    for n in (61, 160, 39):
+        a.run_dem(n); b.run_dem(n)
+        assert np.array_equal(a.kinematics, b.kinematics), a.nbsteps
+    la, sa, slots, resident = a.dem_chain_stats()
+    assert resident == slots == 64 and sa >= 250, (la, sa, slots, resident)
+    assert a.dem_chain_recoveries() == 0
+    # the case is what it says: a tile with more distinct partners outside itself than the 256 staged ones, all in its eighth
+    cumul, nbrs, _ = a.verlet()             # the reference's form: pairs (i < j), cumul = running end offsets
+    first = np.concatenate([[0], cumul[:-1]])
+    counts = np.maximum(cumul - first, 0); counts[-1] = 0
+    npairs = int(counts.sum())
+    own = np.repeat(np.arange(len(r)), counts)
+    pairs = np.concatenate([np.stack([own, nbrs[:npairs]], 1), np.stack([nbrs[:npairs], own], 1)])
+    assert np.all(pairs[:, 0] // 512 == pairs[:, 1] // 512)
+    off = pairs[pairs[:, 0] // 64 != pairs[:, 1] // 64]
+    most = max(len(np.unique(off[off[:, 0] // 64 == t, 1])) for t in range(64))
+    assert most > 256, most
+    a.close(); b.close()
+
+
+GIVEUP_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import __graft_entry__ as ge, samples
+pkg = ge.load_package()
+mode = sys.argv[1]
+lx, ly = 1024, 640
+r, x, y = samples.row_packing(lx, ly, 2500, seed=5)
+r, x1, x2 = samples.to_metres(r, x, y)
+a = pkg.LbmDem(lx, ly, r, x1, x2)          # the multi-sub-step kernel, one launch made to give up
+b = pkg.LbmDem(lx, ly, r, x1, x2); b.set_dem_chain(0)
+k = a.kinematics
+k[:, 3:6] = np.random.default_rng(17).normal(0, 1, (len(r), 3)) * (0.05, 0.05, 30.0)
+a.kinematics = k; b.kinematics = k
+step = (lambda s, n: s.run_dem(n)) if mode == "dem" else (lambda s, n: s.renderScene(n))
+a.debug_chain_giveup(2 if mode == "download" else (9 if mode in ("inloop", "inloop_late") else 3))
+runs = (37, 1, 12, 200, 95)
+if mode == "inloop":                       # LBMDEM_CHAIN_CAP=2: the run loop drains the stream every second launch and finds it itself
+    runs = (345,)
+if mode == "inloop_late":                  # ... found by the loop of a LATER call than the launch's
+    runs = (37, 1, 12, 36, 12, 24, 95)
+if mode == "download":                     # found by the first call that is not a run: a download right behind the launch
+    step(a, 37); step(b, 37)
+    la = a.dem_chain_stats()[0]
+    assert la >= 3, la
+    assert np.array_equal(a.kinematics, b.kinematics)
+    assert a.dem_chain_recoveries() == 1
+    runs = (1, 12, 200, 95)
+for n in runs:                             # nothing but runs in between: the failed launch is found at the end
+    step(a, n); step(b, n)
+assert a.nbsteps == b.nbsteps
+assert np.array_equal(a.kinematics, b.kinematics)
+assert a.dem_chain_recoveries() == 1, a.dem_chain_recoveries()
+assert np.array_equal(a.grain_pressure, b.grain_pressure)
+if mode != "dem":
+    assert np.array_equal(a.fhf, b.fhf) and np.array_equal(a.obst, b.obst) and np.array_equal(a.f, b.f)
+# the handle carries on one launch per sub-step, and takes the kernel back when asked to
+la0 = a.dem_chain_stats()[0]
+step(a, 40); step(b, 40)
+assert a.dem_chain_stats()[0] == la0
+a.set_dem_chain(128); a.debug_chain_giveup(-1)
+step(a, 60); step(b, 60)
+assert a.dem_chain_stats()[0] > la0 and a.dem_chain_recoveries() == 1
+assert np.array_equal(a.kinematics, b.kinematics)
+print("recovered:", mode, "launches", a.dem_chain_stats()[0])
+"""
+
+
+@pytest.mark.parametrize("mode", ["coupled", "dem", "download", "inloop", "inloop_late"])
+def test_a_launch_that_gives_up_is_undone_and_the_run_goes_on(mode):
+    """k_dem_chain needs all its workgroups resident at once; a launch that gives up (here: made to, in the experiment build,
+    half way through its sub-steps) raises the handle's stop word, the kernels queued behind it do nothing, and the library
+    goes back to the state before the launch and repeats the calls since with one launch per sub-step: bit-equal to a handle
+    that never used the kernel -- fluid, maps, forces and grains, found at the end of a sequence of runs or by a download."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "2d-lbm-dem_amd", "liblbmdem_hip_ab.so")
+    if not os.path.exists(lib):
+        pytest.skip("the experiment build (make -C 2d-lbm-dem_amd/csrc AB=1) is not there")
+    env = dict(os.environ, LBMDEM_HIP_LIBRARY=lib)
+    if mode == "inloop": env["LBMDEM_CHAIN_CAP"] = "2"
+    if mode == "inloop_late": env["LBMDEM_CHAIN_CAP"] = "5"
+    out = subprocess.run([sys.executable, "-c", GIVEUP_SCRIPT, mode], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "recovered: " + mode in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
