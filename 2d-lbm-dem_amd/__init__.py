@@ -130,6 +130,8 @@ def _open_library(LIB_PATH):
     L.lbmdem_set_force_mode.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_set_dem_chain.argtypes = [C.c_void_p, C.c_int]
     L.lbmdem_dem_chain_paints.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+    if hasattr(L, "lbmdem_set_dem_tiles"):
+        L.lbmdem_set_dem_tiles.argtypes = [C.c_void_p, C.c_int]
     if hasattr(L, "lbmdem_dem_chain_recoveries"):   # (older builds kept for A/B runs do not have it)
         L.lbmdem_dem_chain_recoveries.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
     if hasattr(L, "lbmdem_debug_chain_giveup"):   # experiment build only
@@ -557,8 +559,14 @@ class LbmDem:
         _chk(self._L.lbmdem_dem_chain_paints(self._h, C.byref(a)))
         return a.value
 
+    def set_dem_tiles(self, mode):
+        """1: the tiles of the multi-sub-step DEM kernel are patches of the packing (default); 0: 64 consecutive indices"""
+        _chk(self._L.lbmdem_set_dem_tiles(self._h, int(mode)))
+
     def dem_chain_recoveries(self):
         """launches of the multi-sub-step kernel that gave up and were undone (the run went on one launch per sub-step)"""
+        if not hasattr(self._L, "lbmdem_dem_chain_recoveries"):
+            return 0
         a = C.c_long(0)
         _chk(self._L.lbmdem_dem_chain_recoveries(self._h, C.byref(a)))
         return a.value

@@ -23,6 +23,7 @@
 // diagnostics" below.
 
 #include "lbmdem_internal.h"
+#include <vector>
 
 #include <hipcub/hipcub.hpp>
 
@@ -457,7 +458,7 @@ constexpr int CH_SLOTS = DEM_TILE + DEM_CHAIN_HALO;   // grains staged in LDS: t
 constexpr int CH_ENTRIES = 448;                       // list entries staged per round (k_dem_entries: DEM_ENTRIES); the reference's own 50 000-grain packing has up to 387 per tile
 constexpr int CH_META = 768;                          // list entries whose emeta word is kept in LDS
 constexpr int CH_ITEMS = 3;                          // 16-byte slots a lane has in flight per pass of the halo fetch (153 grains)
-constexpr unsigned CH_SPINS = 1u << 18;
+constexpr unsigned CH_SPINS = 1u << 22;   // (~ seconds: a workgroup that is late -- the first launch of a process, another stream's kernels -- is not one that never comes)
 constexpr unsigned CH_POISON = 0xFFFFFFFEu;
 constexpr unsigned CH_SKIP = 0xFFFFFFFFu;             // emeta of an entry nobody adds up (its grain is not integrated here)
 
@@ -506,6 +507,8 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
                                                            const int* __restrict__ nbr, const unsigned* __restrict__ emeta,
                                                            const int* __restrict__ halo_ids,
                                                            const int* __restrict__ halo_cnt,
+                                                           const int* __restrict__ tile_grains,
+                                                           const int* __restrict__ where,
                                                            const unsigned char* __restrict__ tile_far,
                                                            const unsigned char* __restrict__ wallflags,
                                                            real* __restrict__ pout, DemParams P,
@@ -525,7 +528,8 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
   // per grain of the tile, kept out of the registers: the angle (no contact needs it), the hydrodynamic force, 1 / the
   // inertia terms' divisors and the gravity terms
   __shared__ real sX3[DEM_TILE], sFh[3 * DEM_TILE], sMI[2 * DEM_TILE], sG[2 * DEM_TILE];
-  __shared__ int sK[2 * DEM_TILE];            // first and last list entry of the tile's grains (for the rasterisation at the end)
+  __shared__ int sK[2 * DEM_TILE];            // first and last list entry of the tile's grains
+  __shared__ int sPre[DEM_TILE + 1];          // ... and where their entries stand among the tile's (the tile's entries: its grains' list ranges one after the other)
   __shared__ int sLast, sFail, sScan[2];
   const int tid = threadIdx.x;
   const bool one_xcd = (flags & 1) != 0;
@@ -565,10 +569,9 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   const bool placed = true;
 #endif
-  const int g0 = tile * DEM_GRAINS;
-  const int g1 = g0 + DEM_GRAINS < P.n ? g0 + DEM_GRAINS : P.n;
-  const int i = g0 + tid;
-  const bool have = tid < DEM_GRAINS && i < P.n;
+  // the tile's grains: a patch of the packing (VerletDevice::tile_grains), ascending, one per lane of the first wavefront
+  const int i = tid < DEM_GRAINS ? tile_grains[(long)tile * DEM_TILE + tid] : -1;
+  const bool have = i >= 0;
   const bool mine = have && (!active || active[i]);
   const unsigned tag0 = chain_tag(stamp0), stag = 0x80000000u | tag0;
   // the grains of this tile, as the previous sub-step left them
@@ -591,18 +594,40 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
     }
     return;
   }
-  const int e0 = offsets[g0], e1 = offsets[g1];
+  {   // the grains' list ranges and their places among the tile's entries
+    const int kk0 = have ? offsets[i] : 0, cnt = have ? offsets[i + 1] - kk0 : 0;
+    if (tid < DEM_GRAINS) {
+      int incl = cnt;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (tid >= d) incl += up;
+      }
+      sK[tid] = kk0; sK[DEM_TILE + tid] = kk0 + cnt; sPre[tid + 1] = incl;
+      if (tid == 0) sPre[0] = 0;
+    }
+  }
+  __syncthreads();
+  const int E = sPre[DEM_TILE];   // entries of the tile
+  // position among the tile's entries -> the list entry (the few places that need the entry itself: a partner beyond the
+  // staged halo, the record of the tile's last contact, entries beyond the staged meta words)
+  auto entry_of = [&](int p) {
+    int lo = 0, hi = DEM_TILE - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sPre[mid] <= p) lo = mid; else hi = mid - 1; }
+    return sK[lo] + (p - sPre[lo]);
+  };
   const int hcnt = halo_cnt[tile];
   const int nitems = hcnt * 5;
   for (int h = tid; h < hcnt; h += DEM_THREADS) {
     const int g = halo_ids[(long)tile * DEM_CHAIN_HALO + h];
     // bit 0: read the remote copy (the grain's tile is expected on another XCD)
-    sHoff[h] = (unsigned)g * 128u | ((!one_xcd && (g / DEM_TILE) / tiles_per_xcd != tile / tiles_per_xcd) ? 1u : 0u);
+    sHoff[h] = (unsigned)g * 128u | ((!one_xcd && (where[g] >> 6) / tiles_per_xcd != tile / tiles_per_xcd) ? 1u : 0u);
     sR[DEM_TILE + h] = r[g];
   }
-  for (int k = tid; k < CH_META && e0 + k < e1; k += DEM_THREADS) {
-    unsigned w = emeta[e0 + k];
-    if (active && !active[g0 + (int)(w & 63u)]) w = CH_SKIP;
+  auto grain_at = [&](int li) { return tile_grains[(long)tile * DEM_TILE + li]; };   // (rare paths)
+  for (int k = tid; k < CH_META && k < E; k += DEM_THREADS) {
+    unsigned w = emeta[entry_of(k)];
+    if (active && !active[grain_at((int)(w & 63u))]) w = CH_SKIP;
     sMeta[k] = w;
   }
   real pr = 0.0;
@@ -614,7 +639,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
   }
   if (mine) {
     sFh[tid] = fhf[i]; sFh[DEM_TILE + tid] = fhf[P.n + i]; sFh[2 * DEM_TILE + tid] = fhf[2 * P.n + i];   // main.c:1429-1431: constant between two fluid steps
-    k0 = offsets[i]; k1 = offsets[i + 1];
+    k0 = sPre[tid]; k1 = sPre[tid + 1];   // this grain's entries, as positions among the tile's
     wf = wallflags[i];
     const real mi = m[i], mw = 0.0;
     sMI[tid] = mi; sMI[DEM_TILE + tid] = It[i];
@@ -636,7 +661,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
   const bool any_far = !one_xcd && tile_far[tile];
   // which copy of grain g's lines a reader in THIS tile takes when g is not among the staged halo grains (as sHoff's bit 0)
   auto direct_copy = [&](int g) -> unsigned {
-    return (!one_xcd && (g / DEM_TILE) / tiles_per_xcd != tile / tiles_per_xcd) ? remote : 0u;
+    return (!one_xcd && (where[g] >> 6) / tiles_per_xcd != tile / tiles_per_xcd) ? remote : 0u;
   };
   GrainState me{};
   me.r = tid < DEM_GRAINS ? sR[tid] : (real)0.;
@@ -742,12 +767,12 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
     int last_e = -1, slast = -1;
     real last_ft = 0., last_f3 = 0.;
     bool lost = false;
-    for (int base = e0; base < e1; base += CH_ENTRIES) {
-      const int lim = base + CH_ENTRIES < e1 ? base + CH_ENTRIES : e1;
+    for (int base = 0; base < E; base += CH_ENTRIES) {   // (positions among the tile's entries)
+      const int lim = base + CH_ENTRIES < E ? base + CH_ENTRIES : E;
       for (int e = base + tid; e < lim; e += DEM_THREADS) {
         unsigned w;
-        if (e - e0 < CH_META) w = sMeta[e - e0];
-        else { w = emeta[e]; if (active && !active[g0 + (int)(w & 63u)]) w = CH_SKIP; }
+        if (e < CH_META) w = sMeta[e];
+        else { w = emeta[entry_of(e)]; if (active && !active[grain_at((int)(w & 63u))]) w = CH_SKIP; }
         if (w == CH_SKIP) continue;
         const int li = (int)(w & 63u);
         const bool lower = (w & 64u) != 0;
@@ -759,7 +784,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
           b.x1 = sS[slot]; b.x2 = sS[CH_SLOTS + slot]; b.v1 = sS[2 * CH_SLOTS + slot]; b.v2 = sS[3 * CH_SLOTS + slot];
           b.v3 = sS[4 * CH_SLOTS + slot]; b.r = sR[slot];
         } else {
-          const int gj = nbr[e];
+          const int gj = nbr[entry_of(e)];
           ChainRead R{};
           // (the copy its tile is expected to write: the remote one only exists for tiles with a partner in another XCD's
           // eighth -- which a tile read from another eighth is, the list being symmetric)
@@ -836,7 +861,8 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
     if (T.stamp && last_own >= 0) {   // the tile's last grain contact, for the carries
       const long rec = (long)tile * 4 + CARRY_GRAIN;
       T.stamp[rec] = stamp; T.val[2 * rec] = last_ft; T.val[2 * rec + 1] = last_f3;
-      T.who[rec] = ((long long)(g0 + (int)(((last_own - e0 < CH_META) ? sMeta[last_own - e0] : emeta[last_own]) & 63u)) << 32) | (unsigned)nbr[last_own];
+      const int le = entry_of(last_own);
+      T.who[rec] = ((long long)grain_at((int)(((last_own < CH_META) ? sMeta[last_own] : emeta[le]) & 63u)) << 32) | (unsigned)nbr[le];
     }
     if (T.stamp && tid < DEM_GRAINS) {   // per wall, the highest grain of the tile that touched it
 #pragma unroll
@@ -860,7 +886,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
   if (dbg && tid == 0) {
     long long* d = dbg + (long)tile * 16;
     for (int k = 0; k < 8; ++k) d[8 + k] = ph[k];
-    d[0] = t_wait; d[1] = t_work; d[2] = n_spins; d[3] = placed ? 1 : 0; d[4] = hcnt; d[5] = e1 - e0;
+    d[0] = t_wait; d[1] = t_work; d[2] = n_spins; d[3] = placed ? 1 : 0; d[4] = hcnt; d[5] = E;
     d[6] = t_begin; d[7] = wall_clock64();
     int nfar = 0;
     for (int h = 0; h < hcnt; ++h) nfar += (int)(sHoff[h] & 1u);
@@ -893,12 +919,11 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
     __syncthreads();
     if (tid < DEM_GRAINS) {   // the velocities of the fluid-side record are the final ones
       sS[2 * CH_SLOTS + tid] = v1; sS[3 * CH_SLOTS + tid] = v2; sS[4 * CH_SLOTS + tid] = v3;
-      sK[tid] = k0; sK[DEM_TILE + tid] = k1;
     }
     __syncthreads();
     const LatticeView& L = paint.L;
-    const int g = tid >> 2, hl = tid & 3, gi = g0 + g;
-    const bool there = gi < P.n;
+    const int g = tid >> 2, hl = tid & 3, gi = grain_at(g);
+    const bool there = gi >= 0;
     const bool inplace = paint.was.xc != nullptr;
     const long long stamp_l = stamp0 + nsteps - 1;
     const real gx1 = sS[g], gx2 = sS[CH_SLOTS + g];
@@ -937,7 +962,8 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
     }
     // the partners' final positions: staged slot, or (beyond the staged halo) the published line
     auto partner_pos = [&](int k, real& jx, real& jy) {
-      const unsigned w = (k - e0 < CH_META) ? sMeta[k - e0] : emeta[k];
+      const int pk = sPre[g] + (k - sK[g]);   // (k: one of THIS grain's list entries)
+      const unsigned w = (pk < CH_META) ? sMeta[pk] : emeta[k];
       const unsigned slot = w >> 8;
       if (slot != DEM_CHAIN_DIRECT) { jx = sS[slot]; jy = sS[CH_SLOTS + slot]; return true; }
       const unsigned off = direct_copy(nbr[k]) + ((stamp_l & 1) ? line_par : 0u) + (unsigned)nbr[k] * 128u;
@@ -1335,20 +1361,25 @@ __global__ void k_diag_walls(DiagExtra X, Kin in, const real* __restrict__ r, De
 }
 
 // The carries as the reference holds them now: per carry the youngest record among the kinds that assign it, in
-// program order (sub-step, then grain contacts < bottom < left < right wall, then grain index = tile).
+// program order: sub-step, then grain contacts < bottom < left < right wall, then the grain the record is about (every tile
+// leaves the LAST of its contacts in the reference's order, i.e. of its highest grain that has one: the youngest of all is the
+// record with the highest grain -- whatever grains the tiles are made of, and whichever kernel's tiling wrote the record).
 __global__ __launch_bounds__(256) void k_carry_resolve(CarryTrack T, long long min_stamp) {
   LBMDEM_GATE(T.gate);
   __shared__ unsigned long long best[3];
   if (threadIdx.x < 3) best[threadIdx.x] = 0ull;
   __syncthreads();
+  // 0 = nothing; grains < 2^24 (dem_chain_alloc), kinds 2 bits, the rest for the sub-step
+  auto key_of = [&](long rec, int kind) -> unsigned long long {
+    const long long st = T.stamp[rec];
+    if (st < min_stamp) return 0ull;
+    return ((unsigned long long)(st + 1) << 26) | ((unsigned long long)kind << 24) | ((unsigned long long)(T.who[rec] >> 32) & 0xFFFFFFull);
+  };
   unsigned long long b_ft = 0ull, b_ff = 0ull, b_f = 0ull;
   for (int t = threadIdx.x; t < T.tiles; t += 256) {
 #pragma unroll
     for (int kind = 0; kind < 4; ++kind) {
-      const long long st = T.stamp[(long)t * 4 + kind];
-      if (st < min_stamp) continue;
-      // 0 = nothing; tiles < 2^24, kinds 2 bits, the rest for the sub-step
-      const unsigned long long key = ((unsigned long long)(st + 1) << 26) | ((unsigned long long)kind << 24) | (unsigned)t;
+      const unsigned long long key = key_of((long)t * 4 + kind, kind);
       if (key > b_ft) b_ft = key;                                                    // pft: all four
       if ((kind == CARRY_GRAIN || kind == CARRY_BOTTOM) && key > b_ff) b_ff = key;   // pff
       if ((kind == CARRY_BOTTOM || kind == CARRY_LEFT) && key > b_f) b_f = key;      // pf
@@ -1358,16 +1389,23 @@ __global__ __launch_bounds__(256) void k_carry_resolve(CarryTrack T, long long m
   if (b_ff) atomicMax(&best[1], b_ff);
   if (b_f) atomicMax(&best[2], b_f);
   __syncthreads();
-  if (threadIdx.x < 3) {
-    // what won, in rank-independent terms, for the cross-rank resolve of a strip decomposition:
-    // best_key[c] = {(stamp + 1) * 4 + kind, (grain << 32) | partner}; {0, 0} = this handle has no record
-    T.best_key[2 * threadIdx.x] = 0; T.best_key[2 * threadIdx.x + 1] = 0;
-    if (best[threadIdx.x] != 0ull) {
-      const unsigned long long key = best[threadIdx.x];
-      const long rec = (long)(key & 0xFFFFFFu) * 4 + (long)((key >> 24) & 3u);
-      T.carry[threadIdx.x] = T.val[2 * rec + (threadIdx.x == 1 ? 1 : 0)];   // pft, pf: ft; pff: f3
-      T.best_key[2 * threadIdx.x] = (long long)((key >> 26) * 4 + ((key >> 24) & 3u));
-      T.best_key[2 * threadIdx.x + 1] = T.who[rec];
+  if (threadIdx.x < 3) { T.best_key[2 * threadIdx.x] = 0; T.best_key[2 * threadIdx.x + 1] = 0; }
+  __syncthreads();
+  // what won, in rank-independent terms, for the cross-rank resolve of a strip decomposition:
+  // best_key[c] = {(stamp + 1) * 4 + kind, (grain << 32) | partner}; {0, 0} = this handle has no record
+  for (int t = threadIdx.x; t < T.tiles; t += 256) {
+#pragma unroll
+    for (int kind = 0; kind < 4; ++kind) {
+      const long rec = (long)t * 4 + kind;
+      const unsigned long long key = key_of(rec, kind);
+      if (key == 0ull) continue;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (key == best[c]) {   // (a key names one record: a grain is in one tile)
+          T.carry[c] = T.val[2 * rec + (c == 1 ? 1 : 0)];   // pft, pf: ft; pff: f3
+          T.best_key[2 * c] = (long long)((key >> 26) * 4 + ((key >> 24) & 3u));
+          T.best_key[2 * c + 1] = T.who[rec];
+        }
     }
   }
 }
@@ -1506,7 +1544,8 @@ __global__ void k_fill_own(int n, const int* __restrict__ offsets, int* __restri
 // hash set, then numbered by a scan over the table) and every entry's emeta word. Which halo slot a grain gets depends on
 // the order the atomics arrive in -- only the LDS placement, never a result.
 __global__ __launch_bounds__(256) void k_tile_halo(int n, const int* __restrict__ offsets, const int* __restrict__ nbr,
-                                                   const int* __restrict__ own, int* __restrict__ halo_ids,
+                                                   const int* __restrict__ tile_grains, const int* __restrict__ where,
+                                                   int* __restrict__ halo_ids,
                                                    int* __restrict__ halo_cnt, unsigned* __restrict__ emeta,
                                                    unsigned char* __restrict__ tile_far, int tiles_per_xcd,
                                                    const int* __restrict__ gate) {
@@ -1514,17 +1553,36 @@ __global__ __launch_bounds__(256) void k_tile_halo(int n, const int* __restrict_
   constexpr int CELLS = 1024;
   __shared__ int table[CELLS], cidx[CELLS];
   __shared__ int wsum[4];
+  __shared__ int sK0[DEM_TILE], sPre[DEM_TILE + 1];   // first list entry of the tile's grains; their entries' positions in the tile
   const int tile = blockIdx.x, tid = threadIdx.x;
-  const int g0 = tile * DEM_TILE;
-  const int g1 = g0 + DEM_TILE < n ? g0 + DEM_TILE : n;
-  const int e0 = offsets[g0], e1 = offsets[g1];
   for (int c = tid; c < CELLS; c += 256) table[c] = -1;
+  if (tid < 64) {   // the tile's entries: its grains' list ranges one after the other
+    const int g = tile_grains[(long)tile * DEM_TILE + tid];
+    const int k0 = g >= 0 ? offsets[g] : 0, cnt = g >= 0 ? offsets[g + 1] - k0 : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if (tid >= d) incl += up;
+    }
+    sK0[tid] = k0; sPre[tid + 1] = incl;
+    if (tid == 0) sPre[0] = 0;
+  }
   __syncthreads();
+  const int E = sPre[DEM_TILE];
+  auto entry_of = [&](int p, int& li) {   // position in the tile -> the grain's place in the tile and the list entry
+    int lo = 0, hi = DEM_TILE - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sPre[mid] <= p) lo = mid; else hi = mid - 1; }
+    li = lo;
+    return sK0[lo] + (p - sPre[lo]);
+  };
   bool farp = false;
-  for (int e = e0 + tid; e < e1; e += 256) {
-    const int gj = nbr[e];
-    if (gj >= g0 && gj < g1) continue;
-    farp = farp || (gj / DEM_TILE) / tiles_per_xcd != tile / tiles_per_xcd;
+  for (int p = tid; p < E; p += 256) {
+    int li;
+    const int gj = nbr[entry_of(p, li)];
+    const int tj = where[gj] >> 6;
+    if (tj == tile) continue;
+    farp = farp || tj / tiles_per_xcd != tile / tiles_per_xcd;
     unsigned hsh = ((unsigned)gj * 2654435761u) >> 22;   // 10 bits
     for (int probe = 0; probe < CELLS; ++probe) {
       const int old = atomicCAS(&table[hsh], -1, gj);
@@ -1560,10 +1618,12 @@ __global__ __launch_bounds__(256) void k_tile_halo(int n, const int* __restrict_
   // does this tile have a partner in a tile of another XCD's eighth? (then it publishes through memory, for everybody)
   const int anyfar = __syncthreads_or(farp ? 1 : 0);
   if (tid == 0) tile_far[tile] = (unsigned char)(anyfar ? 1 : 0);
-  for (int e = e0 + tid; e < e1; e += 256) {
-    const int gi = own[e], gj = nbr[e];
+  for (int p = tid; p < E; p += 256) {
+    int li;
+    const int e = entry_of(p, li);
+    const int gi = tile_grains[(long)tile * DEM_TILE + li], gj = nbr[e];
     unsigned slot = DEM_CHAIN_DIRECT;
-    if (gj >= g0 && gj < g1) slot = (unsigned)(gj - g0);
+    if ((where[gj] >> 6) == tile) slot = (unsigned)(where[gj] & 63);
     else {
       unsigned hsh = ((unsigned)gj * 2654435761u) >> 22;
       for (int probe = 0; probe < CELLS; ++probe) {
@@ -1573,7 +1633,7 @@ __global__ __launch_bounds__(256) void k_tile_halo(int n, const int* __restrict_
         hsh = (hsh + 1) & (CELLS - 1);
       }
     }
-    emeta[e] = (unsigned)(gi - g0) | (gi < gj ? 64u : 0u) | (slot << 8);
+    emeta[e] = (unsigned)li | (gi < gj ? 64u : 0u) | (slot << 8);
   }
 }
 
@@ -1631,6 +1691,7 @@ int verlet_alloc(VerletDevice& V, int n, real cs, real ox, real oy, real wx, rea
     A((void**)&V.halo_ids, sizeof(int) * tiles * DEM_CHAIN_HALO); A((void**)&V.halo_cnt, sizeof(int) * tiles);
     A((void**)&V.emeta, sizeof(unsigned) * V.cap);
     A((void**)&V.tile_far, tiles);
+    A((void**)&V.tile_grains, sizeof(int) * tiles * DEM_TILE); A((void**)&V.where, sizeof(int) * (size_t)n);
     A((void**)&V.xreb, sizeof(real) * 2 * (size_t)n);
   }
   if (e != hipSuccess) return -1;
@@ -1646,14 +1707,37 @@ int verlet_alloc(VerletDevice& V, int n, real cs, real ox, real oy, real wx, rea
   if (hipMemset(V.offsets, 0, sizeof(int) * (n + 1)) != hipSuccess) return -1;
   if (hipMemset(V.wallflags, 0, n) != hipSuccess) return -1;
   if (hipMemset(V.overflow, 0, sizeof(int)) != hipSuccess) return -1;
+  {   // tiles by index until somebody says otherwise (verlet_set_tiles)
+    const size_t tiles = ((size_t)n + DEM_TILE - 1) / DEM_TILE;
+    std::vector<int> tg(tiles * DEM_TILE);
+    for (size_t k = 0; k < tg.size(); ++k) tg[k] = k < (size_t)n ? (int)k : -1;
+    if (verlet_set_tiles(V, n, tg.data()) != 0) return -1;
+  }
   // the consumers run on a non-blocking stream that does not order itself after the NULL stream's memsets
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   return 0;
 }
 
+int verlet_set_tiles(VerletDevice& V, int n, const int* tg) {
+  const size_t tiles = ((size_t)n + DEM_TILE - 1) / DEM_TILE;
+  std::vector<int> where((size_t)n, -1);
+  for (size_t k = 0; k < tiles * DEM_TILE; ++k) {
+    const int g = tg[k];
+    if (g < 0) continue;
+    if (g >= n || where[g] != -1) return -1;                                      // every grain exactly once
+    if ((k % DEM_TILE) != 0 && tg[k - 1] >= 0 && tg[k - 1] >= g) return -1;       // ascending within a tile
+    where[g] = (int)k;                                                            // = tile << 6 | position (DEM_TILE = 64)
+  }
+  for (int g = 0; g < n; ++g) if (where[g] < 0) return -1;
+  static_assert(DEM_TILE == 64, "where[] packs the position into six bits");
+  if (hipMemcpy(V.tile_grains, tg, sizeof(int) * tiles * DEM_TILE, hipMemcpyHostToDevice) != hipSuccess) return -1;
+  if (hipMemcpy(V.where, where.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) return -1;
+  return 0;
+}
+
 void verlet_free(VerletDevice& V) {
   void* ps[] = {V.keys_in, V.vals_in, V.vals_out, V.cell_start, V.cell_end,
-                V.scan_tmp, V.counts, V.offsets, V.nbr, V.own, V.wallflags, V.overflow, V.halo_ids, V.halo_cnt, V.emeta, V.tile_far, V.xreb};
+                V.scan_tmp, V.counts, V.offsets, V.nbr, V.own, V.wallflags, V.overflow, V.halo_ids, V.halo_cnt, V.emeta, V.tile_far, V.xreb, V.tile_grains, V.where};
   for (void* p : ps) if (p) (void)hipFree(p);
   V = VerletDevice{};
 }
@@ -1778,8 +1862,8 @@ void launch_dem_substep(const Kin& in, const Kin& out, const real* r, const real
 
 void launch_tile_halo(const VerletDevice& V, int n, hipStream_t st) {
   const int tiles = (n + DEM_TILE - 1) / DEM_TILE;
-  hipLaunchKernelGGL(k_tile_halo, dim3(tiles), dim3(256), 0, st, n, V.offsets, V.nbr, V.own, V.halo_ids, V.halo_cnt, V.emeta,
-                     V.tile_far, dem_chain_tslots(n) >> 3, V.gate);
+  hipLaunchKernelGGL(k_tile_halo, dim3(tiles), dim3(256), 0, st, n, V.offsets, V.nbr, V.tile_grains, V.where, V.halo_ids,
+                     V.halo_cnt, V.emeta, V.tile_far, dem_chain_tslots(n) >> 3, V.gate);
 }
 
 int dem_chain_tslots(int n) { return DEM_GRID((n + DEM_GRAINS - 1) / DEM_GRAINS); }
@@ -1822,7 +1906,7 @@ int dem_chain_census(DemChain& C, int tslots, hipStream_t st) {
   if (hipMemsetAsync(C.census, 0, 4 * sizeof(int), st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 0;
   *C.err_host = 0;
   hipLaunchKernelGGL(k_dem_chain, dim3(tslots), dim3(DEM_THREADS), 0, st, Kin{}, Kin{}, nullptr, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, DemParams{}, nullptr, CarryTrack{}, 0ll,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, DemParams{}, nullptr, CarryTrack{}, 0ll,
                      nullptr, ObstFillJob{}, tslots, -1, C.pub, (unsigned)C.pub_bytes, C.err, C.census, nullptr, 0, ChainPaint{}, nullptr);
   int seen[4] = {0, 0, 0, 0};
   if (hipMemcpyAsync(seen, C.census, sizeof(seen), hipMemcpyDeviceToHost, st) != hipSuccess) return 0;
@@ -1866,6 +1950,6 @@ void launch_dem_chain(const Kin& in, const Kin& out, const real* r, const real* 
   if (C.capacity < 0) one_xcd |= 1 << 17;   // lbmdem_debug_chain_giveup: a tile of this launch gives up half way
 #endif
   hipLaunchKernelGGL(k_dem_chain, dim3(((one_xcd & 1) ? nbe * 8 : DEM_GRID(nbe)) + extra), dim3(DEM_THREADS), 0, st, in, out, r, m, It, fhf, V.offsets,
-                     V.nbr, V.emeta, V.halo_ids, V.halo_cnt, V.tile_far, V.wallflags, pout, P, active, T, stamp0, owner, fill, nbe, nsteps,
+                     V.nbr, V.emeta, V.halo_ids, V.halo_cnt, V.tile_grains, V.where, V.tile_far, V.wallflags, pout, P, active, T, stamp0, owner, fill, nbe, nsteps,
                      C.pub, (unsigned)C.pub_bytes, C.err, C.census, C.dbg, one_xcd, paint, C.gate);
 }

@@ -551,7 +551,11 @@ __device__ __forceinline__ void march_item(const real* __restrict__ fin, real* _
 #endif
             const int rel = slot_line(k.gx - ex, k.gy - ey, ex, ey, gS.xc, gS.yc) + S.half;
             if ((unsigned)rel < (unsigned)S.spd)
+#if defined(LBMDEM_AB) && defined(MARCH_TAB_NT)   /* experiment: the link sums past the L2's retention */
+              __builtin_nontemporal_store(k.own_qo + out, &S.tab[((long)owner * 8 + (k.q - 1)) * S.spd + rel]);
+#else
               S.tab[((long)owner * 8 + (k.q - 1)) * S.spd + rel] = k.own_qo + out;
+#endif
           }
         }
         __builtin_amdgcn_wave_barrier();

@@ -6,6 +6,7 @@
 
 
 #include "lbmdem_handle.h"
+#include <algorithm>
 
 #include <mutex>
 
@@ -192,6 +193,52 @@ static int paint_into(lbmdem_handle* h, int* obst) {
   h->obst_reset_rows = 0;
   h->slots_valid = false;  // the grain geometry the table is indexed with has changed
   HIP_TRY(hipGetLastError());
+  return LBMDEM_OK;
+}
+
+// The grains of the tiles of k_dem_chain (VerletDevice::tile_grains). mode 1: consecutive stretches of 64 grains along a
+// Hilbert curve over the positions -- compact patches of the packing, whatever the numbering of the grains; mode 0: by index.
+// Only the speed of that kernel depends on it. (A position that is not a number -- a grain some rank does not hold -- sorts
+// to the origin.)
+static int dem_tiles_compose(lbmdem_handle* h, const double* x1, const double* x2, int mode) {
+  const int n = h->n;
+  const size_t tiles = ((size_t)n + DEM_TILE - 1) / DEM_TILE;
+  std::vector<int> tg(tiles * DEM_TILE, -1);
+  std::vector<int> order((size_t)n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  if (mode == 1 && n > DEM_TILE) {
+    double lo1 = 1e300, hi1 = -1e300, lo2 = 1e300, hi2 = -1e300;
+    for (int i = 0; i < n; ++i) {
+      if (x1[i] == x1[i]) { lo1 = x1[i] < lo1 ? x1[i] : lo1; hi1 = x1[i] > hi1 ? x1[i] : hi1; }
+      if (x2[i] == x2[i]) { lo2 = x2[i] < lo2 ? x2[i] : lo2; hi2 = x2[i] > hi2 ? x2[i] : hi2; }
+    }
+    const double span = (hi1 - lo1 > hi2 - lo2 ? hi1 - lo1 : hi2 - lo2);
+    const double scale = span > 0 ? 65535.0 / span : 0.0;
+    std::vector<unsigned long long> key((size_t)n);
+    for (int i = 0; i < n; ++i) {
+      unsigned x = x1[i] == x1[i] ? (unsigned)((x1[i] - lo1) * scale) : 0u, y = x2[i] == x2[i] ? (unsigned)((x2[i] - lo2) * scale) : 0u;
+      if (x > 65535u) x = 65535u;
+      if (y > 65535u) y = 65535u;
+      unsigned long long d = 0;   // xy -> distance along the Hilbert curve of order 16
+      for (unsigned sft = 32768u; sft > 0; sft >>= 1) {
+        const unsigned rx = (x & sft) ? 1u : 0u, ry = (y & sft) ? 1u : 0u;
+        d += (unsigned long long)sft * sft * ((3u * rx) ^ ry);
+        if (ry == 0) {
+          if (rx == 1) { x = 65535u - x; y = 65535u - y; }
+          const unsigned t = x; x = y; y = t;
+        }
+      }
+      key[i] = d;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
+  }
+  for (size_t t = 0; t < tiles; ++t) {
+    const size_t b = t * DEM_TILE, e = b + DEM_TILE < (size_t)n ? b + DEM_TILE : (size_t)n;
+    std::sort(order.begin() + b, order.begin() + e);   // ascending within a tile: lane order = index order = list order
+    for (size_t k = b; k < e; ++k) tg[k] = order[k];
+  }
+  if (verlet_set_tiles(h->V, n, tg.data()) != 0) return fail(LBMDEM_EHIP, "the tiles of the DEM run could not be set");
+  h->dem_tiles_mode = mode;
   return LBMDEM_OK;
 }
 
@@ -387,6 +434,7 @@ int lbmdem_create(const lbmdem_config* cfg, const double* r, const double* x1, c
       return rc;
     }
   }
+  if (dem_tiles_compose(h, x1, x2, 1) != LBMDEM_OK) { lbmdem_destroy(h); return LBMDEM_EHIP; }
 #ifdef LBMDEM_AB
   if (const char* e = getenv("LBMDEM_DEM_CHAIN")) h->chain_max = atoi(e);   // A/B: 0 = one launch per sub-step
 #endif
@@ -1013,6 +1061,39 @@ int lbmdem_set_dem_chain(lbmdem_handle* h, int max_substeps) {
   if (max_substeps < 0) { h->chain_paint = false; return LBMDEM_OK; }   // (A/B: runs as before, without the rasterisation at their end)
   h->chain_max = max_substeps;
   return LBMDEM_OK;
+}
+
+// A rank of a strip decomposition integrates the grains of its strip and a margin: with the grains numbered along the
+// packing's rows (the bench packing) those are index ranges, and tiles of consecutive indices are either wholly the rank's or
+// not at all -- a rank then runs 27 % more tiles than its share. (Patches along a curve would do as well in principle; with
+// several ranks on ONE GPU, the tests' stand-in for several GPUs, their launches did not get their workgroups in side by side.)
+int lbmdem_dem_tiles_by_index(lbmdem_handle* h) {
+  if (h->dem_tiles_mode == 0) return LBMDEM_OK;
+  RC_TRY(dem_tiles_compose(h, nullptr, nullptr, 0));
+  if (h->verlet_ok) {
+    launch_tile_halo(h->V, h->n, h->stream);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  return LBMDEM_OK;
+}
+
+int lbmdem_set_dem_tiles(lbmdem_handle* h, int mode) try {
+  CHECK_H(h);
+  if (mode != 0 && mode != 1) return fail(LBMDEM_EINVAL, "lbmdem_set_dem_tiles: 0 (by index) or 1 (patches of the packing)");
+  const int n = h->n;
+  std::vector<real> pos(2 * (size_t)n);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(pos.data(), h->kin[h->kcur].x1, sizeof(real) * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(pos.data() + n, h->kin[h->kcur].x2, sizeof(real) * n, hipMemcpyDeviceToHost));
+  std::vector<double> x1(pos.begin(), pos.begin() + n), x2(pos.begin() + n, pos.end());
+  RC_TRY(dem_tiles_compose(h, x1.data(), x2.data(), mode));
+  if (h->verlet_ok) {   // what the run's kernel needs of the list depends on the tiles
+    launch_tile_halo(h->V, n, h->stream);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  return LBMDEM_OK;
+} catch (const std::bad_alloc&) {
+  return fail(LBMDEM_ENOMEM, "host memory allocation failed");
 }
 
 int lbmdem_dem_chain_stats(lbmdem_handle* h, long* launches, long* substeps, int* tile_slots, int* resident) {

@@ -145,6 +145,7 @@ struct lbmdem_handle {
   bool chain_painted = false;
   bool chain_paint = true;     // (lbmdem_set_dem_chain: max_substeps < 0 switches only this off, for A/B)
   long chain_paints = 0;
+  int dem_tiles_mode = 0;      // how the tiles of k_dem_chain are composed (lbmdem_set_dem_tiles)
   // launches of k_dem_chain that have not been seen to finish, the calls they belong to, and how often one had to be undone
   std::vector<ChainSnap> chain_pending;
   std::vector<RunLogEntry> runlog;
@@ -249,6 +250,7 @@ static inline DemParams dem_params(const lbmdem_handle* h) {
 LBMDEM_INTERNAL int lbmdem_write_vtk_file(const char* path, int nx, int ny, const char* name, int dim, const float* data);
 LBMDEM_INTERNAL int lbmdem_verlet_build_lists(lbmdem_handle* h);
 LBMDEM_INTERNAL int lbmdem_chain_settle(lbmdem_handle* h);
+LBMDEM_INTERNAL int lbmdem_dem_tiles_by_index(lbmdem_handle* h);
 // the next obst_construction will update obst[1 - ocur] in place: nobody resets that canvas beforehand
 static inline bool obst_update_planned(const lbmdem_handle* h) {
   return h->obst_update && !h->dist && h->snap_ok[1 - h->ocur] && h->verlet_ok && h->verlet_tracks_positions &&

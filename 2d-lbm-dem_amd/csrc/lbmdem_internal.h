@@ -320,6 +320,14 @@ struct VerletDevice {
   int* halo_cnt;             // [tiles]
   unsigned* emeta;           // [cap] own grain's index in its tile | (own < partner) << 6 | partner's staging slot << 8
   unsigned char* tile_far;   // [tiles] the tile has a partner in a tile that is expected on another XCD
+  // The tiles of k_dem_chain are COMPOSED: tile t holds the grains tile_grains[t][0 .. DEM_TILE) (ascending; -1 = none),
+  // where[g] = t << 6 | position. By index (tile t = grains [64 t, 64 t + 64)) on distributed handles; by a space-filling
+  // curve over the initial positions otherwise -- a tile is a compact patch of the packing whatever the grains' numbering, so
+  // its partners outside itself are the patch's rim (~45 grains instead of 83 on the row-numbered bench packing, of 164 on
+  // the reference's own bin/50000.data), and the tiles of one XCD eighth are a compact region. Nothing a grain's sums
+  // depend on: entries stay in list order per grain, contacts in the (lower, higher) index frame.
+  int* tile_grains;          // [tiles][DEM_TILE]
+  int* where;                // [n]
   real *xreb, *yreb;         // [n] the positions the list was built from
   const int* gate;           // the handle's stop word (LatticeView::gate): a rebuild behind a failed launch leaves the list alone
 };
@@ -361,6 +369,7 @@ struct CarryTrack {
   real* carry;     // [3] pft, pff, pf
   int tiles;
   long long* who;       // [tiles][4] the contact of the record: (grain << 32) | partner (walls: partner 0)
+  const int* where;     // VerletDevice::where (which tile a grain's record lies in does not depend on it; kept for tools)
   long long* best_key;  // [3][2] left by launch_carry_resolve: {(stamp + 1) * 4 + kind, who} of the record each carry came from
   const int* gate;      // the handle's stop word (LatticeView::gate)
 };
@@ -375,6 +384,8 @@ void launch_diag_extra(const DiagExtra& X, const Kin& in, const real* r, const V
                        const DemParams& P, int film, hipStream_t st);
 void launch_fill_own(const VerletDevice& V, int n, hipStream_t st);
 void launch_tile_halo(const VerletDevice& V, int n, hipStream_t st);   // halo_ids / halo_cnt / emeta from offsets, nbr, own
+// the composition of the tiles: tile_grains_host[tiles * DEM_TILE] (ascending within a tile, -1 padded) -> V.tile_grains, V.where
+int verlet_set_tiles(VerletDevice& V, int n, const int* tile_grains_host);
 // A slice of the obstacle map that the next rasterisation starts from (obst = -1 / wall codes, main.c:997-999), reset by
 // extra workgroups of a DEM sub-step launch: the sub-step kernel is a latency chain that leaves the GPU idle, the reset is
 // 67 MB of stores per fluid step -- in npDEM slices they disappear under the sub-steps. map == nullptr: nothing to do.

@@ -64,6 +64,7 @@ int lbmdem_dist_default_margin(lbmdem_handle* h) {
 // from the packing; a restart takes them from the checkpoint: neighbours must agree on the message sizes)
 int lbmdem_dist_enable_caps(lbmdem_handle* h, int M, long cap_g, long cap_t, long cap_l) {
   if (dist_alloc(h->dd, h->n, (int)cap_g, (int)cap_t, (int)cap_l) != 0) { dist_free(h->dd); return fail(LBMDEM_ENOMEM, "dist_alloc failed"); }
+  RC_TRY(lbmdem_dem_tiles_by_index(h));   // (see there)
   h->dist = true;
   h->dist_margin = M;
   h->fs.mask = h->dd.fluidmask;

@@ -512,6 +512,8 @@ def main():
     # In the same process, after the driver's timed region (its --steps 20 are 17 ms): SURVEY 8-d's window -- 200 coupled
     # steps of the SAME run, the fused kernel timed around every 8th launch (25 launches) ...
     long_leg = None
+    if os.environ.get("LBMDEM_BENCH_NO_LEGS"):      # (the profiling scripts: only the timed region's launches in their traces)
+        args.long_steps = args.real_steps = 0
     if world == 1 and not args.strips and args.long_steps > 0 and args.steps < args.long_steps:
         sim.profile_enable(8)
         sync()

@@ -193,6 +193,12 @@ int lbmdem_dem_chain_paints(lbmdem_handle* h, long* paints);
  * sub-steps since, one launch each: the same bits. lbmdem_dem_chain_recoveries: how often that has happened (0 on a GPU of
  * its own). Distributed handles (lbmdem_dist_*) report the failure instead: a rank cannot go back alone. */
 int lbmdem_dem_chain_recoveries(lbmdem_handle* h, long* count);
+/* The grains of that kernel's workgroups ("tiles" of 64). mode 1 (default): consecutive stretches along a space-filling
+ * curve over the positions at lbmdem_create (or at this call) -- compact patches of the packing whatever the numbering of the
+ * grains, so that a tile's partners outside itself are the patch's rim: the reference's own bin/50000.data, whose numbering
+ * is not coherent in space, then runs at the pace of a row-numbered packing. 0: by index (tile t = grains 64 t .. 64 t + 63).
+ * Only speed depends on it: a grain's sums keep the reference's order (partners ascending by index, main.c:1427-1451). */
+int lbmdem_set_dem_tiles(lbmdem_handle* h, int mode);
 
 /* ---- state in / out (host layout) ------------------------------------------------------------ */
 

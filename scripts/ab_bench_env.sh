@@ -1,6 +1,7 @@
 #!/bin/bash
 # same-box A/B of environment switches of the experiment build on the default bench: scripts/ab_bench_env.sh "VAR=1" "" ...
 # ("" = no switch; each variant twice, interleaved). LIB=<library> to choose the build (default: liblbmdem_hip_ab.so)
+export LBMDEM_BENCH_NO_LEGS=1   # bench.py: no 200-step / real50k legs behind the timed region
 export LBMDEM_HIP_LIBRARY=$PWD/${LIB:-2d-lbm-dem_amd/liblbmdem_hip_ab.so}
 mkdir -p gpurun_out
 for rep in 1 2; do

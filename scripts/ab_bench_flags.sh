@@ -1,5 +1,6 @@
 #!/bin/bash
 # same-box A/B of bench.py flag sets, each twice, interleaved: scripts/ab_bench_flags.sh "--obst-update 1" "--obst-update 0" ...
+export LBMDEM_BENCH_NO_LEGS=1   # bench.py: no 200-step / real50k legs behind the timed region
 mkdir -p gpurun_out
 for rep in 1 2; do
   for fl in "$@"; do

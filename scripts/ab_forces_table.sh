@@ -1,6 +1,7 @@
 #!/bin/bash
 # same-box A/B of library builds for the force-table kernel: scripts/ab_forces_table.sh lib1.so lib2.so ...
 # (each twice, interleaved; k_forces_table's average from rocprofv3 --kernel-trace --stats, the step time from bench.py)
+export LBMDEM_BENCH_NO_LEGS=1   # bench.py: no 200-step / real50k legs behind the timed region
 cd /tmp && export TMPDIR=/tmp; cd - >/dev/null
 mkdir -p gpurun_out
 for rep in 1 2; do

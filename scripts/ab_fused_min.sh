@@ -1,5 +1,6 @@
 # interleaved A/B of library builds on ONE GPU, fused-kernel time: REPS rounds over all builds, then min / median per build
 # usage: bash scripts/ab_fused_min.sh <suffix> ...   (liblbmdem_hip<suffix>.so; REPS, STEPS from the env)
+export LBMDEM_BENCH_NO_LEGS=1   # bench.py: no 200-step / real50k legs behind the timed region
 cd $GRAFT_REPO_ROOT
 P='import sys,json; d=json.loads(sys.stdin.read()); print(d["collide_stream_kernel_ms"], d["ms_per_step"])'
 rm -f /tmp/ab_*.txt

@@ -116,6 +116,11 @@ def phase_table():
     span("lbm_device.h", r"long fbase_xy\(", "population address (fbase_xy)")
     span("lbm_device.h", r"unsigned mbcnt\(", "bounce-back compaction (mbcnt, LDS slots)")
     span("lbm_device.h", r"bool pull_classify\(", "classification, edge rows (pull_classify)")
+    span("lbm_march.h", r"real buf_load_real\(", "row loads (load_raw)")
+    span("lbm_march.h", r"void buf_store_real\(", "the row's nine stores (results of the links merged in)")
+    span("lbm_march.h", r"int fcol_bytes\(", "population address (fbase_xy)")
+    span("lbm_device.h", r"GPv load_gpv\(", "grain-record gather (load_gp)")
+    span("lbm_device.h", r"real link_delta\(", "bounce-back evaluation (ibb_eval_rt)")
     span("lbm_march.h", r"Ids3 load_ids\(", "obstacle ids (load_ids)")
     span("lbm_march.h", r"bool node_active\(", "act (node_active)")
     span("lbm_march.h", r"struct RecRing", "record ring (LDS put/get)", r"^};")
@@ -159,9 +164,11 @@ def fused_marks():
     at(r"real Fo\[9\], In\[9\];", "pull context: DPP shifts")
     at(r"const int gx = L.gx0 \+ x;", "classification + stores, deep rows (lane masks)")
     at(r"// rows and windows next to a lattice edge: the general", "classification, edge rows (pull_classify)")
-    at(r"for \(int base = 0; base < T; base \+= 64\)", "bounce-back compaction (mbcnt, LDS slots)")
+    at(r"auto store_row = ", "the row's nine stores (results of the links merged in)")
+    at(r"for \(int base = 0; base < T; base \+= LINK_SLOTS\)", "bounce-back compaction (mbcnt, LDS slots)")
     at(r"if \(base \+ lane < T\)", "bounce-back evaluation (ibb_eval_rt)")
     at(r"if \(S.tab != nullptr\)", "link-sum store (slot_line + table address)")
+    at(r"if \(merged\) \{", "the row's nine stores (results of the links merged in)")
     at(r"ring.put\(x \+ 3, lane, rec_next", "record ring (LDS put/get)")
     at(r"// rotate", "loop glue: row rotation, buffers")
     at(r"for \(int x = xs; x < xe; x \+= 2\)", "loop glue: row rotation, buffers")
@@ -205,18 +212,33 @@ def parse(asm_path, kernel_substr):
     return out
 
 
-def main_loop(items):
-    """[first, last] indices of the outermost loop with the most instructions"""
-    pos = {it[1]: i for i, it in enumerate(items) if it[0] == "label"}
-    best = None
+def main_loop(items, which):
+    """[first, last] indices of one of the kernel's two row loops (depth-1 loops of more than 1000 instructions): the
+    kernel holds two instantiations of the work item -- `interior` (no lattice-edge logic: 94 % of a 4096^2 lattice's items)
+    is the shorter one, `edge` the general one"""
+    loops = []
+    hdr = None
     for i, it in enumerate(items):
-        if it[0] == "instr" and it[1].startswith(("s_cbranch", "s_branch")):
-            tgt = it[2].split()[-1]
-            if tgt in pos and pos[tgt] < i:
-                n = i - pos[tgt]
-                if best is None or n > best[2]:
-                    best = (pos[tgt], i, n)
-    return best[0], best[1]
+        if it[0] == "label":
+            c = it[2]
+            if "Loop Header: Depth=1" in c:
+                hdr = it[1]
+                loops.append([hdr, i, i])
+            elif hdr and ("Header=" + hdr[2:] + " ") in c + " ":
+                loops[-1][2] = i
+    out = []
+    for name, a, b in loops:
+        j = b + 1
+        while j < len(items) and items[j][0] != "label":
+            j += 1
+        n = sum(1 for it in items[a:j] if it[0] == "instr")
+        if n > 1000:
+            out.append((n, a, j - 1))
+    out.sort()
+    if not out:
+        raise SystemExit("no row loop found")
+    n, a, b = out[0] if which == "interior" else out[-1]
+    return a, b
 
 
 def main():
@@ -226,6 +248,7 @@ def main():
     ap.add_argument("--asm", default=None, help="use this assembly (with .loc) instead of compiling")
     ap.add_argument("-o", "--out", default=None)
     ap.add_argument("--extra", default="", help="extra compiler flags")
+    ap.add_argument("--loop", choices=["interior", "edge"], default="interior")
     a = ap.parse_args()
     extra = a.extra.split()
     if a.asm:
@@ -239,7 +262,7 @@ def main():
         if n_g != n_p:
             raise SystemExit(f"line tables changed the code: {n_g} vs {n_p} instructions")
     items = parse(asm_g, a.kernel)
-    lo, hi = main_loop(items)
+    lo, hi = main_loop(items, a.loop)
     tab = phase_table()
     marks = fused_marks()
 
@@ -288,7 +311,7 @@ def main():
                "salu", "s_nop", "s_waitcnt", "branch", "lds", "vmem_load", "vmem_store", "other"]
     lines = []
     n_all = sum(total.values())
-    lines.append(f"kernel {a.kernel}: main loop = {n_all} instructions for TWO rows (static, every conditional path counted once)")
+    lines.append(f"kernel {a.kernel}, {a.loop} instantiation of the work item: row loop = {n_all} instructions for TWO rows (static, every conditional path counted once)")
     lines.append("")
     lines.append("class totals: " + ", ".join(f"{c} {total[c]} ({100.0 * total[c] / n_all:.1f} %)" for c in classes if total[c]))
     valu = sum(total[c] for c in VALU)

@@ -1,5 +1,6 @@
 #!/bin/bash
 # per-launch durations of one kernel, in launch order: scripts/kernel_durations.sh <kernel substring> [bench args]
+export LBMDEM_BENCH_NO_LEGS=1   # bench.py: no 200-step / real50k legs behind the timed region
 cd /tmp && export TMPDIR=/tmp; cd - >/dev/null
 K=$1; shift
 rm -rf gpurun_out/kd; mkdir -p gpurun_out

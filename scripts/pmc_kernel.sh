@@ -1,4 +1,5 @@
 # usage: bash scripts/pmc_kernel.sh <tag> <kernel-substring> "<counters>"
+export LBMDEM_BENCH_NO_LEGS=1   # bench.py: no 200-step / real50k legs behind the timed region
 tag=$1; pat=$2; ctrs=$3
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmck_$tag   # (a pass whose counters do not exist must not read the previous pass's file)

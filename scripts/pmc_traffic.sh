@@ -1,6 +1,7 @@
 # HBM traffic of the fused kernel from PMC counters, calibrated on copy kernels of known size.
 # FETCH_SIZE and WRITE_SIZE need separate passes (TCC slots). Output: gpurun_out/traffic/*.csv + summary.
 # (the calibration binary is git-ignored: built where it is missing)
+export LBMDEM_BENCH_NO_LEGS=1   # bench.py: no 200-step / real50k legs behind the timed region
 [ -x $GRAFT_REPO_ROOT/scripts/micro/stream_pattern ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $GRAFT_REPO_ROOT/scripts/micro/stream_pattern $GRAFT_REPO_ROOT/scripts/micro/stream_pattern.hip
 cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/traffic; mkdir -p $O

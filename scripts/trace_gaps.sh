@@ -1,6 +1,7 @@
 #!/bin/bash
 # the launches of the coupled steps of a bench run in order, with the idle time before each (rocprofv3 kernel trace):
 # scripts/trace_gaps.sh [bench args] -> per kernel: mean duration and mean gap since the previous kernel's end, over the timed steps
+export LBMDEM_BENCH_NO_LEGS=1   # bench.py: no 200-step / real50k legs behind the timed region
 cd /tmp && export TMPDIR=/tmp; cd - >/dev/null
 rm -rf gpurun_out/tg; mkdir -p gpurun_out
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tg -o tg -- python bench.py --steps ${STEPS:-40} --warmup 5 --no-cpu-baseline "$@" > gpurun_out/tg.json 2>gpurun_out/tg.err

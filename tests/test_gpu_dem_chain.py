@@ -32,11 +32,15 @@ def kick(sim_list, n, seed, scale=(0.05, 0.05, 30.0)):
     return k
 
 
+@pytest.mark.parametrize("tiles", [1, 0])
 @pytest.mark.parametrize("shuffle", [False, True])
-def test_chain_equals_one_launch_per_substep(pkg, shuffle):
+def test_chain_equals_one_launch_per_substep(pkg, shuffle, tiles):
+    """(tiles: the kernel's workgroups hold patches of the packing -- consecutive grains along a space-filling curve, the
+    default -- or 64 consecutive indices, lbmdem_set_dem_tiles: the same bits either way, and with any numbering)"""
     lx, ly = 1024, 640
     r, x1, x2 = packing(lx, ly, 2500, 5, shuffle)
     a = pkg.LbmDem(lx, ly, r, x1, x2)
+    a.set_dem_tiles(tiles)
     b = pkg.LbmDem(lx, ly, r, x1, x2)
     b.set_dem_chain(0)
     kick([a, b], len(r), 17)
