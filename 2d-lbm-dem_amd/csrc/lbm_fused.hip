@@ -290,6 +290,7 @@ __device__ __forceinline__ void march_item(const real* __restrict__ fin, real* _
   int oo1 = MARCH_OLD(xs + 1, iD);   // previous-map ids of rows x+1, x+2
   int oo2 = MARCH_OLD(xs + 2, iE);
   GP rec_next = grain_rec(inext);  // owner record of row x+3, goes into the ring next iteration
+  GPv gv_next = ring.getv(xs + 1, lane);
   load_raw(xs + 1, bufA);
   load_raw(xs + 2, bufB);
   // The flags of a row as lane masks (lbm_march.h): sol* = the node belongs to a grain or a lattice-edge wall (id != -1),
@@ -329,10 +330,10 @@ __device__ __forceinline__ void march_item(const real* __restrict__ fin, real* _
 #endif
     // f* of row x+1. The record of a node's PREVIOUS owner (reinit_obst_density, main.c:966-986) is the ring's record of
     // its current one except at the few nodes that have changed hands since the previous map: only a row that has such a
-    // node (wave-uniform) fetches records from memory -- nothing is carried in registers from the iteration before.
+    // node (wave-uniform) fetches records from memory.
     {
       const bool in = interior(x + 1), re = in && oo1 != -1, moved = re && oo1 != iD;
-      GPv g = ring.getv(x + 1, lane);
+      GPv g = gv_next;   // (the ring's record of (x + 1, y), requested at the end of the iteration before)
       // (opaque: otherwise the compiler selects between the two ADDRESSES and reads through a flat pointer, under the
       // branch, with the wait that drains the row prefetch)
       asm volatile("" : "+v"(g.x1), "+v"(g.x2), "+v"(g.v1), "+v"(g.v2), "+v"(g.v3));
@@ -436,7 +437,11 @@ __device__ __forceinline__ void march_item(const real* __restrict__ fin, real* _
       // < q + number in direction q on lower lanes. In a deep row with at most 64 links the pass leaves its results in the
       // links' slots and the lanes pick them up for the row's nine coalesced stores (`merged`); else every population but
       // the links' is stored first and the pass stores each result to the node it belongs to.
+#if defined(LBMDEM_AB) && defined(MARCH_SCATTER)   /* experiment: every result stored by the lane that evaluated it (+13 us) */
+      const bool merged = false;
+#else
       const bool merged = deep && T <= LINK_SLOTS;
+#endif
       auto store_row = [&](auto with_results) {   // the nine stores of a deep row
         if (lane_of(wm)) {
           buf_store_real<0>(Fo[0], fout_rs, fcol, so_row);
@@ -575,6 +580,7 @@ __device__ __forceinline__ void march_item(const real* __restrict__ fin, real* _
     // those of row x+4 (consumed at this point of the next iteration)
     ring.put(x + 3, lane, rec_next, iF);
     rec_next = grain_rec(inext);
+    gv_next = ring.getv(x + 2, lane);   // position and velocities of the owner of (x + 2, y): the next iteration's re-initialisation
     // rotate
 #pragma unroll
     for (int q = 0; q < 9; ++q) { Fm[q] = F0[q]; F0[q] = Fp[q]; }

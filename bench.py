@@ -51,7 +51,7 @@ import samples  # noqa: E402
 BYTES_PER_LUP = 148.0   # 9x8 B read + 9x8 B write + 4 B obstacle id
 # PMC-measured HBM bytes per launch of the fused kernel (scripts/pmc_traffic.sh: rocprofv3 cannot run inside this process).
 # The file names the sources the measured library was built from (SHA-256); a number measured on other sources is NOT reported.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
 
 
 def library_source_sha256():

@@ -22,6 +22,11 @@ REPS=6 bash scripts/ab_fused_min.sh _r5 "" > $O/ab_vs_round5.txt 2>&1
 bash scripts/ab_real50k.sh > $O/ab_vs_round5_real50k.txt 2>&1
 # the DEM run with its tiles by index / as patches of the packing, both packings
 for w in bench real; do for t in 0 1; do python scripts/dem_rate.py $w $t 2>/dev/null | tail -3 >> $O/dem_rate_tiles.txt; done; done
+CT=$PWD/2d-lbm-dem_amd/liblbmdem_hip_ab_ct.so   # make AB=1 ABTAG=_ct ABFLAGS=-DLBMDEM_CHAIN_TIMING: where a tile's sub-step goes
+if [ -f $CT ]; then
+  LBMDEM_HIP_LIBRARY=$CT python scripts/dem_chain_times.py 50000 96 2>/dev/null > $O/dem_chain_tiles.txt
+  echo >> $O/dem_chain_tiles.txt; LBMDEM_HIP_LIBRARY=$CT python scripts/dem_chain_times.py 50000 96 real 2>/dev/null >> $O/dem_chain_tiles.txt
+fi
 LBMDEM_RCCL_LIBRARY=$PWD/tests/rccl_shim/librccl.so.1 LBMDEM_BENCH_DEVICES=0,0 python bench.py --gpus 2 --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_two_ranks_one_gpu.json
 bash scripts/strip_proxy_c.sh r06_final 8 4096 > $O/strip_proxy_c_4096.log 2>&1
 bash scripts/strip_proxy_c.sh r06_final8k 8 8192 > $O/strip_proxy_c_8192.log 2>&1
