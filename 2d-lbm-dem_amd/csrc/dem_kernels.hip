@@ -730,11 +730,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
             }
             ok = ok && g;
           }
-        if (__any(bad) || ++spins > CH_SPINS) {
-#ifdef CHAIN_DEBUG_PRINT
-          if ((tid & 63) == 0) printf("tile %d s %d: halo fetch gave up, bad %d spins %u first %d\n", tile, s, (int)__any(bad), spins, first);
-#endif
-          sFail = 1; break; }
+        if (__any(bad) || ++spins > CH_SPINS) { sFail = 1; break; }
 #ifdef LBMDEM_CHAIN_TIMING
         ++n_spins;
 #endif
@@ -788,13 +784,7 @@ __global__ __launch_bounds__(DEM_THREADS, 4) void k_dem_chain(Kin in, Kin out, c
           ChainRead R{};
           // (the copy its tile is expected to write: the remote one only exists for tiles with a partner in another XCD's
           // eighth -- which a tile read from another eighth is, the list being symmetric)
-          if (!chain_read_direct(rs, direct_copy(gj) + pbase + (unsigned)gj * 128u, tag, stag, R)) {
-            lost = true;
-#ifdef CHAIN_DEBUG_PRINT
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, direct_copy(gj) + pbase + (unsigned)gj * 128u, 0, 16);
-            printf("tile %d s %d: direct read of grain %d (tile %d) lost: tags %u %u want %u copy %u\n", tile, s, gj, gj / DEM_TILE, v.y, v.w, tag, direct_copy(gj));
-#endif
-          }
+          if (!chain_read_direct(rs, direct_copy(gj) + pbase + (unsigned)gj * 128u, tag, stag, R)) lost = true;
           b.x1 = R.x1; b.x2 = R.x2; b.v1 = R.v1; b.v2 = R.v2; b.v3 = R.v3; b.r = r[gj];
         }
         bool touched;

@@ -12,15 +12,17 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 //
 // One WAVEFRONT owns a window of 64 consecutive y (MARCH_WW = 60 produce output -- a window's stores then start on a
-// 32-byte sector boundary, lbm_fused.hip -- the two edge lanes on either side only feed their neighbours) and walks along x over LX rows. Each lane keeps the f* of its column for three
-// consecutive rows in registers; row x+1 is re-initialised/collided and rotated in while row x is
-// produced. The six diagonal/vertical neighbours a pull needs live in the adjacent lanes and are
-// fetched with cross-lane shuffles; the obstacle ids of the 3x3 neighbourhood are read directly (they
-// are 4-byte, cached). No barriers: waves are independent, every load of a row is a full 512-byte
-// coalesced request, and the loads of the next two rows are in flight while the current one is
-// computed. LDS is used only wave-privately: a ring of grain records (RecRing) and the scratch of the
-// compacted bounce-back evaluation. Redundant work: 4 of 64 lanes and 3 of LX+3 rows.
-// DESIGN.md section 4 lists what was measured on the way (in-order vmcnt, no loads under branches, ...).
+// 32-byte sector boundary, lbm_fused.hip -- the two edge lanes on either side only feed their neighbours) and walks along x
+// over its rows. Each lane keeps the f* of its column for three consecutive rows in registers; row x+1 is
+// re-initialised/collided and rotated in while row x is produced. The six diagonal/vertical neighbours a pull needs live in
+// the adjacent lanes and are fetched with full-wave DPP shifts. A lane loads ONE obstacle id per row; what a row's nodes are
+// (grain or fluid, active, the end of a bounce-back link) is kept as wave-uniform 64-bit lane masks (below), and a node's
+// column neighbours are the same masks shifted by one. No barriers: waves are independent, every load of a row is a full
+// 512-byte coalesced request through a buffer resource, and the loads of the next two rows are in flight while the current
+// one is computed. LDS is used only wave-privately: a ring of grain records (RecRing), the slots of the compacted bounce-back
+// evaluation and a copy of the lattice's constants. Redundant work: 4 of 64 lanes and 3 of LX+3 rows.
+// DESIGN.md section 4.1 and LABBOOK.md (rounds 1-6) list what was measured on the way (in-order vmcnt, no loads under
+// branches, ...).
 
 struct Ids3 { int m, c, p; };  // obstacle ids at (y-1, y, y+1) of one row
 
