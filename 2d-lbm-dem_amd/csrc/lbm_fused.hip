@@ -601,8 +601,14 @@ __device__ __forceinline__ void march_item(const real* __restrict__ fin, real* _
   MT_FLUSH
 }
 
+// wavefronts per workgroup of k_cs_march (they share nothing: the workgroup is the unit the dispatcher places and retires)
+#ifndef MARCH_WPB
+#define MARCH_WPB 4
+#endif
+constexpr int WPB = MARCH_WPB;
+
 template <int LX, int MINW, int WW, bool CHG = false>
-__global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__ fin, real* __restrict__ fout,
+__global__ __launch_bounds__(64 * WPB, MINW) void k_cs_march(const real* __restrict__ fin, real* __restrict__ fout,
                                                   const int* __restrict__ ob_old,
                                                   const int* __restrict__ ob_new, LatticeView L,
                                                   GrainFluidView G, ForceSlots S, int nstrips, int nwork,
@@ -612,7 +618,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
   int blk = blockIdx.x;
   int w, strip, xs, rows_per_wave;
   if (LX == 0 && P.nlev > 0) {
-    const int band = blk & 7, local = (blk >> 3) * 4 + (threadIdx.x >> 6);
+    const int band = blk & 7, local = (blk >> 3) * WPB + (threadIdx.x >> 6);
     if (local >= P.first[P.nlev]) return;  // whole wave
     int l = 0;
 #pragma unroll
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
       const int per = gridDim.x >> 3;
       blk = (blk & 7) * per + (blk >> 3);
     }
-    w = blk * 4 + (threadIdx.x >> 6);
+    w = blk * WPB + (threadIdx.x >> 6);
     if (w >= nwork) return;  // whole wave
     const int seg = w / nstrips;
     strip = w - seg * nstrips;
@@ -644,20 +650,20 @@ __global__ __launch_bounds__(256, MINW) void k_cs_march(const real* __restrict__
   strip = __builtin_amdgcn_readfirstlane(strip);
   xs = __builtin_amdgcn_readfirstlane(xs);
   const int xe = __builtin_amdgcn_readfirstlane(xs + rows_per_wave < L.xo1 ? xs + rows_per_wave : L.xo1);
-  __shared__ real2 sRec[4 * REC_RING * 4 * 64];
-  __shared__ int sRid[4 * REC_RING * 64];
+  __shared__ real2 sRec[WPB * REC_RING * 4 * 64];
+  __shared__ int sRid[WPB * REC_RING * 64];
   const RecRing ring{sRec + (threadIdx.x >> 6) * (REC_RING * 4 * 64), sRid + (threadIdx.x >> 6) * (REC_RING * 64)};
   // wave-private scratch for the compacted bounce-back evaluation: 64 link slots
   // (Round 3 measured a spare 65th slot that lanes without a link write to, instead of sitting out the writes under an
   // exec mask: eight mask round trips per row less, but 12 B of scratch and twice the scalar spill reloads: +1.7 %.)
-  __shared__ real sPay[4 * LINK_SLOTS * 4];
-  __shared__ int sDesc[4 * LINK_SLOTS];
+  __shared__ real sPay[WPB * LINK_SLOTS * 4];
+  __shared__ int sDesc[WPB * LINK_SLOTS];
   real* const pay = sPay + (threadIdx.x >> 6) * (LINK_SLOTS * 4);
   int* const desc = sDesc + (threadIdx.x >> 6) * LINK_SLOTS;
   // The lattice's constants once more in LDS, wave-private: the arithmetic routines (collision, grain equilibrium,
   // bounce-back) read their reals from there, at the point of use, through the vector unit -- thirteen doubles that would
   // otherwise sit in 26 scalar registers for the whole loop, in a kernel whose scalar registers are spilled to vector lanes.
-  __shared__ LatticeView sLat[4];
+  __shared__ LatticeView sLat[WPB];
   LatticeView* const Lk = sLat + (threadIdx.x >> 6);
   if (lane == 0) *Lk = L;
   __builtin_amdgcn_wave_barrier();
@@ -825,13 +831,13 @@ static void launch_march(const real* fin, real* fout, const int* obst_old, const
   }
   const int nseg = (rows + seg_rows - 1) / seg_rows;
   int nwork = nstrips * nseg;
-  int grid = (nwork + 3) / 4;
+  int grid = (nwork + WPB - 1) / WPB;
   if (remap) grid = ((grid + 7) / 8) * 8;
   MarchPlan P{};
   if (LX == 0 && remap) P = product_plan(rows, nstrips, seg_rows);   // a large row range: the tapered work order
   if (P.nlev > 0) {
     nwork = 8 * P.first[P.nlev];
-    grid = 8 * ((P.first[P.nlev] + 3) / 4);
+    grid = 8 * ((P.first[P.nlev] + WPB - 1) / WPB);
   }
 #ifdef LBMDEM_AB   // k_cs_march3 (lbm_fused_ab.hip) only exists in the experiment build
   if constexpr (WW == 62) {
@@ -848,11 +854,11 @@ static void launch_march(const real* fin, real* fout, const int* obst_old, const
   dyn_lds = (unsigned)env_lds;
 #endif
   if (LX == 0 && chg.bits != nullptr) {
-    hipLaunchKernelGGL((k_cs_march<LX, MINW, WW, LX == 0>), dim3(grid), dim3(256), dyn_lds, st, fin, fout, obst_old, obst_new, L, G,
+    hipLaunchKernelGGL((k_cs_march<LX, MINW, WW, LX == 0>), dim3(grid), dim3(64 * WPB), dyn_lds, st, fin, fout, obst_old, obst_new, L, G,
                        S, nstrips, nwork, remap, seg_rows, seg_rows, P, chg);
     return;
   }
-  hipLaunchKernelGGL((k_cs_march<LX, MINW, WW>), dim3(grid), dim3(256), dyn_lds, st, fin, fout, obst_old, obst_new, L, G,
+  hipLaunchKernelGGL((k_cs_march<LX, MINW, WW>), dim3(grid), dim3(64 * WPB), dyn_lds, st, fin, fout, obst_old, obst_new, L, G,
                      S, nstrips, nwork, remap, seg_rows, seg_rows, P, chg);
 }
 
@@ -866,7 +872,7 @@ static void launch_march_two_ranges(const real* fin, real* fout, const int* obst
   Ls.xo0 = lo0; Ls.xo1 = hi0 + w;
   const int nstrips = (L.ly + WW - 1) / WW;
   const int nwork = nstrips * 2;
-  const int grid = (nwork + 3) / 4;
+  const int grid = (nwork + WPB - 1) / WPB;
 #ifdef LBMDEM_AB
   if (march_kernel() == 3) {   // (k_cs_march3 is laid out for 62-column windows)
     const int ns3 = (L.ly + 61) / 62, nw3 = ns3 * 2;
@@ -874,7 +880,7 @@ static void launch_march_two_ranges(const real* fin, real* fout, const int* obst
     return;
   }
 #endif
-  hipLaunchKernelGGL((k_cs_march<0, 2, WW>), dim3(grid), dim3(256), 0, st, fin, fout, obst_old, obst_new, Ls, G, S, nstrips,
+  hipLaunchKernelGGL((k_cs_march<0, 2, WW>), dim3(grid), dim3(64 * WPB), 0, st, fin, fout, obst_old, obst_new, Ls, G, S, nstrips,
                      nwork, 0, w, hi0 - lo0, MarchPlan{}, ObstChange{nullptr, 0, 0, 0});
 }
 
