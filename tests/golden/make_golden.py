@@ -243,9 +243,9 @@ def make_dem_output_fixture(dry=False):
 REAL_CASES = {
     # name: (sample file under /root/reference/bin, lx, ly, fluid steps at which the state is hashed)
     "real_a08d83_600x500": ("a08d83.data", 600, 500, (1, 10, 20)),             # SURVEY.md section 8c known answers
-    "real_7000_2048x2048": ("a08_a4b4r18_7000.data", 2048, 2048, (1, 2)),      # BASELINE.json configs[2]
+    "real_7000_2048x2048": ("a08_a4b4r18_7000.data", 2048, 2048, (1, 2, 50)),  # BASELINE.json configs[2]
     "real_50000_4096x4096": ("50000.data", 4096, 4096, (1, 2, 10, 20, 100)),       # BASELINE.json configs[3]
-    "real_50000test_3072x3072": ("50000-test.data", 3072, 3072, (1, 2)),       # BASELINE.json configs[0] (47 980 grains)
+    "real_50000test_3072x3072": ("50000-test.data", 3072, 3072, (1, 2, 30)),   # BASELINE.json configs[0] (47 980 grains)
     "real_50000_8192x4096": ("50000.data", 8192, 4096, (1, 2, 10, 20)),        # BASELINE.json configs[4] (one domain = 8 strips)
     # the JUBE cases of the reference's own benchmark.xml (lines 7, 13-27) at scale 1, and the remaining shipped samples
     "real_a08d83_2000x1000": ("a08d83.data", 2000, 1000, (1, 2, 10)),
